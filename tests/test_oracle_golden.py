@@ -1,0 +1,110 @@
+"""CPU: the oracle (oracle/torch_ref.py) against golden vectors produced by the imported reference model.
+
+This is what pins the oracle (tests/golden/make_goldens.py ran the reference itself).  Tolerance: 1e-5 abs on
+logits (fp32, same torch CPU kernels, only reassociation from the K/V hoist), ids identical."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as R
+from helpers import load_case, weights_and_inputs
+
+SMALL = ['small_msvd', 'small_msrvtt', 'small_noobj', 'small_baseline1']
+
+
+def build(tag):
+    args, vocab, g, kind = load_case(tag)
+    torch.manual_seed(0)
+    net = (R.CapGnnModelRef if kind == 'capgnn' else R.CapBaseline1Ref)(args, vocab).eval()
+    sd, frames, regions, caps, lens = weights_and_inputs(net, g, args)
+    net.load_state_dict(sd, strict=True)
+    return net, g, frames, regions, caps, lens, kind
+
+
+@pytest.mark.parametrize('tag', SMALL)
+def test_state_dict_keys_and_forward(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    ref_keys = sorted(k[2:] for k in g if k.startswith('w.'))
+    assert ref_keys == sorted(net.state_dict().keys())
+    inter = {} if kind == 'capgnn' else None
+    with torch.no_grad():
+        if kind == 'capgnn':
+            logits, obj, mot, alpha = net(frames, regions, caps, 26, 1.0, inter=inter)
+        else:
+            logits = net(frames, regions, caps, 26, 1.0)[0]
+    assert np.abs(logits.numpy() - g['logits']).max() <= 1e-5
+    if kind == 'capgnn':
+        assert np.abs(obj.numpy() - g['obj_psl']).max() <= 1e-5
+        assert np.abs(mot.numpy() - g['mot_psl']).max() <= 1e-5
+        assert np.abs(alpha.numpy() - g['alpha']).max() <= 1e-5
+        for k, v in inter.items():
+            if 'i.' + k in g:
+                assert np.abs(v.numpy() - g['i.' + k]).max() <= 1e-5, k
+
+
+@pytest.mark.parametrize('tag', SMALL)
+def test_greedy_and_beam_ids(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    with torch.no_grad():
+        net.update_beam_size(1)
+        ids = net(frames, regions, None)[0]
+        assert np.array_equal(ids.numpy(), g['greedy_ids'])
+        net.update_beam_size(5)
+        ids = net(frames, regions, None)[0]
+        assert np.array_equal(ids.numpy(), g['beam5_ids'])
+
+
+@pytest.mark.parametrize('tag', SMALL)
+def test_scheduled_sampling_coin_order(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    random.seed(12)
+    with torch.no_grad():
+        logits = net(frames, regions, caps, 26, 0.6)[0]
+    assert np.abs(logits.numpy() - g['ss_logits']).max() <= 1e-5
+
+
+@pytest.mark.parametrize('tag', SMALL)
+def test_train_step_loss_grads_adam(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    opt = R.make_optimizer(net)
+    opt.zero_grad()
+    outs = net(frames, regions, caps, 26, 1.0)[0]
+    loss = R.ragged_ce(outs, caps, lens)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5
+    for k, p in net.named_parameters():
+        if 'gnone.' + k in g:
+            assert p.grad is None, k
+        else:
+            ref = g['g.' + k]
+            assert np.abs(p.grad.numpy() - ref).max() <= 1e-5 + 1e-4 * np.abs(ref).max(), k
+    opt.step()
+    for k, p in net.named_parameters():
+        s, a = g['post.' + k]
+        assert abs(float(p.detach().double().sum()) - s) <= 1e-5 * max(1.0, a), k
+
+
+def test_masked_self_attention(golden_dir):
+    g = dict(np.load(golden_dir + '/sa_mask.npz'))
+    m = R.SelfAttentionP(32, 32, 16, 0.3).eval()
+    m.load_state_dict({k[2:]: torch.from_numpy(v) for k, v in g.items() if k.startswith('w.')})
+    x = torch.from_numpy(g['x'])
+    with torch.no_grad():
+        y = R.self_attention(m, x, torch.from_numpy(g['mask']))
+        y0 = R.self_attention(m, x)
+    assert np.abs(y.numpy() - g['y_masked']).max() <= 1e-5
+    assert np.abs(y0.numpy() - g['y']).max() <= 1e-5
+
+
+@pytest.mark.parametrize('tag', ['full_msvd_b2'])
+def test_full_size_msvd(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    with torch.no_grad():
+        logits = net(frames, regions, caps, 26, 1.0)[0]
+        assert np.abs(logits.numpy() - g['logits']).max() <= 2e-5
+        net.update_beam_size(1)
+        assert np.array_equal(net(frames, regions, None)[0].numpy(), g['greedy_ids'])
+        net.update_beam_size(5)
+        assert np.array_equal(net(frames, regions, None)[0].numpy(), g['beam5_ids'])
