@@ -1,0 +1,72 @@
+// Shared device helpers for the D-LSG hot-path kernels (gfx950 / CDNA4 only, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DLSG_OK 0
+#define DLSG_EINVAL (-1)
+#define DLSG_ELAUNCH (-2)
+#define DLSG_EALIGN (-3)
+
+#define DLSG_CHECK_LAUNCH()                                  \
+    do {                                                     \
+        hipError_t e__ = hipGetLastError();                  \
+        if (e__ != hipSuccess) return DLSG_ELAUNCH;          \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace dlsg {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum over blockDim.x threads (multiple of 64, <= 1024).  `red` = >= 16 floats of LDS.
+// Every thread gets the result.  Two barriers; safe to call repeatedly with the same `red`.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// Counter-based dropout mask: keep iff hash(seed, site, idx) >= p.  Stateless, so the backward pass
+// recomputes the same mask from (seed, site, idx) instead of storing it.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint32_t site, uint64_t idx, float p) {
+    // returns 0 (dropped) or 1/(1-p) (kept)
+    uint32_t h = mix32((uint32_t)idx ^ mix32((uint32_t)(idx >> 32) + 0x9e3779b9U * site + (uint32_t)seed));
+    h = mix32(h ^ (uint32_t)(seed >> 32));
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    return u < p ? 0.f : 1.f / (1.f - p);
+}
+
+}  // namespace dlsg

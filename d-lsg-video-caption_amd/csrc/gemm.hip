@@ -1,0 +1,267 @@
+// Grouped / batched fp32 GEMM on the gfx950 f32-input matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Every dense product on the D-LSG path runs through this one kernel family (see include/dlsg.h):
+// projections (NT), input gradients (NN) and weight gradients (TN).  fp32 in / fp32 accumulate keeps the
+// reference's fp32 numerics (bitwise a k-ordered fmaf chain), at the fp32 matrix rate (157 TFLOP/s peak).
+//
+// Layout: 256 threads = 4 waves as 2x2; block tile BMxBN (128x128 or 64x64), BK = 32.
+//   * global -> registers -> LDS staging with the next K-tile's loads in flight under the MFMAs
+//   * k-contiguous operands are stored [row][32+4] (b128 fragment reads, conflict free: slot stride 9 mod 16)
+//     m/n-contiguous operands are stored [k][rows+4] (b32 fragment reads, lanes on consecutive banks)
+//   * lane (r = lane&31, h = lane>>5) feeds k = 16h + s for MFMA s of a K-tile: A and B use the same k order
+//   * block ids are remapped so that the blocks an XCD receives (id % 8) walk consecutive tiles of one A row
+//     panel: the panel stays in that XCD's L2 instead of being fetched by all eight.
+#include "common.hpp"
+#include "dlsg.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+
+template <int ROWS, bool T>
+struct TileGeom {
+    // float4 count per tile and per thread
+    static constexpr int NV = ROWS * BK / 4 / NT;
+    static constexpr int LD = T ? (ROWS + 4) : (BK + 4);
+    static constexpr int ELEMS = T ? BK * (ROWS + 4) : ROWS * (BK + 4);
+};
+
+// Load one operand tile (ROWS x BK) into registers.  T=false: element (row,k) at base[row*ld + k];
+// T=true: element (row,k) at base[k*ld + row].  Out-of-range elements read as zero.
+template <int ROWS, bool T>
+__device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax,
+                                          int K, bool vec_ok, f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
+    constexpr int NV = TileGeom<ROWS, T>::NV;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = threadIdx.x + NT * j;
+        int gr, gk, nvalid;
+        const float* ptr;
+        if (!T) {
+            const int row = f >> 3, kq = f & 7;
+            gr = row0 + row;
+            gk = k0 + 4 * kq;
+            ptr = base + (int64_t)gr * ld + gk;
+            nvalid = (gr < rmax) ? min(max(K - gk, 0), 4) : 0;
+        } else {
+            const int k = f / (ROWS / 4), mq = f % (ROWS / 4);
+            gk = k0 + k;
+            gr = row0 + 4 * mq;
+            ptr = base + (int64_t)gk * ld + gr;
+            nvalid = (gk < K) ? min(max(rmax - gr, 0), 4) : 0;
+        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid == 4 && vec_ok) {
+            v = *reinterpret_cast<const f32x4*>(ptr);
+        } else {
+            if (nvalid > 0) v[0] = ptr[0];
+            if (nvalid > 1) v[1] = ptr[1];
+            if (nvalid > 2) v[2] = ptr[2];
+            if (nvalid > 3) v[3] = ptr[3];
+        }
+        regs[j] = v;
+    }
+}
+
+template <int ROWS, bool T>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
+    constexpr int NV = TileGeom<ROWS, T>::NV;
+    constexpr int LD = TileGeom<ROWS, T>::LD;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = threadIdx.x + NT * j;
+        int off;
+        if (!T) {
+            off = (f >> 3) * LD + 4 * (f & 7);
+        } else {
+            off = (f / (ROWS / 4)) * LD + 4 * (f % (ROWS / 4));
+        }
+        *reinterpret_cast<f32x4*>(lds + off) = regs[j];
+    }
+}
+
+// Fragment of 16 k-values for one 32-row subtile: element s <-> k = 16h + s.
+template <int ROWS, bool T>
+__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rowbase, int r, int h, float (&a)[16]) {
+    constexpr int LD = TileGeom<ROWS, T>::LD;
+    if (!T) {
+        const float* p = lds + (rowbase + r) * LD + 16 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
+            a[4 * q + 0] = v[0]; a[4 * q + 1] = v[1]; a[4 * q + 2] = v[2]; a[4 * q + 3] = v[3];
+        }
+    } else {
+        const float* p = lds + (16 * h) * LD + rowbase + r;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a[s] = p[s * LD];
+    }
+}
+
+struct KArgs {
+    int M, N, ldc, ngroups, flags;
+    int64_t bsa, bsb, bsc;
+    float alpha;
+    const float* bias;
+    dlsg_gemm_group g[DLSG_GEMM_MAXG];
+};
+
+template <int BM, int BN, bool AT, bool BT>
+__global__ __launch_bounds__(NT) void gemm_kernel(const KArgs p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    using GA = TileGeom<BM, AT>;
+    using GB = TileGeom<BN, BT>;
+    __shared__ __attribute__((aligned(16))) float lds[GA::ELEMS + GB::ELEMS];
+    float* ldsA = lds;
+    float* ldsB = lds + GA::ELEMS;
+
+    // ---- XCD-aware tile order (bijective for any block count)
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nblk >> 3, rmd = nblk & 7;
+        bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.y;
+    const int gi = z % p.ngroups, bi = z / p.ngroups;
+    const dlsg_gemm_group grp = p.g[gi];
+    const float* A = grp.A + (int64_t)bi * p.bsa;
+    const float* B = grp.B + (int64_t)bi * p.bsb;
+    float* C = grp.C + (int64_t)bi * p.bsc;
+    const int K = grp.K;
+    const bool vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((grp.lda & 3) == 0);
+    const bool vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[GA::NV], rb[GB::NV];
+    const int nk = (K + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile<BM, AT>(A, grp.lda, m0, 0, p.M, K, vecA, ra);
+        load_tile<BN, BT>(B, grp.ldb, n0, 0, p.N, K, vecB, rb);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile<BM, AT>(ldsA, ra);
+        store_tile<BN, BT>(ldsB, rb);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            load_tile<BM, AT>(A, grp.lda, m0, (kt + 1) * BK, p.M, K, vecA, ra);
+            load_tile<BN, BT>(B, grp.ldb, n0, (kt + 1) * BK, p.N, K, vecB, rb);
+        }
+        float fa[TM][16], fb[TN][16];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) read_frag<BM, AT>(ldsA, wm * WM + i * 32, r, h, fa[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) read_frag<BN, BT>(ldsB, wn * WN + j * 32, r, h, fb[j]);
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && p.bias != nullptr;
+    const bool do_tanh = p.flags & DLSG_GEMM_TANH;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + r;
+            if (col >= p.N) continue;
+            const float bv = use_bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float* cp = C + (int64_t)row * p.ldc + col;
+                float v = p.alpha * acc[i][j][e] + bv;
+                if (accum) v += *cp;
+                if (do_tanh) v = tanhf(v);
+                *cp = v;
+            }
+        }
+}
+
+template <int BM, int BN>
+int launch(const dlsg_gemm_args* a, hipStream_t st) {
+    KArgs k;
+    k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
+    k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias;
+    for (int i = 0; i < a->ngroups; ++i) k.g[i] = a->g[i];
+    const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+    dim3 grid(tiles, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
+    switch (a->mode) {
+        case 0: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, block, 0, st, k); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, block, 0, st, k); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, block, 0, st, k); break;
+        default: return DLSG_EINVAL;
+    }
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+// out = sum of slabs (+bias) (tanh)
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, int64_t stride,
+                                   const float* __restrict__ bias, float* __restrict__ out, int64_t rows, int n,
+                                   int ldo, int flags) {
+    const int64_t total = rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t rrow = i / n;
+        const int col = (int)(i - rrow * n);
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+        if ((flags & DLSG_GEMM_BIAS) && bias) s += bias[col];
+        float* op = out + rrow * ldo + col;
+        if (flags & DLSG_GEMM_ACCUM) s += *op;
+        if (flags & DLSG_GEMM_TANH) s = tanhf(s);
+        *op = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int dlsg_abi_version(void) { return DLSG_ABI_VERSION; }
+
+extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
+    if (!a || a->ngroups < 1 || a->ngroups > DLSG_GEMM_MAXG || a->nbatch < 1 || a->M < 0 || a->N < 0) return DLSG_EINVAL;
+    if (a->M == 0 || a->N == 0) return DLSG_OK;
+    if ((int64_t)a->ngroups * a->nbatch > 65535) return DLSG_EINVAL;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t z = (int64_t)a->ngroups * a->nbatch;
+    const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
+    if (tilesL >= 192) return launch<128, 128>(a, st);
+    return launch<64, 64>(a, st);
+}
+
+extern "C" int dlsg_slab_reduce(const float* slabs, int nslab, int64_t slab_stride, const float* bias, float* out,
+                                int64_t rows, int n, int ldo, int flags, void* stream) {
+    if (!slabs || !out || nslab < 1) return DLSG_EINVAL;
+    const int64_t total = rows * n;
+    if (total == 0) return DLSG_OK;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), slabs,
+                       nslab, slab_stride, bias, out, rows, n, ldo, flags);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}

@@ -1,0 +1,606 @@
+// Row-wise / pointwise kernels of the D-LSG hot path (gfx950): tanh+LayerNorm(+PE)(+dropout) forward/backward,
+// strided softmax, LSTM cell pointwise, embedding gather/scatter, argmax, ragged cross entropy, Adam.
+// All are HBM/L2-bound streaming kernels: one pass over the row held in registers, float4 where aligned.
+#include "common.hpp"
+#include "dlsg.h"
+
+using namespace dlsg;
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_MAXPT = 8;  // n <= 2048
+
+// ------------------------------------------------------------------------------------------------ rowln fwd
+__global__ __launch_bounds__(LN_THREADS) void rowln_fwd_kernel(const dlsg_rowln_args a) {
+    __shared__ float red[16];
+    const int n = a.n;
+    for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
+        const float* x = a.x + (int64_t)row * a.ldx;
+        const float* res = a.res ? a.res + (int64_t)row * a.ldres : nullptr;
+        float t[LN_MAXPT];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPT; ++i) {
+            const int j = threadIdx.x + i * LN_THREADS;
+            float z = 0.f;
+            if (j < n) {
+                z = x[j];
+                if (res) z += res[j];
+                if (a.pre_tanh == 1) z = tanhf(z);
+                s += z;
+            }
+            t[i] = z;
+        }
+        const float mean = block_sum(s, red) / n;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPT; ++i) {
+            const int j = threadIdx.x + i * LN_THREADS;
+            if (j < n) { const float d = t[i] - mean; q += d * d; }
+        }
+        const float rstd = rsqrtf(block_sum(q, red) / n + a.eps);
+        if (a.stats && threadIdx.x == 0) { a.stats[2 * (int64_t)row] = mean; a.stats[2 * (int64_t)row + 1] = rstd; }
+        float* y = a.y + (int64_t)row * a.ldy;
+        const float* pe = a.pe ? a.pe + (int64_t)(row % a.pe_rows) * n : nullptr;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPT; ++i) {
+            const int j = threadIdx.x + i * LN_THREADS;
+            if (j < n) {
+                float v = (t[i] - mean) * rstd * a.gamma[j] + a.beta[j];
+                if (a.post_tanh) v = tanhf(v);
+                const uint64_t idx = (uint64_t)row * n + j;
+                if (a.p1 > 0.f) v *= drop_scale(a.seed, a.site1, idx, a.p1);
+                if (pe) {
+                    v += pe[j];
+                    if (a.p2 > 0.f) v *= drop_scale(a.seed, a.site2, idx, a.p2);
+                }
+                y[j] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rowln bwd
+// Each block walks rows blockIdx.x, +gridDim.x, ... and keeps per-column dgamma/dbeta partial sums in registers.
+__global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_bwd_args b) {
+    __shared__ float red[16];
+    const dlsg_rowln_args& a = b.f;
+    const int n = a.n;
+    float dg[LN_MAXPT], db[LN_MAXPT];
+#pragma unroll
+    for (int i = 0; i < LN_MAXPT; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
+        const float* x = a.x + (int64_t)row * a.ldx;
+        const float* res = a.res ? a.res + (int64_t)row * a.ldres : nullptr;
+        const float* dy = b.dy + (int64_t)row * b.lddy;
+        float mean, rstd;
+        float t[LN_MAXPT];
+        if (a.stats) {
+            mean = a.stats[2 * (int64_t)row]; rstd = a.stats[2 * (int64_t)row + 1];
+#pragma unroll
+            for (int i = 0; i < LN_MAXPT; ++i) {
+                const int j = threadIdx.x + i * LN_THREADS;
+                float z = 0.f;
+                if (j < n) { z = x[j]; if (res) z += res[j]; if (a.pre_tanh == 1) z = tanhf(z); }
+                t[i] = z;
+            }
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXPT; ++i) {
+                const int j = threadIdx.x + i * LN_THREADS;
+                float z = 0.f;
+                if (j < n) { z = x[j]; if (res) z += res[j]; if (a.pre_tanh == 1) z = tanhf(z); s += z; }
+                t[i] = z;
+            }
+            mean = block_sum(s, red) / n;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < LN_MAXPT; ++i) {
+                const int j = threadIdx.x + i * LN_THREADS;
+                if (j < n) { const float d = t[i] - mean; q += d * d; }
+            }
+            rstd = rsqrtf(block_sum(q, red) / n + a.eps);
+        }
+        float gx[LN_MAXPT];   // dL/dxhat
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPT; ++i) {
+            const int j = threadIdx.x + i * LN_THREADS;
+            gx[i] = 0.f;
+            if (j < n) {
+                const float xh = (t[i] - mean) * rstd;
+                float g = dy[j];
+                const uint64_t idx = (uint64_t)row * n + j;
+                if (a.pe && a.p2 > 0.f) g *= drop_scale(a.seed, a.site2, idx, a.p2);
+                if (a.p1 > 0.f) g *= drop_scale(a.seed, a.site1, idx, a.p1);
+                if (a.post_tanh) {
+                    const float yp = tanhf(xh * a.gamma[j] + a.beta[j]);
+                    g *= (1.f - yp * yp);
+                }
+                dg[i] += g * xh;
+                db[i] += g;
+                const float gxh = g * a.gamma[j];
+                gx[i] = gxh;
+                s1 += gxh;
+                s2 += gxh * xh;
+            }
+        }
+        const float m1 = block_sum(s1, red) / n;
+        const float m2 = block_sum(s2, red) / n;
+        float* dx = b.dx + (int64_t)row * b.lddx;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPT; ++i) {
+            const int j = threadIdx.x + i * LN_THREADS;
+            if (j < n) {
+                const float xh = (t[i] - mean) * rstd;
+                float d = rstd * (gx[i] - m1 - xh * m2);
+                if (a.pre_tanh) d *= (1.f - t[i] * t[i]);   // mode 1: t = tanh(x); mode 2: x is already a tanh output
+                if (b.accum_dx) d += dx[j];
+                dx[j] = d;
+            }
+        }
+    }
+    if (b.dgb_part) {
+        float* pg = b.dgb_part + (int64_t)blockIdx.x * 2 * n;
+#pragma unroll
+        for (int i = 0; i < LN_MAXPT; ++i) {
+            const int j = threadIdx.x + i * LN_THREADS;
+            if (j < n) { pg[j] = dg[i]; pg[n + j] = db[i]; }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ column sum
+// block = 64 columns x 16 row-lanes; deterministic (fixed order) tree through LDS.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int64_t ld, int rows, int n,
+                                                      float* __restrict__ out, int accum) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (col < n)
+        for (int r = rl; r < rows; r += 16) s += part[(int64_t)r * ld + col];
+    red[rl][c] = s;
+    __syncthreads();
+    if (rl == 0 && col < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][c];
+        if (accum) t += out[col];
+        out[col] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ softmax (outer, n, inner)
+// one wave per (outer, inner) line; lanes stride over n.
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ x, const float* __restrict__ mask,
+                                                          float* __restrict__ y, int64_t outer, int n, int inner) {
+    const int lane = threadIdx.x & 63;
+    const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= outer * inner) return;
+    const int64_t o = line / inner, in = line % inner;
+    const float* xp = x + o * n * inner + in;
+    const float* mp = mask ? mask + o * n * inner + in : nullptr;
+    float* yp = y + o * n * inner + in;
+    float m = -INFINITY;
+    for (int j = lane; j < n; j += 64) {
+        float v = xp[(int64_t)j * inner];
+        if (mp && !(mp[(int64_t)j * inner] > 0.f)) v = -9e15f;
+        m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        float v = xp[(int64_t)j * inner];
+        if (mp && !(mp[(int64_t)j * inner] > 0.f)) v = -9e15f;
+        s += __expf(v - m);
+    }
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int j = lane; j < n; j += 64) {
+        float v = xp[(int64_t)j * inner];
+        if (mp && !(mp[(int64_t)j * inner] > 0.f)) v = -9e15f;
+        yp[(int64_t)j * inner] = __expf(v - m) * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, int64_t outer, int n, int inner) {
+    const int lane = threadIdx.x & 63;
+    const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= outer * inner) return;
+    const int64_t o = line / inner, in = line % inner;
+    const int64_t base = o * n * inner + in;
+    float s = 0.f;
+    for (int j = lane; j < n; j += 64) s += y[base + (int64_t)j * inner] * dy[base + (int64_t)j * inner];
+    s = wave_sum(s);
+    for (int j = lane; j < n; j += 64) {
+        const int64_t k = base + (int64_t)j * inner;
+        dx[k] = y[k] * (dy[k] - s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LSTM pointwise
+__global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(const dlsg_lstm_pw_args a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= a.H) return;
+    const int H = a.H;
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = g * H + j;
+        float s = 0.f;
+        for (int k = 0; k < a.nslab; ++k) s += a.slabs[k * a.slab_stride + (int64_t)b * 4 * H + col];
+        if (a.addend) s += a.addend[(int64_t)b * a.ldadd + col];
+        if (a.b_ih) s += a.b_ih[col];
+        if (a.b_hh) s += a.b_hh[col];
+        pre[g] = s;
+    }
+    const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+    const float cp = a.c_prev ? a.c_prev[(int64_t)b * a.ldcp + j] : 0.f;
+    const float c = fg * cp + ig * gg;
+    const float h = og * tanhf(c);
+    a.c[(int64_t)b * a.ldc_ + j] = c;
+    if (a.h) a.h[(int64_t)b * a.ldh + j] = h;
+    if (a.h2) {
+        float h2 = h;
+        if (a.p > 0.f) h2 *= drop_scale(a.seed, a.site, (uint64_t)b * H + j, a.p);
+        a.h2[(int64_t)b * a.ldh2 + j] = h2;
+    }
+    if (a.gates) {
+        float* gp = a.gates + (int64_t)b * a.ldg;
+        gp[j] = ig; gp[H + j] = fg; gp[2 * H + j] = gg; gp[3 * H + j] = og;
+    }
+}
+
+__global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(const dlsg_lstm_pw_bwd_args a) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (j >= a.H) return;
+    const int H = a.H;
+    const float* gp = a.gates + (int64_t)b * a.ldg;
+    const float ig = gp[j], fg = gp[H + j], gg = gp[2 * H + j], og = gp[3 * H + j];
+    const float c = a.c[(int64_t)b * a.ldc_ + j];
+    const float cp = a.c_prev ? a.c_prev[(int64_t)b * a.ldcp + j] : 0.f;
+    float dh = a.dh ? a.dh[(int64_t)b * a.lddh + j] : 0.f;
+    if (a.dh2) {
+        float d2 = a.dh2[(int64_t)b * a.lddh2 + j];
+        if (a.p > 0.f) d2 *= drop_scale(a.seed, a.site, (uint64_t)b * H + j, a.p);
+        dh += d2;
+    }
+    const float tc = tanhf(c);
+    float dc = dh * og * (1.f - tc * tc);
+    if (a.dc_next) dc += a.dc_next[(int64_t)b * a.lddcn + j];
+    float* dgp = a.dgates + (int64_t)b * a.lddg;
+    dgp[j] = dc * gg * ig * (1.f - ig);
+    dgp[H + j] = dc * cp * fg * (1.f - fg);
+    dgp[2 * H + j] = dc * ig * (1.f - gg * gg);
+    dgp[3 * H + j] = dh * tc * og * (1.f - og);
+    if (a.dc_prev) a.dc_prev[(int64_t)b * a.lddcp + j] = dc * fg;
+}
+
+// ------------------------------------------------------------------------------------------------ small movers
+__global__ void mean_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t ldo, int P, int H) {
+    const int b = blockIdx.y;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += x[((int64_t)b * P + p) * H + h];
+    out[(int64_t)b * ldo + h] = s / P;
+}
+__global__ void mean_rows_bwd_kernel(const float* __restrict__ dout, int64_t lddo, float* __restrict__ dx, int P, int H,
+                                     int accum) {
+    const int b = blockIdx.y;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    const float g = dout[(int64_t)b * lddo + h] / P;
+    for (int p = 0; p < P; ++p) {
+        float* d = dx + ((int64_t)b * P + p) * H + h;
+        *d = accum ? *d + g : g;
+    }
+}
+
+__global__ void embed_fwd_kernel(const float* __restrict__ E, const int64_t* __restrict__ ids, float* __restrict__ out,
+                                 int64_t ldo, int W, float p, uint64_t seed, uint32_t site, int64_t row0) {
+    const int r = blockIdx.x;
+    const int64_t id = ids[r];
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        float v = E[id * W + j];
+        if (p > 0.f) v *= drop_scale(seed, site, (uint64_t)(row0 + r) * W + j, p);
+        out[(int64_t)r * ldo + j] = v;
+    }
+}
+__global__ void embed_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const int64_t* __restrict__ ids,
+                                 float* __restrict__ dE, int W, float p, uint64_t seed, uint32_t site, int64_t row0) {
+    const int r = blockIdx.x;
+    const int64_t id = ids[r];
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        float g = dout[(int64_t)r * lddo + j];
+        if (p > 0.f) g *= drop_scale(seed, site, (uint64_t)(row0 + r) * W + j, p);
+        atomicAdd(dE + id * W + j, g);
+    }
+}
+
+// first maximum wins (torch.max / argmax tie rule on CPU and GPU for exact ties: lowest index)
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int64_t ld, int64_t* __restrict__ ids,
+                                                     int V) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    const int r = blockIdx.x;
+    const float* x = logits + (int64_t)r * ld;
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) {
+        const float v = x[j];
+        if (v > best || (v == best && j < idx)) { best = v; idx = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { bv[w] = best; bi[w] = idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (bv[k] > best || (bv[k] == best && bi[k] < idx)) { best = bv[k]; idx = bi[k]; }
+        ids[r] = idx;
+    }
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int rows,
+                              int n, int accum) {
+    const int64_t total = (int64_t)rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n;
+        const int j = (int)(i - r * n);
+        const float v = src[r * lds_ + j];
+        float* d = dst + r * ldd + j;
+        *d = accum ? *d + v : v;
+    }
+}
+__global__ void dropout_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int rows, int n,
+                               float p, uint64_t seed, uint32_t site) {
+    const int64_t total = (int64_t)rows * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / n;
+        const int j = (int)(i - r * n);
+        y[r * ldy + j] = x[r * ldx + j] * drop_scale(seed, site, (uint64_t)i, p);
+    }
+}
+__global__ void permute_tb_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int B, int n) {
+    const int64_t total = (int64_t)T * B * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % n);
+        const int64_t rb = i / n;           // destination row b*T + t
+        const int t = (int)(rb % T), b = (int)(rb / T);
+        dst[i] = src[((int64_t)t * B + b) * n + j];
+    }
+}
+__global__ void fill_kernel(float* __restrict__ dst, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ ragged CE
+__global__ __launch_bounds__(256) void ce_ragged_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                        const int64_t* __restrict__ lens, float* __restrict__ dlogits,
+                                                        float* __restrict__ row_loss, int B, int L, int V, int tm) {
+    __shared__ float red[16];
+    const int row = blockIdx.x;
+    const int b = tm ? row % B : row / L, t = tm ? row / B : row % L;
+    const float* x = logits + (int64_t)row * V;
+    float* dx = dlogits + (int64_t)row * V;
+    int64_t len = lens[b];
+    if (len > L) len = L;
+    if (t >= len) {
+        for (int j = threadIdx.x; j < V; j += blockDim.x) dx[j] = 0.f;
+        if (threadIdx.x == 0) row_loss[row] = 0.f;
+        return;
+    }
+    int64_t ntot = 0;
+    for (int i = 0; i < B; ++i) ntot += (lens[i] > L ? L : lens[i]);
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) m = fmaxf(m, x[j]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) s += __expf(x[j] - m);
+    s = block_sum(s, red);
+    const int64_t tgt = targets[(int64_t)b * L + t];
+    const float inv = 1.f / s, invn = 1.f / (float)ntot;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) {
+        float p = __expf(x[j] - m) * inv;
+        if (j == tgt) p -= 1.f;
+        dx[j] = p * invn;
+    }
+    if (threadIdx.x == 0) row_loss[row] = (logf(s) + m - x[tgt]) * invn;
+}
+__global__ __launch_bounds__(256) void sum_to_scalar_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += v[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ logits, float* __restrict__ out, int V) {
+    __shared__ float red[16];
+    const float* x = logits + (int64_t)blockIdx.x * V;
+    float* y = out + (int64_t)blockIdx.x * V;
+    float m = -INFINITY;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) m = fmaxf(m, x[j]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) s += expf(x[j] - m);
+    s = block_sum(s, red);
+    const float lse = logf(s) + m;
+    for (int j = threadIdx.x; j < V; j += blockDim.x) y[j] = x[j] - lse;
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+inline int grid_for(int64_t total, int threads = 256, int cap = 4096) {
+    int64_t b = (total + threads - 1) / threads;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+}  // namespace
+
+extern "C" int dlsg_rowln_fwd(const dlsg_rowln_args* a, void* stream) {
+    if (!a || a->n < 1 || a->n > LN_THREADS * LN_MAXPT) return DLSG_EINVAL;
+    if (a->rows == 0) return DLSG_OK;
+    int grid = a->rows < 4096 ? a->rows : 4096;
+    hipLaunchKernelGGL(rowln_fwd_kernel, dim3(grid), dim3(LN_THREADS), 0, ST(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_rowln_bwd_nblk(int rows) { return rows < 256 ? (rows < 1 ? 1 : rows) : 256; }
+extern "C" int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream) {
+    if (!a || a->f.n < 1 || a->f.n > LN_THREADS * LN_MAXPT) return DLSG_EINVAL;
+    if (a->f.rows == 0) return DLSG_OK;
+    const int grid = dlsg_rowln_bwd_nblk(a->f.rows);
+    if (a->dgb_part && a->nblk != grid) return DLSG_EINVAL;
+    hipLaunchKernelGGL(rowln_bwd_kernel, dim3(grid), dim3(LN_THREADS), 0, ST(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_colsum(const float* part, int64_t ld, int rows, int n, float* out, int accum, void* stream) {
+    if (!part || !out || n < 1) return DLSG_EINVAL;
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_softmax_fwd(const float* x, const float* mask, float* y, int64_t outer, int n, int inner, void* stream) {
+    const int64_t lines = outer * inner;
+    if (lines == 0) return DLSG_OK;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, ST(stream), x, mask, y, outer, n,
+                       inner);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t outer, int n, int inner, void* stream) {
+    const int64_t lines = outer * inner;
+    if (lines == 0) return DLSG_OK;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, ST(stream), y, dy, dx, outer, n,
+                       inner);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_lstm_pw_fwd(const dlsg_lstm_pw_args* a, void* stream) {
+    if (!a || a->H < 1) return DLSG_EINVAL;
+    if (a->B == 0) return DLSG_OK;
+    hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3((a->H + 255) / 256, a->B), dim3(256), 0, ST(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_lstm_pw_bwd(const dlsg_lstm_pw_bwd_args* a, void* stream) {
+    if (!a || a->H < 1) return DLSG_EINVAL;
+    if (a->B == 0) return DLSG_OK;
+    hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3((a->H + 255) / 256, a->B), dim3(256), 0, ST(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_mean_rows_fwd(const float* x, float* out, int64_t ldo, int B, int P, int H, void* stream) {
+    if (B == 0) return DLSG_OK;
+    hipLaunchKernelGGL(mean_rows_fwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, ST(stream), x, out, ldo, P, H);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_mean_rows_bwd(const float* dout, int64_t lddo, float* dx, int B, int P, int H, int accum, void* stream) {
+    if (B == 0) return DLSG_OK;
+    hipLaunchKernelGGL(mean_rows_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, ST(stream), dout, lddo, dx, P, H, accum);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_embed_fwd(const float* E, const int64_t* ids, float* out, int64_t ldo, int rows, int W, float p,
+                              uint64_t seed, uint32_t site, int64_t row0, void* stream) {
+    if (rows == 0) return DLSG_OK;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows), dim3(128), 0, ST(stream), E, ids, out, ldo, W, p, seed, site, row0);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* ids, float* dE, int rows, int W, float p,
+                              uint64_t seed, uint32_t site, int64_t row0, void* stream) {
+    if (rows == 0) return DLSG_OK;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, ST(stream), dout, lddo, ids, dE, W, p, seed, site, row0);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_argmax(const float* logits, int64_t ld, int64_t* ids, int rows, int V, void* stream) {
+    if (rows == 0) return DLSG_OK;
+    hipLaunchKernelGGL(argmax_kernel, dim3(rows), dim3(256), 0, ST(stream), logits, ld, ids, V);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_copy2d(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int n, int accum, void* stream) {
+    if ((int64_t)rows * n == 0) return DLSG_OK;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((int64_t)rows * n)), dim3(256), 0, ST(stream), src, lds_, dst, ldd, rows, n,
+                       accum);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int n, float p, uint64_t seed,
+                            uint32_t site, void* stream) {
+    if ((int64_t)rows * n == 0) return DLSG_OK;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((int64_t)rows * n)), dim3(256), 0, ST(stream), x, ldx, y, ldy, rows, n, p,
+                       seed, site);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_fill(float* dst, int64_t n, float value, void* stream) {
+    if (n == 0) return DLSG_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), dst, n, value);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_permute_tb(const float* src, float* dst, int T, int B, int n, void* stream) {
+    const int64_t total = (int64_t)T * B * n;
+    if (total == 0) return DLSG_OK;
+    hipLaunchKernelGGL(permute_tb_kernel, dim3(grid_for(total)), dim3(256), 0, ST(stream), src, dst, T, B, n);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_ce_ragged(const float* logits, const int64_t* targets, const int64_t* lens, float* dlogits, float* row_loss,
+                              float* loss, int B, int L, int V, int time_major, void* stream) {
+    if (B * L == 0) return DLSG_OK;
+    hipLaunchKernelGGL(ce_ragged_kernel, dim3(B * L), dim3(256), 0, ST(stream), logits, targets, lens, dlogits, row_loss, B, L, V,
+                       time_major);
+    hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, ST(stream), row_loss, B * L, loss);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_log_softmax(const float* logits, float* out, int rows, int V, void* stream) {
+    if (rows == 0) return DLSG_OK;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, ST(stream), logits, out, V);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                         int step, float grad_scale, void* stream) {
+    if (n == 0) return DLSG_OK;
+    const float bc1 = 1.f - powf(b1, (float)step);
+    const float bc2s = sqrtf(1.f - powf(b2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, b1, b2, eps, bc1,
+                       bc2s, grad_scale);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}

@@ -1,0 +1,686 @@
+"""Forward / backward schedules of the CapGnnModel hot path over the kernel interface (`ops`, see hip.py).
+
+The reference runs this path as ~8.7k eager ATen calls per forward.  Here the same
+arithmetic is an explicit launch schedule over a handful of hand-written kernels:
+
+  encoder  (models/layer.py:46-61,172-201; models/sublayer.py:63-82,189-198)
+    * every projection is one fp32-MFMA GEMM; tanh is fused in the obj_embed epilogue
+    * object->frame graph: one fused kernel (LayerNorm on the fly + scores + online softmax + aggregation)
+    * LatentPSL / self-attention cores: batched GEMMs + a strided softmax kernel
+    * BiLSTM: input gates for all 26 steps in one GEMM, then 26 x (grouped K-split GEMM + pointwise cell)
+  decoder  (models/layer.py:394-462,569-602; models/sublayer.py:28-43)
+    * step-invariant work hoisted out of the word loop: K' = (m W_K^T) W_Q, V' = (m W_V^T) W_O^T, the
+      global-feature part of the query gates; so a step is 2 grouped GEMMs + 2 cell kernels + 1 attention
+      kernel + 3 LayerNorm kernels, and the vocab projection of all 26 steps is ONE GEMM at the end
+    * internal buffers are time-major (L, B, .) so weight gradients are single (L*B)-deep TN GEMMs
+
+Backward is hand-scheduled (no autograd inside): activations the backward needs are kept in the `sv` dict.
+Nothing here touches torch arithmetic: tensors are storage + strides for the kernels.
+"""
+import math
+
+import torch
+
+from .hip import GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH
+
+# dropout sites (stateless masks are keyed by (seed, site, element index))
+SITE_PSL_OBJ, SITE_PSL_MOT, SITE_LSTM, SITE_PE, SITE_SA, SITE_WORD, SITE_QUERY, SITE_ATT1, SITE_ATT2, SITE_LANG = range(1, 11)
+# per-step sites add STEP_SITE*(t+1)
+STEP_SITE = 64
+
+
+def _empty(ref, *shape, dtype=torch.float32):
+    return torch.empty(*shape, dtype=dtype, device=ref.device)
+
+
+def _zeros(ref, *shape, dtype=torch.float32):
+    return torch.zeros(*shape, dtype=dtype, device=ref.device)
+
+
+def _ksplit_bounds(K, nsplit):
+    """Split [0,K) into <= nsplit chunks whose boundaries are multiples of 32 (the GEMM K tile)."""
+    nsplit = max(1, min(nsplit, (K + 127) // 128))
+    step = ((K + nsplit - 1) // nsplit + 31) // 32 * 32
+    out, k = [], 0
+    while k < K:
+        out.append((k, min(K, k + step)))
+        k += step
+    return out
+
+
+def _nsplit_for(M, N, nseg, target=384, cap=16):
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    n = max(1, target // max(1, tiles * nseg))
+    return max(1, min(n, cap // max(1, nseg)))
+
+
+def seg_gemm_nt(ops, segs, M, N, ref):
+    """sum_i  x_i @ W_i^T  as ONE grouped launch writing K-split slabs.  segs: list of (x (M,K_i), W (N,K_i)).
+    Returns slabs (S, M, N); the consumer kernel (lstm_pw / slab_reduce) sums them."""
+    ns = _nsplit_for(M, N, len(segs))
+    groups = []
+    for x, W in segs:
+        for k0, k1 in _ksplit_bounds(x.shape[1], ns):
+            groups.append((x[:, k0:k1], W[:, k0:k1]))
+    slabs = _empty(ref, len(groups), M, N)
+    ops.gemm(GEMM_NT, [(a, b, slabs[i]) for i, (a, b) in enumerate(groups)])
+    return slabs
+
+
+def gemm_nn_split(ops, dy, W, out, ref, accum=False):
+    """out (M, Kin) (+)= dy (M, Nout) @ W (Nout, Kin) with the contraction split over slabs (small M)."""
+    M, Nn = dy.shape
+    Kin = W.shape[1]
+    ns = _nsplit_for(M, Kin, 1)
+    bounds = _ksplit_bounds(Nn, ns)
+    if len(bounds) == 1:
+        ops.gemm(GEMM_NN, [(dy, W, out)], flags=F_ACCUM if accum else 0)
+        return
+    slabs = _empty(ref, len(bounds), M, Kin)
+    ops.gemm(GEMM_NN, [(dy[:, k0:k1], W[k0:k1, :], slabs[i]) for i, (k0, k1) in enumerate(bounds)])
+    ops.slab_reduce(slabs, out, flags=F_ACCUM if accum else 0)
+
+
+def lin(ops, x, W, out, bias=None, tanh=False, accum=False):
+    ops.gemm(GEMM_NT, [(x, W, out)], flags=(F_TANH if tanh else 0) | (F_ACCUM if accum else 0), bias=bias)
+
+
+class Grads(object):
+    """name -> gradient view (all views of one flat fp32 arena, zero-filled at the start of a backward)."""
+
+    def __init__(self, named_params, arena, offsets):
+        self.arena, self.offsets = arena, offsets
+        self.views = {}
+        for name, p in named_params:
+            o = offsets[name]
+            self.views[name] = arena[o:o + p.numel()].view(p.shape)
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+
+def ln_grads(ops, part, G, prefix, n):
+    """fold rowln_bwd partials (nblk, 2, n) into the LayerNorm weight/bias gradients."""
+    p2 = part.view(-1, 2 * n)
+    ops.colsum(p2[:, :n], G[prefix + '.weight'], accum=True)
+    ops.colsum(p2[:, n:], G[prefix + '.bias'], accum=True)
+
+
+# ================================================================================================ TUN encoder
+def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2v=True, nsplit=None):
+    """EncoderVisualGraphTUN.forward (models/layer.py:172-201).  visual: (B*T, Hin) view."""
+    B, T, O, R = regions.shape
+    H = m.visual_norm[1].weight.numel()
+    P = m.v2l_layer.theta.shape[0]
+    ref = regions
+    s = sv[pfx] = {}
+    if m.use_embed:
+        v_pre = _empty(ref, B * T, H)
+        lin(ops, visual, m.visual_embed.weight, v_pre, m.visual_embed.bias)
+    else:
+        v_pre = visual
+    v = _empty(ref, B * T, H); st_v = _empty(ref, B * T, 2)
+    ops.rowln_fwd(v_pre, m.visual_norm[1].weight, m.visual_norm[1].bias, v, st_v, pre_tanh=1)
+    s.update(visual=visual, v_pre=v_pre, v=v, st_v=st_v)
+    if O >= 5:
+        NO = T * O
+        y = _empty(ref, B * NO, H)
+        lin(ops, regions.view(B * NO, R), m.obj_embed.weight, y, m.obj_embed.bias, tanh=True)
+        z = _empty(ref, B * T, H); ostats = _empty(ref, B * NO, 2); S = _empty(ref, B, NO, T)
+        scale = 1.0 / math.sqrt(R)
+        g_o, b_o = m.obj_norm[1].weight, m.obj_norm[1].bias
+        if fused_o2v and ops.o2v_supported(T, H):
+            if nsplit is None:
+                tiles = (NO + 31) // 32
+                nsplit = max(1, min(tiles, (512 + B - 1) // B))
+            ml = _empty(ref, B * T, 2)
+            ops.o2v_fwd(y.view(B, NO, H), v.view(B, T, H), g_o, b_o, z, ml, ostats, S, scale, nsplit)
+        else:
+            o = _empty(ref, B * NO, H)
+            ops.rowln_fwd(y, g_o, b_o, o, ostats)
+            ops.gemm(GEMM_NT, [(o.view(B, NO, H), v.view(B, T, H), S)], alpha=scale)
+            Pm = _empty(ref, B, NO, T)
+            ops.softmax_fwd(S, Pm, B, NO, T)
+            ops.copy2d(v, z)
+            ops.gemm(GEMM_TN, [(Pm, o.view(B, NO, H), z.view(B, T, H))], flags=F_ACCUM)
+        ov = _empty(ref, B * T, H); st_ov = _empty(ref, B * T, 2)
+        ops.rowln_fwd(z, m.obj_visual_norm[1].weight, m.obj_visual_norm[1].bias, ov, st_ov, pre_tanh=1)
+        s.update(y=y, z=z, ostats=ostats, S=S, ov=ov, st_ov=st_ov, scale=scale)
+    else:
+        ov = v
+        s.update(ov=ov)
+    if m.baseline:
+        return ov
+    # LatentPSL (models/sublayer.py:189-198)
+    theta = m.v2l_layer.theta
+    lg = _empty(ref, B, T, P)
+    ops.gemm(GEMM_NT, [(ov.view(B, T, H), theta.unsqueeze(0).expand(B, P, H), lg)])
+    adj = _empty(ref, B, T, P)
+    ops.softmax_fwd(lg, adj, B, T, P)
+    u = _empty(ref, B * P, H)
+    ops.gemm(GEMM_TN, [(adj, ov.view(B, T, H), u.view(B, P, H))])
+    psl = _empty(ref, B * P, H); st_p = _empty(ref, B * P, 2)
+    ln = m.v2l_layer.out_norm[1]
+    pd = 0.3 if training else 0.0
+    ops.rowln_fwd(u, ln.weight, ln.bias, psl, st_p, pre_tanh=1, p1=pd, site1=psl_site, seed=seed)
+    s.update(adj=adj, u=u, st_p=st_p, pd=pd, psl_site=psl_site)
+    return psl.view(B, P, H)
+
+
+def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed):
+    """Backward of tun_fwd.  dpsl (B,P,H).  Returns d(visual input) when the stream has no embed, else None."""
+    B, T, O, R = regions.shape
+    s = sv[pfx]
+    H = m.visual_norm[1].weight.numel()
+    P = m.v2l_layer.theta.shape[0]
+    ref = regions
+    name = pfx
+    ln = m.v2l_layer.out_norm[1]
+    nb = ops.rowln_bwd_nblk(B * P)
+    part = _empty(ref, nb, 2, H)
+    du = _empty(ref, B * P, H)
+    ops.rowln_bwd(dpsl.reshape(B * P, H), s['u'], ln.weight, ln.bias, du, stats=s['st_p'], pre_tanh=1, p1=s['pd'],
+                  site1=s['psl_site'], seed=seed, dgb_part=part)
+    ln_grads(ops, part, G, name + '.v2l_layer.out_norm.1', H)
+    ov, adj, theta = s['ov'], s['adj'], m.v2l_layer.theta
+    du3 = du.view(B, P, H)
+    dadj = _empty(ref, B, T, P)
+    ops.gemm(GEMM_NT, [(ov.view(B, T, H), du3, dadj)])
+    dov = _empty(ref, B * T, H)
+    ops.gemm(GEMM_NN, [(adj, du3, dov.view(B, T, H))])
+    dlg = _empty(ref, B, T, P)
+    ops.softmax_bwd(adj, dadj, dlg, B, T, P)
+    ops.gemm(GEMM_NN, [(dlg, theta.unsqueeze(0).expand(B, P, H), dov.view(B, T, H))], flags=F_ACCUM)
+    ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[name + '.v2l_layer.theta'])], flags=F_ACCUM)
+    if O >= 5:
+        NO = T * O
+        lnv = m.obj_visual_norm[1]
+        nb = ops.rowln_bwd_nblk(B * T)
+        part = _empty(ref, nb, 2, H)
+        dz = _empty(ref, B * T, H)
+        ops.rowln_bwd(dov, s['z'], lnv.weight, lnv.bias, dz, stats=s['st_ov'], pre_tanh=1, dgb_part=part)
+        ln_grads(ops, part, G, name + '.obj_visual_norm.1', H)
+        g_o, b_o = m.obj_norm[1].weight, m.obj_norm[1].bias
+        y, v, S, scale = s['y'], s['v'], s['S'], s['scale']
+        o = _empty(ref, B * NO, H)
+        ops.rowln_fwd(y, g_o, b_o, o, None)
+        o3, dz3, v3 = o.view(B, NO, H), dz.view(B, T, H), v.view(B, T, H)
+        Pm = _empty(ref, B, NO, T)
+        ops.softmax_fwd(S, Pm, B, NO, T)
+        dP = _empty(ref, B, NO, T)
+        ops.gemm(GEMM_NT, [(o3, dz3, dP)])
+        dS = _empty(ref, B, NO, T)
+        ops.softmax_bwd(Pm, dP, dS, B, NO, T)
+        do = _empty(ref, B * NO, H)
+        ops.gemm(GEMM_NN, [(Pm, dz3, do.view(B, NO, H))])
+        ops.gemm(GEMM_NN, [(dS, v3, do.view(B, NO, H))], alpha=scale, flags=F_ACCUM)
+        dv = _empty(ref, B * T, H)
+        ops.copy2d(dz, dv)
+        ops.gemm(GEMM_TN, [(dS, o3, dv.view(B, T, H))], alpha=scale, flags=F_ACCUM)
+        nb = ops.rowln_bwd_nblk(B * NO)
+        part = _empty(ref, nb, 2, H)
+        dy = o   # reuse the scratch: rowln_bwd reads y/stats, not o
+        ops.rowln_bwd(do, y, g_o, b_o, dy, stats=s['ostats'], pre_tanh=2, dgb_part=part)
+        ln_grads(ops, part, G, name + '.obj_norm.1', H)
+        ops.gemm(GEMM_TN, [(dy, regions.view(B * NO, R), G[name + '.obj_embed.weight'])], flags=F_ACCUM)
+        ops.colsum(dy, G[name + '.obj_embed.bias'], accum=True)
+    else:
+        dv = dov
+    lnv = m.visual_norm[1]
+    nb = ops.rowln_bwd_nblk(B * T)
+    part = _empty(ref, nb, 2, H)
+    dv_pre = _empty(ref, B * T, H)
+    ops.rowln_bwd(dv, s['v_pre'], lnv.weight, lnv.bias, dv_pre, stats=s['st_v'], pre_tanh=1, dgb_part=part)
+    ln_grads(ops, part, G, name + '.visual_norm.1', H)
+    if m.use_embed:
+        ops.gemm(GEMM_TN, [(dv_pre, s['visual'], G[name + '.visual_embed.weight'])], flags=F_ACCUM)
+        ops.colsum(dv_pre, G[name + '.visual_embed.bias'], accum=True)
+        return None
+    return dv_pre
+
+
+# ================================================================================================ EncoderVisual
+def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
+    """EncoderVisual.forward (models/layer.py:46-61).  frames2d (B*T, A+M).  Returns (B*T, H)."""
+    H = m.hidden_size
+    ref = frames2d
+    s = sv[pfx] = {}
+    e = _empty(ref, B * T, H)
+    lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
+    lstm = m.lstm
+    Wih = [lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]
+    Whh = [lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]
+    bih = [lstm.bias_ih_l0, lstm.bias_ih_l0_reverse]
+    bhh = [lstm.bias_hh_l0, lstm.bias_hh_l0_reverse]
+    xg = [_empty(ref, B * T, 4 * H), _empty(ref, B * T, 4 * H)]
+    ops.gemm(GEMM_NT, [(e, Wih[0], xg[0]), (e, Wih[1], xg[1])])
+    out = _empty(ref, B, T, 2 * H)
+    hprev = [_zeros(ref, B, T, H), _zeros(ref, B, T, H)]       # h of the previous step of each direction
+    cst = [_empty(ref, B, T, H), _empty(ref, B, T, H)]
+    gates = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
+    ns = _nsplit_for(B, 4 * H, 2)
+    bounds = _ksplit_bounds(H, ns)
+    for step in range(T):
+        tt = [step, T - 1 - step]
+        tp = [step - 1, T - step]                                # previous time index per direction
+        slabs = None
+        if step > 0:
+            slabs = _empty(ref, 2 * len(bounds), B, 4 * H)
+            groups = []
+            for d in range(2):
+                hp = hprev[d][:, tt[d]]
+                for i, (k0, k1) in enumerate(bounds):
+                    groups.append((hp[:, k0:k1], Whh[d][:, k0:k1], slabs[d * len(bounds) + i]))
+            ops.gemm(GEMM_NT, groups)
+        for d in range(2):
+            t = tt[d]
+            nxt = t + 1 if d == 0 else t - 1
+            h2 = hprev[d][:, nxt] if 0 <= nxt < T else None
+            ops.lstm_pw_fwd(slabs[d * len(bounds):(d + 1) * len(bounds)] if slabs is not None else None,
+                            cst[d][:, t], B, H, addend=xg[d].view(B, T, 4 * H)[:, t], b_ih=bih[d], b_hh=bhh[d],
+                            c_prev=cst[d][:, tp[d]] if step > 0 else None, h=out[:, t, d * H:(d + 1) * H], h2=h2,
+                            gates=gates[d][:, t])
+    out2 = out.view(B * T, 2 * H)
+    pd = m.p_drop if training else 0.0
+    s.update(e=e, out=out2, hprev=hprev, cst=cst, gates=gates, pd=pd)
+    ln = m.layernorm_lstm
+    if m.baseline:
+        hl = _empty(ref, B * T, 2 * H); st_l = _empty(ref, B * T, 2)
+        ops.rowln_fwd(out2, ln.weight, ln.bias, hl, st_l, p1=pd, site1=SITE_LSTM, seed=seed)
+        res = _empty(ref, B * T, H)
+        lin(ops, hl, m.out_try.weight, res, m.out_try.bias)
+        s.update(hl=hl, st_l=st_l)
+        return res
+    sa = m.self_attention
+    D2 = 2 * H
+    pe = sa.pe.pe[0, :T]
+    x = _empty(ref, B * T, D2); st_l = _empty(ref, B * T, 2)
+    ops.rowln_fwd(out2, ln.weight, ln.bias, x, st_l, pe=pe, p1=pd, site1=SITE_LSTM, p2=0.2 if training else 0.0,
+                  site2=SITE_PE, seed=seed)
+    Kp, Qp, Vp = _empty(ref, B * T, D2), _empty(ref, B * T, D2), _empty(ref, B * T, D2)
+    ops.gemm(GEMM_NT, [(x, sa.K.weight, Kp), (x, sa.Q.weight, Qp), (x, sa.V.weight, Vp)])
+    scale = 1.0 / math.sqrt(sa.attention_size)
+    lg = _empty(ref, B, T, T)
+    ops.gemm(GEMM_NT, [(Kp.view(B, T, D2), Qp.view(B, T, D2), lg)], alpha=scale)
+    w = _empty(ref, B, T, T)
+    ops.softmax_fwd(lg, w, B * T, T, 1)
+    att = _empty(ref, B * T, D2)
+    ops.gemm(GEMM_NN, [(w, Vp.view(B, T, D2), att.view(B, T, D2))])
+    so = _empty(ref, B * T, H)
+    lin(ops, att, sa.output_layer[0].weight, so)
+    psa = sa.dropout if training else 0.0
+    if psa > 0:
+        ops.dropout(so, so, psa, seed, SITE_SA)
+    res = _empty(ref, B * T, H); st_s = _empty(ref, B * T, 2)
+    ops.rowln_fwd(so, m.layernorm_sa.weight, m.layernorm_sa.bias, res, st_s)
+    s.update(x=x, st_l=st_l, Kp=Kp, Qp=Qp, Vp=Vp, w=w, att=att, so=so, st_s=st_s, scale=scale, psa=psa, pe=pe)
+    return res
+
+
+def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
+    H = m.hidden_size
+    ref = frames2d
+    s = sv[pfx]
+    name = pfx
+    ln = m.layernorm_lstm
+    out2 = s['out']
+    D2 = 2 * H
+    dout = _empty(ref, B * T, D2)
+    if m.baseline:
+        ops.gemm(GEMM_TN, [(dres, s['hl'], G[name + '.out_try.weight'])], flags=F_ACCUM)
+        ops.colsum(dres, G[name + '.out_try.bias'], accum=True)
+        dhl = _empty(ref, B * T, D2)
+        ops.gemm(GEMM_NN, [(dres, m.out_try.weight, dhl)])
+        nb = ops.rowln_bwd_nblk(B * T)
+        part = _empty(ref, nb, 2, D2)
+        ops.rowln_bwd(dhl, out2, ln.weight, ln.bias, dout, stats=s['st_l'], p1=s['pd'], site1=SITE_LSTM, seed=seed,
+                      dgb_part=part)
+        ln_grads(ops, part, G, name + '.layernorm_lstm', D2)
+    else:
+        sa = m.self_attention
+        nb = ops.rowln_bwd_nblk(B * T)
+        part = _empty(ref, nb, 2, H)
+        dso = _empty(ref, B * T, H)
+        ops.rowln_bwd(dres, s['so'], m.layernorm_sa.weight, m.layernorm_sa.bias, dso, stats=s['st_s'], dgb_part=part)
+        ln_grads(ops, part, G, name + '.layernorm_sa', H)
+        if s['psa'] > 0:
+            ops.dropout(dso, dso, s['psa'], seed, SITE_SA)
+        att, w, Kp, Qp, Vp, x, scale = s['att'], s['w'], s['Kp'], s['Qp'], s['Vp'], s['x'], s['scale']
+        ops.gemm(GEMM_TN, [(dso, att, G[name + '.self_attention.output_layer.0.weight'])], flags=F_ACCUM)
+        datt = _empty(ref, B * T, D2)
+        ops.gemm(GEMM_NN, [(dso, sa.output_layer[0].weight, datt)])
+        datt3 = datt.view(B, T, D2)
+        dw = _empty(ref, B, T, T)
+        ops.gemm(GEMM_NT, [(datt3, Vp.view(B, T, D2), dw)])
+        dV = _empty(ref, B * T, D2)
+        ops.gemm(GEMM_TN, [(w, datt3, dV.view(B, T, D2))])
+        dlg = _empty(ref, B, T, T)
+        ops.softmax_bwd(w, dw, dlg, B * T, T, 1)
+        dK = _empty(ref, B * T, D2); dQ = _empty(ref, B * T, D2)
+        ops.gemm(GEMM_NN, [(dlg, Qp.view(B, T, D2), dK.view(B, T, D2))], alpha=scale)
+        ops.gemm(GEMM_TN, [(dlg, Kp.view(B, T, D2), dQ.view(B, T, D2))], alpha=scale)
+        dx = _empty(ref, B * T, D2)
+        ops.gemm(GEMM_NN, [(dK, sa.K.weight, dx)])
+        ops.gemm(GEMM_NN, [(dQ, sa.Q.weight, dx)], flags=F_ACCUM)
+        ops.gemm(GEMM_NN, [(dV, sa.V.weight, dx)], flags=F_ACCUM)
+        ops.gemm(GEMM_TN, [(dK, x, G[name + '.self_attention.K.weight'])], flags=F_ACCUM)
+        ops.gemm(GEMM_TN, [(dQ, x, G[name + '.self_attention.Q.weight'])], flags=F_ACCUM)
+        ops.gemm(GEMM_TN, [(dV, x, G[name + '.self_attention.V.weight'])], flags=F_ACCUM)
+        nb = ops.rowln_bwd_nblk(B * T)
+        part = _empty(ref, nb, 2, D2)
+        ops.rowln_bwd(dx, out2, ln.weight, ln.bias, dout, stats=s['st_l'], pe=s['pe'], p1=s['pd'], site1=SITE_LSTM,
+                      p2=0.2 if training else 0.0, site2=SITE_PE, seed=seed, dgb_part=part)
+        ln_grads(ops, part, G, name + '.layernorm_lstm', D2)
+    # ---- BiLSTM backward through time
+    lstm = m.lstm
+    Wih = [lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]
+    Whh = [lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]
+    sfx = ['', '_reverse']
+    dout3 = dout.view(B, T, D2)
+    gates, cst, hprev = s['gates'], s['cst'], s['hprev']
+    dG = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
+    dhrec = [_empty(ref, B, H), _empty(ref, B, H)]
+    dcrec = [_empty(ref, B, H), _empty(ref, B, H)]
+    for step in range(T - 1, -1, -1):
+        tt = [step, T - 1 - step]
+        tp = [step - 1, T - step]
+        last = step == T - 1
+        for d in range(2):
+            t = tt[d]
+            ops.lstm_pw_bwd(gates[d][:, t], cst[d][:, t], dG[d][:, t], B, H,
+                            c_prev=cst[d][:, tp[d]] if step > 0 else None,
+                            dh=dout3[:, t, d * H:(d + 1) * H], dh2=None if last else dhrec[d],
+                            dc_next=None if last else dcrec[d], dc_prev=dcrec[d])
+            if step > 0:
+                gemm_nn_split(ops, dG[d][:, t], Whh[d], dhrec[d], ref)
+    de = _empty(ref, B * T, H)
+    e = s['e']
+    for d in range(2):
+        dg2 = dG[d].view(B * T, 4 * H)
+        ops.gemm(GEMM_NN, [(dg2, Wih[d], de)], flags=F_ACCUM if d else 0)
+        ops.gemm(GEMM_TN, [(dg2, e, G[name + '.lstm.weight_ih_l0' + sfx[d]])], flags=F_ACCUM)
+        ops.gemm(GEMM_TN, [(dg2, hprev[d].view(B * T, H), G[name + '.lstm.weight_hh_l0' + sfx[d]])], flags=F_ACCUM)
+        ops.colsum(dg2, G[name + '.lstm.bias_ih_l0' + sfx[d]], accum=True)
+        ops.colsum(dg2, G[name + '.lstm.bias_hh_l0' + sfx[d]], accum=True)
+    ops.gemm(GEMM_TN, [(de, frames2d, G[name + '.linear_embed.weight'])], flags=F_ACCUM)
+    ops.colsum(de, G[name + '.linear_embed.bias'], accum=True)
+
+
+# ================================================================================================ decoder
+class DecPlan(object):
+    """Column layout of the two LSTMCells' input weights (models/layer.py:313-327,571,587)."""
+
+    def __init__(self, dec, n_global):
+        self.H, self.W = dec.visual_hidden_size, dec.word_size
+        self.Q, self.D = dec.query_hidden_size, dec.decode_hidden_size
+        self.G = n_global                      # width of the global feature (2H multi-modal, H baseline)
+        self.ns = 2 if dec.multi_modal else 1  # attention streams feeding the language LSTM
+        # query_lstm input = [lang_h (D) | global (G) | word (W)]
+        self.q_lang = (0, self.D)
+        self.q_glob = (self.D, self.D + self.G)
+        self.q_word = (self.D + self.G, self.D + self.G + self.W)
+        # lang_lstm input = [ctx_1 (H) | (ctx_2 (H)) | q_cur (Q)]
+        self.l_ctx = [(i * self.H, (i + 1) * self.H) for i in range(self.ns)]
+        self.l_q = (self.ns * self.H, self.ns * self.H + self.Q)
+
+
+def _att_modules(dec):
+    return [dec.context_att] + ([dec.context_att_2] if dec.multi_modal else [])
+
+
+def dec_prepare(ops, dec, mems, sv, training, seed):
+    """Step-invariant work: global feature + its gate contribution, K' and V' of every attention stream.
+    mems: list of proposal tensors (B,P,H) -- one per attention stream (already concatenated for the
+    non-multi-modal two-stream case).  gsrc: tensors averaged into the global feature."""
+    s = sv['dec'] = {}
+    gsrc = sv['dec_gsrc']
+    ref = mems[0]
+    B = ref.shape[0]
+    H = dec.visual_hidden_size
+    plan = DecPlan(dec, H * len(gsrc))
+    Q = plan.Q
+    gfeat = _empty(ref, B, plan.G)
+    for i, g in enumerate(gsrc):
+        ops.mean_rows_fwd(g, gfeat[:, i * H:(i + 1) * H])
+    Wq = dec.query_lstm.weight_ih
+    gq = _empty(ref, B, 4 * Q)
+    lin(ops, gfeat, Wq[:, plan.q_glob[0]:plan.q_glob[1]], gq)
+    Kc, Vc, Kp, Vp = [], [], [], []
+    for att, mem in zip(_att_modules(dec), mems):
+        Bm, P, _ = mem.shape
+        m2 = mem.reshape(Bm * P, H)
+        K = _empty(ref, Bm * P, H); V = _empty(ref, Bm * P, H)
+        ops.gemm(GEMM_NT, [(m2, att.K.weight, K), (m2, att.V.weight, V)])
+        kp = _empty(ref, Bm * P, Q); vp = _empty(ref, Bm * P, H)
+        ops.gemm(GEMM_NN, [(K, att.Q.weight, kp)])                     # K' = K W_Q
+        lin(ops, V, att.output_layer[0].weight, vp)                    # V' = V W_O^T
+        Kc.append(K); Vc.append(V); Kp.append(kp.view(Bm, P, Q)); Vp.append(vp.view(Bm, P, H))
+    s.update(plan=plan, gfeat=gfeat, gq=gq, K=Kc, V=Vc, Kp=Kp, Vp=Vp, mems=mems)
+    return s
+
+
+def dec_step(ops, dec, s, t, ref, training, seed, B, word_dropout=True):
+    """One Decoder.decode (models/layer.py:569-602) on time-major state buffers; step t reads slot t, writes t+1."""
+    plan = s['plan']
+    H, Q, D = plan.H, plan.Q, plan.D
+    ql, ll = dec.query_lstm, dec.lang_lstm
+    pd = dec.p_drop if training else 0.0
+    site = STEP_SITE * (t + 1)
+    # ---- query LSTM
+    segs = [(s['WE'][t], ql.weight_ih[:, plan.q_word[0]:plan.q_word[1]])]
+    if t > 0 or s.get('warm', False):
+        segs += [(s['LHP'][t], ql.weight_ih[:, plan.q_lang[0]:plan.q_lang[1]]), (s['QH'][t], ql.weight_hh)]
+    slabs = seg_gemm_nt(ops, segs, B, 4 * Q, ref)
+    ops.lstm_pw_fwd(slabs, s['QC'][t + 1], B, Q, addend=s['gq'], b_ih=ql.bias_ih, b_hh=ql.bias_hh, c_prev=s['QC'][t],
+                    h=s['QH'][t + 1], gates=s['GQ'][t])
+    lnq = dec.query_lstm_layernorm
+    ops.rowln_fwd(s['QH'][t + 1], lnq.weight, lnq.bias, s['QCUR'][t], s['ST_Q'][t], p1=pd, site1=site + SITE_QUERY,
+                  seed=seed)
+    # ---- attention over the cached proposals
+    ns = plan.ns
+    scale = 1.0 / math.sqrt(H)
+    ops.decatt_fwd(s['Kp'], s['Vp'], s['QCUR'][t], [s['CPRE'][i][t] for i in range(ns)], s['ALPHA'][t], scale)
+    for i, att in enumerate(_att_modules(dec)):
+        ln = att.output_layer[2]
+        ops.rowln_fwd(s['CPRE'][i][t], ln.weight, ln.bias, s['CTX'][i][t], s['ST_C'][i][t], pre_tanh=1,
+                      p1=att.dropout if training else 0.0, site1=site + SITE_ATT1 + i, seed=seed)
+    # ---- language LSTM
+    segs = [(s['CTX'][i][t], ll.weight_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]]) for i in range(ns)]
+    segs.append((s['QCUR'][t], ll.weight_ih[:, plan.l_q[0]:plan.l_q[1]]))
+    if t > 0 or s.get('warm', False):
+        segs.append((s['LHP'][t], ll.weight_hh))
+    slabs = seg_gemm_nt(ops, segs, B, 4 * D, ref)
+    ops.lstm_pw_fwd(slabs, s['LC'][t + 1], B, D, b_ih=ll.bias_ih, b_hh=ll.bias_hh, c_prev=s['LC'][t], h2=s['LHP'][t + 1],
+                    gates=s['GL'][t], p=pd, site=site + SITE_LANG, seed=seed)
+
+
+def dec_logits(ops, dec, s, t0, t1):
+    """logits of steps [t0,t1): tanh(LN(lang_h)) -> word_restore (models/layer.py:599-600)."""
+    plan = s['plan']
+    D = plan.D
+    B = s['LHP'].shape[1]
+    V = dec.vocab_size
+    n = (t1 - t0) * B
+    lnl = dec.lang_lstm_layernorm
+    x = s['LHP'][t0 + 1:t1 + 1].view(n, D)
+    ops.rowln_fwd(x, lnl.weight, lnl.bias, s['DOUT'][t0:t1].view(n, D), s['ST_L'][t0:t1].view(n, 2), post_tanh=1)
+    lin(ops, s['DOUT'][t0:t1].view(n, D), dec.word_restore.weight, s['LOGITS'][t0:t1].view(n, V), dec.word_restore.bias)
+
+
+def dec_alloc(dec, s, ref, B, L):
+    plan = s['plan']
+    H, W, Q, D, ns = plan.H, plan.W, plan.Q, plan.D, plan.ns
+    V = dec.vocab_size
+    P = s['Kp'][0].shape[1]
+    s['LHP'] = _zeros(ref, L + 1, B, D)
+    s['QH'] = _zeros(ref, L + 1, B, Q)
+    s['QC'] = _zeros(ref, L + 1, B, Q)
+    s['LC'] = _zeros(ref, L + 1, B, D)
+    s['WE'] = _empty(ref, L + 1, B, W)
+    s['IDS'] = _zeros(ref, L + 1, B, dtype=torch.int64)
+    s['QCUR'] = _empty(ref, L, B, Q)
+    s['ST_Q'] = _empty(ref, L, B, 2)
+    s['CPRE'] = [_empty(ref, L, B, H) for _ in range(ns)]
+    s['CTX'] = [_empty(ref, L, B, H) for _ in range(ns)]
+    s['ST_C'] = [_empty(ref, L, B, 2) for _ in range(ns)]
+    s['GQ'] = _empty(ref, L, B, 4 * Q)
+    s['GL'] = _empty(ref, L, B, 4 * D)
+    s['ALPHA'] = _empty(ref, L, B, ns * P)
+    s['DOUT'] = _empty(ref, L, B, D)
+    s['ST_L'] = _empty(ref, L, B, 2)
+    s['LOGITS'] = _empty(ref, L, B, V)
+
+
+def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed):
+    """Decoder.forward, training / greedy branch (models/layer.py:394-447).
+    coins[i] True -> step i feeds captions[:, i] to step i+1, else the argmax of its own logits.
+    captions None -> greedy inference (all coins False).  Returns the decoder state dict."""
+    s = dec_prepare(ops, dec, mems, sv, training, seed)
+    ref = mems[0]
+    B = ref.shape[0]
+    dec_alloc(dec, s, ref, B, L)
+    E = dec.word_embed.weight
+    pw = dec.p_drop if training else 0.0
+    ids = s['IDS']
+    ids[0].fill_(dec.vocab('<start>'))
+    if captions is not None:
+        tf_steps = [i for i in range(L) if coins[i]]
+        for i in tf_steps:
+            ids[i + 1].copy_(captions[:, i])
+    # embed every step input that is known up front (start token + teacher-forced words), word dropout per row
+    ops.embed_fwd(E, ids.view(-1), s['WE'].view((L + 1) * B, -1), p=pw, seed=seed, site=SITE_WORD)
+    for t in range(L):
+        dec_step(ops, dec, s, t, ref, training, seed, B)
+        if not coins[t]:
+            dec_logits(ops, dec, s, t, t + 1)
+            ops.argmax(s['LOGITS'][t], ids[t + 1])
+            # same (seed, site, row) mask stream as the bulk call above: rows (t+1)*B.. of the WE matrix
+            ops.embed_fwd(E, ids[t + 1], s['WE'][t + 1], p=pw, seed=seed, site=SITE_WORD, row0=(t + 1) * B)
+    s['coins'] = list(coins)
+    s['pw'] = pw
+    dec_logits(ops, dec, s, 0, L)
+    return s
+
+
+def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
+    """Backward of dec_fwd.  dlogits_tm (L,B,V).  Returns list of d(mem) per attention stream and d(global src)."""
+    s = sv['dec']
+    plan = s['plan']
+    H, W, Q, D, ns = plan.H, plan.W, plan.Q, plan.D, plan.ns
+    L, B, V = dlogits_tm.shape
+    ref = dlogits_tm
+    ql, ll = dec.query_lstm, dec.lang_lstm
+    pd = dec.p_drop if training else 0.0
+    n = L * B
+    dl2 = dlogits_tm.view(n, V)
+    # ---- vocab projection + tanh(LN(lang_h))
+    ops.gemm(GEMM_TN, [(dl2, s['DOUT'].view(n, D), G['decoder.word_restore.weight'])], flags=F_ACCUM)
+    ops.colsum(dl2, G['decoder.word_restore.bias'], accum=True)
+    ddout = _empty(ref, n, D)
+    ops.gemm(GEMM_NN, [(dl2, dec.word_restore.weight, ddout)])
+    lnl = dec.lang_lstm_layernorm
+    nb = ops.rowln_bwd_nblk(n)
+    part = _empty(ref, nb, 2, D)
+    dLHo = _empty(ref, L, B, D)
+    ops.rowln_bwd(ddout, s['LHP'][1:].view(n, D), lnl.weight, lnl.bias, dLHo.view(n, D), stats=s['ST_L'].view(n, 2),
+                  post_tanh=1, dgb_part=part)
+    ln_grads(ops, part, G, 'decoder.lang_lstm_layernorm', D)
+
+    dGQ = _empty(ref, L, B, 4 * Q)
+    dGL = _empty(ref, L, B, 4 * D)
+    dLH = _empty(ref, B, D)             # grad wrt the dropped lang h of the step being processed
+    dLHrec = _zeros(ref, B, D)          # contributions from step t+1 (query input + lang recurrent)
+    dQHrec = _zeros(ref, B, Q)
+    dQC = _zeros(ref, B, Q)
+    dLC = _zeros(ref, B, D)
+    dXL = _empty(ref, B, ns * H + Q)    # grad wrt lang_lstm input [ctx.. | qcur]
+    dCPRE = [_empty(ref, B, H) for _ in range(ns)]
+    dQH = _empty(ref, B, Q)
+    dKp = [torch.zeros_like(k) for k in s['Kp']]
+    dVp = [torch.zeros_like(v) for v in s['Vp']]
+    atts = _att_modules(dec)
+    nbB = ops.rowln_bwd_nblk(B)
+    part_q = _zeros(ref, L, nbB, 2, Q)
+    part_c = [_zeros(ref, L, nbB, 2, H) for _ in range(ns)]
+    lnq = dec.query_lstm_layernorm
+    scale = 1.0 / math.sqrt(H)
+    Wl_in = ll.weight_ih
+    for t in range(L - 1, -1, -1):
+        site = STEP_SITE * (t + 1)
+        # total grad on lang h_t (dropped): from the vocab head + from step t+1
+        ops.copy2d(dLHo[t], dLH)
+        if t < L - 1:
+            ops.copy2d(dLHrec, dLH, accum=True)
+        ops.lstm_pw_bwd(s['GL'][t], s['LC'][t + 1], dGL[t], B, D, c_prev=s['LC'][t], dh2=dLH, dc_next=dLC, dc_prev=dLC,
+                        p=pd, site=site + SITE_LANG, seed=seed)
+        # input grads of the language cell
+        gemm_nn_split(ops, dGL[t], Wl_in, dXL, ref)
+        if t > 0:
+            gemm_nn_split(ops, dGL[t], ll.weight_hh, dLHrec, ref)
+        for i, att in enumerate(atts):
+            ln = att.output_layer[2]
+            ops.rowln_bwd(dXL[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]], s['CPRE'][i][t], ln.weight, ln.bias, dCPRE[i],
+                          stats=s['ST_C'][i][t], pre_tanh=1, p1=att.dropout if training else 0.0,
+                          site1=site + SITE_ATT1 + i, seed=seed, dgb_part=part_c[i][t])
+        dq = dXL[:, plan.l_q[0]:plan.l_q[1]]
+        ops.decatt_bwd(s['Kp'], s['Vp'], s['QCUR'][t], s['ALPHA'][t], dCPRE, dKp, dVp, dq, scale, accum_dq=True,
+                       dalpha=dalpha_tm[t] if dalpha_tm is not None else None)
+        ops.rowln_bwd(dq, s['QH'][t + 1], lnq.weight, lnq.bias, dQH, stats=s['ST_Q'][t], p1=pd, site1=site + SITE_QUERY,
+                      seed=seed, dgb_part=part_q[t])
+        if t < L - 1:
+            ops.copy2d(dQHrec, dQH, accum=True)
+        ops.lstm_pw_bwd(s['GQ'][t], s['QC'][t + 1], dGQ[t], B, Q, c_prev=s['QC'][t], dh=dQH, dc_next=dQC, dc_prev=dQC)
+        if t > 0:
+            gemm_nn_split(ops, dGQ[t], ql.weight_hh, dQHrec, ref)
+            gemm_nn_split(ops, dGQ[t], ql.weight_ih[:, plan.q_lang[0]:plan.q_lang[1]], dLHrec, ref, accum=True)
+    # ---- LayerNorm parameter grads of the per-step norms
+    ln_grads(ops, part_q.view(L * nbB, 2, Q), G, 'decoder.query_lstm_layernorm', Q)
+    att_names = ['decoder.context_att', 'decoder.context_att_2']
+    for i in range(ns):
+        ln_grads(ops, part_c[i].view(L * nbB, 2, H), G, att_names[i] + '.output_layer.2', H)
+    # ---- weight gradients: one (L*B)-deep TN GEMM per weight block
+    dgq2, dgl2 = dGQ.view(n, 4 * Q), dGL.view(n, 4 * D)
+    Gq_ih, Gl_ih = G['decoder.query_lstm.weight_ih'], G['decoder.lang_lstm.weight_ih']
+    ops.gemm(GEMM_TN, [(dgq2, s['LHP'][:L].view(n, D), Gq_ih[:, plan.q_lang[0]:plan.q_lang[1]])], flags=F_ACCUM)
+    ops.gemm(GEMM_TN, [(dgq2, s['WE'][:L].view(n, W), Gq_ih[:, plan.q_word[0]:plan.q_word[1]])], flags=F_ACCUM)
+    ops.gemm(GEMM_TN, [(dgq2, s['QH'][:L].view(n, Q), G['decoder.query_lstm.weight_hh'])], flags=F_ACCUM)
+    dgq_sum = _empty(ref, B, 4 * Q)
+    ops.slab_reduce(dGQ, dgq_sum)
+    ops.gemm(GEMM_TN, [(dgq_sum, s['gfeat'], Gq_ih[:, plan.q_glob[0]:plan.q_glob[1]])], flags=F_ACCUM)
+    ops.colsum(dgq2, G['decoder.query_lstm.bias_ih'], accum=True)
+    ops.colsum(dgq2, G['decoder.query_lstm.bias_hh'], accum=True)
+    for i in range(ns):
+        ops.gemm(GEMM_TN, [(dgl2, s['CTX'][i].view(n, H), Gl_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]])], flags=F_ACCUM)
+    ops.gemm(GEMM_TN, [(dgl2, s['QCUR'].view(n, Q), Gl_ih[:, plan.l_q[0]:plan.l_q[1]])], flags=F_ACCUM)
+    ops.gemm(GEMM_TN, [(dgl2, s['LHP'][:L].view(n, D), G['decoder.lang_lstm.weight_hh'])], flags=F_ACCUM)
+    ops.colsum(dgl2, G['decoder.lang_lstm.bias_ih'], accum=True)
+    ops.colsum(dgl2, G['decoder.lang_lstm.bias_hh'], accum=True)
+    # ---- word embedding rows
+    dWE = _empty(ref, n, W)
+    ops.gemm(GEMM_NN, [(dgq2, ql.weight_ih[:, plan.q_word[0]:plan.q_word[1]], dWE)])
+    # one mask stream (site SITE_WORD, row = slot*B + b) covers the bulk embed and the argmax re-embeds
+    ops.embed_bwd(dWE, s['IDS'][:L].view(-1), G['decoder.word_embed.weight'], p=s['pw'], seed=seed, site=SITE_WORD)
+    # ---- global feature
+    dgfeat = _empty(ref, B, plan.G)
+    ops.gemm(GEMM_NN, [(dgq_sum, ql.weight_ih[:, plan.q_glob[0]:plan.q_glob[1]], dgfeat)])
+    # ---- attention caches: K' = K W_Q, V' = V W_O^T, K = m W_K^T, V = m W_V^T
+    dmems = []
+    for i, att in enumerate(atts):
+        nm = att_names[i]
+        mem = s['mems'][i]
+        Bm, P, _ = mem.shape
+        m2 = mem.reshape(Bm * P, H)
+        dkp, dvp = dKp[i].view(Bm * P, Q), dVp[i].view(Bm * P, H)
+        K, Vv = s['K'][i], s['V'][i]
+        ops.gemm(GEMM_TN, [(K, dkp, G[nm + '.Q.weight'])], flags=F_ACCUM)                     # dW_Q = K^T dK'
+        ops.gemm(GEMM_TN, [(dvp, Vv, G[nm + '.output_layer.0.weight'])], flags=F_ACCUM)       # dW_O = dV'^T V
+        dK = _empty(ref, Bm * P, H); dV = _empty(ref, Bm * P, H)
+        ops.gemm(GEMM_NT, [(dkp, att.Q.weight, dK)])                                           # dK = dK' W_Q^T
+        ops.gemm(GEMM_NN, [(dvp, att.output_layer[0].weight, dV)])                             # dV = dV' W_O
+        ops.gemm(GEMM_TN, [(dK, m2, G[nm + '.K.weight'])], flags=F_ACCUM)
+        ops.gemm(GEMM_TN, [(dV, m2, G[nm + '.V.weight'])], flags=F_ACCUM)
+        dm = _empty(ref, Bm * P, H)
+        ops.gemm(GEMM_NN, [(dK, att.K.weight, dm)])
+        ops.gemm(GEMM_NN, [(dV, att.V.weight, dm)], flags=F_ACCUM)
+        dmems.append(dm.view(Bm, P, H))
+    return dmems, dgfeat

@@ -1,0 +1,391 @@
+"""ctypes binding of libdlsg_hip.so (include/dlsg.h) -- the only device compute path of this package.
+
+There is no CPU or eager-PyTorch fallback here: constructing `HipOps` raises if the library is missing or no
+MI355X is visible.  Tensors are only device memory + strides; every op is a hand-written HIP kernel launched on
+PyTorch's current HIP stream.
+
+All methods take torch *views*: 2-d (rows, cols) with unit inner stride and an arbitrary row stride, or 3-d
+(batch, rows, cols) for batched GEMMs (the batch stride may be 0 via .expand()).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
+MAXG = 16
+
+c_f32p = C.c_void_p
+i32, i64, u32, u64, f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+
+
+class GemmGroup(C.Structure):
+    _fields_ = [('A', c_f32p), ('B', c_f32p), ('C', c_f32p), ('lda', i64), ('ldb', i64), ('K', i32), ('pad_', i32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [('mode', i32), ('M', i32), ('N', i32), ('ldc', i32), ('ngroups', i32), ('nbatch', i32), ('flags', i32),
+                ('pad_', i32), ('bsa', i64), ('bsb', i64), ('bsc', i64), ('alpha', f32), ('pad2_', i32),
+                ('bias', c_f32p), ('g', GemmGroup * MAXG)]
+
+
+class RowLnArgs(C.Structure):
+    _fields_ = [('x', c_f32p), ('ldx', i64), ('res', c_f32p), ('ldres', i64), ('gamma', c_f32p), ('beta', c_f32p),
+                ('y', c_f32p), ('ldy', i64), ('stats', c_f32p), ('pe', c_f32p), ('pe_rows', i32), ('rows', i32),
+                ('n', i32), ('pre_tanh', i32), ('post_tanh', i32), ('eps', f32), ('p1', f32), ('p2', f32),
+                ('seed', u64), ('site1', u32), ('site2', u32)]
+
+
+class RowLnBwdArgs(C.Structure):
+    _fields_ = [('f', RowLnArgs), ('dy', c_f32p), ('lddy', i64), ('dx', c_f32p), ('lddx', i64), ('accum_dx', i32),
+                ('dgb_part', c_f32p), ('nblk', i32)]
+
+
+class O2VArgs(C.Structure):
+    _fields_ = [('y', c_f32p), ('v', c_f32p), ('g_obj', c_f32p), ('b_obj', c_f32p), ('z', c_f32p), ('ml', c_f32p),
+                ('ostats', c_f32p), ('S', c_f32p), ('ws', c_f32p), ('ws_bytes', i64), ('B', i32), ('T', i32),
+                ('NO', i32), ('H', i32), ('nsplit', i32), ('scale', f32), ('eps', f32)]
+
+
+class DecAttArgs(C.Structure):
+    _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
+                ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
+
+
+class DecAttBwdArgs(C.Structure):
+    _fields_ = [('f', DecAttArgs), ('dc', c_f32p * 2), ('lddc', i64), ('dalpha', c_f32p), ('dKp', c_f32p * 2),
+                ('dVp', c_f32p * 2), ('dq', c_f32p), ('lddq', i64), ('accum_dq', i32)]
+
+
+class LstmPwArgs(C.Structure):
+    _fields_ = [('slabs', c_f32p), ('nslab', i32), ('pad_', i32), ('slab_stride', i64), ('addend', c_f32p),
+                ('ldadd', i64), ('b_ih', c_f32p), ('b_hh', c_f32p), ('c_prev', c_f32p), ('ldcp', i64), ('c', c_f32p),
+                ('ldc_', i64), ('h', c_f32p), ('ldh', i64), ('h2', c_f32p), ('ldh2', i64), ('gates', c_f32p), ('ldg', i64),
+                ('B', i32), ('H', i32), ('p', f32), ('site', u32), ('seed', u64)]
+
+
+class LstmPwBwdArgs(C.Structure):
+    _fields_ = [('gates', c_f32p), ('ldg', i64), ('c', c_f32p), ('ldc_', i64), ('c_prev', c_f32p), ('ldcp', i64), ('dh', c_f32p),
+                ('lddh', i64), ('dh2', c_f32p), ('lddh2', i64), ('dc_next', c_f32p), ('lddcn', i64),
+                ('dgates', c_f32p), ('lddg', i64), ('dc_prev', c_f32p), ('lddcp', i64), ('B', i32), ('H', i32), ('p', f32),
+                ('site', u32), ('seed', u64)]
+
+
+# every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
+SYMBOLS = ['dlsg_abi_version', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
+           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd',
+           'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
+           'dlsg_lstm_pw_bwd', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
+           'dlsg_argmax', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
+           'dlsg_adam', 'dlsg_permute_tb']
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise RuntimeError('libdlsg_hip.so not built (%s): run `python -c "import __graft_entry__ as g; g.build()"` '
+                           'or `make -C d-lsg-video-caption_amd/csrc`; there is no fallback path' % path)
+    lib = C.CDLL(path)
+    for s in SYMBOLS:
+        getattr(lib, s)  # AttributeError if the library does not export what the header declares
+    vp, P = C.c_void_p, C.POINTER
+    sig = {
+        'dlsg_abi_version': [],
+        'dlsg_gemm': [P(GemmArgs), vp],
+        'dlsg_slab_reduce': [vp, i32, i64, vp, vp, i64, i32, i32, i32, vp],
+        'dlsg_rowln_fwd': [P(RowLnArgs), vp],
+        'dlsg_rowln_bwd': [P(RowLnBwdArgs), vp],
+        'dlsg_rowln_bwd_nblk': [i32],
+        'dlsg_colsum': [vp, i64, i32, i32, vp, i32, vp],
+        'dlsg_o2v_workspace_bytes': [i32, i32, i32, i32],
+        'dlsg_o2v_fwd': [P(O2VArgs), vp],
+        'dlsg_softmax_fwd': [vp, vp, vp, i64, i32, i32, vp],
+        'dlsg_softmax_bwd': [vp, vp, vp, i64, i32, i32, vp],
+        'dlsg_decatt_fwd': [P(DecAttArgs), vp],
+        'dlsg_decatt_bwd': [P(DecAttBwdArgs), vp],
+        'dlsg_lstm_pw_fwd': [P(LstmPwArgs), vp],
+        'dlsg_lstm_pw_bwd': [P(LstmPwBwdArgs), vp],
+        'dlsg_mean_rows_fwd': [vp, vp, i64, i32, i32, i32, vp],
+        'dlsg_mean_rows_bwd': [vp, i64, vp, i32, i32, i32, i32, vp],
+        'dlsg_embed_fwd': [vp, vp, vp, i64, i32, i32, f32, u64, u32, i64, vp],
+        'dlsg_embed_bwd': [vp, i64, vp, vp, i32, i32, f32, u64, u32, i64, vp],
+        'dlsg_argmax': [vp, i64, vp, i32, i32, vp],
+        'dlsg_copy2d': [vp, i64, vp, i64, i32, i32, i32, vp],
+        'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp],
+        'dlsg_fill': [vp, i64, f32, vp],
+        'dlsg_ce_ragged': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        'dlsg_log_softmax': [vp, vp, i32, i32, vp],
+        'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp],
+        'dlsg_permute_tb': [vp, vp, i32, i32, i32, vp],
+    }
+    assert sorted(sig) == sorted(SYMBOLS)
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int64 if name == 'dlsg_o2v_workspace_bytes' else C.c_int
+    return lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk2(t):
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.size(1) == 1) and t.dtype == torch.float32, (t.shape, t.stride())
+    return t
+
+
+class HipOps(object):
+    """Launches the HIP kernels on torch's current stream.  Raises if the library or the GPU is missing."""
+
+    name = 'hip'
+
+    def __init__(self):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError('dlsg_amd needs an MI355X (gfx950) device: torch.cuda.is_available() is False and '
+                               'there is no CPU fallback')
+        if self.lib.dlsg_abi_version() != 1:
+            raise RuntimeError('libdlsg_hip.so ABI mismatch')
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _check(rc, what):
+        if rc != 0:
+            raise RuntimeError('%s failed with code %d' % (what, rc))
+
+    # ------------------------------------------------------------------ GEMM
+    def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None):
+        """groups: list of (A, B, C) views (2-d, or 3-d batched with identical batch strides across groups)."""
+        a = GemmArgs()
+        A0, B0, C0 = groups[0]
+        batched = A0.dim() == 3
+        if batched:
+            nb = C0.size(0)
+            a.bsa, a.bsb, a.bsc = A0.stride(0), B0.stride(0), C0.stride(0)
+        else:
+            nb = 1
+            a.bsa = a.bsb = a.bsc = 0
+        M, N = C0.shape[-2], C0.shape[-1]
+        a.mode, a.M, a.N, a.ldc = mode, M, N, C0.stride(-2)
+        a.ngroups, a.nbatch, a.flags, a.alpha = len(groups), nb, flags | (F_BIAS if bias is not None else 0), alpha
+        a.bias = _p(bias)
+        assert len(groups) <= MAXG
+        for i, (A, B, Cc) in enumerate(groups):
+            if mode == GEMM_TN:
+                K = A.shape[-2]
+                assert A.shape[-1] == M and B.shape[-2] == K and B.shape[-1] == N, (A.shape, B.shape, Cc.shape)
+            elif mode == GEMM_NN:
+                K = A.shape[-1]
+                assert A.shape[-2] == M and B.shape[-2] == K and B.shape[-1] == N, (A.shape, B.shape, Cc.shape)
+            else:
+                K = A.shape[-1]
+                assert A.shape[-2] == M and B.shape[-1] == K and B.shape[-2] == N, (A.shape, B.shape, Cc.shape)
+            for t in (A, B, Cc):
+                assert t.dtype == torch.float32 and (t.stride(-1) == 1 or t.size(-1) == 1), (t.shape, t.stride())
+            assert Cc.stride(-2) == a.ldc and Cc.shape[-2:] == C0.shape[-2:]
+            if batched:
+                assert (A.stride(0), B.stride(0), Cc.stride(0)) == (a.bsa, a.bsb, a.bsc)
+            g = a.g[i]
+            g.A, g.B, g.C = _p(A), _p(B), _p(Cc)
+            g.lda, g.ldb, g.K = A.stride(-2), B.stride(-2), K
+        self._check(self.lib.dlsg_gemm(C.byref(a), self._stream()), 'dlsg_gemm')
+
+    def slab_reduce(self, slabs, out, bias=None, flags=0):
+        """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""
+        S, rows, n = slabs.shape
+        assert slabs.stride(2) == 1 and slabs.stride(1) == n
+        self._check(self.lib.dlsg_slab_reduce(_p(slabs), S, i64(slabs.stride(0)), _p(bias), _p(out), i64(rows), n,
+                                              int(out.stride(0)), flags | (F_BIAS if bias is not None else 0),
+                                              self._stream()), 'dlsg_slab_reduce')
+
+    # ------------------------------------------------------------------ row kernels
+    def _rowln_args(self, x, gamma, beta, y, stats, res, pe, pre_tanh, post_tanh, p1, site1, p2, site2, seed, eps):
+        a = RowLnArgs()
+        _chk2(x)
+        a.x, a.ldx = _p(x), x.stride(0)
+        a.res, a.ldres = _p(res), (res.stride(0) if res is not None else 0)
+        a.gamma, a.beta = _p(gamma), _p(beta)
+        a.y, a.ldy = _p(y), (y.stride(0) if y is not None else 0)
+        a.stats = _p(stats)
+        a.pe, a.pe_rows = _p(pe), (pe.size(0) if pe is not None else 1)
+        a.rows, a.n = x.size(0), x.size(1)
+        a.pre_tanh, a.post_tanh, a.eps = pre_tanh, post_tanh, eps
+        a.p1, a.p2, a.seed, a.site1, a.site2 = p1, p2, seed, site1, site2
+        return a
+
+    def rowln_fwd(self, x, gamma, beta, y, stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0, site1=0,
+                  p2=0.0, site2=0, seed=0, eps=1e-5):
+        a = self._rowln_args(x, gamma, beta, y, stats, res, pe, pre_tanh, post_tanh, p1, site1, p2, site2, seed, eps)
+        self._check(self.lib.dlsg_rowln_fwd(C.byref(a), self._stream()), 'dlsg_rowln_fwd')
+
+    def rowln_bwd_nblk(self, rows):
+        return self.lib.dlsg_rowln_bwd_nblk(int(rows))
+
+    def rowln_bwd(self, dy, x, gamma, beta, dx, stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0,
+                  site1=0, p2=0.0, site2=0, seed=0, eps=1e-5, dgb_part=None, accum_dx=False):
+        b = RowLnBwdArgs()
+        b.f = self._rowln_args(x, gamma, beta, None, stats, res, pe, pre_tanh, post_tanh, p1, site1, p2, site2, seed,
+                               eps)
+        b.dy, b.lddy, b.dx, b.lddx = _p(dy), dy.stride(0), _p(dx), dx.stride(0)
+        b.accum_dx = int(accum_dx)
+        b.dgb_part = _p(dgb_part)
+        b.nblk = dgb_part.size(0) if dgb_part is not None else 0
+        self._check(self.lib.dlsg_rowln_bwd(C.byref(b), self._stream()), 'dlsg_rowln_bwd')
+
+    def colsum(self, part, out, accum=False):
+        """out[j] (+)= sum over rows of part (rows, n) view."""
+        _chk2(part)
+        self._check(self.lib.dlsg_colsum(_p(part), i64(part.stride(0)), part.size(0), part.size(1), _p(out), int(accum),
+                                         self._stream()), 'dlsg_colsum')
+
+    def softmax_fwd(self, x, y, outer, n, inner, mask=None):
+        self._check(self.lib.dlsg_softmax_fwd(_p(x), _p(mask), _p(y), i64(outer), n, inner, self._stream()), 'softmax_fwd')
+
+    def softmax_bwd(self, y, dy, dx, outer, n, inner):
+        self._check(self.lib.dlsg_softmax_bwd(_p(y), _p(dy), _p(dx), i64(outer), n, inner, self._stream()), 'softmax_bwd')
+
+    # ------------------------------------------------------------------ o2v graph
+    def o2v_supported(self, T, H):
+        return T <= 32 and H in (64, 512, 1024)
+
+    def o2v_fwd(self, y, v, g_obj, b_obj, z, ml, ostats, S, scale, nsplit, eps=1e-5):
+        B, NO, H = y.shape
+        T = v.shape[1]
+        a = O2VArgs()
+        wsb = self.lib.dlsg_o2v_workspace_bytes(B, T, H, nsplit)
+        ws = torch.empty(wsb // 4, dtype=torch.float32, device=y.device)
+        a.y, a.v, a.g_obj, a.b_obj, a.z, a.ml, a.ostats, a.S = _p(y), _p(v), _p(g_obj), _p(b_obj), _p(z), _p(ml), \
+            _p(ostats), _p(S)
+        a.ws, a.ws_bytes = _p(ws), wsb
+        a.B, a.T, a.NO, a.H, a.nsplit, a.scale, a.eps = B, T, NO, H, nsplit, scale, eps
+        self._check(self.lib.dlsg_o2v_fwd(C.byref(a), self._stream()), 'dlsg_o2v_fwd')
+
+    # ------------------------------------------------------------------ decoder attention
+    def _decatt_args(self, Kp, Vp, q, c, alpha, scale):
+        a = DecAttArgs()
+        ns = len(Kp)
+        B, P, Q = Kp[0].shape
+        H = Vp[0].shape[2]
+        for s in range(ns):
+            a.Kp[s], a.Vp[s] = Kp[s].data_ptr(), Vp[s].data_ptr()
+            if c is not None:
+                a.c[s] = c[s].data_ptr()
+        a.q, a.ldq = _p(q), q.stride(0)
+        a.ldc = c[0].stride(0) if c is not None else 0
+        a.alpha = _p(alpha)
+        a.B, a.P, a.Q, a.H, a.nstream, a.scale = B, P, Q, H, ns, scale
+        return a
+
+    def decatt_fwd(self, Kp, Vp, q, c, alpha, scale):
+        a = self._decatt_args(Kp, Vp, q, c, alpha, scale)
+        self._check(self.lib.dlsg_decatt_fwd(C.byref(a), self._stream()), 'dlsg_decatt_fwd')
+
+    def decatt_bwd(self, Kp, Vp, q, alpha, dc, dKp, dVp, dq, scale, accum_dq=False, dalpha=None):
+        b = DecAttBwdArgs()
+        b.f = self._decatt_args(Kp, Vp, q, None, alpha, scale)
+        for s in range(len(Kp)):
+            b.dc[s], b.dKp[s], b.dVp[s] = dc[s].data_ptr(), dKp[s].data_ptr(), dVp[s].data_ptr()
+        b.lddc = dc[0].stride(0)
+        b.dalpha = _p(dalpha)
+        b.dq, b.lddq, b.accum_dq = _p(dq), dq.stride(0), int(accum_dq)
+        self._check(self.lib.dlsg_decatt_bwd(C.byref(b), self._stream()), 'dlsg_decatt_bwd')
+
+    # ------------------------------------------------------------------ LSTM pointwise
+    def lstm_pw_fwd(self, slabs, c, B, H, addend=None, b_ih=None, b_hh=None, c_prev=None, h=None, h2=None, gates=None,
+                    p=0.0, site=0, seed=0):
+        a = LstmPwArgs()
+        if slabs is not None:
+            a.slabs, a.nslab, a.slab_stride = _p(slabs), slabs.size(0), slabs.stride(0)
+        else:
+            a.slabs, a.nslab, a.slab_stride = None, 0, 0
+        a.addend, a.ldadd = _p(addend), (addend.stride(0) if addend is not None else 0)
+        a.b_ih, a.b_hh = _p(b_ih), _p(b_hh)
+        a.c_prev, a.ldcp = _p(c_prev), (c_prev.stride(0) if c_prev is not None else 0)
+        a.c, a.ldc_ = _p(c), c.stride(0)
+        a.h, a.ldh = _p(h), (h.stride(0) if h is not None else 0)
+        a.h2, a.ldh2 = _p(h2), (h2.stride(0) if h2 is not None else 0)
+        a.gates, a.ldg = _p(gates), (gates.stride(0) if gates is not None else 0)
+        a.B, a.H, a.p, a.site, a.seed = B, H, p, site, seed
+        self._check(self.lib.dlsg_lstm_pw_fwd(C.byref(a), self._stream()), 'dlsg_lstm_pw_fwd')
+
+    def lstm_pw_bwd(self, gates, c, dgates, B, H, c_prev=None, dh=None, dh2=None, dc_next=None, dc_prev=None, p=0.0,
+                    site=0, seed=0):
+        a = LstmPwBwdArgs()
+        a.gates, a.ldg, a.c, a.ldc_ = _p(gates), gates.stride(0), _p(c), c.stride(0)
+        a.c_prev, a.ldcp = _p(c_prev), (c_prev.stride(0) if c_prev is not None else 0)
+        a.dh, a.lddh = _p(dh), (dh.stride(0) if dh is not None else 0)
+        a.dh2, a.lddh2 = _p(dh2), (dh2.stride(0) if dh2 is not None else 0)
+        a.dc_next, a.lddcn = _p(dc_next), (dc_next.stride(0) if dc_next is not None else 0)
+        a.dgates, a.lddg = _p(dgates), dgates.stride(0)
+        a.dc_prev, a.lddcp = _p(dc_prev), (dc_prev.stride(0) if dc_prev is not None else 0)
+        a.B, a.H, a.p, a.site, a.seed = B, H, p, site, seed
+        self._check(self.lib.dlsg_lstm_pw_bwd(C.byref(a), self._stream()), 'dlsg_lstm_pw_bwd')
+
+    # ------------------------------------------------------------------ movers
+    def mean_rows_fwd(self, x, out):
+        B, P, H = x.shape
+        self._check(self.lib.dlsg_mean_rows_fwd(_p(x), _p(out), i64(out.stride(0)), B, P, H, self._stream()), 'mean_rows_fwd')
+
+    def mean_rows_bwd(self, dout, dx, accum=False):
+        B, P, H = dx.shape
+        self._check(self.lib.dlsg_mean_rows_bwd(_p(dout), i64(dout.stride(0)), _p(dx), B, P, H, int(accum), self._stream()),
+                    'mean_rows_bwd')
+
+    def embed_fwd(self, E, ids, out, p=0.0, seed=0, site=0, row0=0):
+        rows, W = out.shape
+        self._check(self.lib.dlsg_embed_fwd(_p(E), _p(ids), _p(out), i64(out.stride(0)), rows, W, f32(p), u64(seed), u32(site),
+                                            i64(row0), self._stream()), 'embed_fwd')
+
+    def embed_bwd(self, dout, ids, dE, p=0.0, seed=0, site=0, row0=0):
+        rows, W = dout.shape
+        self._check(self.lib.dlsg_embed_bwd(_p(dout), i64(dout.stride(0)), _p(ids), _p(dE), rows, W, f32(p), u64(seed),
+                                            u32(site), i64(row0), self._stream()), 'embed_bwd')
+
+    def argmax(self, logits, ids):
+        rows, V = logits.shape
+        self._check(self.lib.dlsg_argmax(_p(logits), i64(logits.stride(0)), _p(ids), rows, V, self._stream()), 'argmax')
+
+    def copy2d(self, src, dst, accum=False):
+        rows, n = src.shape
+        self._check(self.lib.dlsg_copy2d(_p(src), i64(src.stride(0)), _p(dst), i64(dst.stride(0)), rows, n, int(accum),
+                                         self._stream()), 'copy2d')
+
+    def dropout(self, x, y, p, seed, site):
+        rows, n = x.shape
+        self._check(self.lib.dlsg_dropout(_p(x), i64(x.stride(0)), _p(y), i64(y.stride(0)), rows, n, f32(p), u64(seed),
+                                          u32(site), self._stream()), 'dropout')
+
+    def fill(self, t, value):
+        assert t.is_contiguous()
+        self._check(self.lib.dlsg_fill(_p(t), i64(t.numel()), f32(value), self._stream()), 'fill')
+
+    def permute_tb(self, src, dst):
+        """dst[b, t, :] = src[t, b, :]  (both contiguous 3-d)."""
+        T, B, n = src.shape
+        self._check(self.lib.dlsg_permute_tb(_p(src), _p(dst), T, B, n, self._stream()), 'permute_tb')
+
+    # ------------------------------------------------------------------ loss / optimizer
+    def ce_ragged(self, logits, targets, lens, dlogits, row_loss, loss, time_major):
+        """logits (B,L,V) or, time_major, (L,B,V); targets (B,L) int64; lens (B,) int64."""
+        if time_major:
+            L, B, V = logits.shape
+        else:
+            B, L, V = logits.shape
+        self._check(self.lib.dlsg_ce_ragged(_p(logits), _p(targets), _p(lens), _p(dlogits), _p(row_loss), _p(loss), B, L, V,
+                                            int(time_major), self._stream()), 'ce_ragged')
+
+    def log_softmax(self, logits, out):
+        rows, V = logits.shape
+        self._check(self.lib.dlsg_log_softmax(_p(logits), _p(out), rows, V, self._stream()), 'log_softmax')
+
+    def adam(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+        self._check(self.lib.dlsg_adam(_p(p), _p(g), _p(m), _p(v), i64(p.numel()), f32(lr), f32(b1), f32(b2), f32(eps),
+                                       int(step), f32(grad_scale), self._stream()), 'adam')

@@ -1,0 +1,367 @@
+"""Drop-in model surface of the hot path: CapGnnModel / CapBaseline1 with the reference's construction and
+forward() signatures (models/model.py:25-43,94-107), state_dict layout and
+`.decoder.decode_tokens` / `update_beam_size`, running on the HIP kernels of libdlsg_hip.so.
+
+`forward` is one torch.autograd.Function around the hand-scheduled engine, so reference-style callers
+(`loss.backward()` + torch.optim, DDP wrapping) work unchanged; `Trainer` is the fast path the benchmark uses:
+fused ragged cross-entropy, hand-scheduled backward into a flat gradient arena, bucketed RCCL all-reduce that
+overlaps the encoder backward, and one fused Adam kernel over the flat parameter arena.
+"""
+import math
+import random
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .modules import CapGnnEncoder, Decoder, EncoderVisual
+
+_ALIGN = 64  # floats: every parameter starts 256-B aligned inside the arena (vector loads need 16 B)
+
+
+def _default_ops():
+    from .hip import HipOps
+    return HipOps()
+
+
+class _HipModel(nn.Module):
+    """Shared machinery: flat parameter / gradient arenas, ops handle, autograd bridge."""
+
+    def __init__(self):
+        super().__init__()
+        self._ops_obj = None
+        self._flat = None
+        self._gflat = None
+        self._offsets = None
+        self.rng = random          # scheduled-sampling coins come from Python's `random`, like layer.py:432
+        self.seed_counter = 0
+        self.fused_o2v = True
+
+    # ------------------------------------------------------------------ kernels handle
+    @property
+    def ops(self):
+        if self._ops_obj is None:
+            self._ops_obj = _default_ops()   # raises when the HIP library / GPU is missing: no fallback
+        return self._ops_obj
+
+    def set_ops(self, ops):
+        self._ops_obj = ops
+
+    # ------------------------------------------------------------------ arenas
+    def _arena_ok(self):
+        if self._flat is None:
+            return False
+        for name, p in self.named_parameters():
+            o = self._offsets[name]
+            if p.device != self._flat.device or p.data_ptr() != self._flat.data_ptr() + 4 * o:
+                return False
+        return True
+
+    def flatten_parameters_(self):
+        """(Re)pack all parameters into one flat fp32 arena (views keep the nn.Parameter objects alive, so
+        state_dict / load_state_dict / optimizers keep working) and allocate the matching gradient arena."""
+        if self._arena_ok():
+            return
+        named = list(self.named_parameters())
+        dev = named[0][1].device
+        offsets, tot = {}, 0
+        for name, p in named:
+            offsets[name] = tot
+            tot += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.zeros(tot, dtype=torch.float32, device=dev)
+        for name, p in named:
+            view = flat[offsets[name]:offsets[name] + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+        self._flat, self._offsets = flat, offsets
+        self._gflat = torch.zeros(tot, dtype=torch.float32, device=dev)
+        self._G = E.Grads(named, self._gflat, offsets)
+
+    def grad_views(self):
+        return self._G
+
+    def next_seed(self):
+        self.seed_counter += 1
+        return (0x5DEECE66D * self.seed_counter + 0xB) & 0xFFFFFFFFFFFF
+
+    # ------------------------------------------------------------------ to be provided by subclasses
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv):
+        raise NotImplementedError
+
+    def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed):
+        raise NotImplementedError
+
+    def _draw_coins(self, L, infer, tf_ratio):
+        # reference draws one coin per step only when not inferring (layer.py:432)
+        if infer:
+            return [False] * L
+        return [self.rng.random() < tf_ratio for _ in range(L)]
+
+
+class _ModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, frames, regions, captions, L, coins, seed, *params):
+        sv = {}
+        training = model.training
+        outs = model._engine_forward(frames, regions, captions, L, coins, training, seed, sv)
+        ctx.model, ctx.sv, ctx.seed, ctx.training = model, sv, seed, training
+        ctx.nparams = len(params)
+        return outs
+
+    @staticmethod
+    def backward(ctx, dlogits, dobj, dmot, dalpha):
+        model, ops = ctx.model, ctx.model.ops
+        Bn, L, V = dlogits.shape
+        dl_tm = torch.empty(L, Bn, V, dtype=torch.float32, device=dlogits.device)
+        ops.permute_tb(dlogits.contiguous(), dl_tm)          # (B,L,V) -> (L,B,V)
+        da_tm = None
+        if dalpha is not None and dalpha.numel() > 0:
+            da_tm = torch.empty(L, Bn, dalpha.shape[-1], dtype=torch.float32, device=dlogits.device)
+            ops.permute_tb(dalpha.contiguous(), da_tm)
+        model._engine_backward(ctx.sv, dl_tm, dobj, dmot, da_tm, ctx.training, ctx.seed)
+        G = model.grad_views()
+        grads = []
+        for name, p in model.named_parameters():
+            grads.append(G[name].clone() if name not in model.unused_parameters else None)
+        ctx.sv = None
+        return (None,) * 7 + tuple(grads)
+
+
+class CapGnnModel(_HipModel):
+    """models/model.py:25-43.  forward(visual_feats, region_feats, caption, max_words=None,
+    teacher_forcing_ratio=1.0) -> (outputs, obj_proposals, motion_proposals, alpha_all)."""
+
+    @property
+    def unused_parameters(self):
+        """constructed by the reference but never used in forward: they get no gradient;
+        with num_obj < 5 the graph is skipped (layer.py:181-182) and obj_visual_norm is unused too."""
+        names = ['encoder.obj_encoder.att_l2l_norm.weight', 'encoder.obj_encoder.att_l2l_norm.bias',
+                 'encoder.motion_encoder.att_l2l_norm.weight', 'encoder.motion_encoder.att_l2l_norm.bias',
+                 'decoder.context_layernorm.weight', 'decoder.context_layernorm.bias']
+        if not self.encoder.obj_encoder.has_obj:
+            for e in ('obj_encoder', 'motion_encoder'):
+                names += ['encoder.%s.obj_visual_norm.1.weight' % e, 'encoder.%s.obj_visual_norm.1.bias' % e]
+        return frozenset(names)
+
+    def __init__(self, args, vocab):
+        super().__init__()
+        self.use_visual_gan = args.use_visual_gan
+        self.encoder = CapGnnEncoder(args)
+        self.decoder = Decoder(args, vocab, multi_modal=True)
+
+    def update_beam_size(self, beam_size):
+        self.decoder.update_beam_size(beam_size)
+
+    # ------------------------------------------------------------------ engine schedules
+    def _encode(self, frames, regions, training, seed, sv):
+        ops, enc = self.ops, self.encoder
+        B, T, F = frames.shape
+        A = enc.a_feature_size
+        f2 = frames.view(B * T, F)
+        obj = E.tun_fwd(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv, training, seed,
+                        E.SITE_PSL_OBJ, self.fused_o2v)
+        mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed)
+        mot = E.tun_fwd(ops, enc.motion_encoder, 'encoder.motion_encoder', mot_in, regions, sv, training, seed,
+                        E.SITE_PSL_MOT, self.fused_o2v)
+        return obj, mot
+
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv):
+        ops = self.ops
+        frames = frames.contiguous().float()
+        regions = regions.contiguous().float()
+        obj, mot = self._encode(frames, regions, training, seed, sv)
+        sv['frames'], sv['regions'] = frames, regions
+        sv['dec_gsrc'] = [obj, mot]
+        s = E.dec_fwd(ops, self.decoder, [obj, mot], sv, captions, L, coins, training, seed)
+        B = frames.shape[0]
+        V = self.decoder.vocab_size
+        logits = torch.empty(B, L, V, dtype=torch.float32, device=frames.device)
+        ops.permute_tb(s['LOGITS'], logits)
+        alpha = torch.empty(B, L, s['ALPHA'].shape[-1], dtype=torch.float32, device=frames.device)
+        ops.permute_tb(s['ALPHA'], alpha)
+        return logits, obj, mot, alpha
+
+    def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed, on_bucket=None):
+        ops, enc = self.ops, self.encoder
+        G = self._G
+        ops.fill(self._gflat, 0.0)
+        frames, regions = sv['frames'], sv['regions']
+        B, T, F = frames.shape
+        H = self.decoder.visual_hidden_size
+        dmems, dgfeat = E.dec_bwd(ops, self.decoder, sv, G, dlogits_tm, seed, training, dalpha_tm)
+        if on_bucket:
+            on_bucket('decoder')
+        dob, dmo = dmems
+        ops.mean_rows_bwd(dgfeat[:, :H], dob, accum=True)
+        ops.mean_rows_bwd(dgfeat[:, H:], dmo, accum=True)
+        if dobj is not None:
+            ops.copy2d(dobj.reshape(-1, H), dob.view(-1, H), accum=True)
+        if dmot is not None:
+            ops.copy2d(dmot.reshape(-1, H), dmo.view(-1, H), accum=True)
+        f2 = frames.view(B * T, F)
+        dmot_in = E.tun_bwd(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, G, dmo, training, seed)
+        if on_bucket:
+            on_bucket('encoder.motion_encoder')
+        E.encvis_bwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, G, dmot_in, training, seed)
+        if on_bucket:
+            on_bucket('encoder.motion_pre_encoder')
+        E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed)
+        if on_bucket:
+            on_bucket('encoder.obj_encoder')
+
+    # ------------------------------------------------------------------ public forward
+    def forward(self, visual_feats, region_feats, caption, max_words=None, teacher_forcing_ratio=1.0):
+        self.flatten_parameters_()
+        dec = self.decoder
+        infer = caption is None
+        L = dec.max_words if max_words is None else max_words
+        if infer and dec.beam_size != 1:
+            from .beam import beam_infer
+            return beam_infer(self, visual_feats, region_feats)
+        coins = self._draw_coins(L, infer, teacher_forcing_ratio)
+        seed = self.next_seed()
+        if infer:
+            sv = {}
+            with torch.no_grad():
+                self._engine_forward(visual_feats, region_feats, None, L, coins, False, seed, sv)
+            ids = sv['dec']['IDS'][1:].t().contiguous()
+            return ids, sv['dec_gsrc'][0], sv['dec_gsrc'][1], []
+        params = [p for _, p in self.named_parameters()]
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if not needs_grad:
+            with torch.no_grad():
+                return self._engine_forward(visual_feats, region_feats, caption, L, coins, self.training, seed, {})
+        return _ModelFn.apply(self, visual_feats, region_feats, caption, L, coins, seed, *params)
+
+
+class CapBaseline1(_HipModel):
+    """models/model.py:94-107: frames-only variant, EncoderVisual(baseline) + Decoder(baseline)."""
+    unused_parameters = frozenset(['decoder.context_layernorm.weight', 'decoder.context_layernorm.bias'])
+
+    def __init__(self, args, vocab):
+        super().__init__()
+        self.use_visual_gan = args.use_visual_gan
+        self.encoder = EncoderVisual(args, baseline=True)
+        self.decoder = Decoder(args, vocab, multi_modal=False, baseline=True)
+
+    def update_beam_size(self, beam_size):
+        self.decoder.update_beam_size(beam_size)
+
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv):
+        ops = self.ops
+        frames = frames.contiguous().float()
+        B, T, F = frames.shape
+        H = self.decoder.visual_hidden_size
+        enc = E.encvis_fwd(ops, self.encoder, 'encoder', frames.view(B * T, F), B, T, sv, training, seed).view(B, T, H)
+        sv['frames'] = frames
+        sv['dec_gsrc'] = [enc]
+        s = E.dec_fwd(ops, self.decoder, [enc], sv, captions, L, coins, training, seed)
+        V = self.decoder.vocab_size
+        logits = torch.empty(B, L, V, dtype=torch.float32, device=frames.device)
+        ops.permute_tb(s['LOGITS'], logits)
+        return logits, enc, enc, torch.empty(0, device=frames.device)
+
+    def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed, on_bucket=None):
+        ops = self.ops
+        G = self._G
+        ops.fill(self._gflat, 0.0)
+        frames = sv['frames']
+        B, T, F = frames.shape
+        dmems, dgfeat = E.dec_bwd(ops, self.decoder, sv, G, dlogits_tm, seed, training, None)
+        denc = dmems[0]
+        ops.mean_rows_bwd(dgfeat, denc, accum=True)
+        E.encvis_bwd(ops, self.encoder, 'encoder', frames.view(B * T, F), B, T, sv, G, denc.view(B * T, -1), training, seed)
+        if on_bucket:
+            on_bucket('decoder'); on_bucket('encoder')
+
+    def forward(self, visual_feats, region_feats, caption, max_words=None, teacher_forcing_ratio=1.0):
+        self.flatten_parameters_()
+        dec = self.decoder
+        infer = caption is None
+        L = dec.max_words if max_words is None else max_words
+        if infer and dec.beam_size != 1:
+            from .beam import beam_infer
+            return beam_infer(self, visual_feats, region_feats)
+        coins = self._draw_coins(L, infer, teacher_forcing_ratio)
+        seed = self.next_seed()
+        if infer:
+            sv = {}
+            with torch.no_grad():
+                self._engine_forward(visual_feats, region_feats, None, L, coins, False, seed, sv)
+            return sv['dec']['IDS'][1:].t().contiguous(), 0, 0, 0
+        params = [p for _, p in self.named_parameters()]
+        if not (torch.is_grad_enabled() and any(p.requires_grad for p in params)):
+            with torch.no_grad():
+                return self._engine_forward(visual_feats, region_feats, caption, L, coins, self.training, seed, {})[0], 0, 0, 0
+        out = _ModelFn.apply(self, visual_feats, region_feats, caption, L, coins, seed, *params)
+        return out[0], 0, 0, 0
+
+
+# ================================================================================================ fast training path
+def ss_epsilon(epoch, ss_factor=20):
+    """scheduled-sampling probability, run_gun.py:136"""
+    return max(0.6, ss_factor / (ss_factor + math.exp(epoch / ss_factor)))
+
+
+class Trainer(object):
+    """The reference's per-iteration use of the model (run_gun.py:153-160,181-198,233-234) as one fused schedule:
+    forward -> ragged CrossEntropy (mean over sum(cap_lens) rows) -> backward -> [RCCL all-reduce] -> Adam.
+
+    Data parallel: one process per GPU; every rank runs its own shard, gradients are summed with
+    torch.distributed all_reduce (RCCL over xGMI) bucket by bucket as the backward finishes each module group and
+    divided by world size inside the Adam kernel (DDP mean-of-means semantics, run_gun.py:63-64)."""
+
+    def __init__(self, model, lr=1.6e-4, betas=(0.5, 0.9), eps=1e-8, process_group=None, world_size=1):
+        self.model = model
+        model.flatten_parameters_()
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.m = torch.zeros_like(model._flat)
+        self.v = torch.zeros_like(model._flat)
+        self.t = 0
+        self.world_size = world_size
+        self.pg = process_group
+        self._works = []
+        # contiguous arena range of each backward bucket (named_parameters order == arena order)
+        self._ranges = {}
+        for name, p in model.named_parameters():
+            key = name.split('.')[0] if not name.startswith('encoder.') or not hasattr(model.encoder, 'obj_encoder') \
+                else '.'.join(name.split('.')[:2])
+            o = model._offsets[name]
+            end = o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            lo, hi = self._ranges.get(key, (o, end))
+            self._ranges[key] = (min(lo, o), max(hi, end))
+
+    def _on_bucket(self, key):
+        if self.world_size <= 1:
+            return
+        import torch.distributed as dist
+        lo, hi = self._ranges[key]
+        self._works.append(dist.all_reduce(self.model._gflat[lo:hi], group=self.pg, async_op=True))
+
+    @torch.no_grad()
+    def step(self, frames, regions, captions, cap_lens, tf_ratio, max_len=26):
+        """One optimisation step.  Returns the (device) scalar loss of this rank's shard."""
+        model, ops = self.model, self.model.ops
+        model.flatten_parameters_()
+        captions = captions[:, :max_len].contiguous()
+        cap_lens = torch.as_tensor(cap_lens).to(device=captions.device, dtype=torch.int64)
+        L = captions.shape[1]
+        coins = model._draw_coins(L, False, tf_ratio)
+        seed = model.next_seed()
+        sv = {}
+        training = model.training
+        model._engine_forward(frames, regions, captions, L, coins, training, seed, sv)
+        s = sv['dec']
+        Bn = captions.shape[0]
+        dl = torch.empty_like(s['LOGITS'])
+        row_loss = torch.empty(L * Bn, dtype=torch.float32, device=dl.device)
+        loss = torch.empty(1, dtype=torch.float32, device=dl.device)
+        ops.ce_ragged(s['LOGITS'], captions, cap_lens, dl, row_loss, loss, time_major=True)
+        self._works = []
+        model._engine_backward(sv, dl, None, None, None, training, seed, on_bucket=self._on_bucket)
+        for w in self._works:
+            w.wait()
+        self.t += 1
+        ops.adam(model._flat, model._gflat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
+                 1.0 / self.world_size)
+        return loss

@@ -1,0 +1,152 @@
+"""Parameter containers of the hot path.
+
+These nn.Modules only HOLD parameters/buffers, under the reference's attribute names so that
+`state_dict()` keys/shapes are identical to the reference's and a reference checkpoint loads
+with strict=True.  They are never called: all arithmetic is done by the HIP kernels driven from engine.py.
+Construction order follows the reference constructors so default initialisation draws the same RNG stream
+(models/layer.py:8-37,140-170,277-346; models/sublayer.py:11-26,47-61,177-187; models/model.py:26-30,57-67).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+
+def sinusoid_pe(d_model, max_len=72):
+    """PositionalEncoding_old table (models/sublayer.py:91-98)."""
+    pe = torch.zeros(max_len, d_model)
+    pos = torch.arange(0., max_len).unsqueeze(1)
+    div = torch.exp(torch.arange(0., d_model, 2) * -(math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(0)
+
+
+class _PE(nn.Module):
+    def __init__(self, d_model):
+        super().__init__()
+        self.register_buffer('pe', sinusoid_pe(d_model))
+
+
+class AttentionShare(nn.Module):
+    def __init__(self, value_size, key_size, out_size, dropout=0.1):
+        super().__init__()
+        self.attention_size = out_size
+        self.dropout = dropout
+        self.K = nn.Linear(value_size, out_size, bias=False)
+        self.Q = nn.Linear(key_size, out_size, bias=False)
+        self.V = nn.Linear(value_size, out_size, bias=False)
+        self.output_layer = nn.Sequential(nn.Linear(out_size, out_size, bias=False), nn.Tanh(),
+                                          nn.LayerNorm(out_size), nn.Dropout(dropout))
+
+
+class SelfAttention(nn.Module):
+    def __init__(self, input_size, attention_size, output_size, dropout=0.2, get_pe=False):
+        super().__init__()
+        self.attention_size = attention_size
+        self.dropout = dropout
+        self.get_pe = get_pe
+        self.pe = _PE(attention_size)
+        self.K = nn.Linear(input_size, attention_size, bias=False)
+        self.Q = nn.Linear(input_size, attention_size, bias=False)
+        self.V = nn.Linear(input_size, attention_size, bias=False)
+        self.output_layer = nn.Sequential(nn.Linear(attention_size, output_size, bias=False), nn.Dropout(dropout))
+
+
+class LatentPSL(nn.Module):
+    def __init__(self, input_size, num_psl):
+        super().__init__()
+        self.theta = nn.Parameter(torch.empty(num_psl, input_size))
+        nn.init.xavier_uniform_(self.theta, gain=nn.init.calculate_gain('tanh'))
+        self.out_norm = nn.Sequential(nn.Tanh(), nn.LayerNorm(input_size), nn.Dropout(0.3))
+
+
+class EncoderVisual(nn.Module):
+    def __init__(self, args, baseline=False):
+        super().__init__()
+        H = args.visual_hidden_size
+        self.hidden_size = H
+        self.p_drop = args.dropout
+        self.linear_embed = nn.Linear(args.a_feature_size + args.m_feature_size, H)
+        nn.init.xavier_normal_(self.linear_embed.weight)
+        self.lstm = nn.LSTM(H, H, batch_first=True, bidirectional=True)
+        self.layernorm_lstm = nn.LayerNorm(2 * H)
+        self.baseline = baseline
+        if not baseline:
+            self.self_attention = SelfAttention(2 * H, 2 * H, H, args.dropout, True)
+            self.layernorm_sa = nn.LayerNorm(H)
+        else:
+            self.out_try = nn.Linear(2 * H, H)
+            nn.init.xavier_normal_(self.out_try.weight)
+
+
+class EncoderVisualGraphTUN(nn.Module):
+    def __init__(self, args, input_type='motion', use_embed=True, baseline=False):
+        super().__init__()
+        self.baseline = baseline
+        self.has_obj = args.num_obj > 4
+        if self.has_obj:
+            self.obj_embed = nn.Linear(args.region_feature_size, args.region_projected_size)
+            self.obj_norm = nn.Sequential(nn.Tanh(), nn.LayerNorm(args.region_projected_size))
+        vin = args.m_feature_size if input_type == 'motion' else args.a_feature_size
+        self.use_embed = use_embed
+        if use_embed:
+            self.visual_embed = nn.Linear(vin, args.visual_hidden_size)
+        self.visual_norm = nn.Sequential(nn.Tanh(), nn.LayerNorm(args.visual_hidden_size))
+        self.obj_visual_norm = nn.Sequential(nn.Tanh(), nn.LayerNorm(args.visual_hidden_size))
+        self.v2l_layer = LatentPSL(args.visual_hidden_size, args.num_proposals)
+        self.att_l2l_norm = nn.LayerNorm(args.visual_hidden_size)   # constructed, unused (layer.py:167)
+
+
+class CapGnnEncoder(nn.Module):
+    def __init__(self, args, baseline=False):
+        super().__init__()
+        self.a_feature_size = args.a_feature_size
+        self.obj_encoder = EncoderVisualGraphTUN(args, 'object', baseline=baseline)
+        self.motion_pre_encoder = EncoderVisual(args)
+        self.motion_encoder = EncoderVisualGraphTUN(args, 'motion', use_embed=False, baseline=baseline)
+
+
+class Decoder(nn.Module):
+    def __init__(self, args, vocab, multi_modal=False, baseline=False):
+        super().__init__()
+        self.vocab = vocab
+        self.vocab_size = len(vocab)
+        self.word_size = args.word_size
+        self.max_words = args.max_words
+        self.beam_size = args.beam_size
+        self.p_drop = args.dropout
+        self.query_hidden_size = args.query_hidden_size
+        self.decode_hidden_size = args.decode_hidden_size
+        self.visual_hidden_size = args.visual_hidden_size
+        self.multi_modal = multi_modal
+        self.baseline = baseline
+        H, W, Q, D = args.visual_hidden_size, args.word_size, args.query_hidden_size, args.decode_hidden_size
+        self.word_embed = nn.Embedding(self.vocab_size, W)
+        q_in = H + W + D + (0 if baseline else H)
+        self.query_lstm = nn.LSTMCell(q_in, Q)
+        self.query_lstm_layernorm = nn.LayerNorm(Q)
+        l_in = H + Q + (H if multi_modal else 0)
+        self.lang_lstm = nn.LSTMCell(l_in, D)
+        self.lang_lstm_layernorm = nn.LayerNorm(D)
+        self.context_att = AttentionShare(H, Q, H)
+        self.context_layernorm = nn.LayerNorm(D)                 # constructed, unused (layer.py:334)
+        if multi_modal:
+            self.context_att_2 = AttentionShare(H, Q, H)
+        self.word_restore = nn.Linear(D, self.vocab_size)
+        nn.init.xavier_normal_(self.word_restore.weight)
+
+    def update_beam_size(self, beam_size):
+        """models/layer.py:348-350"""
+        self.beam_size = beam_size
+
+    def decode_tokens(self, tokens):
+        """models/layer.py:464-477: ids -> words until <end>."""
+        words = []
+        end = self.vocab('<end>')
+        for tok in tokens:
+            tok = int(tok)
+            if tok == end:
+                break
+            words.append(self.vocab.idx2word[tok])
+        return ' '.join(words)

@@ -1,0 +1,215 @@
+/* dlsg.h -- C ABI of libdlsg_hip.so: the MI355X (gfx950) kernels under the D-LSG CapGnnModel hot path.
+ *
+ * The reference (baiyang4/D-LSG-Video-Caption) has no native layer: every device op is a stock torch.nn call.
+ * Each entry point below replaces the stock op(s) at the cited reference location.  All pointers are device
+ * pointers owned by the caller; the library allocates nothing, keeps no global state, launches asynchronously
+ * on `stream` (a hipStream_t passed as void*) and returns 0 or a negative DLSG_E* code.  All tensors are dense
+ * fp32 row-major unless a leading dimension is given; ids are int64.
+ *
+ * Host-side bindings: d-lsg-video-caption_amd/dlsg_amd/hip.py (ctypes).  See INTEGRATION.md.
+ */
+#ifndef DLSG_H
+#define DLSG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLSG_ABI_VERSION 1
+int dlsg_abi_version(void);
+
+/* ---------------------------------------------------------------- GEMM (fp32-in / fp32-acc MFMA 32x32x2)
+ * Replaces every nn.Linear / LSTM gate matmul / torch.matmul on the path and their backward products:
+ *   obj_embed layer.py:184, visual_embed :179, linear_embed :51, nn.LSTM :52, SelfAttention K/Q/V/out
+ *   sublayer.py:66-68,80, AttentionShare K/V/Q/out sublayer.py:29-31,41, LSTMCell layer.py:571,593,
+ *   word_restore layer.py:600.
+ * C_g[b] (M x N, ldc) = alpha * opA(A_g[b]) . opB(B_g[b])  (+ bias[n]) (+ C) (tanh)   for every group g, batch b
+ *   mode 0 "NT": A[m*lda+k], B[n*ldb+k]      (y = x W^T, Linear forward)
+ *   mode 1 "NN": A[m*lda+k], B[k*ldb+n]      (dx = dy W)
+ *   mode 2 "TN": A[k*lda+m], B[k*ldb+n]      (dW = dy^T x)
+ * Groups share M, N, mode and flags but have their own operands, K and output: a K-split or a sum of several
+ * (activation, weight) segments is expressed as groups writing separate slabs that the consumer kernel sums.
+ */
+#define DLSG_GEMM_MAXG 16
+#define DLSG_GEMM_ACCUM 1 /* C += result */
+#define DLSG_GEMM_BIAS 2  /* + bias[n]   */
+#define DLSG_GEMM_TANH 4  /* tanh(.)     */
+typedef struct {
+    const float* A;
+    const float* B;
+    float* C;
+    int64_t lda, ldb;
+    int32_t K;
+    int32_t pad_;
+} dlsg_gemm_group;
+typedef struct {
+    int32_t mode, M, N, ldc;
+    int32_t ngroups, nbatch, flags, pad_;
+    int64_t bsa, bsb, bsc; /* batch strides in elements */
+    float alpha;
+    int32_t pad2_;
+    const float* bias;
+    dlsg_gemm_group g[DLSG_GEMM_MAXG];
+} dlsg_gemm_args;
+int dlsg_gemm(const dlsg_gemm_args* args, void* stream);
+
+/* out[r, :] = sum_s slabs[s][r, :] (+ bias) (tanh); slabs are nslab consecutive (rows x n) arrays. */
+int dlsg_slab_reduce(const float* slabs, int nslab, int64_t slab_stride, const float* bias, float* out,
+                     int64_t rows, int n, int ldo, int flags, void* stream);
+
+/* ---------------------------------------------------------------- row kernels: (tanh) -> LayerNorm -> (tanh) (+pe) (dropout)
+ * Replaces nn.Sequential(Tanh, LayerNorm[, Dropout]) at layer.py:145-163, sublayer.py:183-187,21-26, and
+ * the bare LayerNorms at layer.py:53,57,574,599 (+ PositionalEncoding_old add sublayer.py:102-104).
+ *   z = x (+ res);  t = pre_tanh ? tanh(z) : z;  y = LN(t)*gamma+beta;  y = post_tanh ? tanh(y) : y;
+ *   y = drop1(y);  if pe: y = drop2(y + pe[row % pe_rows]).   stats[row] = {mean, rstd}.
+ */
+typedef struct {
+    const float* x; int64_t ldx;
+    const float* res; int64_t ldres;      /* optional residual (NULL = none) */
+    const float* gamma; const float* beta;
+    float* y; int64_t ldy;
+    float* stats;                          /* rows x 2, optional */
+    const float* pe; int32_t pe_rows;     /* optional positional table (pe_rows x n) */
+    int32_t rows, n;
+    int32_t pre_tanh, post_tanh;
+    float eps;
+    float p1, p2;                          /* dropout probs (0 = off) */
+    uint64_t seed; uint32_t site1, site2;
+} dlsg_rowln_args;
+int dlsg_rowln_fwd(const dlsg_rowln_args* a, void* stream);
+/* backward: dy -> dx (same shape as x; residual gets the same gradient), dgamma/dbeta partial sums are written
+ * to dgb_part (nblk x 2 x n) and folded by dlsg_colsum. */
+typedef struct {
+    dlsg_rowln_args f;                     /* same descriptor as forward (y unused) */
+    const float* dy; int64_t lddy;
+    float* dx; int64_t lddx;
+    int32_t accum_dx;                      /* dx += instead of = */
+    float* dgb_part; int32_t nblk;         /* workspace: nblk x 2 x n ; nblk = grid size used */
+} dlsg_rowln_bwd_args;
+int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream);
+int dlsg_rowln_bwd_nblk(int rows);
+/* out[j] (+)= sum_r part[r*ld + j], r < rows */
+int dlsg_colsum(const float* part, int64_t ld, int rows, int n, float* out, int accum, void* stream);
+
+/* ---------------------------------------------------------------- object->frame conditional graph (layer.py:184-193)
+ * y (B, NO, H) = tanh(obj_embed(regions)) (the GEMM epilogue applied tanh); LayerNorm(obj_norm) is applied on the
+ * fly.  v (B, T, H) = visual_norm output.  Computes
+ *   S[n,t] = LN(y_n).v_t / sqrt(obj_size);  P = softmax over n;  agg_t = sum_n P[n,t] LN(y_n);  z = agg + v
+ * Partial kernel: grid (B, nsplit) online-softmax over an object chunk; combine merges chunks, writes z (pre
+ * obj_visual_norm), the softmax statistics m,l (B,T) and the object LN stats (B*NO x 2).
+ */
+typedef struct {
+    const float* y; const float* v;
+    const float* g_obj; const float* b_obj;     /* obj_norm.1 weight/bias */
+    float* z;                                    /* (B,T,H) agg + v */
+    float* ml;                                   /* (B,T,2) softmax max / sum (of exp(S-max)) */
+    float* ostats;                               /* (B*NO,2) LN mean/rstd of y rows */
+    float* S;                                    /* (B,NO,T) raw scaled scores, saved for backward */
+    float* ws; int64_t ws_bytes;                 /* workspace for partials */
+    int32_t B, T, NO, H, nsplit;
+    float scale, eps;
+} dlsg_o2v_args;
+int64_t dlsg_o2v_workspace_bytes(int B, int T, int H, int nsplit);
+int dlsg_o2v_fwd(const dlsg_o2v_args* a, void* stream);
+/* The backward of the graph runs through dlsg_softmax_fwd/bwd on the saved scores S (P = softmax_n(S),
+ * dS = P*(dP - sum_n P dP)) and batched dlsg_gemm products; see engine.py tun_bwd. */
+
+/* ---------------------------------------------------------------- softmax along the middle axis of (outer, n, inner)
+ * LatentPSL softmax over frames (sublayer.py:192: outer=B, n=T, inner=P), SelfAttention row softmax
+ * (sublayer.py:74: inner=1, optional mask: mask<=0 -> -9e15 as sublayer.py:70-72), o2v softmax over objects
+ * (layer.py:188: n=T*O, inner=T).  The dense products around them run through dlsg_gemm (batched). */
+int dlsg_softmax_fwd(const float* x, const float* mask, float* y, int64_t outer, int n, int inner, void* stream);
+/* dx = y * (dy - sum_n y*dy) */
+int dlsg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t outer, int n, int inner, void* stream);
+
+/* ---------------------------------------------------------------- decoder attention over cached K', V' (sublayer.py:28-43)
+ * For stream s in {0,1}: score_p = K'_s[b,p,:].q[b,:] * scale; w = softmax over p; c = sum_p w_p V'_s[b,p,:].
+ * K' = (m W_K^T) W_Q and V' = (m W_V^T) W_O^T are precomputed once per forward (step-invariant), so the per-step
+ * work is this kernel only.  Writes c (pre tanh/LN) and alpha (B, 2P). */
+typedef struct {
+    const float* Kp[2]; const float* Vp[2];   /* (B,P,Q) and (B,P,H) */
+    const float* q; int64_t ldq;              /* (B,Q) */
+    float* c[2]; int64_t ldc;                 /* (B,H) each */
+    float* alpha;                             /* (B, nstream*P) */
+    int32_t B, P, Q, H, nstream;
+    float scale;
+} dlsg_decatt_args;
+int dlsg_decatt_fwd(const dlsg_decatt_args* a, void* stream);
+typedef struct {
+    dlsg_decatt_args f;
+    const float* dc[2]; int64_t lddc;         /* (B,H) */
+    const float* dalpha;                      /* optional (B, nstream*P) */
+    float* dKp[2]; float* dVp[2];             /* accumulated (+=) over steps */
+    float* dq; int64_t lddq; int32_t accum_dq;
+} dlsg_decatt_bwd_args;
+int dlsg_decatt_bwd(const dlsg_decatt_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------- LSTM cell pointwise (nn.LSTM layer.py:52, nn.LSTMCell :571,593)
+ * gates = sum_s slabs[s] (+ addend) (+ b_ih + b_hh), PyTorch gate order i,f,g,o;
+ * c = f*c_prev + i*g; h = o*tanh(c).  Saves activated gates (B,4H) for backward.  h is written to up to two
+ * destinations (strided); h2 receives dropout(h) when p>0 (lang_lstm_drop layer.py:594). */
+typedef struct {
+    const float* slabs; int32_t nslab; int32_t pad_; int64_t slab_stride;
+    const float* addend; int64_t ldadd;        /* optional precomputed gate part (B,4H) */
+    const float* b_ih; const float* b_hh;      /* optional */
+    const float* c_prev; int64_t ldcp;         /* NULL = zeros */
+    float* c; int64_t ldc_;
+    float* h; int64_t ldh;                     /* raw h (recurrent state) */
+    float* h2; int64_t ldh2;                   /* optional second copy (dropout applied if p>0) */
+    float* gates; int64_t ldg;                 /* (B,4H) activated gates (row stride ldg), optional */
+    int32_t B, H;
+    float p; uint32_t site; uint64_t seed;
+} dlsg_lstm_pw_args;
+int dlsg_lstm_pw_fwd(const dlsg_lstm_pw_args* a, void* stream);
+/* backward: dh (B,H) [+ dh2 through dropout], dc_next -> dgates (B,4H pre-activation grads), dc_prev */
+typedef struct {
+    const float* gates; int64_t ldg;           /* activated gates from forward, row stride ldg */
+    const float* c; int64_t ldc_;
+    const float* c_prev; int64_t ldcp;
+    const float* dh; int64_t lddh;             /* optional */
+    const float* dh2; int64_t lddh2;           /* optional, goes through the dropout mask */
+    const float* dc_next; int64_t lddcn;       /* optional */
+    float* dgates; int64_t lddg;               /* (B,4H) pre-activation gate grads, row stride lddg */
+    float* dc_prev; int64_t lddcp;
+    int32_t B, H;
+    float p; uint32_t site; uint64_t seed;
+} dlsg_lstm_pw_bwd_args;
+int dlsg_lstm_pw_bwd(const dlsg_lstm_pw_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------- small data movement on the path
+ * mean over P proposals (layer.py:407-410): out[b, off + h] = mean_p x[b,p,h]; and its backward (accumulating) */
+int dlsg_mean_rows_fwd(const float* x, float* out, int64_t ldo, int B, int P, int H, void* stream);
+int dlsg_mean_rows_bwd(const float* dout, int64_t lddo, float* dx, int B, int P, int H, int accum, void* stream);
+/* embedding gather + dropout (layer.py:421-422,438-439): out[r, :] = drop(E[ids[r], :]); the dropout mask of
+ * element (r, j) is keyed by (row0 + r) * W + j so a slice of a larger call reproduces the same mask. */
+int dlsg_embed_fwd(const float* E, const int64_t* ids, float* out, int64_t ldo, int rows, int W, float p, uint64_t seed,
+                   uint32_t site, int64_t row0, void* stream);
+/* dE[ids[r], :] += drop(dout[r, :])   (atomic adds; rows sharing an id collide) */
+int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* ids, float* dE, int rows, int W, float p,
+                   uint64_t seed, uint32_t site, int64_t row0, void* stream);
+/* argmax over logits rows (first max wins, like torch.max) */
+int dlsg_argmax(const float* logits, int64_t ld, int64_t* ids, int rows, int V, void* stream);
+/* strided 2-d copy / add: dst[r*ldd + j] (+)= src[r*lds + j] */
+int dlsg_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int n, int accum, void* stream);
+/* elementwise dropout with the stateless mask: y = x * keep(seed, site, r*n+j)/(1-p) */
+int dlsg_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int n, float p, uint64_t seed,
+                 uint32_t site, void* stream);
+int dlsg_fill(float* dst, int64_t n, float value, void* stream);
+/* dst[b,t,:] = src[t,b,:]: time-major decoder buffers -> the (B,L,V) layout Decoder.forward returns (layer.py:447) */
+int dlsg_permute_tb(const float* src, float* dst, int T, int B, int n, void* stream);
+
+/* ---------------------------------------------------------------- loss + optimizer (run_gun.py:189-198, :91)
+ * Ragged CrossEntropy: row (b,t) counts iff t < lens[b]; loss = mean over counted rows; dlogits written for all
+ * rows (zeros for padded ones).  row_loss (B*L) is scratch; loss[0] receives the mean.  time_major: logits and
+ * dlogits are laid out (L,B,V) (the decoder's internal layout) instead of (B,L,V); targets stay (B,L). */
+int dlsg_ce_ragged(const float* logits, const int64_t* targets, const int64_t* lens, float* dlogits, float* row_loss,
+                   float* loss, int B, int L, int V, int time_major, void* stream);
+int dlsg_log_softmax(const float* logits, float* out, int rows, int V, void* stream);
+/* torch.optim.Adam semantics (no weight decay, no amsgrad); step = 1-based step count; grad_scale folds 1/world */
+int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step,
+              float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,314 @@
+"""TEST INFRASTRUCTURE ONLY: a CPU emulation of the kernel interface (dlsg_amd.hip.HipOps) in plain torch.
+
+Purpose: let the `-m "not gpu"` suite check the HOST logic of d-lsg-video-caption_amd/dlsg_amd/engine.py (launch
+schedule, buffer layout, strides, hand-written backward) against the oracle without a GPU, and give the GPU suite a
+train-mode (dropout on) reference that uses the same stateless mask hash as csrc/common.hpp.
+The product never imports this file; the product path has no CPU fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
+
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x):
+    x = x & _M32
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & _M32
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & _M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def drop_scale(seed, site, idx, p):
+    """numpy restatement of dlsg::drop_scale (csrc/common.hpp).  idx: uint64 ndarray."""
+    idx = idx.astype(np.uint64)
+    seed = np.uint64(seed)
+    lo = idx & _M32
+    hi = idx >> np.uint64(32)
+    inner = (hi + (np.uint64(0x9e3779b9) * np.uint64(site) & _M32) + (seed & _M32)) & _M32
+    h = _mix32(lo ^ _mix32(inner))
+    h = _mix32(h ^ (seed >> np.uint64(32)))
+    u = (h >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    keep = u >= np.float32(p)
+    return torch.from_numpy(np.where(keep, np.float32(1.0) / (np.float32(1.0) - np.float32(p)), np.float32(0.0)).astype(np.float32))
+
+
+def _mask(seed, site, rows, n, p, row0=0):
+    idx = (np.arange(rows, dtype=np.uint64)[:, None] + np.uint64(row0)) * np.uint64(n) + np.arange(n, dtype=np.uint64)[None, :]
+    return drop_scale(seed, site, idx, p)
+
+
+class EmulOps(object):
+    name = 'emul'
+
+    def __init__(self, fused_supported=True):
+        self.fused_supported = fused_supported
+        self.calls = {}
+
+    def _count(self, k):
+        self.calls[k] = self.calls.get(k, 0) + 1
+
+    # ------------------------------------------------------------------ GEMM
+    def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None):
+        self._count('gemm')
+        for A, B, C in groups:
+            if mode == GEMM_NT:
+                r = A @ B.transpose(-1, -2)
+            elif mode == GEMM_NN:
+                r = A @ B
+            else:
+                r = A.transpose(-1, -2) @ B
+            r = alpha * r
+            if bias is not None:
+                r = r + bias
+            if flags & F_ACCUM:
+                r = r + C
+            if flags & F_TANH:
+                r = torch.tanh(r)
+            C.copy_(r)
+
+    def slab_reduce(self, slabs, out, bias=None, flags=0):
+        self._count('slab_reduce')
+        r = slabs.sum(0)
+        if bias is not None:
+            r = r + bias
+        if flags & F_ACCUM:
+            r = r + out
+        if flags & F_TANH:
+            r = torch.tanh(r)
+        out.copy_(r)
+
+    # ------------------------------------------------------------------ row kernels
+    def _ln_core(self, x, res, pre_tanh, eps):
+        z = x if res is None else x + res
+        t = torch.tanh(z) if pre_tanh == 1 else z
+        mean = t.mean(1, keepdim=True)
+        var = ((t - mean) ** 2).mean(1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(var + eps)
+        return t, mean, rstd
+
+    def rowln_fwd(self, x, gamma, beta, y, stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0, site1=0,
+                  p2=0.0, site2=0, seed=0, eps=1e-5):
+        self._count('rowln_fwd')
+        rows, n = x.shape
+        t, mean, rstd = self._ln_core(x, res, pre_tanh, eps)
+        v = (t - mean) * rstd * gamma + beta
+        if post_tanh:
+            v = torch.tanh(v)
+        if p1 > 0:
+            v = v * _mask(seed, site1, rows, n, p1)
+        if pe is not None:
+            idx = torch.arange(rows) % pe.shape[0]
+            v = v + pe[idx]
+            if p2 > 0:
+                v = v * _mask(seed, site2, rows, n, p2)
+        if stats is not None:
+            stats.copy_(torch.cat([mean, rstd], 1))
+        y.copy_(v)
+
+    def rowln_bwd_nblk(self, rows):
+        return rows if rows < 256 else 256
+
+    def rowln_bwd(self, dy, x, gamma, beta, dx, stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0,
+                  site1=0, p2=0.0, site2=0, seed=0, eps=1e-5, dgb_part=None, accum_dx=False):
+        self._count('rowln_bwd')
+        rows, n = x.shape
+        t, mean, rstd = self._ln_core(x, res, pre_tanh, eps)
+        xh = (t - mean) * rstd
+        g = dy.clone()
+        if pe is not None and p2 > 0:
+            g = g * _mask(seed, site2, rows, n, p2)
+        if p1 > 0:
+            g = g * _mask(seed, site1, rows, n, p1)
+        if post_tanh:
+            yp = torch.tanh(xh * gamma + beta)
+            g = g * (1 - yp * yp)
+        gx = g * gamma
+        m1 = gx.mean(1, keepdim=True)
+        m2 = (gx * xh).mean(1, keepdim=True)
+        d = rstd * (gx - m1 - xh * m2)
+        if pre_tanh:
+            d = d * (1 - t * t)
+        if accum_dx:
+            d = d + dx
+        dx.copy_(d)
+        if dgb_part is not None:
+            nb = dgb_part.shape[0]
+            dgb_part.zero_()
+            for b in range(nb):
+                sel = slice(b, rows, nb)
+                dgb_part[b, 0] = (g[sel] * xh[sel]).sum(0)
+                dgb_part[b, 1] = g[sel].sum(0)
+
+    def colsum(self, part, out, accum=False):
+        self._count('colsum')
+        r = part.sum(0)
+        out.copy_(r + out if accum else r)
+
+    def softmax_fwd(self, x, y, outer, n, inner, mask=None):
+        self._count('softmax')
+        xv = x.reshape(outer, n, inner)
+        if mask is not None:
+            xv = torch.where(mask.reshape(outer, n, inner) > 0, xv, torch.full_like(xv, -9e15))
+        y.copy_(torch.softmax(xv, 1).reshape(y.shape))
+
+    def softmax_bwd(self, y, dy, dx, outer, n, inner):
+        self._count('softmax_bwd')
+        yv, dv = y.reshape(outer, n, inner), dy.reshape(outer, n, inner)
+        s = (yv * dv).sum(1, keepdim=True)
+        dx.copy_((yv * (dv - s)).reshape(dx.shape))
+
+    # ------------------------------------------------------------------ o2v
+    def o2v_supported(self, T, H):
+        return self.fused_supported and T <= 32
+
+    def o2v_fwd(self, y, v, g_obj, b_obj, z, ml, ostats, S, scale, nsplit, eps=1e-5):
+        self._count('o2v_fwd')
+        B, NO, H = y.shape
+        mean = y.mean(2, keepdim=True)
+        rstd = 1.0 / torch.sqrt(((y - mean) ** 2).mean(2, keepdim=True) + eps)
+        o = (y - mean) * rstd * g_obj + b_obj
+        s = scale * (o @ v.transpose(1, 2))
+        S.copy_(s)
+        m = s.max(1, keepdim=True)[0]
+        e = torch.exp(s - m)
+        l = e.sum(1, keepdim=True)
+        p = e / l
+        z.copy_((p.transpose(1, 2) @ o + v).reshape(z.shape))
+        ml.copy_(torch.stack([m.reshape(-1), l.reshape(-1)], 1))
+        ostats.copy_(torch.cat([mean.reshape(-1, 1), rstd.reshape(-1, 1)], 1))
+
+    # ------------------------------------------------------------------ decoder attention
+    def decatt_fwd(self, Kp, Vp, q, c, alpha, scale):
+        self._count('decatt_fwd')
+        P = Kp[0].shape[1]
+        for s in range(len(Kp)):
+            sc = (Kp[s] @ q.unsqueeze(2)).squeeze(2) * scale
+            w = torch.softmax(sc, 1)
+            c[s].copy_((w.unsqueeze(1) @ Vp[s]).squeeze(1))
+            alpha[:, s * P:(s + 1) * P] = w
+
+    def decatt_bwd(self, Kp, Vp, q, alpha, dc, dKp, dVp, dq, scale, accum_dq=False, dalpha=None):
+        self._count('decatt_bwd')
+        P = Kp[0].shape[1]
+        acc = dq.clone() if accum_dq else torch.zeros_like(dq)
+        for s in range(len(Kp)):
+            w = alpha[:, s * P:(s + 1) * P]
+            dw = (Vp[s] @ dc[s].unsqueeze(2)).squeeze(2)
+            if dalpha is not None:
+                dw = dw + dalpha[:, s * P:(s + 1) * P]
+            dot = (w * dw).sum(1, keepdim=True)
+            ds = w * (dw - dot) * scale
+            dVp[s] += w.unsqueeze(2) * dc[s].unsqueeze(1)
+            dKp[s] += ds.unsqueeze(2) * q.unsqueeze(1)
+            acc = acc + (ds.unsqueeze(1) @ Kp[s]).squeeze(1)
+        dq.copy_(acc)
+
+    # ------------------------------------------------------------------ LSTM pointwise
+    def lstm_pw_fwd(self, slabs, c, B, H, addend=None, b_ih=None, b_hh=None, c_prev=None, h=None, h2=None, gates=None,
+                    p=0.0, site=0, seed=0):
+        self._count('lstm_pw_fwd')
+        pre = torch.zeros(B, 4 * H) if slabs is None else slabs.sum(0)
+        if addend is not None:
+            pre = pre + addend
+        if b_ih is not None:
+            pre = pre + b_ih
+        if b_hh is not None:
+            pre = pre + b_hh
+        i, f, g, o = pre[:, :H].sigmoid(), pre[:, H:2 * H].sigmoid(), pre[:, 2 * H:3 * H].tanh(), pre[:, 3 * H:].sigmoid()
+        cp = c_prev if c_prev is not None else torch.zeros(B, H)
+        cn = f * cp + i * g
+        hn = o * torch.tanh(cn)
+        c.copy_(cn)
+        if h is not None:
+            h.copy_(hn)
+        if h2 is not None:
+            h2.copy_(hn * _mask(seed, site, B, H, p) if p > 0 else hn)
+        if gates is not None:
+            gates.copy_(torch.cat([i, f, g, o], 1))
+
+    def lstm_pw_bwd(self, gates, c, dgates, B, H, c_prev=None, dh=None, dh2=None, dc_next=None, dc_prev=None, p=0.0,
+                    site=0, seed=0):
+        self._count('lstm_pw_bwd')
+        i, f, g, o = gates[:, :H], gates[:, H:2 * H], gates[:, 2 * H:3 * H], gates[:, 3 * H:]
+        cp = c_prev if c_prev is not None else torch.zeros(B, H)
+        d = torch.zeros(B, H) if dh is None else dh.clone()
+        if dh2 is not None:
+            d = d + (dh2 * _mask(seed, site, B, H, p) if p > 0 else dh2)
+        tc = torch.tanh(c)
+        dc = d * o * (1 - tc * tc)
+        if dc_next is not None:
+            dc = dc + dc_next
+        out = torch.cat([dc * g * i * (1 - i), dc * cp * f * (1 - f), dc * i * (1 - g * g), d * tc * o * (1 - o)], 1)
+        dgates.copy_(out)
+        if dc_prev is not None:
+            dc_prev.copy_(dc * f)
+
+    # ------------------------------------------------------------------ movers
+    def mean_rows_fwd(self, x, out):
+        out.copy_(x.mean(1))
+
+    def mean_rows_bwd(self, dout, dx, accum=False):
+        g = (dout / dx.shape[1]).unsqueeze(1).expand_as(dx)
+        dx.copy_(dx + g if accum else g)
+
+    def embed_fwd(self, E, ids, out, p=0.0, seed=0, site=0, row0=0):
+        v = E[ids]
+        if p > 0:
+            v = v * _mask(seed, site, out.shape[0], out.shape[1], p, row0)
+        out.copy_(v)
+
+    def embed_bwd(self, dout, ids, dE, p=0.0, seed=0, site=0, row0=0):
+        g = dout
+        if p > 0:
+            g = g * _mask(seed, site, dout.shape[0], dout.shape[1], p, row0)
+        dE.index_add_(0, ids, g)
+
+    def argmax(self, logits, ids):
+        ids.copy_(logits.max(1)[1])
+
+    def copy2d(self, src, dst, accum=False):
+        dst.copy_(dst + src if accum else src)
+
+    def dropout(self, x, y, p, seed, site):
+        y.copy_(x * _mask(seed, site, x.shape[0], x.shape[1], p))
+
+    def fill(self, t, value):
+        t.fill_(value)
+
+    def permute_tb(self, src, dst):
+        dst.copy_(src.transpose(0, 1))
+
+    # ------------------------------------------------------------------ loss / optimizer
+    def ce_ragged(self, logits, targets, lens, dlogits, row_loss, loss, time_major):
+        lg = logits.transpose(0, 1) if time_major else logits          # (B,L,V)
+        B, L, V = lg.shape
+        lens_c = lens.clamp(max=L)
+        valid = torch.arange(L).unsqueeze(0) < lens_c.unsqueeze(1)     # (B,L)
+        ntot = int(lens_c.sum())
+        lsm = torch.log_softmax(lg, -1)
+        nll = -lsm.gather(2, targets.unsqueeze(2)).squeeze(2)
+        rl = torch.where(valid, nll, torch.zeros_like(nll)) / ntot
+        d = (torch.softmax(lg, -1) - torch.nn.functional.one_hot(targets, V).float()) / ntot
+        d = d * valid.unsqueeze(2)
+        if time_major:
+            dlogits.copy_(d.transpose(0, 1)); row_loss.copy_(rl.t().reshape(-1))
+        else:
+            dlogits.copy_(d); row_loss.copy_(rl.reshape(-1))
+        loss.copy_(rl.sum().reshape(1))
+
+    def log_softmax(self, logits, out):
+        out.copy_(torch.log_softmax(logits, 1))
+
+    def adam(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+        gi = g * grad_scale
+        m.mul_(b1).add_(gi, alpha=1 - b1)
+        v.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+        bc1 = 1 - b1 ** step
+        bc2s = math.sqrt(1 - b2 ** step)
+        p.sub_((lr / bc1) * (m / (v.sqrt() / bc2s + eps)))

@@ -1,0 +1,105 @@
+"""CPU: host logic of the engine (launch schedule, buffer layout, hand-written backward) checked against the golden
+vectors of the reference, with the kernels replaced by the test-only torch emulation (tests/emul_ops.py).
+The same checks run against the real HIP kernels in tests/test_gpu_parity.py (-m gpu)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import dlsg_amd
+from emul_ops import EmulOps
+from helpers import load_case, weights_and_inputs
+
+SMALL = ['small_msvd', 'small_msrvtt', 'small_noobj', 'small_baseline1']
+
+
+def build(tag, fused=True):
+    args, vocab, g, kind = load_case(tag)
+    torch.manual_seed(0)
+    net = (dlsg_amd.CapGnnModel if kind == 'capgnn' else dlsg_amd.CapBaseline1)(args, vocab).eval()
+    net.set_ops(EmulOps(fused_supported=fused))
+    sd, frames, regions, caps, lens = weights_and_inputs(net, g, args)
+    net.load_state_dict(sd, strict=True)
+    return net, g, frames, regions, caps, lens, kind
+
+
+@pytest.mark.parametrize('tag', SMALL)
+@pytest.mark.parametrize('fused', [True, False])
+def test_forward_matches_reference(tag, fused):
+    net, g, frames, regions, caps, lens, kind = build(tag, fused)
+    assert sorted(net.state_dict().keys()) == sorted(k[2:] for k in g if k.startswith('w.'))
+    with torch.no_grad():
+        out = net(frames, regions, caps, 26, 1.0)
+    assert np.abs(out[0].numpy() - g['logits']).max() <= 2e-5
+    if kind == 'capgnn':
+        assert np.abs(out[1].numpy() - g['obj_psl']).max() <= 2e-5
+        assert np.abs(out[2].numpy() - g['mot_psl']).max() <= 2e-5
+        assert np.abs(out[3].numpy() - g['alpha']).max() <= 2e-5
+
+
+@pytest.mark.parametrize('tag', SMALL)
+def test_greedy_ids_and_scheduled_sampling(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    net.update_beam_size(1)
+    with torch.no_grad():
+        ids = net(frames, regions, None)[0]
+    assert np.array_equal(ids.numpy(), g['greedy_ids'])
+    random.seed(12)
+    with torch.no_grad():
+        logits = net(frames, regions, caps, 26, 0.6)[0]
+    assert np.abs(logits.numpy() - g['ss_logits']).max() <= 2e-5
+
+
+@pytest.mark.parametrize('tag', SMALL)
+def test_autograd_path_grads(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    outs = net(frames, regions, caps, 26, 1.0)[0]
+    rows = torch.cat([outs[j][:lens[j]] for j in range(outs.shape[0])], 0)
+    tgt = torch.cat([caps[j][:lens[j]] for j in range(outs.shape[0])], 0)
+    loss = torch.nn.functional.cross_entropy(rows, tgt)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5
+    for k, p in net.named_parameters():
+        if 'gnone.' + k in g:
+            assert p.grad is None, k
+        else:
+            ref = g['g.' + k]
+            assert np.abs(p.grad.numpy() - ref).max() <= 2e-5 + 2e-4 * np.abs(ref).max(), k
+
+
+@pytest.mark.parametrize('tag', SMALL)
+def test_trainer_step_matches_reference_adam(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    tr = dlsg_amd.Trainer(net)
+    loss = tr.step(frames, regions, caps, lens, 1.0)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-5
+    for k, p in net.named_parameters():
+        s, a = g['post.' + k]
+        assert abs(float(p.detach().double().sum()) - s) <= 2e-5 * max(1.0, a), k
+
+
+def test_train_mode_dropout_backward_is_consistent():
+    """dropout on: the analytic gradient must match a directional finite difference of the same (seeded) loss."""
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    net.train()
+    net = net.double() if False else net
+    tr = dlsg_amd.Trainer(net, lr=0.0)
+    net.seed_counter = 41
+    random.seed(3)
+    tr.step(frames, regions, caps, lens, 1.0)
+    grad = net._gflat.clone()
+    torch.manual_seed(5)
+    d = torch.randn_like(grad) * (grad != 0)
+    d /= d.norm()
+    base = net._flat.clone()
+
+    def loss_at(eps):
+        net._flat.copy_(base + eps * d)
+        net.seed_counter = 41
+        random.seed(3)
+        return float(tr.step(frames, regions, caps, lens, 1.0))
+    h = 2e-2
+    fd = (loss_at(h) - loss_at(-h)) / (2 * h)
+    an = float((grad * d).sum())
+    assert abs(fd - an) <= 0.05 * max(abs(an), 1e-3), (fd, an)
