@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the D-LSG hot path on MI355X: clips/sec of one TRAIN step (forward + ragged CE + backward + gradient
+all-reduce + Adam) of CapGnnModel on synthetic MSVD-shaped features, as BASELINE.json names it.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): batch 64 clips per GPU, 26 frames x (2048 + 4096) frame features, 16 x 2048
+region features, vocab 1000, fp32, dropout active, scheduled-sampling eps = 0.95 (epoch 0).  Weak scaling: the
+per-GPU batch is fixed, gradients are summed over ranks by bucketed RCCL all-reduce overlapping the backward.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the dominant kernel (the fp32-MFMA
+GEMM); `roofline_graph_attention` is the HBM-bound object->frame graph kernel the north_star names;
+`cpu_baseline` times the oracle (CPU port of the reference path) on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'd-lsg-video-caption_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle (oracle/torch_ref.py, kind 'port') train step at BASELINE configs[0]: B=8, MSVD-shaped, CPU fp32."""
+    import dlsg_amd
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    from oracle import torch_ref as R
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    args = dlsg_amd.msvd_shaped()
+    vocab = dlsg_amd.make_vocab(1000)
+    torch.manual_seed(0)
+    net = R.CapGnnModelRef(args, vocab)
+    net.load_state_dict(synth_state_dict(net.state_dict(), 0))
+    net.train()
+    opt = R.make_optimizer(net)
+    B = 8
+    frames, regions, caps, lens = synth_batch(args, 1000, B, 1)
+    random.seed(12)
+    R.train_step(net, opt, frames, regions, caps, lens, 0.95)     # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 50):
+        R.train_step(net, opt, frames, regions, caps, lens, 0.95)
+        n += 1
+    dt = time.time() - t0
+    return {'value': round(B * n / dt, 3), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d train steps (fwd+CE+bwd+Adam) of oracle/torch_ref.py, batch %d, MSVD-shaped 26x(2048+4096)+16x2048 '
+                      'regions, vocab 1000, torch CPU fp32, %d threads' % (n, B, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=64, help='clips per GPU (BASELINE configs[1]: 64)')
+    ap.add_argument('--shape', default='msvd', choices=['msvd', 'msrvtt'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eval-mode', action='store_true', help='dropout off (not the reported configuration)')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    import dlsg_amd
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+    assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+
+    if a.shape == 'msvd':
+        args, V = dlsg_amd.msvd_shaped(), 1000
+    else:
+        args, V = dlsg_amd.msrvtt_shaped(), 10000
+    vocab = dlsg_amd.make_vocab(V)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab)
+    net.load_state_dict(synth_state_dict(net.state_dict(), 0))       # identical random-init weights on every rank
+    net = net.to(dev)
+    net.train(not a.eval_mode)
+    frames, regions, caps, lens = synth_batch(args, V, a.batch, 1 + rank)   # each rank its own shard
+    frames, regions, caps, lens = frames.to(dev), regions.to(dev), caps.to(dev), lens.to(dev)
+    tr = dlsg_amd.Trainer(net, process_group=pg, world_size=world)
+    random.seed(12)                                                  # same coin sequence on all ranks (train_debug.py:34-36)
+    eps = dlsg_amd.ss_epsilon(0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = tr.step(frames, regions, caps, lens, eps)
+    barrier()
+    net.ops.prof = {}
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(frames, regions, caps, lens, eps)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = net.ops.prof_summary()
+    net.ops.prof = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_v = float(loss)
+
+    if rank == 0:
+        n_clips = a.batch * world * a.steps
+        out = {
+            'metric': 'clips/sec (train step, 26x(2048+4096) feats)', 'value': round(n_clips / dt, 2), 'unit': 'clips/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'CapGnnModel train step (fwd + ragged CE + bwd + Adam%s), %s-shaped: 26 frames x (2048+4096), '
+                                   '%d x 2048 regions, vocab %d, dropout %s, tf eps %.3f'
+                                   % (' + RCCL grad all-reduce' if world > 1 else '', a.shape.upper(), args.num_obj, V,
+                                      'off' if a.eval_mode else 'on', eps),
+                       'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'parallelism': 'dp%d' % world,
+                       'final_loss': round(loss_v, 5)},
+        }
+        g = prof.get('gemm_f32_mfma_128x128')
+        if g and g['ms_total'] > 0:
+            ach = g['work_total'] / (g['ms_total'] * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get('gemm_f32_mfma_128x128')
+                except Exception:
+                    traffic = None
+            out['roofline'] = {'kernel': 'gemm_kernel<128,128> (fp32 MFMA 32x32x2)', 'bound': 'mfma', 'achieved': round(ach, 2),
+                               'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                               'traffic': traffic, 'launches_timed': g['launches'],
+                               'avg_launch_ms': round(g['ms_total'] / g['launches'], 4),
+                               'share_of_step': round(g['ms_total'] / (1e3 * dt), 3)}
+        o = prof.get('o2v_graph_fwd')
+        if o and o['ms_total'] > 0:
+            ach = o['work_total'] / (o['ms_total'] * 1e-3) / 1e9
+            out['roofline_graph_attention'] = {'kernel': 'o2v_partial_kernel + o2v_combine_kernel', 'bound': 'hbm',
+                                               'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                               'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+                                               'avg_launch_ms': round(o['ms_total'] / o['launches'], 4)}
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

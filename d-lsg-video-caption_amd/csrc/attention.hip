@@ -355,6 +355,20 @@ __global__ __launch_bounds__(DA_THREADS) void decatt_bwd_kernel(const dlsg_decat
 
 }  // namespace
 
+extern "C" int dlsg_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(dlsg_gemm_args);
+        case 1: return (int)sizeof(dlsg_rowln_args);
+        case 2: return (int)sizeof(dlsg_rowln_bwd_args);
+        case 3: return (int)sizeof(dlsg_o2v_args);
+        case 4: return (int)sizeof(dlsg_decatt_args);
+        case 5: return (int)sizeof(dlsg_decatt_bwd_args);
+        case 6: return (int)sizeof(dlsg_lstm_pw_args);
+        case 7: return (int)sizeof(dlsg_lstm_pw_bwd_args);
+        default: return -1;
+    }
+}
+
 extern "C" int64_t dlsg_o2v_workspace_bytes(int B, int T, int H, int nsplit) {
     return (int64_t)B * nsplit * ((int64_t)T * H + 64) * 4;
 }

@@ -382,6 +382,12 @@ __global__ void permute_tb_kernel(const float* __restrict__ src, float* __restri
         dst[i] = src[((int64_t)t * B + b) * n + j];
     }
 }
+__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ idx,
+                                   float* __restrict__ dst, int64_t ldd, int n) {
+    const int r = blockIdx.x;
+    const float* s = src + idx[r] * lds_;
+    for (int j = threadIdx.x; j < n; j += blockDim.x) dst[(int64_t)r * ldd + j] = s[j];
+}
 __global__ void fill_kernel(float* __restrict__ dst, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
 }
@@ -563,6 +569,13 @@ extern "C" int dlsg_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, 
     if ((int64_t)rows * n == 0) return DLSG_OK;
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((int64_t)rows * n)), dim3(256), 0, ST(stream), x, ldx, y, ldy, rows, n, p,
                        seed, site);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_gather_rows(const float* src, int64_t lds_, const int64_t* idx, float* dst, int64_t ldd, int rows, int n,
+                                void* stream) {
+    if (rows == 0 || n == 0) return DLSG_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, ST(stream), src, lds_, idx, dst, ldd, n);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -76,12 +76,12 @@ class LstmPwBwdArgs(C.Structure):
 
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
-SYMBOLS = ['dlsg_abi_version', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
+SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
            'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
-           'dlsg_adam', 'dlsg_permute_tb']
+           'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows']
 
 
 def load_library(path=LIB_PATH):
@@ -94,6 +94,7 @@ def load_library(path=LIB_PATH):
     vp, P = C.c_void_p, C.POINTER
     sig = {
         'dlsg_abi_version': [],
+        'dlsg_struct_size': [i32],
         'dlsg_gemm': [P(GemmArgs), vp],
         'dlsg_slab_reduce': [vp, i32, i64, vp, vp, i64, i32, i32, i32, vp],
         'dlsg_rowln_fwd': [P(RowLnArgs), vp],
@@ -120,6 +121,7 @@ def load_library(path=LIB_PATH):
         'dlsg_log_softmax': [vp, vp, i32, i32, vp],
         'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp],
         'dlsg_permute_tb': [vp, vp, i32, i32, i32, vp],
+        'dlsg_gather_rows': [vp, i64, vp, vp, i64, i32, i32, vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -127,6 +129,9 @@ def load_library(path=LIB_PATH):
         fn.argtypes = args
         fn.restype = C.c_int64 if name == 'dlsg_o2v_workspace_bytes' else C.c_int
     return lib
+
+
+STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs]
 
 
 def _p(t):
@@ -150,6 +155,30 @@ class HipOps(object):
                                'there is no CPU fallback')
         if self.lib.dlsg_abi_version() != 1:
             raise RuntimeError('libdlsg_hip.so ABI mismatch')
+        self.prof = None          # set to {} by bench.py: key -> list of (start event, end event, algorithmic work)
+
+    # ------------------------------------------------------------------ live per-kernel timing (bench.py roofline)
+    def _prof_begin(self):
+        if self.prof is None:
+            return None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        return e0
+
+    def _prof_end(self, key, e0, work):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.prof.setdefault(key, []).append((e0, e1, work))
+
+    def prof_summary(self):
+        """key -> dict(launches, ms_total, work_total); call after torch.cuda.synchronize()."""
+        out = {}
+        for key, rec in (self.prof or {}).items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in rec)
+            out[key] = dict(launches=len(rec), ms_total=ms, work_total=float(sum(w for _, _, w in rec)))
+        return out
 
     # ------------------------------------------------------------------ plumbing
     @staticmethod
@@ -196,7 +225,15 @@ class HipOps(object):
             g = a.g[i]
             g.A, g.B, g.C = _p(A), _p(B), _p(Cc)
             g.lda, g.ldb, g.K = A.stride(-2), B.stride(-2), K
+        e0 = None
+        if self.prof is not None:
+            flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))
+            if flops >= 2e9:     # only the heavy launches are timed, so the events do not perturb the step
+                big = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups) >= 192
+                e0 = self._prof_begin()
         self._check(self.lib.dlsg_gemm(C.byref(a), self._stream()), 'dlsg_gemm')
+        if e0 is not None:
+            self._prof_end('gemm_f32_mfma_128x128' if big else 'gemm_f32_mfma_64x64', e0, flops)
 
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""
@@ -266,7 +303,10 @@ class HipOps(object):
             _p(ostats), _p(S)
         a.ws, a.ws_bytes = _p(ws), wsb
         a.B, a.T, a.NO, a.H, a.nsplit, a.scale, a.eps = B, T, NO, H, nsplit, scale, eps
+        e0 = self._prof_begin()
         self._check(self.lib.dlsg_o2v_fwd(C.byref(a), self._stream()), 'dlsg_o2v_fwd')
+        # algorithmic bytes: read y once + read v + write z
+        self._prof_end('o2v_graph_fwd', e0, 4.0 * B * (NO * H + 2 * T * H))
 
     # ------------------------------------------------------------------ decoder attention
     def _decatt_args(self, Kp, Vp, q, c, alpha, scale):
@@ -366,6 +406,12 @@ class HipOps(object):
     def fill(self, t, value):
         assert t.is_contiguous()
         self._check(self.lib.dlsg_fill(_p(t), i64(t.numel()), f32(value), self._stream()), 'fill')
+
+    def gather_rows(self, src, idx, dst):
+        """dst[r] = src[idx[r]] (2-d views; dst must not alias src)."""
+        rows, n = dst.shape
+        self._check(self.lib.dlsg_gather_rows(_p(src), i64(src.stride(0)), _p(idx), _p(dst), i64(dst.stride(0)), rows, n,
+                                              self._stream()), 'gather_rows')
 
     def permute_tb(self, src, dst):
         """dst[b, t, :] = src[t, b, :]  (both contiguous 3-d)."""

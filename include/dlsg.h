@@ -17,6 +17,9 @@ extern "C" {
 
 #define DLSG_ABI_VERSION 1
 int dlsg_abi_version(void);
+/* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
+ * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args): lets a binding verify its struct layout without a GPU. */
+int dlsg_struct_size(int which);
 
 /* ---------------------------------------------------------------- GEMM (fp32-in / fp32-acc MFMA 32x32x2)
  * Replaces every nn.Linear / LSTM gate matmul / torch.matmul on the path and their backward products:
@@ -195,6 +198,8 @@ int dlsg_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int rows
 int dlsg_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int n, float p, uint64_t seed,
                  uint32_t site, void* stream);
 int dlsg_fill(float* dst, int64_t n, float value, void* stream);
+/* dst[r, :] = src[idx[r], :]  (beam-search state reorder by back-pointer, allennlp_beamsearch.py:248-260) */
+int dlsg_gather_rows(const float* src, int64_t lds, const int64_t* idx, float* dst, int64_t ldd, int rows, int n, void* stream);
 /* dst[b,t,:] = src[t,b,:]: time-major decoder buffers -> the (B,L,V) layout Decoder.forward returns (layer.py:447) */
 int dlsg_permute_tb(const float* src, float* dst, int T, int B, int n, void* stream);
 

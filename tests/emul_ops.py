@@ -281,6 +281,9 @@ class EmulOps(object):
     def fill(self, t, value):
         t.fill_(value)
 
+    def gather_rows(self, src, idx, dst):
+        dst.copy_(src[idx])
+
     def permute_tb(self, src, dst):
         dst.copy_(src.transpose(0, 1))
 

@@ -103,3 +103,12 @@ def test_train_mode_dropout_backward_is_consistent():
     fd = (loss_at(h) - loss_at(-h)) / (2 * h)
     an = float((grad * d).sum())
     assert abs(fd - an) <= 0.05 * max(abs(an), 1e-3), (fd, an)
+
+
+@pytest.mark.parametrize('tag', SMALL)
+def test_beam5_ids(tag):
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    net.update_beam_size(5)
+    with torch.no_grad():
+        ids = net(frames, regions, None)[0]
+    assert np.array_equal(ids.numpy(), g['beam5_ids'])

@@ -1,0 +1,316 @@
+"""GPU (-m gpu): every HIP kernel of libdlsg_hip.so against the torch emulation of the same interface, on identical
+views (strides, offsets, ragged edges).  Tolerances are fp32: 2e-5 relative to the output scale unless stated."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from emul_ops import EmulOps, GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from dlsg_amd.hip import HipOps
+    return HipOps()
+
+
+def rnd(gen, *shape, scale=1.0):
+    return torch.randn(*shape, generator=gen) * scale
+
+
+def both(hip, build, run, outs, tol=2e-5, name=''):
+    """build(gen) -> dict of CPU base tensors; run(ops, t) executes the op on dict t (views are made inside run);
+    outs = names of tensors to compare."""
+    gen = torch.Generator().manual_seed(1234)
+    base = build(gen)
+    tc = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in base.items()}
+    tg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in base.items()}
+    run(EmulOps(), tc)
+    run(hip, tg)
+    torch.cuda.synchronize()
+    for o in outs:
+        a, b = tc[o], tg[o].cpu()
+        if a.dtype in (torch.int64, torch.int32):
+            assert torch.equal(a, b), (name, o)
+            continue
+        assert torch.isfinite(b).all(), (name, o, 'non-finite')
+        err = (a - b).abs().max().item()
+        ref = max(a.abs().max().item(), 1e-6)
+        assert err <= tol * max(ref, 1.0) + tol, (name, o, 'max err %g (ref scale %g)' % (err, ref))
+
+
+GEMM_SHAPES = [
+    # M, N, K
+    (64, 64, 32), (128, 128, 64), (1, 1, 1), (3, 50, 244), (70, 33, 100), (200, 130, 37), (257, 129, 65),
+    (26, 26, 2048), (416, 26, 64), (64, 4096, 300), (512, 1000, 96),
+]
+
+
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
+@pytest.mark.parametrize('shape', GEMM_SHAPES)
+def test_gemm_plain(hip, mode, shape):
+    M, N, K = shape
+
+    def build(g):
+        if mode == GEMM_NT:
+            A, B = rnd(g, M, K), rnd(g, N, K)
+        elif mode == GEMM_NN:
+            A, B = rnd(g, M, K), rnd(g, K, N)
+        else:
+            A, B = rnd(g, K, M), rnd(g, K, N)
+        return dict(A=A, B=B, C=torch.zeros(M, N), bias=rnd(g, N))
+
+    def run(ops, t):
+        ops.gemm(mode, [(t['A'], t['B'], t['C'])], alpha=0.5, bias=t['bias'])
+    both(hip, build, run, ['C'], tol=1e-5 * max(1.0, math.sqrt(K)), name='gemm%d %s' % (mode, shape))
+
+
+def test_gemm_asymmetric_identity(hip):
+    """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
+    n = 96
+    A = torch.eye(n)
+    B = torch.arange(n * n, dtype=torch.float32).view(n, n) / 7.0
+    for mode, Bm in ((GEMM_NT, B.t().contiguous()), (GEMM_NN, B), (GEMM_TN, B)):
+        C = torch.zeros(n, n).cuda()
+        hip.gemm(mode, [(A.cuda(), Bm.cuda(), C)])
+        torch.cuda.synchronize()
+        assert torch.equal(C.cpu(), B), mode
+
+
+def test_gemm_strided_views_flags_groups(hip):
+    def build(g):
+        return dict(X=rnd(g, 70, 300), W=rnd(g, 90, 300), out=rnd(g, 4, 70, 96), big=rnd(g, 70, 200))
+
+    def run(ops, t):
+        X, W = t['X'], t['W']
+        # column-sliced operands (unaligned offsets 3 and 5 -> scalar load path), accumulate + tanh into a strided C
+        ops.gemm(GEMM_NT, [(X[:, 3:131], W[:, 5:133], t['big'][:, 10:100])], flags=F_ACCUM | F_TANH)
+        # K-split groups into slabs
+        ops.gemm(GEMM_NT, [(X[:, 0:128], W[:, 0:128], t['out'][0, :, :90]), (X[:, 128:300], W[:, 128:300], t['out'][1, :, :90])])
+    both(hip, build, run, ['big', 'out'], tol=3e-5, name='gemm views')
+
+
+def test_gemm_batched(hip):
+    def build(g):
+        return dict(A=rnd(g, 5, 26, 64), Bm=rnd(g, 5, 40, 64), th=rnd(g, 8, 64), C1=torch.zeros(5, 26, 40),
+                    C2=torch.zeros(5, 26, 8), C3=torch.zeros(5, 64, 64), P=rnd(g, 5, 26, 40))
+
+    def run(ops, t):
+        ops.gemm(GEMM_NT, [(t['A'], t['Bm'], t['C1'])], alpha=0.25)
+        ops.gemm(GEMM_NT, [(t['A'], t['th'].unsqueeze(0).expand(5, 8, 64), t['C2'])])
+        ops.gemm(GEMM_TN, [(t['A'], t['A'], t['C3'])])
+    both(hip, build, run, ['C1', 'C2', 'C3'], name='gemm batched')
+
+
+def test_gemm_large_tile_path(hip):
+    def build(g):
+        return dict(A=rnd(g, 1700, 520), B=rnd(g, 1030, 520), C=torch.zeros(1700, 1030), bias=rnd(g, 1030))
+
+    def run(ops, t):
+        ops.gemm(GEMM_NT, [(t['A'], t['B'], t['C'])], bias=t['bias'], flags=F_TANH)
+    both(hip, build, run, ['C'], tol=2e-5, name='gemm 128 tile')
+
+
+def test_slab_reduce_colsum(hip):
+    def build(g):
+        return dict(s=rnd(g, 5, 33, 70), out=rnd(g, 33, 80), b=rnd(g, 70), part=rnd(g, 1000, 130), cs=rnd(g, 130))
+
+    def run(ops, t):
+        ops.slab_reduce(t['s'], t['out'][:, :70], bias=t['b'], flags=F_ACCUM)
+        ops.colsum(t['part'][:, 5:125], t['cs'][:120], accum=True)
+    both(hip, build, run, ['out', 'cs'], tol=5e-5, name='slab/colsum')
+
+
+@pytest.mark.parametrize('n', [48, 64, 1024, 2048, 100])
+@pytest.mark.parametrize('variant', ['plain', 'tanh', 'post', 'pe_drop', 'res'])
+def test_rowln_fwd_bwd(hip, n, variant):
+    rows = 77
+    kw = dict(plain=dict(), tanh=dict(pre_tanh=1), post=dict(post_tanh=1),
+              pe_drop=dict(p1=0.3, site1=3, p2=0.2, site2=4, seed=99), res=dict(pre_tanh=1))[variant]
+
+    def build(g):
+        d = dict(x=rnd(g, rows, n + 8), gamma=1 + 0.2 * rnd(g, n), beta=0.2 * rnd(g, n), y=torch.zeros(rows, n),
+                 st=torch.zeros(rows, 2), dy=rnd(g, rows, n), dx=torch.zeros(rows, n), pe=rnd(g, 26, n),
+                 res=rnd(g, rows, n), part=torch.zeros(min(rows, 256), 2, n))
+        return d
+
+    def run(ops, t):
+        x = t['x'][:, 4:4 + n]
+        extra = dict(kw)
+        if variant == 'pe_drop':
+            extra['pe'] = t['pe']
+        if variant == 'res':
+            extra['res'] = t['res']
+        ops.rowln_fwd(x, t['gamma'], t['beta'], t['y'], t['st'], **extra)
+        ops.rowln_bwd(t['dy'], x, t['gamma'], t['beta'], t['dx'], stats=t['st'], dgb_part=t['part'], **extra)
+        t['dgb'] = t['part'].sum(0)
+    both(hip, build, run, ['y', 'st', 'dx', 'dgb'], tol=3e-5, name='rowln %d %s' % (n, variant))
+
+
+def test_rowln_bwd_mode2_and_accum(hip):
+    def build(g):
+        return dict(y=torch.tanh(rnd(g, 300, 64)), gamma=1 + 0.1 * rnd(g, 64), beta=0.1 * rnd(g, 64), dy=rnd(g, 300, 64),
+                    dx=rnd(g, 300, 64), part=torch.zeros(256, 2, 64))
+
+    def run(ops, t):
+        ops.rowln_bwd(t['dy'], t['y'], t['gamma'], t['beta'], t['dx'], pre_tanh=2, dgb_part=t['part'], accum_dx=True)
+        t['dgb'] = t['part'].sum(0)
+    both(hip, build, run, ['dx', 'dgb'], tol=3e-5, name='rowln mode2')
+
+
+@pytest.mark.parametrize('shape', [(3, 26, 8), (78, 26, 1), (2, 416, 26), (4, 936, 26)])
+def test_softmax_fwd_bwd(hip, shape):
+    outer, n, inner = shape
+
+    def build(g):
+        return dict(x=rnd(g, outer, n, inner, scale=3.0), y=torch.zeros(outer, n, inner), dy=rnd(g, outer, n, inner),
+                    dx=torch.zeros(outer, n, inner), mask=(torch.rand(outer, n, inner, generator=g) > 0.3).float())
+
+    def run(ops, t):
+        ops.softmax_fwd(t['x'], t['y'], outer, n, inner)
+        ops.softmax_bwd(t['y'], t['dy'], t['dx'], outer, n, inner)
+        if inner == 1:
+            t['ym'] = torch.zeros_like(t['y'])
+            ops.softmax_fwd(t['x'], t['ym'], outer, n, inner, mask=t['mask'])
+    both(hip, build, run, ['y', 'dx'] + (['ym'] if inner == 1 else []), tol=1e-5, name='softmax %s' % (shape,))
+
+
+O2V_CASES = [
+    # B, T, O, H, nsplit
+    (3, 26, 16, 64, 1), (3, 26, 16, 64, 4), (2, 26, 6, 64, 3), (2, 7, 5, 64, 2), (2, 32, 9, 64, 13),
+    (2, 26, 16, 1024, 1), (3, 26, 16, 1024, 4), (2, 26, 36, 1024, 8), (1, 26, 16, 512, 2),
+]
+
+
+@pytest.mark.parametrize('case', O2V_CASES)
+def test_o2v_fused(hip, case):
+    B, T, O, H, ns = case
+    NO = T * O
+
+    def build(g):
+        return dict(y=torch.tanh(rnd(g, B, NO, H)), v=rnd(g, B, T, H), go=1 + 0.2 * rnd(g, H), bo=0.2 * rnd(g, H),
+                    z=torch.zeros(B * T, H), ml=torch.zeros(B * T, 2), os=torch.zeros(B * NO, 2), S=torch.zeros(B, NO, T))
+
+    def run(ops, t):
+        ops.o2v_fwd(t['y'], t['v'], t['go'], t['bo'], t['z'], t['ml'], t['os'], t['S'], 1.0 / math.sqrt(H / 4.0), ns)
+        # the online-softmax (m, l) pair is only defined up to the split; compare the invariant log-sum-exp
+        t['lse'] = t['ml'][:, 0] + torch.log(t['ml'][:, 1])
+    both(hip, build, run, ['z', 'os', 'S', 'lse'], tol=3e-5, name='o2v %s' % (case,))
+
+
+def test_o2v_online_softmax_rescale_branch(hip):
+    """Force the running max to jump at a late tile (guide 5.4 rule 26): one object aligned with one frame."""
+    B, T, O, H = 2, 26, 16, 64
+    NO = T * O
+    g = torch.Generator().manual_seed(5)
+    y = torch.tanh(rnd(g, B, NO, H)) * 0.1
+    v = rnd(g, B, T, H)
+    y[:, NO - 3] = torch.tanh(v[:, 11] * 3.0)          # huge score for frame 11 in the last tile
+    y[:, 40] = torch.tanh(v[:, 5] * 3.0)
+    go, bo = torch.ones(H), torch.zeros(H)
+    outs = {}
+    for nm, ops, dev in (('c', EmulOps(), 'cpu'), ('g', hip, 'cuda')):
+        z = torch.zeros(B * T, H, device=dev); ml = torch.zeros(B * T, 2, device=dev)
+        os_ = torch.zeros(B * NO, 2, device=dev); S = torch.zeros(B, NO, T, device=dev)
+        ops.o2v_fwd(y.to(dev), v.to(dev), go.to(dev), bo.to(dev), z, ml, os_, S, 1.0, 1)
+        outs[nm] = z.cpu()
+    assert torch.isfinite(outs['g']).all()
+    assert (outs['c'] - outs['g']).abs().max().item() <= 5e-5
+
+
+@pytest.mark.parametrize('dims', [(5, 8, 48, 64, 2), (64, 8, 1024, 1024, 2), (3, 26, 48, 64, 1), (7, 5, 1024, 1024, 2)])
+def test_decatt_fwd_bwd(hip, dims):
+    B, P, Q, H, ns = dims
+
+    def build(g):
+        d = dict(q=rnd(g, B, Q + 4), alpha=torch.zeros(B, ns * P), dalpha=rnd(g, B, ns * P), dq=rnd(g, B, Q + 8))
+        for s in range(ns):
+            d['K%d' % s] = rnd(g, B, P, Q, scale=0.2); d['V%d' % s] = rnd(g, B, P, H)
+            d['c%d' % s] = torch.zeros(B, H); d['dc%d' % s] = rnd(g, B, H)
+            d['dK%d' % s] = rnd(g, B, P, Q); d['dV%d' % s] = rnd(g, B, P, H)
+        return d
+
+    def run(ops, t):
+        Kp = [t['K%d' % s] for s in range(ns)]; Vp = [t['V%d' % s] for s in range(ns)]
+        q = t['q'][:, 2:2 + Q]
+        ops.decatt_fwd(Kp, Vp, q, [t['c%d' % s] for s in range(ns)], t['alpha'], 0.3)
+        ops.decatt_bwd(Kp, Vp, q, t['alpha'], [t['dc%d' % s] for s in range(ns)], [t['dK%d' % s] for s in range(ns)],
+                       [t['dV%d' % s] for s in range(ns)], t['dq'][:, 4:4 + Q], 0.3, accum_dq=True, dalpha=t['dalpha'])
+    outs = ['alpha', 'dq'] + [k % s for s in range(ns) for k in ('c%d', 'dK%d', 'dV%d')]
+    both(hip, build, run, outs, tol=3e-5, name='decatt %s' % (dims,))
+
+
+@pytest.mark.parametrize('dims', [(3, 48), (64, 1024), (5, 96)])
+def test_lstm_pointwise(hip, dims):
+    B, H = dims
+
+    def build(g):
+        return dict(slabs=rnd(g, 3, B, 4 * H), add=rnd(g, B, 2, 4 * H), bi=rnd(g, 4 * H), bh=rnd(g, 4 * H), cp=rnd(g, B, H),
+                    c=torch.zeros(B, H), h=torch.zeros(B, 2 * H), h2=torch.zeros(B, H), gates=torch.zeros(B, 3, 4 * H),
+                    dh=rnd(g, B, H), dh2=rnd(g, B, H), dcn=rnd(g, B, H), dg=torch.zeros(B, 4 * H), dcp=torch.zeros(B, H))
+
+    def run(ops, t):
+        gates = t['gates'][:, 1]
+        ops.lstm_pw_fwd(t['slabs'], t['c'], B, H, addend=t['add'][:, 1], b_ih=t['bi'], b_hh=t['bh'], c_prev=t['cp'],
+                        h=t['h'][:, H:], h2=t['h2'], gates=gates, p=0.3, site=7, seed=5)
+        ops.lstm_pw_bwd(gates, t['c'], t['dg'], B, H, c_prev=t['cp'], dh=t['dh'], dh2=t['dh2'], dc_next=t['dcn'],
+                        dc_prev=t['dcp'], p=0.3, site=7, seed=5)
+        t['c0'] = torch.zeros_like(t['c']); t['g0'] = torch.zeros(B, 4 * H, device=t['c'].device)
+        ops.lstm_pw_fwd(None, t['c0'], B, H, addend=t['add'][:, 0], gates=t['g0'])
+    both(hip, build, run, ['c', 'h', 'h2', 'gates', 'dg', 'dcp', 'c0', 'g0'], tol=1e-5, name='lstm_pw %s' % (dims,))
+
+
+def test_movers_embed_argmax(hip):
+    def build(g):
+        lg = rnd(g, 9, 1000)
+        lg[3, 17] = lg[3, 900] = 50.0           # exact tie -> lowest index
+        lg[5, 999] = 60.0
+        return dict(x=rnd(g, 4, 8, 64), out=torch.zeros(4, 200), dout=rnd(g, 4, 200), dx=rnd(g, 4, 8, 64),
+                    E=rnd(g, 50, 20), ids=torch.randint(0, 50, (30,), generator=g), we=torch.zeros(30, 24),
+                    dwe=rnd(g, 30, 24), dE=torch.zeros(50, 20), lg=lg, am=torch.zeros(9, dtype=torch.int64),
+                    src=rnd(g, 26, 5, 33), dst=torch.zeros(5, 26, 33), dr=rnd(g, 40, 64), dro=torch.zeros(40, 64),
+                    f=rnd(g, 1000))
+
+    def run(ops, t):
+        ops.mean_rows_fwd(t['x'], t['out'][:, 100:164])
+        ops.mean_rows_bwd(t['dout'][:, 3:67], t['dx'], accum=True)
+        ops.embed_fwd(t['E'], t['ids'], t['we'][:, :20], p=0.3, seed=11, site=6, row0=60)
+        ops.embed_bwd(t['dwe'][:, 2:22], t['ids'], t['dE'], p=0.3, seed=11, site=6, row0=60)
+        ops.argmax(t['lg'], t['am'])
+        ops.permute_tb(t['src'], t['dst'])
+        ops.dropout(t['dr'], t['dro'], 0.3, 77, 5)
+        ops.copy2d(t['dr'][:, :32], t['dro'][:, 32:], accum=True)
+        ops.fill(t['f'], 2.5)
+    both(hip, build, run, ['out', 'dx', 'we', 'dE', 'am', 'dst', 'dro', 'f'], tol=1e-5, name='movers')
+
+
+@pytest.mark.parametrize('tm', [True, False])
+def test_ce_ragged_and_log_softmax(hip, tm):
+    B, L, V = 5, 26, 61
+
+    def build(g):
+        lg = rnd(g, L, B, V, scale=2.0) if tm else rnd(g, B, L, V, scale=2.0)
+        return dict(lg=lg, tgt=torch.randint(0, V, (B, L), generator=g), lens=torch.tensor([26, 19, 30, 5, 1]),
+                    dl=torch.zeros_like(lg), rl=torch.zeros(B * L), loss=torch.zeros(1), ls=torch.zeros(B * L, V))
+
+    def run(ops, t):
+        ops.ce_ragged(t['lg'], t['tgt'], t['lens'], t['dl'], t['rl'], t['loss'], tm)
+        ops.log_softmax(t['lg'].view(B * L, V), t['ls'])
+    both(hip, build, run, ['dl', 'loss', 'ls'], tol=1e-5, name='ce')
+
+
+def test_adam_matches_torch_optim(hip):
+    g = torch.Generator().manual_seed(3)
+    p0, grads = rnd(g, 5000), [rnd(g, 5000) for _ in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1.6e-4, betas=(0.5, 0.9))
+    p = p0.clone().cuda(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for i, gr in enumerate(grads):
+        ref.grad = gr.clone() / 4
+        opt.step()
+        hip.adam(p, gr.cuda(), m, v, 1.6e-4, 0.5, 0.9, 1e-8, i + 1, 0.25)
+    torch.cuda.synchronize()
+    assert (p.cpu() - ref.detach()).abs().max().item() <= 1e-6
