@@ -32,12 +32,37 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """Oracle (oracle/torch_ref.py, kind 'port') train step at BASELINE configs[0]: B=8, MSVD-shaped, CPU fp32."""
+def usable_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box reports 256 logical
+    CPUs but a container quota far below that; oversubscribing torch's thread pool there is pathologically slow)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle (oracle/torch_ref.py, kind 'port') train step at BASELINE configs[0]: B=8, MSVD-shaped, CPU fp32.
+    Bounded: one warm-up step, then steps until the budget is spent; if the warm-up alone exceeds the budget it IS
+    the sample."""
     import dlsg_amd
     from dlsg_amd.synth import synth_state_dict, synth_batch
     from oracle import torch_ref as R
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     args = dlsg_amd.msvd_shaped()
     vocab = dlsg_amd.make_vocab(1000)
@@ -49,13 +74,17 @@ def cpu_baseline(seconds_budget=25.0):
     B = 8
     frames, regions, caps, lens = synth_batch(args, 1000, B, 1)
     random.seed(12)
-    R.train_step(net, opt, frames, regions, caps, lens, 0.95)     # warm-up
     t0 = time.time()
-    n = 0
-    while n < 2 or (time.time() - t0 < seconds_budget and n < 50):
-        R.train_step(net, opt, frames, regions, caps, lens, 0.95)
-        n += 1
-    dt = time.time() - t0
+    R.train_step(net, opt, frames, regions, caps, lens, 0.95)     # warm-up (also the sample if the host is slow)
+    warm = time.time() - t0
+    n, dt = 1, warm
+    if warm < seconds_budget / 3:
+        t0 = time.time()
+        n = 0
+        while time.time() - t0 < seconds_budget - warm and n < 40:
+            R.train_step(net, opt, frames, regions, caps, lens, 0.95)
+            n += 1
+        dt = time.time() - t0
     return {'value': round(B * n / dt, 3), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
             'sample': '%d train steps (fwd+CE+bwd+Adam) of oracle/torch_ref.py, batch %d, MSVD-shaped 26x(2048+4096)+16x2048 '
                       'regions, vocab 1000, torch CPU fp32, %d threads' % (n, B, cores)}
