@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: the data-parallel path of dlsg_amd.Trainer (bucketed gradient all-reduce + 1/world
+folded into Adam) equals the single-process mean of the two shards' gradients (DDP mean-of-means, run_gun.py:63-64).
+Kernels are the test-only emulation; what is under test is the sharding / bucketing / reduction logic."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    import dlsg_amd
+    from emul_ops import EmulOps
+    from helpers import load_case, weights_and_inputs
+    args, vocab, g, kind = load_case('small_msrvtt')       # batch 4 -> two shards of 2
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab).eval()
+    net.set_ops(EmulOps())
+    sd, frames, regions, caps, lens = weights_and_inputs(net, g, args)
+    net.load_state_dict(sd)
+    return net, frames, regions, caps, lens
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'd-lsg-video-caption_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import dlsg_amd
+    net, frames, regions, caps, lens = _build()
+    sl = slice(rank * 2, rank * 2 + 2)
+    tr = dlsg_amd.Trainer(net, world_size=world)
+    loss = tr.step(frames[sl], regions[sl], caps[sl], lens[sl], 1.0)
+    np.save(os.path.join(out_dir, 'flat%d.npy' % rank), net._flat.numpy())
+    np.save(os.path.join(out_dir, 'loss%d.npy' % rank), loss.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_step_equals_mean_of_shard_gradients(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    f0, f1 = np.load(tmp_path / 'flat0.npy'), np.load(tmp_path / 'flat1.npy')
+    assert np.array_equal(f0, f1)                           # replicas stay bit-identical
+    # single process: gradients of each shard, averaged, one Adam step
+    import dlsg_amd
+    net, frames, regions, caps, lens = _build()
+    tr = dlsg_amd.Trainer(net, lr=0.0)
+    grads = []
+    for r in range(2):
+        sl = slice(r * 2, r * 2 + 2)
+        tr.step(frames[sl], regions[sl], caps[sl], lens[sl], 1.0)
+        grads.append(net._gflat.clone())
+    net2, *_ = _build()
+    tr2 = dlsg_amd.Trainer(net2)
+    net2._gflat.copy_((grads[0] + grads[1]))
+    tr2.t = 1
+    net2.ops.adam(net2._flat, net2._gflat, tr2.m, tr2.v, tr2.lr, 0.5, 0.9, 1e-8, 1, 0.5)
+    assert np.abs(net2._flat.numpy() - f0).max() <= 1e-6
