@@ -271,87 +271,158 @@ int o2v_launch(const dlsg_o2v_args* a, hipStream_t st) {
 }
 
 // ================================================================================================ decoder attention
-constexpr int DA_THREADS = 256;
+// One workgroup per clip: 2 x 256 threads, each half owns one attention stream (proposal set).  K' (P x Q) and
+// V' (P x H) of the clip are streamed once with 16-B loads (this is the "decoder attention over cached K,V" traffic of
+// 2*P*(Q+H)*4 B per clip, stream and step); dots are wave reductions, softmax over P <= 32 in LDS.
+constexpr int DA_HALF = 256;
+constexpr int DA_THREADS = 2 * DA_HALF;
 constexpr int DA_MAXP = 32;
+constexpr int DA_MAXQ = 2048;
 
-__global__ __launch_bounds__(DA_THREADS) void decatt_fwd_kernel(const dlsg_decatt_args a) {
-    __shared__ float sc[DA_MAXP];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int P = a.P, Q = a.Q, H = a.H;
-    const float* q = a.q + (int64_t)b * a.ldq;
-    for (int s = 0; s < a.nstream; ++s) {
-        const float* Kp = a.Kp[s] + (int64_t)b * P * Q;
-        const float* Vp = a.Vp[s] + (int64_t)b * P * H;
-        __syncthreads();
-        for (int p = w; p < P; p += DA_THREADS / 64) {
-            float d = 0.f;
-            for (int j = lane; j < Q; j += 64) d += Kp[(int64_t)p * Q + j] * q[j];
-            d = wave_sum(d);
-            if (lane == 0) sc[p] = d * a.scale;
+template <bool VEC>
+__device__ __forceinline__ float dot_row(const float* __restrict__ a, const float* __restrict__ b, int n, int lane) {
+    float d = 0.f;
+    if (VEC) {
+        for (int j = 4 * lane; j < n; j += 256) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(a + j);
+            const f32x4 y = *reinterpret_cast<const f32x4*>(b + j);
+            d += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
         }
-        __syncthreads();
-        float m = -INFINITY;
-        for (int p = 0; p < P; ++p) m = fmaxf(m, sc[p]);
-        float l = 0.f;
-        for (int p = 0; p < P; ++p) l += __expf(sc[p] - m);
-        const float inv = 1.f / l;
-        if (threadIdx.x < P && a.alpha) a.alpha[(int64_t)b * a.nstream * P + s * P + threadIdx.x] = __expf(sc[threadIdx.x] - m) * inv;
-        float* c = a.c[s] + (int64_t)b * a.ldc;
-        for (int j = threadIdx.x; j < H; j += DA_THREADS) {
+    } else {
+        for (int j = lane; j < n; j += 64) d += a[j] * b[j];
+    }
+    return wave_sum(d);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(DA_THREADS) void decatt_fwd_kernel(const dlsg_decatt_args a) {
+    __shared__ float sc[2][DA_MAXP];
+    const int b = blockIdx.x;
+    const int s = threadIdx.x / DA_HALF, tid = threadIdx.x % DA_HALF;
+    const int lane = tid & 63, w = tid >> 6;
+    const int P = a.P, Q = a.Q, H = a.H;
+    const bool active = s < a.nstream;
+    const float* q = a.q + (int64_t)b * a.ldq;
+    const float* Kp = active ? a.Kp[s] + (int64_t)b * P * Q : nullptr;
+    const float* Vp = active ? a.Vp[s] + (int64_t)b * P * H : nullptr;
+    if (active)
+        for (int p = w; p < P; p += DA_HALF / 64) {
+            const float d = dot_row<VEC>(Kp + (int64_t)p * Q, q, Q, lane);
+            if (lane == 0) sc[s][p] = d * a.scale;
+        }
+    __syncthreads();
+    if (!active) return;
+    float m = -INFINITY;
+    for (int p = 0; p < P; ++p) m = fmaxf(m, sc[s][p]);
+    float l = 0.f;
+    for (int p = 0; p < P; ++p) l += __expf(sc[s][p] - m);
+    const float inv = 1.f / l;
+    if (tid < P && a.alpha) a.alpha[(int64_t)b * a.nstream * P + s * P + tid] = __expf(sc[s][tid] - m) * inv;
+    float* c = a.c[s] + (int64_t)b * a.ldc;
+    if (VEC) {
+        for (int j = 4 * tid; j < H; j += 4 * DA_HALF) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < P; ++p) {
+                const float wp = __expf(sc[s][p] - m) * inv;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Vp + (int64_t)p * H + j);
+                acc[0] += wp * v[0]; acc[1] += wp * v[1]; acc[2] += wp * v[2]; acc[3] += wp * v[3];
+            }
+            *reinterpret_cast<f32x4*>(c + j) = acc;
+        }
+    } else {
+        for (int j = tid; j < H; j += DA_HALF) {
             float acc = 0.f;
-            for (int p = 0; p < P; ++p) acc += __expf(sc[p] - m) * inv * Vp[(int64_t)p * H + j];
+            for (int p = 0; p < P; ++p) acc += __expf(sc[s][p] - m) * inv * Vp[(int64_t)p * H + j];
             c[j] = acc;
         }
     }
 }
 
-// alpha (saved forward weights) is read from a.f.alpha.
+// alpha (saved forward weights) is read from a.f.alpha.  dK', dV' accumulate over the word loop; dq of the two streams
+// is combined through LDS in a fixed order (deterministic).
+template <bool VEC>
 __global__ __launch_bounds__(DA_THREADS) void decatt_bwd_kernel(const dlsg_decatt_bwd_args a) {
-    __shared__ float dw[DA_MAXP];
-    __shared__ float ds[DA_MAXP];
+    __shared__ float dw[2][DA_MAXP];
+    __shared__ float ds[2][DA_MAXP];
+    __shared__ float dqs[2][DA_MAXQ];
     const dlsg_decatt_args& f = a.f;
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int s = threadIdx.x / DA_HALF, tid = threadIdx.x % DA_HALF;
+    const int lane = tid & 63, w = tid >> 6;
     const int P = f.P, Q = f.Q, H = f.H;
+    const bool active = s < f.nstream;
     const float* q = f.q + (int64_t)b * f.ldq;
-    float* dq = a.dq + (int64_t)b * a.lddq;
-    for (int s = 0; s < f.nstream; ++s) {
-        const float* Kp = f.Kp[s] + (int64_t)b * P * Q;
-        const float* Vp = f.Vp[s] + (int64_t)b * P * H;
-        const float* wgt = f.alpha + (int64_t)b * f.nstream * P + s * P;
-        const float* dc = a.dc[s] + (int64_t)b * a.lddc;
-        float* dKp = a.dKp[s] + (int64_t)b * P * Q;
-        float* dVp = a.dVp[s] + (int64_t)b * P * H;
-        __syncthreads();
-        for (int p = w; p < P; p += DA_THREADS / 64) {
-            float d = 0.f;
-            for (int j = lane; j < H; j += 64) d += dc[j] * Vp[(int64_t)p * H + j];
-            d = wave_sum(d);
-            if (lane == 0) dw[p] = d + (a.dalpha ? a.dalpha[(int64_t)b * f.nstream * P + s * P + p] : 0.f);
+    const float* Kp = active ? f.Kp[s] + (int64_t)b * P * Q : nullptr;
+    const float* Vp = active ? f.Vp[s] + (int64_t)b * P * H : nullptr;
+    const float* wgt = active ? f.alpha + (int64_t)b * f.nstream * P + s * P : nullptr;
+    const float* dc = active ? a.dc[s] + (int64_t)b * a.lddc : nullptr;
+    float* dKp = active ? a.dKp[s] + (int64_t)b * P * Q : nullptr;
+    float* dVp = active ? a.dVp[s] + (int64_t)b * P * H : nullptr;
+    if (active)
+        for (int p = w; p < P; p += DA_HALF / 64) {
+            const float d = dot_row<VEC>(Vp + (int64_t)p * H, dc, H, lane);
+            if (lane == 0) dw[s][p] = d + (a.dalpha ? a.dalpha[(int64_t)b * f.nstream * P + s * P + p] : 0.f);
         }
-        __syncthreads();
-        if (threadIdx.x < P) {
-            float dot = 0.f;
-            for (int p = 0; p < P; ++p) dot += wgt[p] * dw[p];
-            ds[threadIdx.x] = wgt[threadIdx.x] * (dw[threadIdx.x] - dot) * f.scale;
-        }
-        __syncthreads();
-        for (int j = threadIdx.x; j < H; j += DA_THREADS) {
-            const float g = dc[j];
-            for (int p = 0; p < P; ++p) dVp[(int64_t)p * H + j] += wgt[p] * g;
-        }
-        for (int j = threadIdx.x; j < Q; j += DA_THREADS) {
-            const float qj = q[j];
-            float acc = (s == 0 && !a.accum_dq) ? 0.f : dq[j];
-            for (int p = 0; p < P; ++p) {
-                dKp[(int64_t)p * Q + j] += ds[p] * qj;
-                acc += ds[p] * Kp[(int64_t)p * Q + j];
+    __syncthreads();
+    if (active && tid < P) {
+        float dot = 0.f;
+        for (int p = 0; p < P; ++p) dot += wgt[p] * dw[s][p];
+        ds[s][tid] = wgt[tid] * (dw[s][tid] - dot) * f.scale;
+    }
+    __syncthreads();
+    if (active) {
+        if (VEC) {
+            for (int j = 4 * tid; j < H; j += 4 * DA_HALF) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dc + j);
+                for (int p = 0; p < P; ++p) {
+                    f32x4* dv = reinterpret_cast<f32x4*>(dVp + (int64_t)p * H + j);
+                    f32x4 t = *dv;
+                    const float wp = wgt[p];
+                    t[0] += wp * g[0]; t[1] += wp * g[1]; t[2] += wp * g[2]; t[3] += wp * g[3];
+                    *dv = t;
+                }
             }
-            dq[j] = acc;
+            for (int j = 4 * tid; j < Q; j += 4 * DA_HALF) {
+                const f32x4 qj = *reinterpret_cast<const f32x4*>(q + j);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int p = 0; p < P; ++p) {
+                    const float dsp = ds[s][p];
+                    f32x4* dk = reinterpret_cast<f32x4*>(dKp + (int64_t)p * Q + j);
+                    f32x4 t = *dk;
+                    t[0] += dsp * qj[0]; t[1] += dsp * qj[1]; t[2] += dsp * qj[2]; t[3] += dsp * qj[3];
+                    *dk = t;
+                    const f32x4 k = *reinterpret_cast<const f32x4*>(Kp + (int64_t)p * Q + j);
+                    acc[0] += dsp * k[0]; acc[1] += dsp * k[1]; acc[2] += dsp * k[2]; acc[3] += dsp * k[3];
+                }
+                dqs[s][j] = acc[0]; dqs[s][j + 1] = acc[1]; dqs[s][j + 2] = acc[2]; dqs[s][j + 3] = acc[3];
+            }
+        } else {
+            for (int j = tid; j < H; j += DA_HALF) {
+                const float g = dc[j];
+                for (int p = 0; p < P; ++p) dVp[(int64_t)p * H + j] += wgt[p] * g;
+            }
+            for (int j = tid; j < Q; j += DA_HALF) {
+                const float qj = q[j];
+                float acc = 0.f;
+                for (int p = 0; p < P; ++p) {
+                    dKp[(int64_t)p * Q + j] += ds[s][p] * qj;
+                    acc += ds[s][p] * Kp[(int64_t)p * Q + j];
+                }
+                dqs[s][j] = acc;
+            }
         }
     }
+    __syncthreads();
+    float* dq = a.dq + (int64_t)b * a.lddq;
+    for (int j = threadIdx.x; j < Q; j += DA_THREADS) {
+        float acc = a.accum_dq ? dq[j] : 0.f;
+        acc += dqs[0][j];
+        if (f.nstream > 1) acc += dqs[1][j];
+        dq[j] = acc;
+    }
 }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
@@ -389,14 +460,25 @@ extern "C" int dlsg_o2v_fwd(const dlsg_o2v_args* a, void* stream) {
 extern "C" int dlsg_decatt_fwd(const dlsg_decatt_args* a, void* stream) {
     if (!a || a->P < 1 || a->P > DA_MAXP || a->nstream < 1 || a->nstream > 2) return DLSG_EINVAL;
     if (a->B == 0) return DLSG_OK;
-    hipLaunchKernelGGL(decatt_fwd_kernel, dim3(a->B), dim3(DA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), *a);
+    bool vec = (a->Q % 4 == 0) && (a->H % 4 == 0) && (a->ldq % 4 == 0) && (a->ldc % 4 == 0) && aligned16(a->q);
+    for (int s = 0; s < a->nstream; ++s) vec = vec && aligned16(a->Kp[s]) && aligned16(a->Vp[s]) && aligned16(a->c[s]);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (vec) hipLaunchKernelGGL(decatt_fwd_kernel<true>, dim3(a->B), dim3(DA_THREADS), 0, st, *a);
+    else hipLaunchKernelGGL(decatt_fwd_kernel<false>, dim3(a->B), dim3(DA_THREADS), 0, st, *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
 extern "C" int dlsg_decatt_bwd(const dlsg_decatt_bwd_args* a, void* stream) {
     if (!a || a->f.P < 1 || a->f.P > DA_MAXP || a->f.nstream < 1 || a->f.nstream > 2 || !a->f.alpha) return DLSG_EINVAL;
+    if (a->f.Q > DA_MAXQ) return DLSG_EINVAL;
     if (a->f.B == 0) return DLSG_OK;
-    hipLaunchKernelGGL(decatt_bwd_kernel, dim3(a->f.B), dim3(DA_THREADS), 0, reinterpret_cast<hipStream_t>(stream), *a);
+    const dlsg_decatt_args& f = a->f;
+    bool vec = (f.Q % 4 == 0) && (f.H % 4 == 0) && (f.ldq % 4 == 0) && (a->lddc % 4 == 0) && aligned16(f.q);
+    for (int s = 0; s < f.nstream; ++s)
+        vec = vec && aligned16(f.Kp[s]) && aligned16(f.Vp[s]) && aligned16(a->dc[s]) && aligned16(a->dKp[s]) && aligned16(a->dVp[s]);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (vec) hipLaunchKernelGGL(decatt_bwd_kernel<true>, dim3(f.B), dim3(DA_THREADS), 0, st, *a);
+    else hipLaunchKernelGGL(decatt_bwd_kernel<false>, dim3(f.B), dim3(DA_THREADS), 0, st, *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -15,6 +15,7 @@ constexpr int LN_MAXPT = 8;  // n <= 2048
 __global__ __launch_bounds__(LN_THREADS) void rowln_fwd_kernel(const dlsg_rowln_args a) {
     __shared__ float red[16];
     const int n = a.n;
+    const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
     for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
         const float* x = a.x + (int64_t)row * a.ldx;
         const float* res = a.res ? a.res + (int64_t)row * a.ldres : nullptr;
@@ -50,10 +51,10 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_fwd_kernel(const dlsg_rowln_
                 float v = (t[i] - mean) * rstd * a.gamma[j] + a.beta[j];
                 if (a.post_tanh) v = tanhf(v);
                 const uint64_t idx = (uint64_t)row * n + j;
-                if (a.p1 > 0.f) v *= drop_scale(a.seed, a.site1, idx, a.p1);
+                if (a.p1 > 0.f) v *= drop_scale(seed, a.site1, idx, a.p1);
                 if (pe) {
                     v += pe[j];
-                    if (a.p2 > 0.f) v *= drop_scale(a.seed, a.site2, idx, a.p2);
+                    if (a.p2 > 0.f) v *= drop_scale(seed, a.site2, idx, a.p2);
                 }
                 y[j] = v;
             }
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_
     __shared__ float red[16];
     const dlsg_rowln_args& a = b.f;
     const int n = a.n;
+    const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
     float dg[LN_MAXPT], db[LN_MAXPT];
 #pragma unroll
     for (int i = 0; i < LN_MAXPT; ++i) { dg[i] = 0.f; db[i] = 0.f; }
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_
                 const float xh = (t[i] - mean) * rstd;
                 float g = dy[j];
                 const uint64_t idx = (uint64_t)row * n + j;
-                if (a.pe && a.p2 > 0.f) g *= drop_scale(a.seed, a.site2, idx, a.p2);
-                if (a.p1 > 0.f) g *= drop_scale(a.seed, a.site1, idx, a.p1);
+                if (a.pe && a.p2 > 0.f) g *= drop_scale(seed, a.site2, idx, a.p2);
+                if (a.p1 > 0.f) g *= drop_scale(seed, a.site1, idx, a.p1);
                 if (a.post_tanh) {
                     const float yp = tanhf(xh * a.gamma[j] + a.beta[j]);
                     g *= (1.f - yp * yp);
@@ -153,23 +155,30 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_
 }
 
 // ------------------------------------------------------------------------------------------------ column sum
-// block = 64 columns x 16 row-lanes; deterministic (fixed order) tree through LDS.
+// block = 64 columns x 16 row-lanes over one row chunk (gridDim.y chunks); fixed-order tree through LDS inside a chunk.
+// One chunk: plain store (deterministic).  Several chunks (tall inputs, e.g. the 26624-row bias gradients): the
+// per-chunk sums are combined with float atomics into `out`, which the caller has initialised (accum semantics).
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int64_t ld, int rows, int n,
-                                                      float* __restrict__ out, int accum) {
+                                                      float* __restrict__ out, int accum, int rows_per_chunk) {
     __shared__ float red[16][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float s = 0.f;
     if (col < n)
-        for (int r = rl; r < rows; r += 16) s += part[(int64_t)r * ld + col];
+        for (int r = r0 + rl; r < r1; r += 16) s += part[(int64_t)r * ld + col];
     red[rl][c] = s;
     __syncthreads();
     if (rl == 0 && col < n) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][c];
-        if (accum) t += out[col];
-        out[col] = t;
+        if (gridDim.y > 1) {
+            atomicAdd(out + col, t);
+        } else {
+            if (accum) t += out[col];
+            out[col] = t;
+        }
     }
 }
 
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(const dlsg_lstm_pw_arg
     if (a.h) a.h[(int64_t)b * a.ldh + j] = h;
     if (a.h2) {
         float h2 = h;
-        if (a.p > 0.f) h2 *= drop_scale(a.seed, a.site, (uint64_t)b * H + j, a.p);
+        if (a.p > 0.f) h2 *= drop_scale(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), a.site, (uint64_t)b * H + j, a.p);
         a.h2[(int64_t)b * a.ldh2 + j] = h2;
     }
     if (a.gates) {
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(const dlsg_lstm_pw_bwd
     float dh = a.dh ? a.dh[(int64_t)b * a.lddh + j] : 0.f;
     if (a.dh2) {
         float d2 = a.dh2[(int64_t)b * a.lddh2 + j];
-        if (a.p > 0.f) d2 *= drop_scale(a.seed, a.site, (uint64_t)b * H + j, a.p);
+        if (a.p > 0.f) d2 *= drop_scale(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), a.site, (uint64_t)b * H + j, a.p);
         dh += d2;
     }
     const float tc = tanhf(c);
@@ -304,7 +313,8 @@ __global__ void mean_rows_bwd_kernel(const float* __restrict__ dout, int64_t ldd
 }
 
 __global__ void embed_fwd_kernel(const float* __restrict__ E, const int64_t* __restrict__ ids, float* __restrict__ out,
-                                 int64_t ldo, int W, float p, uint64_t seed, uint32_t site, int64_t row0) {
+                                 int64_t ldo, int W, float p, uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr) {
+    if (seed_ptr) seed += *seed_ptr;
     const int r = blockIdx.x;
     const int64_t id = ids[r];
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
@@ -314,7 +324,8 @@ __global__ void embed_fwd_kernel(const float* __restrict__ E, const int64_t* __r
     }
 }
 __global__ void embed_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const int64_t* __restrict__ ids,
-                                 float* __restrict__ dE, int W, float p, uint64_t seed, uint32_t site, int64_t row0) {
+                                 float* __restrict__ dE, int W, float p, uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr) {
+    if (seed_ptr) seed += *seed_ptr;
     const int r = blockIdx.x;
     const int64_t id = ids[r];
     for (int j = threadIdx.x; j < W; j += blockDim.x) {
@@ -353,6 +364,53 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     }
 }
 
+// scheduled sampling select + embedding gather: one block per batch row
+__global__ __launch_bounds__(256) void select_embed_kernel(const float* __restrict__ logits, int64_t ld, int V,
+                                                           const int64_t* __restrict__ captions, int L, int t,
+                                                           const int32_t* __restrict__ coins, const float* __restrict__ E,
+                                                           int64_t* __restrict__ ids_out, float* __restrict__ out,
+                                                           int64_t ldo, int W, float p, uint64_t seed, uint32_t site,
+                                                           int64_t row0, const uint64_t* seed_ptr) {
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    __shared__ int64_t chosen;
+    if (seed_ptr) seed += *seed_ptr;
+    const int r = blockIdx.x;
+    if (coins[t] != 0) {
+        if (threadIdx.x == 0) chosen = captions[(int64_t)r * L + t];
+    } else {
+        const float* x = logits + (int64_t)r * ld;
+        float best = -INFINITY;
+        int idx = 0x7fffffff;
+        for (int j = threadIdx.x; j < V; j += blockDim.x) {
+            const float v = x[j];
+            if (v > best || (v == best && j < idx)) { best = v; idx = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(idx, o, 64);
+            if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { bv[w] = best; bi[w] = idx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < 4; ++k)
+                if (bv[k] > best || (bv[k] == best && bi[k] < idx)) { best = bv[k]; idx = bi[k]; }
+            chosen = idx;
+        }
+    }
+    __syncthreads();
+    const int64_t id = chosen;
+    if (threadIdx.x == 0) ids_out[r] = id;
+    for (int j = threadIdx.x; j < W; j += blockDim.x) {
+        float v = E[id * W + j];
+        if (p > 0.f) v *= drop_scale(seed, site, (uint64_t)(row0 + r) * W + j, p);
+        out[(int64_t)r * ldo + j] = v;
+    }
+}
+
 __global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd, int rows,
                               int n, int accum) {
     const int64_t total = (int64_t)rows * n;
@@ -365,7 +423,8 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int64_t lds_, float
     }
 }
 __global__ void dropout_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int rows, int n,
-                               float p, uint64_t seed, uint32_t site) {
+                               float p, uint64_t seed, uint32_t site, const uint64_t* seed_ptr) {
+    if (seed_ptr) seed += *seed_ptr;
     const int64_t total = (int64_t)rows * n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / n;
@@ -449,7 +508,9 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale) {
+                            int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale,
+                            const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = 1.f; bc2s = hyper[1]; }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -491,7 +552,14 @@ extern "C" int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream) {
 }
 extern "C" int dlsg_colsum(const float* part, int64_t ld, int rows, int n, float* out, int accum, void* stream) {
     if (!part || !out || n < 1) return DLSG_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum);
+    int chunks = 1;
+    if (rows >= 4096) {
+        chunks = (rows + 1023) / 1024;
+        if (chunks > 32) chunks = 32;
+    }
+    const int rpc = (rows + chunks - 1) / chunks;
+    if (chunks > 1 && !accum) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, ST(stream), out, (int64_t)n, 0.f);
+    hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum, rpc);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
@@ -538,16 +606,25 @@ extern "C" int dlsg_mean_rows_bwd(const float* dout, int64_t lddo, float* dx, in
     return DLSG_OK;
 }
 extern "C" int dlsg_embed_fwd(const float* E, const int64_t* ids, float* out, int64_t ldo, int rows, int W, float p,
-                              uint64_t seed, uint32_t site, int64_t row0, void* stream) {
+                              uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream) {
     if (rows == 0) return DLSG_OK;
-    hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows), dim3(128), 0, ST(stream), E, ids, out, ldo, W, p, seed, site, row0);
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(rows), dim3(128), 0, ST(stream), E, ids, out, ldo, W, p, seed, site, row0, seed_ptr);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
 extern "C" int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* ids, float* dE, int rows, int W, float p,
-                              uint64_t seed, uint32_t site, int64_t row0, void* stream) {
+                              uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream) {
     if (rows == 0) return DLSG_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, ST(stream), dout, lddo, ids, dE, W, p, seed, site, row0);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, ST(stream), dout, lddo, ids, dE, W, p, seed, site, row0, seed_ptr);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_select_embed(const float* logits, int64_t ld, int V, const int64_t* captions, int L, int t,
+                                 const int32_t* coins, const float* E, int64_t* ids_out, float* out, int64_t ldo, int rows, int W,
+                                 float p, uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream) {
+    if (rows == 0) return DLSG_OK;
+    hipLaunchKernelGGL(select_embed_kernel, dim3(rows), dim3(256), 0, ST(stream), logits, ld, V, captions, L, t, coins, E, ids_out,
+                       out, ldo, W, p, seed, site, row0, seed_ptr);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
@@ -565,10 +642,10 @@ extern "C" int dlsg_copy2d(const float* src, int64_t lds_, float* dst, int64_t l
     return DLSG_OK;
 }
 extern "C" int dlsg_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int n, float p, uint64_t seed,
-                            uint32_t site, void* stream) {
+                            uint32_t site, const uint64_t* seed_ptr, void* stream) {
     if ((int64_t)rows * n == 0) return DLSG_OK;
     hipLaunchKernelGGL(dropout_kernel, dim3(grid_for((int64_t)rows * n)), dim3(256), 0, ST(stream), x, ldx, y, ldy, rows, n, p,
-                       seed, site);
+                       seed, site, seed_ptr);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
@@ -608,12 +685,12 @@ extern "C" int dlsg_log_softmax(const float* logits, float* out, int rows, int V
     return DLSG_OK;
 }
 extern "C" int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                         int step, float grad_scale, void* stream) {
+                         int step, float grad_scale, const float* hyper, void* stream) {
     if (n == 0) return DLSG_OK;
     const float bc1 = 1.f - powf(b1, (float)step);
     const float bc2s = sqrtf(1.f - powf(b2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, b1, b2, eps, bc1,
-                       bc2s, grad_scale);
+                       bc2s, grad_scale, hyper);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

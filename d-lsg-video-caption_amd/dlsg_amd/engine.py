@@ -531,10 +531,12 @@ def dec_alloc(dec, s, ref, B, L):
     s['LOGITS'] = _empty(ref, L, B, V)
 
 
-def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed):
+def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed, dev_coins=None):
     """Decoder.forward, training / greedy branch (models/layer.py:394-447).
     coins[i] True -> step i feeds captions[:, i] to step i+1, else the argmax of its own logits.
-    captions None -> greedy inference (all coins False).  Returns the decoder state dict."""
+    captions None -> greedy inference (all coins False).  Returns the decoder state dict.
+    dev_coins: optional int32 device array of the same coins; then the word choice happens on device
+    (`select_embed`) and the launch sequence no longer depends on the coin pattern (hipGraph capture)."""
     s = dec_prepare(ops, dec, mems, sv, training, seed)
     ref = mems[0]
     B = ref.shape[0]
@@ -543,6 +545,16 @@ def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed):
     pw = dec.p_drop if training else 0.0
     ids = s['IDS']
     ids[0].fill_(dec.vocab('<start>'))
+    s['pw'] = pw
+    if dev_coins is not None:
+        ops.embed_fwd(E, ids[0], s['WE'][0], p=pw, seed=seed, site=SITE_WORD, row0=0)
+        for t in range(L):
+            dec_step(ops, dec, s, t, ref, training, seed, B)
+            dec_logits(ops, dec, s, t, t + 1)
+            if t + 1 < L:
+                ops.select_embed(s['LOGITS'][t], captions, t, dev_coins, E, ids[t + 1], s['WE'][t + 1], p=pw, seed=seed,
+                                 site=SITE_WORD, row0=(t + 1) * B)
+        return s
     if captions is not None:
         tf_steps = [i for i in range(L) if coins[i]]
         for i in tf_steps:
@@ -556,8 +568,6 @@ def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed):
             ops.argmax(s['LOGITS'][t], ids[t + 1])
             # same (seed, site, row) mask stream as the bulk call above: rows (t+1)*B.. of the WE matrix
             ops.embed_fwd(E, ids[t + 1], s['WE'][t + 1], p=pw, seed=seed, site=SITE_WORD, row0=(t + 1) * B)
-    s['coins'] = list(coins)
-    s['pw'] = pw
     dec_logits(ops, dec, s, 0, L)
     return s
 

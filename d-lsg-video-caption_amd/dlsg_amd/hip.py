@@ -37,7 +37,7 @@ class RowLnArgs(C.Structure):
     _fields_ = [('x', c_f32p), ('ldx', i64), ('res', c_f32p), ('ldres', i64), ('gamma', c_f32p), ('beta', c_f32p),
                 ('y', c_f32p), ('ldy', i64), ('stats', c_f32p), ('pe', c_f32p), ('pe_rows', i32), ('rows', i32),
                 ('n', i32), ('pre_tanh', i32), ('post_tanh', i32), ('eps', f32), ('p1', f32), ('p2', f32),
-                ('seed', u64), ('site1', u32), ('site2', u32)]
+                ('seed', u64), ('site1', u32), ('site2', u32), ('seed_ptr', c_f32p)]
 
 
 class RowLnBwdArgs(C.Structure):
@@ -65,14 +65,14 @@ class LstmPwArgs(C.Structure):
     _fields_ = [('slabs', c_f32p), ('nslab', i32), ('pad_', i32), ('slab_stride', i64), ('addend', c_f32p),
                 ('ldadd', i64), ('b_ih', c_f32p), ('b_hh', c_f32p), ('c_prev', c_f32p), ('ldcp', i64), ('c', c_f32p),
                 ('ldc_', i64), ('h', c_f32p), ('ldh', i64), ('h2', c_f32p), ('ldh2', i64), ('gates', c_f32p), ('ldg', i64),
-                ('B', i32), ('H', i32), ('p', f32), ('site', u32), ('seed', u64)]
+                ('B', i32), ('H', i32), ('p', f32), ('site', u32), ('seed', u64), ('seed_ptr', c_f32p)]
 
 
 class LstmPwBwdArgs(C.Structure):
     _fields_ = [('gates', c_f32p), ('ldg', i64), ('c', c_f32p), ('ldc_', i64), ('c_prev', c_f32p), ('ldcp', i64), ('dh', c_f32p),
                 ('lddh', i64), ('dh2', c_f32p), ('lddh2', i64), ('dc_next', c_f32p), ('lddcn', i64),
                 ('dgates', c_f32p), ('lddg', i64), ('dc_prev', c_f32p), ('lddcp', i64), ('B', i32), ('H', i32), ('p', f32),
-                ('site', u32), ('seed', u64)]
+                ('site', u32), ('seed', u64), ('seed_ptr', c_f32p)]
 
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
@@ -80,7 +80,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
-           'dlsg_argmax', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
+           'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows']
 
 
@@ -111,15 +111,16 @@ def load_library(path=LIB_PATH):
         'dlsg_lstm_pw_bwd': [P(LstmPwBwdArgs), vp],
         'dlsg_mean_rows_fwd': [vp, vp, i64, i32, i32, i32, vp],
         'dlsg_mean_rows_bwd': [vp, i64, vp, i32, i32, i32, i32, vp],
-        'dlsg_embed_fwd': [vp, vp, vp, i64, i32, i32, f32, u64, u32, i64, vp],
-        'dlsg_embed_bwd': [vp, i64, vp, vp, i32, i32, f32, u64, u32, i64, vp],
+        'dlsg_embed_fwd': [vp, vp, vp, i64, i32, i32, f32, u64, u32, i64, vp, vp],
+        'dlsg_embed_bwd': [vp, i64, vp, vp, i32, i32, f32, u64, u32, i64, vp, vp],
+        'dlsg_select_embed': [vp, i64, i32, vp, i32, i32, vp, vp, vp, vp, i64, i32, i32, f32, u64, u32, i64, vp, vp],
         'dlsg_argmax': [vp, i64, vp, i32, i32, vp],
         'dlsg_copy2d': [vp, i64, vp, i64, i32, i32, i32, vp],
-        'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp],
+        'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp, vp],
         'dlsg_fill': [vp, i64, f32, vp],
         'dlsg_ce_ragged': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         'dlsg_log_softmax': [vp, vp, i32, i32, vp],
-        'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp],
+        'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
         'dlsg_permute_tb': [vp, vp, i32, i32, i32, vp],
         'dlsg_gather_rows': [vp, i64, vp, vp, i64, i32, i32, vp],
     }
@@ -136,6 +137,13 @@ STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs
 
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _seed(seed):
+    """seed is an int, or a 1-element int64 device tensor (graph mode: the kernels read it at run time)."""
+    if torch.is_tensor(seed):
+        return 0, C.c_void_p(seed.data_ptr())
+    return int(seed), None
 
 
 def _chk2(t):
@@ -255,7 +263,8 @@ class HipOps(object):
         a.pe, a.pe_rows = _p(pe), (pe.size(0) if pe is not None else 1)
         a.rows, a.n = x.size(0), x.size(1)
         a.pre_tanh, a.post_tanh, a.eps = pre_tanh, post_tanh, eps
-        a.p1, a.p2, a.seed, a.site1, a.site2 = p1, p2, seed, site1, site2
+        a.p1, a.p2, a.site1, a.site2 = p1, p2, site1, site2
+        a.seed, a.seed_ptr = _seed(seed)
         return a
 
     def rowln_fwd(self, x, gamma, beta, y, stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0, site1=0,
@@ -353,7 +362,8 @@ class HipOps(object):
         a.h, a.ldh = _p(h), (h.stride(0) if h is not None else 0)
         a.h2, a.ldh2 = _p(h2), (h2.stride(0) if h2 is not None else 0)
         a.gates, a.ldg = _p(gates), (gates.stride(0) if gates is not None else 0)
-        a.B, a.H, a.p, a.site, a.seed = B, H, p, site, seed
+        a.B, a.H, a.p, a.site = B, H, p, site
+        a.seed, a.seed_ptr = _seed(seed)
         self._check(self.lib.dlsg_lstm_pw_fwd(C.byref(a), self._stream()), 'dlsg_lstm_pw_fwd')
 
     def lstm_pw_bwd(self, gates, c, dgates, B, H, c_prev=None, dh=None, dh2=None, dc_next=None, dc_prev=None, p=0.0,
@@ -366,7 +376,8 @@ class HipOps(object):
         a.dc_next, a.lddcn = _p(dc_next), (dc_next.stride(0) if dc_next is not None else 0)
         a.dgates, a.lddg = _p(dgates), dgates.stride(0)
         a.dc_prev, a.lddcp = _p(dc_prev), (dc_prev.stride(0) if dc_prev is not None else 0)
-        a.B, a.H, a.p, a.site, a.seed = B, H, p, site, seed
+        a.B, a.H, a.p, a.site = B, H, p, site
+        a.seed, a.seed_ptr = _seed(seed)
         self._check(self.lib.dlsg_lstm_pw_bwd(C.byref(a), self._stream()), 'dlsg_lstm_pw_bwd')
 
     # ------------------------------------------------------------------ movers
@@ -381,13 +392,23 @@ class HipOps(object):
 
     def embed_fwd(self, E, ids, out, p=0.0, seed=0, site=0, row0=0):
         rows, W = out.shape
-        self._check(self.lib.dlsg_embed_fwd(_p(E), _p(ids), _p(out), i64(out.stride(0)), rows, W, f32(p), u64(seed), u32(site),
-                                            i64(row0), self._stream()), 'embed_fwd')
+        sd, sp = _seed(seed)
+        self._check(self.lib.dlsg_embed_fwd(_p(E), _p(ids), _p(out), i64(out.stride(0)), rows, W, f32(p), u64(sd), u32(site),
+                                            i64(row0), sp, self._stream()), 'embed_fwd')
+
+    def select_embed(self, logits, captions, t, coins, E, ids_out, out, p=0.0, seed=0, site=0, row0=0):
+        """ids_out[b] = coins[t] ? captions[b, t] : argmax(logits[b]); out[b] = drop(E[id])."""
+        rows, V = logits.shape
+        sd, sp = _seed(seed)
+        self._check(self.lib.dlsg_select_embed(_p(logits), i64(logits.stride(0)), V, _p(captions), captions.shape[1], int(t),
+                                               _p(coins), _p(E), _p(ids_out), _p(out), i64(out.stride(0)), rows, out.shape[1],
+                                               f32(p), u64(sd), u32(site), i64(row0), sp, self._stream()), 'select_embed')
 
     def embed_bwd(self, dout, ids, dE, p=0.0, seed=0, site=0, row0=0):
         rows, W = dout.shape
-        self._check(self.lib.dlsg_embed_bwd(_p(dout), i64(dout.stride(0)), _p(ids), _p(dE), rows, W, f32(p), u64(seed),
-                                            u32(site), i64(row0), self._stream()), 'embed_bwd')
+        sd, sp = _seed(seed)
+        self._check(self.lib.dlsg_embed_bwd(_p(dout), i64(dout.stride(0)), _p(ids), _p(dE), rows, W, f32(p), u64(sd),
+                                            u32(site), i64(row0), sp, self._stream()), 'embed_bwd')
 
     def argmax(self, logits, ids):
         rows, V = logits.shape
@@ -400,8 +421,9 @@ class HipOps(object):
 
     def dropout(self, x, y, p, seed, site):
         rows, n = x.shape
-        self._check(self.lib.dlsg_dropout(_p(x), i64(x.stride(0)), _p(y), i64(y.stride(0)), rows, n, f32(p), u64(seed),
-                                          u32(site), self._stream()), 'dropout')
+        sd, sp = _seed(seed)
+        self._check(self.lib.dlsg_dropout(_p(x), i64(x.stride(0)), _p(y), i64(y.stride(0)), rows, n, f32(p), u64(sd),
+                                          u32(site), sp, self._stream()), 'dropout')
 
     def fill(self, t, value):
         assert t.is_contiguous()
@@ -432,6 +454,7 @@ class HipOps(object):
         rows, V = logits.shape
         self._check(self.lib.dlsg_log_softmax(_p(logits), _p(out), rows, V, self._stream()), 'log_softmax')
 
-    def adam(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+    def adam(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, hyper=None):
+        """hyper: optional device tensor {lr/(1-b1^step), sqrt(1-b2^step)} read at run time (graph replay)."""
         self._check(self.lib.dlsg_adam(_p(p), _p(g), _p(m), _p(v), i64(p.numel()), f32(lr), f32(b1), f32(b2), f32(eps),
-                                       int(step), f32(grad_scale), self._stream()), 'adam')
+                                       int(step), f32(grad_scale), _p(hyper), self._stream()), 'adam')

@@ -165,14 +165,14 @@ class CapGnnModel(_HipModel):
                         E.SITE_PSL_MOT, self.fused_o2v)
         return obj, mot
 
-    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv):
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
         ops = self.ops
         frames = frames.contiguous().float()
         regions = regions.contiguous().float()
         obj, mot = self._encode(frames, regions, training, seed, sv)
         sv['frames'], sv['regions'] = frames, regions
         sv['dec_gsrc'] = [obj, mot]
-        s = E.dec_fwd(ops, self.decoder, [obj, mot], sv, captions, L, coins, training, seed)
+        s = E.dec_fwd(ops, self.decoder, [obj, mot], sv, captions, L, coins, training, seed, dev_coins)
         B = frames.shape[0]
         V = self.decoder.vocab_size
         logits = torch.empty(B, L, V, dtype=torch.float32, device=frames.device)
@@ -247,7 +247,7 @@ class CapBaseline1(_HipModel):
     def update_beam_size(self, beam_size):
         self.decoder.update_beam_size(beam_size)
 
-    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv):
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
         ops = self.ops
         frames = frames.contiguous().float()
         B, T, F = frames.shape
@@ -255,7 +255,7 @@ class CapBaseline1(_HipModel):
         enc = E.encvis_fwd(ops, self.encoder, 'encoder', frames.view(B * T, F), B, T, sv, training, seed).view(B, T, H)
         sv['frames'] = frames
         sv['dec_gsrc'] = [enc]
-        s = E.dec_fwd(ops, self.decoder, [enc], sv, captions, L, coins, training, seed)
+        s = E.dec_fwd(ops, self.decoder, [enc], sv, captions, L, coins, training, seed, dev_coins)
         V = self.decoder.vocab_size
         logits = torch.empty(B, L, V, dtype=torch.float32, device=frames.device)
         ops.permute_tb(s['LOGITS'], logits)
@@ -309,9 +309,15 @@ class Trainer(object):
 
     Data parallel: one process per GPU; every rank runs its own shard, gradients are summed with
     torch.distributed all_reduce (RCCL over xGMI) bucket by bucket as the backward finishes each module group and
-    divided by world size inside the Adam kernel (DDP mean-of-means semantics, run_gun.py:63-64)."""
+    divided by world size inside the Adam kernel (DDP mean-of-means semantics, run_gun.py:63-64).
 
-    def __init__(self, model, lr=1.6e-4, betas=(0.5, 0.9), eps=1e-8, process_group=None, world_size=1):
+    use_graphs: capture the step into hipGraphs (one per backward bucket, so the collectives stay between graph
+    replays and still overlap the rest of the backward).  The step is ~1200 kernel launches, i.e. launch-bound from
+    Python; replaying removes the host from the loop.  Everything that changes between steps is read from device
+    memory: inputs (static buffers), the dropout seed, the scheduled-sampling coins, the Adam bias corrections."""
+
+    def __init__(self, model, lr=1.6e-4, betas=(0.5, 0.9), eps=1e-8, process_group=None, world_size=1, use_graphs=False,
+                 device_coins=None):
         self.model = model
         model.flatten_parameters_()
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -320,7 +326,10 @@ class Trainer(object):
         self.t = 0
         self.world_size = world_size
         self.pg = process_group
+        self.use_graphs = use_graphs
+        self.device_coins = use_graphs if device_coins is None else device_coins
         self._works = []
+        self._graphs = None
         # contiguous arena range of each backward bucket (named_parameters order == arena order)
         self._ranges = {}
         for name, p in model.named_parameters():
@@ -331,12 +340,33 @@ class Trainer(object):
             lo, hi = self._ranges.get(key, (o, end))
             self._ranges[key] = (min(lo, o), max(hi, end))
 
-    def _on_bucket(self, key):
+    # ------------------------------------------------------------------ collectives
+    def _allreduce(self, key):
         if self.world_size <= 1:
             return
         import torch.distributed as dist
         lo, hi = self._ranges[key]
         self._works.append(dist.all_reduce(self.model._gflat[lo:hi], group=self.pg, async_op=True))
+
+    # ------------------------------------------------------------------ one step, as a schedule
+    def _schedule(self, frames, regions, captions, cap_lens, coins, seed, dev_coins, on_bucket):
+        model, ops = self.model, self.model.ops
+        L = captions.shape[1]
+        sv = {}
+        training = model.training
+        model._engine_forward(frames, regions, captions, L, coins, training, seed, sv, dev_coins)
+        s = sv['dec']
+        Bn = captions.shape[0]
+        dl = torch.empty_like(s['LOGITS'])
+        row_loss = torch.empty(L * Bn, dtype=torch.float32, device=dl.device)
+        loss = torch.empty(1, dtype=torch.float32, device=dl.device)
+        ops.ce_ragged(s['LOGITS'], captions, cap_lens, dl, row_loss, loss, time_major=True)
+        model._engine_backward(sv, dl, None, None, None, training, seed, on_bucket=on_bucket)
+        return loss
+
+    def _hyper(self):
+        b1, b2 = self.betas
+        return [self.lr / (1.0 - b1 ** self.t), math.sqrt(1.0 - b2 ** self.t)]
 
     @torch.no_grad()
     def step(self, frames, regions, captions, cap_lens, tf_ratio, max_len=26):
@@ -348,20 +378,75 @@ class Trainer(object):
         L = captions.shape[1]
         coins = model._draw_coins(L, False, tf_ratio)
         seed = model.next_seed()
-        sv = {}
-        training = model.training
-        model._engine_forward(frames, regions, captions, L, coins, training, seed, sv)
-        s = sv['dec']
-        Bn = captions.shape[0]
-        dl = torch.empty_like(s['LOGITS'])
-        row_loss = torch.empty(L * Bn, dtype=torch.float32, device=dl.device)
-        loss = torch.empty(1, dtype=torch.float32, device=dl.device)
-        ops.ce_ragged(s['LOGITS'], captions, cap_lens, dl, row_loss, loss, time_major=True)
+        self.t += 1
+        if self.use_graphs:
+            return self._step_graphs(frames, regions, captions, cap_lens, coins, seed)
+        dev_coins = None
+        if self.device_coins:
+            dev_coins = torch.tensor([int(c) for c in coins], dtype=torch.int32).to(captions.device)
         self._works = []
-        model._engine_backward(sv, dl, None, None, None, training, seed, on_bucket=self._on_bucket)
+        loss = self._schedule(frames, regions, captions, cap_lens, coins, seed, dev_coins, self._allreduce)
         for w in self._works:
             w.wait()
-        self.t += 1
         ops.adam(model._flat, model._gflat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
                  1.0 / self.world_size)
         return loss
+
+    # ------------------------------------------------------------------ hipGraph path
+    def _capture(self, frames, regions, captions, cap_lens):
+        dev = frames.device
+        L = captions.shape[1]
+        st = self._static = dict(frames=frames.clone(), regions=regions.clone(), captions=captions.clone(),
+                                 lens=cap_lens.clone(), coins=torch.ones(L, dtype=torch.int32, device=dev),
+                                 seed=torch.zeros(1, dtype=torch.int64, device=dev),
+                                 hyper=torch.zeros(2, dtype=torch.float32, device=dev))
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        graphs = []
+        with torch.cuda.stream(side):
+            # eager warm-up on the capture stream (allocator warm, one-time kernel attribute calls)
+            self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], None)
+            side.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            cur = [torch.cuda.CUDAGraph()]
+            cur[0].capture_begin(pool=pool)
+
+            def cut(key):
+                if self.world_size <= 1:
+                    return
+                cur[0].capture_end()
+                graphs.append((cur[0], key))
+                cur[0] = torch.cuda.CUDAGraph()
+                cur[0].capture_begin(pool=pool)
+
+            loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut)
+            if self.world_size <= 1:
+                self.model.ops.adam(self.model._flat, self.model._gflat, self.m, self.v, self.lr, self.betas[0],
+                                    self.betas[1], self.eps, 1, 1.0, hyper=st['hyper'])
+            cur[0].capture_end()
+            graphs.append((cur[0], None))
+        torch.cuda.current_stream().wait_stream(side)
+        self._graphs, self._loss = graphs, loss
+
+    def _step_graphs(self, frames, regions, captions, cap_lens, coins, seed):
+        model, ops = self.model, self.model.ops
+        if self._graphs is None:
+            self._capture(frames, regions, captions, cap_lens)
+        st = self._static
+        for k, src in (('frames', frames), ('regions', regions), ('captions', captions), ('lens', cap_lens)):
+            if src.data_ptr() != st[k].data_ptr():
+                st[k].copy_(src, non_blocking=True)
+        st['coins'].copy_(torch.tensor([int(c) for c in coins], dtype=torch.int32), non_blocking=True)
+        st['seed'].copy_(torch.tensor([seed], dtype=torch.int64), non_blocking=True)
+        st['hyper'].copy_(torch.tensor(self._hyper(), dtype=torch.float32), non_blocking=True)
+        self._works = []
+        for g, key in self._graphs:
+            g.replay()
+            if key is not None:
+                self._allreduce(key)
+        if self.world_size > 1:
+            for w in self._works:
+                w.wait()
+            ops.adam(model._flat, model._gflat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
+                     1.0 / self.world_size)
+        return self._loss

@@ -78,6 +78,7 @@ typedef struct {
     float eps;
     float p1, p2;                          /* dropout probs (0 = off) */
     uint64_t seed; uint32_t site1, site2;
+    const uint64_t* seed_ptr;              /* optional device word added to `seed` (graph replay: new masks per replay) */
 } dlsg_rowln_args;
 int dlsg_rowln_fwd(const dlsg_rowln_args* a, void* stream);
 /* backward: dy -> dx (same shape as x; residual gets the same gradient), dgamma/dbeta partial sums are written
@@ -162,6 +163,7 @@ typedef struct {
     float* gates; int64_t ldg;                 /* (B,4H) activated gates (row stride ldg), optional */
     int32_t B, H;
     float p; uint32_t site; uint64_t seed;
+    const uint64_t* seed_ptr;
 } dlsg_lstm_pw_args;
 int dlsg_lstm_pw_fwd(const dlsg_lstm_pw_args* a, void* stream);
 /* backward: dh (B,H) [+ dh2 through dropout], dc_next -> dgates (B,4H pre-activation grads), dc_prev */
@@ -176,6 +178,7 @@ typedef struct {
     float* dc_prev; int64_t lddcp;
     int32_t B, H;
     float p; uint32_t site; uint64_t seed;
+    const uint64_t* seed_ptr;
 } dlsg_lstm_pw_bwd_args;
 int dlsg_lstm_pw_bwd(const dlsg_lstm_pw_bwd_args* a, void* stream);
 
@@ -186,17 +189,23 @@ int dlsg_mean_rows_bwd(const float* dout, int64_t lddo, float* dx, int B, int P,
 /* embedding gather + dropout (layer.py:421-422,438-439): out[r, :] = drop(E[ids[r], :]); the dropout mask of
  * element (r, j) is keyed by (row0 + r) * W + j so a slice of a larger call reproduces the same mask. */
 int dlsg_embed_fwd(const float* E, const int64_t* ids, float* out, int64_t ldo, int rows, int W, float p, uint64_t seed,
-                   uint32_t site, int64_t row0, void* stream);
+                   uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream);
 /* dE[ids[r], :] += drop(dout[r, :])   (atomic adds; rows sharing an id collide) */
 int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* ids, float* dE, int rows, int W, float p,
-                   uint64_t seed, uint32_t site, int64_t row0, void* stream);
+                   uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream);
+/* scheduled sampling on device (layer.py:432-439): id[b] = coins[t] ? captions[b*L + t] : argmax(logits[b, :]);
+ * ids_out[b] = id; out[b, :] = drop(E[id, :]).  coins is a device int32 array, so a captured graph is invariant to the
+ * coin pattern. */
+int dlsg_select_embed(const float* logits, int64_t ld, int V, const int64_t* captions, int L, int t, const int32_t* coins,
+                      const float* E, int64_t* ids_out, float* out, int64_t ldo, int rows, int W, float p, uint64_t seed,
+                      uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream);
 /* argmax over logits rows (first max wins, like torch.max) */
 int dlsg_argmax(const float* logits, int64_t ld, int64_t* ids, int rows, int V, void* stream);
 /* strided 2-d copy / add: dst[r*ldd + j] (+)= src[r*lds + j] */
 int dlsg_copy2d(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int n, int accum, void* stream);
 /* elementwise dropout with the stateless mask: y = x * keep(seed, site, r*n+j)/(1-p) */
 int dlsg_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, int rows, int n, float p, uint64_t seed,
-                 uint32_t site, void* stream);
+                 uint32_t site, const uint64_t* seed_ptr, void* stream);
 int dlsg_fill(float* dst, int64_t n, float value, void* stream);
 /* dst[r, :] = src[idx[r], :]  (beam-search state reorder by back-pointer, allennlp_beamsearch.py:248-260) */
 int dlsg_gather_rows(const float* src, int64_t lds, const int64_t* idx, float* dst, int64_t ldd, int rows, int n, void* stream);
@@ -212,7 +221,9 @@ int dlsg_ce_ragged(const float* logits, const int64_t* targets, const int64_t* l
 int dlsg_log_softmax(const float* logits, float* out, int rows, int V, void* stream);
 /* torch.optim.Adam semantics (no weight decay, no amsgrad); step = 1-based step count; grad_scale folds 1/world */
 int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step,
-              float grad_scale, void* stream);
+              float grad_scale, const float* hyper, void* stream);
+/* hyper (optional, device): {lr / (1 - b1^step), sqrt(1 - b2^step)} -- overrides lr/step so a captured graph can be
+ * replayed with a new step count. */
 
 #ifdef __cplusplus
 }

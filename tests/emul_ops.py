@@ -39,6 +39,8 @@ def drop_scale(seed, site, idx, p):
 
 
 def _mask(seed, site, rows, n, p, row0=0):
+    if torch.is_tensor(seed):
+        seed = int(seed.item())
     idx = (np.arange(rows, dtype=np.uint64)[:, None] + np.uint64(row0)) * np.uint64(n) + np.arange(n, dtype=np.uint64)[None, :]
     return drop_scale(seed, site, idx, p)
 
@@ -269,6 +271,11 @@ class EmulOps(object):
             g = g * _mask(seed, site, dout.shape[0], dout.shape[1], p, row0)
         dE.index_add_(0, ids, g)
 
+    def select_embed(self, logits, captions, t, coins, E, ids_out, out, p=0.0, seed=0, site=0, row0=0):
+        ids = captions[:, t] if int(coins[t]) != 0 else logits.max(1)[1]
+        ids_out.copy_(ids)
+        self.embed_fwd(E, ids, out, p=p, seed=seed, site=site, row0=row0)
+
     def argmax(self, logits, ids):
         ids.copy_(logits.max(1)[1])
 
@@ -308,10 +315,12 @@ class EmulOps(object):
     def log_softmax(self, logits, out):
         out.copy_(torch.log_softmax(logits, 1))
 
-    def adam(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0):
+    def adam(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, hyper=None):
         gi = g * grad_scale
         m.mul_(b1).add_(gi, alpha=1 - b1)
         v.mul_(b2).addcmul_(gi, gi, value=1 - b2)
         bc1 = 1 - b1 ** step
         bc2s = math.sqrt(1 - b2 ** step)
+        if hyper is not None:
+            lr, bc1, bc2s = float(hyper[0]), 1.0, float(hyper[1])
         p.sub_((lr / bc1) * (m / (v.sqrt() / bc2s + eps)))

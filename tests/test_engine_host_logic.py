@@ -112,3 +112,18 @@ def test_beam5_ids(tag):
     with torch.no_grad():
         ids = net(frames, regions, None)[0]
     assert np.array_equal(ids.numpy(), g['beam5_ids'])
+
+
+@pytest.mark.parametrize('tag', ['small_msvd', 'small_baseline1'])
+def test_device_coin_path_matches_host_coin_path(tag):
+    """select_embed (coins applied on device, graph-invariant launch sequence) == the host-branching path."""
+    outs = []
+    for dev in (False, True):
+        net, g, frames, regions, caps, lens, kind = build(tag)
+        tr = dlsg_amd.Trainer(net, device_coins=dev)
+        random.seed(12)
+        loss = tr.step(frames, regions, caps, lens, 0.6)
+        outs.append((float(loss), net._flat.clone()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6
+    # Adam normalises: elements whose gradient is rounding noise may move by a fraction of lr (1.6e-4)
+    assert (outs[0][1] - outs[1][1]).abs().max().item() <= 3e-5

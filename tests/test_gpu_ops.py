@@ -124,6 +124,30 @@ def test_slab_reduce_colsum(hip):
     both(hip, build, run, ['out', 'cs'], tol=5e-5, name='slab/colsum')
 
 
+def test_colsum_tall_chunked(hip):
+    def build(g):
+        return dict(part=rnd(g, 9000, 200), cs=rnd(g, 200), cs2=rnd(g, 130))
+
+    def run(ops, t):
+        ops.colsum(t['part'], t['cs'], accum=True)
+        ops.colsum(t['part'][:, 7:137], t['cs2'], accum=False)
+    both(hip, build, run, ['cs', 'cs2'], tol=1e-4, name='colsum tall')
+
+
+def test_select_embed(hip):
+    def build(g):
+        lg = rnd(g, 6, 50)
+        lg[2, 7] = lg[2, 30] = 40.0
+        return dict(lg=lg, caps=torch.randint(4, 50, (6, 26), generator=g), coins=torch.tensor([1, 0, 1] + [0] * 23, dtype=torch.int32),
+                    E=rnd(g, 50, 20), ids=torch.zeros(3, 6, dtype=torch.int64), out=torch.zeros(3, 6, 24))
+
+    def run(ops, t):
+        for k, step in enumerate((0, 1, 2)):
+            ops.select_embed(t['lg'], t['caps'], step, t['coins'], t['E'], t['ids'][k], t['out'][k][:, :20], p=0.3, seed=9, site=6,
+                             row0=6 * k)
+    both(hip, build, run, ['ids', 'out'], tol=1e-6, name='select_embed')
+
+
 @pytest.mark.parametrize('n', [48, 64, 1024, 2048, 100])
 @pytest.mark.parametrize('variant', ['plain', 'tanh', 'post', 'pe_drop', 'res'])
 def test_rowln_fwd_bwd(hip, n, variant):

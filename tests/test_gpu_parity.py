@@ -177,3 +177,21 @@ def test_oracle_parity_on_fresh_inputs():
         want = orc(frames, regions, caps, 26, 1.0)[0]
         got = net.cuda()(frames.cuda(), regions.cuda(), caps.cuda(), 26, 1.0)[0].cpu()
     assert (want - got).abs().max().item() <= LOGIT_TOL
+
+
+@pytest.mark.parametrize('train_mode', [False, True])
+def test_hipgraph_trainer_matches_eager_trainer(train_mode):
+    """Three optimisation steps: the hipGraph-replayed schedule (device-side coins / seed / Adam step) must track the
+    eager schedule (host-side branching)."""
+    res = []
+    for graphs in (False, True):
+        net, g, frames, regions, caps, lens, kind = build('small_msvd')
+        net.train(train_mode)
+        tr = dlsg_amd.Trainer(net, use_graphs=graphs)
+        random.seed(21)
+        losses = [float(tr.step(frames, regions, caps, lens, 0.7)) for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((losses, net._flat.cpu().clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 2e-4, (res[0][0], res[1][0])
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-4
