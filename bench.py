@@ -99,6 +99,8 @@ def main():
     ap.add_argument('--shape', default='msvd', choices=['msvd', 'msrvtt'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-mode', action='store_true', help='dropout off (not the reported configuration)')
+    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'x3_bwd', 'x3_all'],
+                    help='GEMM arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs/product) for backward / all products')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
     a = ap.parse_args()
 
@@ -126,6 +128,7 @@ def main():
     net.load_state_dict(synth_state_dict(net.state_dict(), 0))       # identical random-init weights on every rank
     net = net.to(dev)
     net.train(not a.eval_mode)
+    net.gemm_precision = a.gemm
     frames, regions, caps, lens = synth_batch(args, V, a.batch, 1 + rank)   # each rank its own shard
     frames, regions, caps, lens = frames.to(dev), regions.to(dev), caps.to(dev), lens.to(dev)
     tr = dlsg_amd.Trainer(net, process_group=pg, world_size=world, use_graphs=not a.no_graphs)
@@ -180,7 +183,7 @@ def main():
                                    % (' + RCCL grad all-reduce' if world > 1 else '', a.shape.upper(), args.num_obj, V,
                                       'off' if a.eval_mode else 'on', eps),
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'parallelism': 'dp%d' % world,
-                       'launch': 'eager' if a.no_graphs else 'hipGraph replay', 'final_loss': round(loss_v, 5)},
+                       'launch': 'eager' if a.no_graphs else 'hipGraph replay', 'gemm_arithmetic': a.gemm, 'final_loss': round(loss_v, 5)},
         }
         g = prof.get('gemm_f32_mfma_128x128')
         if g and g['ms_total'] > 0:

@@ -202,6 +202,133 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------ skinny GEMM (M <= 64)
+// The recurrent products of the path (BiLSTM / LSTMCell gates and their input gradients) have M = batch <= 64 rows:
+// every weight element is used once per launch, so they are weight-streaming and latency-bound, not MFMA-bound.
+// Block = 4 waves on one 64 x 32 output tile; the waves split K in 32-wide chunks (wave w takes chunks w, w+4, ...),
+// operands go straight from global memory to registers (no LDS staging: nothing is reused inside a block), the next
+// chunk's loads are in flight under the current chunk's 32 MFMAs, and the 4 partial tiles are summed through LDS.
+template <bool BT>
+__global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
+    __shared__ float red[4][2][16][64];
+    const int z = blockIdx.y;
+    const int gi = z % p.ngroups, bi = z / p.ngroups;
+    const dlsg_gemm_group grp = p.g[gi];
+    const float* A = grp.A + (int64_t)bi * p.bsa;
+    const float* B = grp.B + (int64_t)bi * p.bsb;
+    float* C = grp.C + (int64_t)bi * p.bsc;
+    const int K = grp.K, M = p.M, N = p.N;
+    const int n0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bool vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((grp.lda & 3) == 0);
+    const bool vecB = !BT && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
+    const int col = n0 + r;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    float a_cur[2][16], b_cur[16], a_nxt[2][16], b_nxt[16];
+
+    auto load_chunk = [&](int c, float (&fa)[2][16], float (&fb)[16]) {
+        const int k0 = c * 32 + 16 * h;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row = r + 32 * mi;
+            const float* ap = A + (int64_t)row * grp.lda + k0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + 4 * q;
+                if (row < M && vecA && k + 3 < K) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 4 * q);
+                    fa[mi][4 * q] = v[0]; fa[mi][4 * q + 1] = v[1]; fa[mi][4 * q + 2] = v[2]; fa[mi][4 * q + 3] = v[3];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[mi][4 * q + i] = (row < M && k + i < K) ? ap[4 * q + i] : 0.f;
+                }
+            }
+        }
+        if (!BT) {      // B element (k, n) at B[n*ldb + k]
+            const float* bp = B + (int64_t)col * grp.ldb + k0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + 4 * q;
+                if (col < N && vecB && k + 3 < K) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+                    fb[4 * q] = v[0]; fb[4 * q + 1] = v[1]; fb[4 * q + 2] = v[2]; fb[4 * q + 3] = v[3];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fb[4 * q + i] = (col < N && k + i < K) ? bp[4 * q + i] : 0.f;
+                }
+            }
+        } else {        // B element (k, n) at B[k*ldb + n]: lanes on consecutive n
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int k = k0 + s2;
+                fb[s2] = (col < N && k < K) ? B[(int64_t)k * grp.ldb + col] : 0.f;
+            }
+        }
+    };
+
+    const int nchunks = (K + 31) / 32;
+    int c = w;
+    if (c < nchunks) load_chunk(c, a_cur, b_cur);
+    while (c < nchunks) {
+        const int cn = c + 4;
+        if (cn < nchunks) load_chunk(cn, a_nxt, b_nxt);
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][s2], b_cur[s2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1][s2], b_cur[s2], acc[1], 0, 0, 0);
+        }
+        if (cn < nchunks) {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) { a_cur[0][s2] = a_nxt[0][s2]; a_cur[1][s2] = a_nxt[1][s2]; b_cur[s2] = b_nxt[s2]; }
+        }
+        c = cn;
+    }
+    // ---- sum the 4 waves' partial tiles through LDS; wave w finalises register group e in [4w, 4w+4)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[w][mi][e][lane] = acc[mi][e];
+    __syncthreads();
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && p.bias != nullptr;
+    const bool do_tanh = p.flags & DLSG_GEMM_TANH;
+    if (col < N) {
+        const float bv = use_bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const int e = 4 * w + ee;
+                const int row = 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = red[0][mi][e][lane] + red[1][mi][e][lane] + red[2][mi][e][lane] + red[3][mi][e][lane];
+                v = p.alpha * v + bv;
+                float* cp = C + (int64_t)row * p.ldc + col;
+                if (accum) v += *cp;
+                if (do_tanh) v = tanhf(v);
+                *cp = v;
+            }
+    }
+}
+
+int launch_skinny(const dlsg_gemm_args* a, hipStream_t st) {
+    KArgs k;
+    k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
+    k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias;
+    for (int i = 0; i < a->ngroups; ++i) k.g[i] = a->g[i];
+    dim3 grid((a->N + 31) / 32, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
+    if (a->mode == 0) hipLaunchKernelGGL((skinny_kernel<false>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((skinny_kernel<true>), grid, block, 0, st, k);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
 template <int BM, int BN>
 int launch(const dlsg_gemm_args* a, hipStream_t st) {
     KArgs k;
@@ -240,6 +367,8 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, i
 
 }  // namespace
 
+int dlsg_gemm_bf16x3_dispatch(const dlsg_gemm_args* a, hipStream_t st);   // gemm_bf16x3.hip
+
 extern "C" int dlsg_abi_version(void) { return DLSG_ABI_VERSION; }
 
 extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
@@ -249,7 +378,14 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t z = (int64_t)a->ngroups * a->nbatch;
     const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
-    if (tilesL >= 192) return launch<128, 128>(a, st);
+    if ((a->flags & DLSG_GEMM_BF16X3) && !(a->M <= 64 && a->mode != 2 && a->N >= 64 && !(a->flags & (DLSG_GEMM_FORCE64 | DLSG_GEMM_FORCE128))))
+        return dlsg_gemm_bf16x3_dispatch(a, st);
+    if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64>(a, st);
+    if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128>(a, st);
+    // M <= 64, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernel
+    if (a->M <= 64 && a->mode != 2 && a->N >= 64) return launch_skinny(a, st);
+    // measured on MI355X (tools/gemm_bench.py): the 128x128 tile only wins once it fills the chip several times over
+    if (tilesL >= 1000) return launch<128, 128>(a, st);
     return launch<64, 64>(a, st);
 }
 

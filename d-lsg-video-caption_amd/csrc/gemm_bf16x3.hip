@@ -1,0 +1,263 @@
+// Split-bf16 ("bf16x3") variant of the grouped GEMM: fp32 operands in HBM, bf16 matrix cores inside.
+//
+// Each fp32 value is split while it is staged through registers: x = hi + lo with hi = bf16(x), lo = bf16(x - hi)
+// (x - hi is exact in fp32).  The product keeps the three leading terms, accumulated in fp32 on
+// v_mfma_f32_32x32x16_bf16:      a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi          (dropped: a_lo*b_lo <= 2^-18 |ab|)
+// Relative error per product ~1e-5 (fp32: 6e-8), against 16x the fp32 matrix rate per instruction => 3 bf16 MFMAs
+// (96 cycles) replace 8 fp32 MFMAs (512 cycles) per 32x32x16 block.  Selected per call with DLSG_GEMM_BF16X3; parity of
+// the whole model with it enabled is asserted in tests/test_gpu_parity.py (logits <= 1e-3, token ids bit-exact).
+//
+// Structure = gemm.hip: 256 threads as 2x2 waves, BMxBN block tile, BK = 32, global -> registers -> LDS with the next
+// K tile in flight.  LDS holds four bf16 planes (A_hi, A_lo, B_hi, B_lo):
+//   * k-contiguous operands : [row][32 + 8] (80-byte rows: 16-B slot stride 5 mod 16, conflict-free ds_read_b128)
+//   * m/n-contiguous operands (NN / TN): kept k-major, [k][rows + 32], written with 8-byte stores of 4 consecutive
+//     rows and read back through the hardware transpose read ds_read_b64_tr_b16 (4 k x 16 rows per 16-lane group);
+//     the row stride (rows+32 bf16 = 16 mod 64 dwords) keeps the four k rows of a read on disjoint banks.
+// The split uses v_cvt_pk_bf16_f32 (round-to-nearest-even): 6 VALU instructions per two elements.
+#include "common.hpp"
+#include "dlsg.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NT = 256;
+constexpr int LDP = BK + 8;   // bf16 elements per LDS row
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short short8 __attribute__((ext_vector_type(8)));
+
+struct KArgs {
+    int M, N, ldc, ngroups, flags;
+    int64_t bsa, bsb, bsc;
+    float alpha;
+    const float* bias;
+    dlsg_gemm_group g[DLSG_GEMM_MAXG];
+};
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+// split two floats into packed hi / lo bf16 pairs (element 0 in the low half); v_cvt_pk_bf16_f32 rounds to nearest even
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    const f32x2 v = {x0, x1};
+    const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 rres = {x0 - __uint_as_float(h << 16), x1 - __uint_as_float(h & 0xFFFF0000u)};
+    hi = h;
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(rres, bf16x2));
+}
+
+template <int ROWS, bool T>
+struct Geom {
+    static constexpr int NV = ROWS * BK / 4 / NT;                     // float4 per thread per tile
+    static constexpr int LDT = ROWS + 32;                             // k-major row stride (bf16)
+    static constexpr int PLANE = T ? BK * LDT : ROWS * LDP;           // bf16 elements per plane
+};
+
+// T=false: (row,k) at base[row*ld + k], one float4 = 4 consecutive k of a row.
+// T=true : (row,k) at base[k*ld + row], one float4 = 4 consecutive rows at one k.
+template <int ROWS, bool T>
+__device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax, int K,
+                                          bool vec_ok, f32x4 (&regs)[Geom<ROWS, T>::NV]) {
+    constexpr int NV = Geom<ROWS, T>::NV;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = threadIdx.x + NT * j;
+        int gr, gk, nvalid;
+        const float* ptr;
+        if (!T) {
+            const int row = f >> 3, kq = f & 7;
+            gr = row0 + row; gk = k0 + 4 * kq;
+            ptr = base + (int64_t)gr * ld + gk;
+            nvalid = (gr < rmax) ? min(max(K - gk, 0), 4) : 0;
+        } else {
+            const int k = f / (ROWS / 4), mq = f % (ROWS / 4);
+            gk = k0 + k; gr = row0 + 4 * mq;
+            ptr = base + (int64_t)gk * ld + gr;
+            nvalid = (gk < K) ? min(max(rmax - gr, 0), 4) : 0;
+        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid == 4 && vec_ok) {
+            v = *reinterpret_cast<const f32x4*>(ptr);
+        } else {
+            if (nvalid > 0) v[0] = ptr[0];
+            if (nvalid > 1) v[1] = ptr[1];
+            if (nvalid > 2) v[2] = ptr[2];
+            if (nvalid > 3) v[3] = ptr[3];
+        }
+        regs[j] = v;
+    }
+}
+
+template <int ROWS, bool T>
+__device__ __forceinline__ void store_tile(unsigned short* __restrict__ hi_p, unsigned short* __restrict__ lo_p,
+                                           const f32x4 (&regs)[Geom<ROWS, T>::NV]) {
+    constexpr int NV = Geom<ROWS, T>::NV;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = threadIdx.x + NT * j;
+        const int off = T ? (f / (ROWS / 4)) * Geom<ROWS, T>::LDT + 4 * (f % (ROWS / 4)) : (f >> 3) * LDP + 4 * (f & 7);
+        uint32_t h0, l0, h1, l1;
+        split2(regs[j][0], regs[j][1], h0, l0);
+        split2(regs[j][2], regs[j][3], h1, l1);
+        *reinterpret_cast<uint2*>(hi_p + off) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(lo_p + off) = make_uint2(l0, l1);
+    }
+}
+
+// MFMA 32x32x16 operand fragment of the 32-row subtile starting at `rowbase`, chunk c (k = 16c + 8h + j, j < 8)
+template <int ROWS, bool T>
+__device__ __forceinline__ bf16x8 ld_frag(const unsigned short* __restrict__ plane, int rowbase, int c, int lane) {
+    if (!T) {
+        const int r = lane & 31, h = lane >> 5;
+        const short8 v = *reinterpret_cast<const short8*>(plane + (rowbase + r) * LDP + 16 * c + 8 * h);
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        // 16-lane group g: rows rowbase + 16*(g&1) + i, k half h = g>>1.  Lane 4q+p of a group addresses k row q,
+        // rows 4p..4p+3 of the 4 x 16 block; it receives the 4 k values of its own row (i = lane & 15).
+        constexpr int LDT = Geom<ROWS, T>::LDT;
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        const int kb = 16 * c + 8 * (g >> 1);
+        const unsigned short* a0 = plane + (kb + q) * LDT + rowbase + 16 * (g & 1) + 4 * pp;
+        typedef short4v __attribute__((address_space(3))) * lds_s4;
+        const short4v lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a0));
+        const short4v hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(a0 + 4 * LDT));
+        const short8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <int BM, int BN, bool AT, bool BT>
+__global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    using GA = Geom<BM, AT>;
+    using GB = Geom<BN, BT>;
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2 * GA::PLANE + 2 * GB::PLANE];
+    unsigned short* a_hi = lds;
+    unsigned short* a_lo = lds + GA::PLANE;
+    unsigned short* b_hi = lds + 2 * GA::PLANE;
+    unsigned short* b_lo = lds + 2 * GA::PLANE + GB::PLANE;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int xcd = bid & 7, q = nblk >> 3, rmd = nblk & 7;
+        bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+    }
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int z = blockIdx.y;
+    const int gi = z % p.ngroups, bi = z / p.ngroups;
+    const dlsg_gemm_group grp = p.g[gi];
+    const float* A = grp.A + (int64_t)bi * p.bsa;
+    const float* B = grp.B + (int64_t)bi * p.bsb;
+    float* C = grp.C + (int64_t)bi * p.bsc;
+    const int K = grp.K;
+    const bool vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((grp.lda & 3) == 0);
+    const bool vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[GA::NV], rb[GB::NV];
+    const int nk = (K + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile<BM, AT>(A, grp.lda, m0, 0, p.M, K, vecA, ra);
+        load_tile<BN, BT>(B, grp.ldb, n0, 0, p.N, K, vecB, rb);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tile<BM, AT>(a_hi, a_lo, ra);
+        store_tile<BN, BT>(b_hi, b_lo, rb);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            load_tile<BM, AT>(A, grp.lda, m0, (kt + 1) * BK, p.M, K, vecA, ra);
+            load_tile<BN, BT>(B, grp.ldb, n0, (kt + 1) * BK, p.N, K, vecB, rb);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {          // two 16-deep MFMA chunks per K tile; lane half h owns k = 16c + 8h + j
+            bf16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fah[i] = ld_frag<BM, AT>(a_hi, wm * WM + i * 32, c, lane);
+                fal[i] = ld_frag<BM, AT>(a_lo, wm * WM + i * 32, c, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fbh[j] = ld_frag<BN, BT>(b_hi, wn * WN + j * 32, c, lane);
+                fbl[j] = ld_frag<BN, BT>(b_lo, wn * WN + j * 32, c, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && p.bias != nullptr;
+    const bool do_tanh = p.flags & DLSG_GEMM_TANH;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + r;
+            if (col >= p.N) continue;
+            const float bv = use_bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                float* cp = C + (int64_t)row * p.ldc + col;
+                float v = p.alpha * acc[i][j][e] + bv;
+                if (accum) v += *cp;
+                if (do_tanh) v = tanhf(v);
+                *cp = v;
+            }
+        }
+}
+
+template <int BM, int BN>
+int launch(const dlsg_gemm_args* a, hipStream_t st) {
+    KArgs k;
+    k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
+    k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias;
+    for (int i = 0; i < a->ngroups; ++i) k.g[i] = a->g[i];
+    const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+    dim3 grid(tiles, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
+    switch (a->mode) {
+        case 0: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, false>), grid, block, 0, st, k); break;
+        case 1: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, true>), grid, block, 0, st, k); break;
+        case 2: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, true, true>), grid, block, 0, st, k); break;
+        default: return DLSG_EINVAL;
+    }
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+}  // namespace
+
+// called from dlsg_gemm (gemm.hip) when DLSG_GEMM_BF16X3 is set
+int dlsg_gemm_bf16x3_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
+    const int64_t z = (int64_t)a->ngroups * a->nbatch;
+    const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
+    if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64>(a, st);
+    if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128>(a, st);
+    if (tilesL >= 512) return launch<128, 128>(a, st);
+    return launch<64, 64>(a, st);
+}

@@ -21,6 +21,7 @@ def _expand_rows(t, k):
 def beam_infer(model, visual_feats, region_feats):
     model.flatten_parameters_()
     ops, dec = model.ops, model.decoder
+    ops.extra_flags = model._gemm_flags(False)
     k = dec.beam_size
     seed = model.next_seed()
     sv = {}

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
+F_FORCE64, F_FORCE128, F_BF16X3 = 256, 512, 1024
 MAXG = 16
 
 c_f32p = C.c_void_p
@@ -164,6 +165,7 @@ class HipOps(object):
         if self.lib.dlsg_abi_version() != 1:
             raise RuntimeError('libdlsg_hip.so ABI mismatch')
         self.prof = None          # set to {} by bench.py: key -> list of (start event, end event, algorithmic work)
+        self.extra_flags = 0      # OR-ed into every dlsg_gemm call (precision policy: F_BF16X3), set by the model
 
     # ------------------------------------------------------------------ live per-kernel timing (bench.py roofline)
     def _prof_begin(self):
@@ -212,7 +214,8 @@ class HipOps(object):
             a.bsa = a.bsb = a.bsc = 0
         M, N = C0.shape[-2], C0.shape[-1]
         a.mode, a.M, a.N, a.ldc = mode, M, N, C0.stride(-2)
-        a.ngroups, a.nbatch, a.flags, a.alpha = len(groups), nb, flags | (F_BIAS if bias is not None else 0), alpha
+        a.ngroups, a.nbatch, a.alpha = len(groups), nb, alpha
+        a.flags = flags | self.extra_flags | (F_BIAS if bias is not None else 0)
         a.bias = _p(bias)
         assert len(groups) <= MAXG
         for i, (A, B, Cc) in enumerate(groups):
@@ -237,11 +240,12 @@ class HipOps(object):
         if self.prof is not None:
             flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))
             if flops >= 2e9:     # only the heavy launches are timed, so the events do not perturb the step
-                big = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups) >= 192
+                big = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups) >= (512 if (a.flags & F_BF16X3) else 1000)
                 e0 = self._prof_begin()
         self._check(self.lib.dlsg_gemm(C.byref(a), self._stream()), 'dlsg_gemm')
         if e0 is not None:
-            self._prof_end('gemm_f32_mfma_128x128' if big else 'gemm_f32_mfma_64x64', e0, flops)
+            x3 = 'bf16x3' if (a.flags & F_BF16X3) else 'f32'
+            self._prof_end('gemm_%s_mfma_%s' % (x3, '128x128' if big else '64x64'), e0, flops)
 
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""

@@ -36,6 +36,9 @@ class _HipModel(nn.Module):
         self.rng = random          # scheduled-sampling coins come from Python's `random`, like layer.py:432
         self.seed_counter = 0
         self.fused_o2v = True
+        # GEMM arithmetic: 'fp32' = exact fp32 MFMA everywhere; 'x3_bwd' = split-bf16 (3 bf16 MFMAs per product,
+        # ~1e-5 relative error) for the backward products only; 'x3_all' = split-bf16 for forward and backward.
+        self.gemm_precision = 'fp32'
 
     # ------------------------------------------------------------------ kernels handle
     @property
@@ -79,6 +82,12 @@ class _HipModel(nn.Module):
 
     def grad_views(self):
         return self._G
+
+    def _gemm_flags(self, backward):
+        from .hip import F_BF16X3
+        mode = self.gemm_precision
+        assert mode in ('fp32', 'x3_bwd', 'x3_all'), mode
+        return F_BF16X3 if (mode == 'x3_all' or (mode == 'x3_bwd' and backward)) else 0
 
     def next_seed(self):
         self.seed_counter += 1
@@ -167,6 +176,7 @@ class CapGnnModel(_HipModel):
 
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
         ops = self.ops
+        ops.extra_flags = self._gemm_flags(False)
         frames = frames.contiguous().float()
         regions = regions.contiguous().float()
         obj, mot = self._encode(frames, regions, training, seed, sv)
@@ -183,6 +193,7 @@ class CapGnnModel(_HipModel):
 
     def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed, on_bucket=None):
         ops, enc = self.ops, self.encoder
+        ops.extra_flags = self._gemm_flags(True)
         G = self._G
         ops.fill(self._gflat, 0.0)
         frames, regions = sv['frames'], sv['regions']
@@ -249,6 +260,7 @@ class CapBaseline1(_HipModel):
 
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
         ops = self.ops
+        ops.extra_flags = self._gemm_flags(False)
         frames = frames.contiguous().float()
         B, T, F = frames.shape
         H = self.decoder.visual_hidden_size
@@ -263,6 +275,7 @@ class CapBaseline1(_HipModel):
 
     def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed, on_bucket=None):
         ops = self.ops
+        ops.extra_flags = self._gemm_flags(True)
         G = self._G
         ops.fill(self._gflat, 0.0)
         frames = sv['frames']

@@ -12,6 +12,7 @@ import torch
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
+F_FORCE64, F_FORCE128, F_BF16X3 = 256, 512, 1024     # tile / precision selectors: no effect on the emulation
 
 _M32 = np.uint64(0xFFFFFFFF)
 
@@ -51,6 +52,7 @@ class EmulOps(object):
     def __init__(self, fused_supported=True):
         self.fused_supported = fused_supported
         self.calls = {}
+        self.extra_flags = 0
 
     def _count(self, k):
         self.calls[k] = self.calls.get(k, 0) + 1

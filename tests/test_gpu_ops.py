@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from emul_ops import EmulOps, GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH
+from emul_ops import EmulOps, GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH, F_BF16X3, F_FORCE64, F_FORCE128
 
 pytestmark = pytest.mark.gpu
 
@@ -68,6 +68,51 @@ def test_gemm_plain(hip, mode, shape):
     both(hip, build, run, ['C'], tol=1e-5 * max(1.0, math.sqrt(K)), name='gemm%d %s' % (mode, shape))
 
 
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
+@pytest.mark.parametrize('force', [F_FORCE64, F_FORCE128])
+@pytest.mark.parametrize('shape', [(128, 128, 64), (3, 50, 244), (70, 33, 100), (257, 129, 65), (416, 26, 64), (300, 1000, 96)])
+def test_gemm_bf16x3(hip, mode, force, shape):
+    """split-bf16 path: three bf16 MFMAs per product; error budget ~1e-5 per product (see csrc/gemm_bf16x3.hip)."""
+    M, N, K = shape
+
+    def build(g):
+        if mode == GEMM_NT:
+            A, B = rnd(g, M, K + 4), rnd(g, N, K + 4)
+        elif mode == GEMM_NN:
+            A, B = rnd(g, M, K + 4), rnd(g, K, N + 4)
+        else:
+            A, B = rnd(g, K, M + 4), rnd(g, K, N + 4)
+        return dict(A=A, B=B, C=rnd(g, M, N + 4), bias=rnd(g, N))
+
+    def run(ops, t):
+        if mode == GEMM_NT:
+            A, B = t['A'][:, :K], t['B'][:, :K]
+        elif mode == GEMM_NN:
+            A, B = t['A'][:, :K], t['B'][:, :N]
+        else:
+            A, B = t['A'][:, :M], t['B'][:, :N]
+        ops.gemm(mode, [(A, B, t['C'][:, :N])], alpha=0.5, bias=t['bias'], flags=F_BF16X3 | F_ACCUM | force)
+    both(hip, build, run, ['C'], tol=3e-5 * max(1.0, math.sqrt(K)), name='x3 gemm%d %s' % (mode, shape))
+
+
+def test_gemm_bf16x3_error_is_compensated(hip):
+    """The three-term split must be ~100x more accurate than a plain bf16 product (which would be ~4e-3)."""
+    g = torch.Generator().manual_seed(0)
+    A, B = rnd(g, 512, 1024), rnd(g, 512, 1024)
+    ref = (A.double() @ B.double().t())
+    C = torch.zeros(512, 512).cuda()
+    hip.gemm(GEMM_NT, [(A.cuda(), B.cuda(), C)], flags=F_BF16X3)
+    torch.cuda.synchronize()
+    rel = ((C.cpu().double() - ref).norm() / ref.norm()).item()
+    assert rel < 3e-5, rel
+    C2 = torch.zeros(512, 512).cuda()
+    hip.gemm(GEMM_NT, [(A.cuda(), B.cuda(), C2)])
+    torch.cuda.synchronize()
+    rel32 = ((C2.cpu().double() - ref).norm() / ref.norm()).item()
+    assert rel32 < 1e-6, rel32
+    print('relative error: bf16x3 %.3g, fp32 mfma %.3g' % (rel, rel32))
+
+
 def test_gemm_asymmetric_identity(hip):
     """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
     n = 96
@@ -91,6 +136,33 @@ def test_gemm_strided_views_flags_groups(hip):
         # K-split groups into slabs
         ops.gemm(GEMM_NT, [(X[:, 0:128], W[:, 0:128], t['out'][0, :, :90]), (X[:, 128:300], W[:, 128:300], t['out'][1, :, :90])])
     both(hip, build, run, ['big', 'out'], tol=3e-5, name='gemm views')
+
+
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN])
+@pytest.mark.parametrize('shape', [(64, 4096, 2348), (37, 100, 77), (64, 96, 1024), (5, 3072, 333), (64, 1024, 4096)])
+def test_gemm_skinny(hip, mode, shape):
+    M, N, K = shape
+
+    def build(g):
+        A = rnd(g, M, K + 4)
+        B = rnd(g, N, K + 8) if mode == GEMM_NT else rnd(g, K, N + 4)
+        return dict(A=A, B=B, C=rnd(g, 3, M, N + 4), bias=rnd(g, N))
+
+    def run(ops, t):
+        A = t['A'][:, 4:4 + K] if K % 4 == 0 else t['A'][:, 1:1 + K]
+        if mode == GEMM_NT:
+            Bv = t['B'][:, 8:8 + K] if K % 4 == 0 else t['B'][:, 3:3 + K]
+        else:
+            Bv = t['B'][:, 2:2 + N]
+        k2 = (K // 2) // 32 * 32 or K
+        Cv = [t['C'][i][:, :N] for i in range(3)]
+        ops.gemm(mode, [(A, Bv, Cv[0])], alpha=0.5, bias=t['bias'], flags=F_ACCUM | F_TANH)
+        if k2 < K:   # K-split groups into slabs, as the engine launches the LSTM cells
+            if mode == GEMM_NT:
+                ops.gemm(mode, [(A[:, :k2], Bv[:, :k2], Cv[1]), (A[:, k2:], Bv[:, k2:], Cv[2])])
+            else:
+                ops.gemm(mode, [(A[:, :k2], Bv[:k2], Cv[1]), (A[:, k2:], Bv[k2:], Cv[2])])
+    both(hip, build, run, ['C'], tol=1e-5 * max(1.0, math.sqrt(K)), name='skinny %d %s' % (mode, shape))
 
 
 def test_gemm_batched(hip):

@@ -195,3 +195,38 @@ def test_hipgraph_trainer_matches_eager_trainer(train_mode):
     for a, b in zip(res[0][0], res[1][0]):
         assert abs(a - b) <= 2e-4, (res[0][0], res[1][0])
     assert (res[0][1] - res[1][1]).abs().max().item() <= 1e-4
+
+
+X3_LOGIT_TOL = 1e-3     # north_star: logits within 1e-3 of the reference
+
+
+@pytest.mark.parametrize('tag', ['small_msvd', 'small_msrvtt', 'small_baseline1', 'full_msvd_b2'])
+@pytest.mark.parametrize('mode', ['x3_all', 'x3_bwd'])
+def test_split_bf16_precision_modes_hold_parity(tag, mode):
+    """gemm_precision x3_*: split-bf16 matrix products must keep the north_star tolerance (logits 1e-3, ids bit-exact)
+    and gradients within 2e-3 of their scale."""
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    net.gemm_precision = mode
+    with torch.no_grad():
+        logits = net(frames, regions, caps, 26, 1.0)[0]
+        err = np.abs(logits.cpu().numpy() - g['logits']).max()
+        net.update_beam_size(1)
+        ids = net(frames, regions, None)[0].cpu().numpy()
+        net.update_beam_size(5)
+        bids = net(frames, regions, None)[0].cpu().numpy()
+    print('%s %s max|dlogit| = %.3g (min top-2 margin of the reference %.3g)' % (tag, mode, err, g['logit_margin'].min()))
+    assert err <= X3_LOGIT_TOL, err
+    assert np.array_equal(ids, g['greedy_ids'])
+    assert np.array_equal(bids, g['beam5_ids'])
+    tr = dlsg_amd.Trainer(net)
+    loss = tr.step(frames, regions, caps, lens, 1.0)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-3
+    G = net.grad_views()
+    for k, p in net.named_parameters():
+        if 'g.' + k in g:
+            ref = g['g.' + k]
+            e = np.abs(G[k].cpu().numpy() - ref).max()
+            assert e <= 2e-5 + 2e-3 * np.abs(ref).max(), (k, e, np.abs(ref).max())
+        elif 'gnorm.' + k in g:
+            ref = float(g['gnorm.' + k])
+            assert abs(float(G[k].double().norm()) - ref) <= 5e-3 * max(ref, 1e-6) + 1e-6, k
