@@ -29,6 +29,7 @@ for p in (ROOT, os.path.join(ROOT, 'd-lsg-video-caption_amd')):
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak; a bf16x3 product costs 3 MFMA flops per flop
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E spec
 
 
@@ -99,7 +100,7 @@ def main():
     ap.add_argument('--shape', default='msvd', choices=['msvd', 'msrvtt'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-mode', action='store_true', help='dropout off (not the reported configuration)')
-    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'x3_bwd', 'x3_all'],
+    ap.add_argument('--gemm', default='x3_bwd', choices=['fp32', 'x3_bwd', 'x3_all'],
                     help='GEMM arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs/product) for backward / all products')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
     a = ap.parse_args()
@@ -166,6 +167,25 @@ def main():
         net.ops.prof = None
         tr.use_graphs = use_graphs
         barrier()
+    # the same step under the other GEMM arithmetic policies (informational; `value` is the --gemm policy)
+    other = {}
+    if world == 1:
+        for mode in ('fp32', 'x3_bwd', 'x3_all'):
+            if mode == a.gemm:
+                continue
+            net.gemm_precision = mode
+            tr2 = dlsg_amd.Trainer(net, use_graphs=not a.no_graphs)
+            tr2.m, tr2.v, tr2.t = tr.m, tr.v, tr.t
+            for _ in range(2):
+                tr2.step(frames, regions, caps, lens, eps)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                tr2.step(frames, regions, caps, lens, eps)
+            torch.cuda.synchronize()
+            other[mode] = {'clips_per_s': round(a.batch * a.steps / (time.perf_counter() - t1), 1)}
+            del tr2
+        net.gemm_precision = a.gemm
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
@@ -177,7 +197,7 @@ def main():
         out = {
             'metric': 'clips/sec (train step, 26x(2048+4096) feats)', 'value': round(n_clips / dt, 2), 'unit': 'clips/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if a.gemm == 'fp32' else 'f32+bf16x3', 'data': 'synthetic',
             'config': {'workload': 'CapGnnModel train step (fwd + ragged CE + bwd + Adam%s), %s-shaped: 26 frames x (2048+4096), '
                                    '%d x 2048 regions, vocab %d, dropout %s, tf eps %.3f'
                                    % (' + RCCL grad all-reduce' if world > 1 else '', a.shape.upper(), args.num_obj, V,
@@ -185,18 +205,24 @@ def main():
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'parallelism': 'dp%d' % world,
                        'launch': 'eager' if a.no_graphs else 'hipGraph replay', 'gemm_arithmetic': a.gemm, 'final_loss': round(loss_v, 5)},
         }
-        g = prof.get('gemm_f32_mfma_128x128')
+        gk = max((k for k in prof if k.startswith('gemm_')), key=lambda k: prof[k]['ms_total'], default=None)
+        g = prof.get(gk) if gk else None
+        out['kernel_time_ms_per_step'] = {k: round(v['ms_total'] / max(1, min(3, a.steps)), 3) for k, v in prof.items()}
         if g and g['ms_total'] > 0:
             ach = g['work_total'] / (g['ms_total'] * 1e-3) / 1e12
+            is_x3 = 'bf16x3' in gk
+            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if is_x3 else PEAK_FP32_MFMA_TFLOPS
             traffic = None
             tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get('gemm_f32_mfma_128x128')
+                    traffic = json.load(open(tpath)).get(gk)
                 except Exception:
                     traffic = None
-            out['roofline'] = {'kernel': 'gemm_kernel<128,128> (fp32 MFMA 32x32x2)', 'bound': 'mfma', 'achieved': round(ach, 2),
-                               'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            out['roofline'] = {'kernel': gk + (' (3 x v_mfma_f32_32x32x16_bf16 per product; peak = 2500/3)' if is_x3
+                                               else ' (v_mfma_f32_32x32x2_f32)'),
+                               'bound': 'mfma', 'achieved': round(ach, 2),
+                               'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'launches_timed': g['launches'],
                                'avg_launch_ms': round(g['ms_total'] / g['launches'], 4),
                                'ms_per_step_in_this_kernel': round(g['ms_total'] / max(1, min(3, a.steps)), 3)}
@@ -209,6 +235,11 @@ def main():
                                                'avg_launch_ms': round(o['ms_total'] / o['launches'], 4)}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
+        out['dtype_note'] = {'fp32': 'all products on fp32-input MFMA (exact fp32)',
+                             'x3_bwd': 'forward: exact fp32 MFMA; backward products: fp32 operands split into bf16 hi+lo, 3 bf16 '
+                                       'MFMAs per product, fp32 accumulate (rel. error ~1e-5)',
+                             'x3_all': 'all products: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate'}[a.gemm]
+        out['other_gemm_arithmetic'] = other
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -378,8 +378,7 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int64_t z = (int64_t)a->ngroups * a->nbatch;
     const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
-    if ((a->flags & DLSG_GEMM_BF16X3) && !(a->M <= 64 && a->mode != 2 && a->N >= 64 && !(a->flags & (DLSG_GEMM_FORCE64 | DLSG_GEMM_FORCE128))))
-        return dlsg_gemm_bf16x3_dispatch(a, st);
+    if (a->flags & DLSG_GEMM_BF16X3) return dlsg_gemm_bf16x3_dispatch(a, st);
     if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64>(a, st);
     if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128>(a, st);
     // M <= 64, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernel

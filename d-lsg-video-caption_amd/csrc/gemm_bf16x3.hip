@@ -250,6 +250,147 @@ int launch(const dlsg_gemm_args* a, hipStream_t st) {
     return DLSG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ skinny (M <= 64) x3
+// Same structure as skinny_kernel in gemm.hip (4 waves split K in 32-wide chunks on one 64 x 32 tile, operands straight
+// to registers, partial tiles summed through LDS); the 16 fp32 values a lane holds per operand row are split in
+// registers into two 8-element hi/lo fragments (k = k0 + 16h + 8c + j) and fed to 12 bf16 MFMAs per chunk.
+__device__ __forceinline__ void split8(const float* x, bf16x8& hi, bf16x8& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split2(x[2 * i], x[2 * i + 1], h[i], l[i]);
+    const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]), lv = make_uint4(l[0], l[1], l[2], l[3]);
+    hi = __builtin_bit_cast(bf16x8, hv);
+    lo = __builtin_bit_cast(bf16x8, lv);
+}
+
+template <bool BT>
+__global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
+    __shared__ float red[4][2][16][64];
+    const int z = blockIdx.y;
+    const int gi = z % p.ngroups, bi = z / p.ngroups;
+    const dlsg_gemm_group grp = p.g[gi];
+    const float* A = grp.A + (int64_t)bi * p.bsa;
+    const float* B = grp.B + (int64_t)bi * p.bsb;
+    float* C = grp.C + (int64_t)bi * p.bsc;
+    const int K = grp.K, M = p.M, N = p.N;
+    const int n0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const bool vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((grp.lda & 3) == 0);
+    const bool vecB = !BT && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
+    const int col = n0 + r;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    float a_cur[2][16], b_cur[16], a_nxt[2][16], b_nxt[16];
+
+    auto load_chunk = [&](int c, float (&fa)[2][16], float (&fb)[16]) {
+        const int k0 = c * 32 + 16 * h;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row = r + 32 * mi;
+            const float* ap = A + (int64_t)row * grp.lda + k0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + 4 * q;
+                if (row < M && vecA && k + 3 < K) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 4 * q);
+                    fa[mi][4 * q] = v[0]; fa[mi][4 * q + 1] = v[1]; fa[mi][4 * q + 2] = v[2]; fa[mi][4 * q + 3] = v[3];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[mi][4 * q + i] = (row < M && k + i < K) ? ap[4 * q + i] : 0.f;
+                }
+            }
+        }
+        if (!BT) {
+            const float* bp = B + (int64_t)col * grp.ldb + k0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + 4 * q;
+                if (col < N && vecB && k + 3 < K) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+                    fb[4 * q] = v[0]; fb[4 * q + 1] = v[1]; fb[4 * q + 2] = v[2]; fb[4 * q + 3] = v[3];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fb[4 * q + i] = (col < N && k + i < K) ? bp[4 * q + i] : 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) {
+                const int k = k0 + s2;
+                fb[s2] = (col < N && k < K) ? B[(int64_t)k * grp.ldb + col] : 0.f;
+            }
+        }
+    };
+
+    const int nchunks = (K + 31) / 32;
+    int c = w;
+    if (c < nchunks) load_chunk(c, a_cur, b_cur);
+    while (c < nchunks) {
+        const int cn = c + 4;
+        if (cn < nchunks) load_chunk(cn, a_nxt, b_nxt);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            bf16x8 bh, bl, ah[2], al[2];
+            split8(&b_cur[8 * cc], bh, bl);
+            split8(&a_cur[0][8 * cc], ah[0], al[0]);
+            split8(&a_cur[1][8 * cc], ah[1], al[1]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh, acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl, acc[mi], 0, 0, 0);
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh, acc[mi], 0, 0, 0);
+            }
+        }
+        if (cn < nchunks) {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) { a_cur[0][s2] = a_nxt[0][s2]; a_cur[1][s2] = a_nxt[1][s2]; b_cur[s2] = b_nxt[s2]; }
+        }
+        c = cn;
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[w][mi][e][lane] = acc[mi][e];
+    __syncthreads();
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && p.bias != nullptr;
+    const bool do_tanh = p.flags & DLSG_GEMM_TANH;
+    if (col < N) {
+        const float bv = use_bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const int e = 4 * w + ee;
+                const int row = 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = red[0][mi][e][lane] + red[1][mi][e][lane] + red[2][mi][e][lane] + red[3][mi][e][lane];
+                v = p.alpha * v + bv;
+                float* cp = C + (int64_t)row * p.ldc + col;
+                if (accum) v += *cp;
+                if (do_tanh) v = tanhf(v);
+                *cp = v;
+            }
+    }
+}
+
+int launch_skinny_x3(const dlsg_gemm_args* a, hipStream_t st) {
+    KArgs k;
+    k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
+    k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias;
+    for (int i = 0; i < a->ngroups; ++i) k.g[i] = a->g[i];
+    dim3 grid((a->N + 31) / 32, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
+    if (a->mode == 0) hipLaunchKernelGGL((skinny_x3_kernel<false>), grid, block, 0, st, k);
+    else hipLaunchKernelGGL((skinny_x3_kernel<true>), grid, block, 0, st, k);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
 }  // namespace
 
 // called from dlsg_gemm (gemm.hip) when DLSG_GEMM_BF16X3 is set
@@ -258,6 +399,7 @@ int dlsg_gemm_bf16x3_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
     if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64>(a, st);
     if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128>(a, st);
+    if (a->M <= 64 && a->mode != 2 && a->N >= 64) return launch_skinny_x3(a, st);
     if (tilesL >= 512) return launch<128, 128>(a, st);
     return launch<64, 64>(a, st);
 }

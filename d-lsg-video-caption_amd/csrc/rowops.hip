@@ -540,7 +540,13 @@ extern "C" int dlsg_rowln_fwd(const dlsg_rowln_args* a, void* stream) {
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
-extern "C" int dlsg_rowln_bwd_nblk(int rows) { return rows < 256 ? (rows < 1 ? 1 : rows) : 256; }
+// grid of the backward = number of per-block dgamma/dbeta partial rows: enough blocks to fill the chip on tall inputs
+extern "C" int dlsg_rowln_bwd_nblk(int rows) {
+    if (rows < 1) return 1;
+    if (rows <= 256) return rows;
+    if (rows <= 4096) return 256;
+    return 1024;
+}
 extern "C" int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream) {
     if (!a || a->f.n < 1 || a->f.n > LN_THREADS * LN_MAXPT) return DLSG_EINVAL;
     if (a->f.rows == 0) return DLSG_OK;

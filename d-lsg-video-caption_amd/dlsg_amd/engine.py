@@ -691,7 +691,7 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     ops.embed_bwd(dWE, s['IDS'][:L].view(-1), G['decoder.word_embed.weight'], p=s['pw'], seed=seed, site=SITE_WORD)
     # ---- global feature
     dgfeat = _empty(ref, B, plan.G)
-    ops.gemm(GEMM_NN, [(dgq_sum, ql.weight_ih[:, plan.q_glob[0]:plan.q_glob[1]], dgfeat)])
+    gemm_nn_split(ops, dgq_sum, ql.weight_ih[:, plan.q_glob[0]:plan.q_glob[1]], dgfeat, ref)
     # ---- attention caches: K' = K W_Q, V' = V W_O^T, K = m W_K^T, V = m W_V^T
     dmems = []
     for i, att in enumerate(atts):

@@ -116,7 +116,9 @@ class EmulOps(object):
         y.copy_(v)
 
     def rowln_bwd_nblk(self, rows):
-        return rows if rows < 256 else 256
+        if rows <= 256:
+            return max(rows, 1)
+        return 256 if rows <= 4096 else 1024
 
     def rowln_bwd(self, dy, x, gamma, beta, dx, stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0,
                   site1=0, p2=0.0, site2=0, seed=0, eps=1e-5, dgb_part=None, accum_dx=False):

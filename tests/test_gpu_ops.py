@@ -139,8 +139,9 @@ def test_gemm_strided_views_flags_groups(hip):
 
 
 @pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN])
+@pytest.mark.parametrize('x3', [0, F_BF16X3])
 @pytest.mark.parametrize('shape', [(64, 4096, 2348), (37, 100, 77), (64, 96, 1024), (5, 3072, 333), (64, 1024, 4096)])
-def test_gemm_skinny(hip, mode, shape):
+def test_gemm_skinny(hip, mode, shape, x3):
     M, N, K = shape
 
     def build(g):
@@ -156,13 +157,13 @@ def test_gemm_skinny(hip, mode, shape):
             Bv = t['B'][:, 2:2 + N]
         k2 = (K // 2) // 32 * 32 or K
         Cv = [t['C'][i][:, :N] for i in range(3)]
-        ops.gemm(mode, [(A, Bv, Cv[0])], alpha=0.5, bias=t['bias'], flags=F_ACCUM | F_TANH)
+        ops.gemm(mode, [(A, Bv, Cv[0])], alpha=0.5, bias=t['bias'], flags=F_ACCUM | F_TANH | x3)
         if k2 < K:   # K-split groups into slabs, as the engine launches the LSTM cells
             if mode == GEMM_NT:
-                ops.gemm(mode, [(A[:, :k2], Bv[:, :k2], Cv[1]), (A[:, k2:], Bv[:, k2:], Cv[2])])
+                ops.gemm(mode, [(A[:, :k2], Bv[:, :k2], Cv[1]), (A[:, k2:], Bv[:, k2:], Cv[2])], flags=x3)
             else:
-                ops.gemm(mode, [(A[:, :k2], Bv[:k2], Cv[1]), (A[:, k2:], Bv[k2:], Cv[2])])
-    both(hip, build, run, ['C'], tol=1e-5 * max(1.0, math.sqrt(K)), name='skinny %d %s' % (mode, shape))
+                ops.gemm(mode, [(A[:, :k2], Bv[:k2], Cv[1]), (A[:, k2:], Bv[k2:], Cv[2])], flags=x3)
+    both(hip, build, run, ['C'], tol=(3e-5 if x3 else 1e-5) * max(1.0, math.sqrt(K)), name='skinny %d %s' % (mode, shape))
 
 
 def test_gemm_batched(hip):
@@ -244,6 +245,19 @@ def test_rowln_fwd_bwd(hip, n, variant):
         ops.rowln_bwd(t['dy'], x, t['gamma'], t['beta'], t['dx'], stats=t['st'], dgb_part=t['part'], **extra)
         t['dgb'] = t['part'].sum(0)
     both(hip, build, run, ['y', 'st', 'dx', 'dgb'], tol=3e-5, name='rowln %d %s' % (n, variant))
+
+
+def test_rowln_bwd_tall(hip):
+    def build(g):
+        return dict(y=torch.tanh(rnd(g, 5000, 64)), gamma=1 + 0.1 * rnd(g, 64), beta=0.1 * rnd(g, 64), dy=rnd(g, 5000, 64),
+                    dx=rnd(g, 5000, 64), part=torch.zeros(1024, 2, 64), st=torch.zeros(5000, 2), o=torch.zeros(5000, 64))
+
+    def run(ops, t):
+        assert ops.rowln_bwd_nblk(5000) == 1024
+        ops.rowln_fwd(t['y'], t['gamma'], t['beta'], t['o'], t['st'])
+        ops.rowln_bwd(t['dy'], t['y'], t['gamma'], t['beta'], t['dx'], stats=t['st'], pre_tanh=2, dgb_part=t['part'])
+        t['dgb'] = t['part'].sum(0)
+    both(hip, build, run, ['dx', 'dgb'], tol=1e-4, name='rowln tall')
 
 
 def test_rowln_bwd_mode2_and_accum(hip):

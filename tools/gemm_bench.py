@@ -71,7 +71,8 @@ for mode, M, N, K, G in SHAPES:
         for ks in (1, 2, 4, 8, 16):
             if G * ks <= 16:
                 a = run(mode, M, N, K, G, 0, ks)
-                extra += ' auto/ks%d: %.3f/%.0fTF' % (ks, a[0], a[1])
+                b = run(mode, M, N, K, G, 1024, ks)
+                extra += ' ks%d: f32 %.3f/%.0fTF x3 %.3f/%.0fTF' % (ks, a[0], a[1], b[0], b[1])
     if False and K >= 1664 and M * N <= 4096 * 2048 * 2:
         for ks in (2, 4, 8):
             if G * ks <= 16:
