@@ -69,60 +69,64 @@ __global__ __launch_bounds__(O2V_THREADS) void o2v_partial_kernel(const dlsg_o2v
         for (int e = 0; e < 16; ++e) acc_o[c][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int n0 = n_begin; n0 < n_end; n0 += O2V_TILE) {
-        // ---- stage 4 rows per wave: global -> registers -> LayerNorm -> LDS
-#pragma unroll 1
+    // rows of the tile being staged (4 per wave): all four rows' loads are issued before the first reduction, so a tile
+    // costs one memory round trip.  (Issuing them one tile ahead, under the aggregation MFMAs, was measured: the 64
+    // extra live registers spill and it is slower, 1.76 vs 1.90 TB/s.)
+    float x[4][G::EPL];
+    auto issue_loads = [&](int n0) {
+#pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int row = 4 * w + rr;
-            const int n = n0 + row;
-            float x[G::EPL];
+            const int n = n0 + 4 * w + rr;
             if (n < n_end) {
                 const float* yp = a.y + ((int64_t)b * NO + n) * H;
-                float s = 0.f;
 #pragma unroll
                 for (int c = 0; c < G::NCH; ++c) {
                     if (G::VEC == 4) {
                         const f32x4 t4 = *reinterpret_cast<const f32x4*>(yp + c * 256 + 4 * lane);
-                        x[4 * c] = t4[0]; x[4 * c + 1] = t4[1]; x[4 * c + 2] = t4[2]; x[4 * c + 3] = t4[3];
+                        x[rr][4 * c] = t4[0]; x[rr][4 * c + 1] = t4[1]; x[rr][4 * c + 2] = t4[2]; x[rr][4 * c + 3] = t4[3];
                     } else {
-                        x[c] = yp[c * 64 + lane];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < G::EPL; ++i) s += x[i];
-                const float mean = wave_sum(s) / H;
-                float q = 0.f;
-#pragma unroll
-                for (int i = 0; i < G::EPL; ++i) { const float d = x[i] - mean; q += d * d; }
-                const float rstd = rsqrtf(wave_sum(q) / H + a.eps);
-                if (a.ostats && lane == 0) {
-                    a.ostats[2 * ((int64_t)b * NO + n)] = mean;
-                    a.ostats[2 * ((int64_t)b * NO + n) + 1] = rstd;
-                }
-#pragma unroll
-                for (int c = 0; c < G::NCH; ++c) {
-                    if (G::VEC == 4) {
-                        const int col = c * 256 + 4 * lane;
-                        const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.g_obj + col);
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_obj + col);
-                        f32x4 o4;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o4[i] = (x[4 * c + i] - mean) * rstd * g4[i] + b4[i];
-                        *reinterpret_cast<f32x4*>(o_lds + row * G::LDO + col) = o4;
-                    } else {
-                        const int col = c * 64 + lane;
-                        o_lds[row * G::LDO + col] = (x[c] - mean) * rstd * a.g_obj[col] + a.b_obj[col];
+                        x[rr][c] = yp[c * 64 + lane];
                     }
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < G::NCH; ++c) {
-                    if (G::VEC == 4) {
-                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                        *reinterpret_cast<f32x4*>(o_lds + row * G::LDO + c * 256 + 4 * lane) = z4;
-                    } else {
-                        o_lds[row * G::LDO + c * 64 + lane] = 0.f;
-                    }
+                for (int i = 0; i < G::EPL; ++i) x[rr][i] = 0.f;
+            }
+        }
+    };
+    for (int n0 = n_begin; n0 < n_end; n0 += O2V_TILE) {
+        // ---- stage: global -> registers -> LayerNorm -> LDS
+        issue_loads(n0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = 4 * w + rr;
+            const int n = n0 + row;
+            const bool valid = n < n_end;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < G::EPL; ++i) s += x[rr][i];
+            const float mean = wave_sum(s) / H;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < G::EPL; ++i) { const float d = x[rr][i] - mean; q += d * d; }
+            const float rstd = rsqrtf(wave_sum(q) / H + a.eps);
+            if (valid && a.ostats && lane == 0) {
+                a.ostats[2 * ((int64_t)b * NO + n)] = mean;
+                a.ostats[2 * ((int64_t)b * NO + n) + 1] = rstd;
+            }
+#pragma unroll
+            for (int c = 0; c < G::NCH; ++c) {
+                if (G::VEC == 4) {
+                    const int col = c * 256 + 4 * lane;
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.g_obj + col);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_obj + col);
+                    f32x4 o4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o4[i] = valid ? (x[rr][4 * c + i] - mean) * rstd * g4[i] + b4[i] : 0.f;
+                    *reinterpret_cast<f32x4*>(o_lds + row * G::LDO + col) = o4;
+                } else {
+                    const int col = c * 64 + lane;
+                    o_lds[row * G::LDO + col] = valid ? (x[rr][c] - mean) * rstd * a.g_obj[col] + a.b_obj[col] : 0.f;
                 }
             }
         }
@@ -184,15 +188,19 @@ __global__ __launch_bounds__(O2V_THREADS) void o2v_partial_kernel(const dlsg_o2v
         m_run = m_new;
 
         // ---- aggregation: acc_o[frame][hcol] = alpha_frame * acc_o + sum_n P[n][frame] * O[n][hcol]
-        float arow[16];
+        {
+            float arow[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) arow[e] = __shfl(alpha, crow(e, h), 64);
+            for (int e = 0; e < 16; ++e) arow[e] = __shfl(alpha, crow(e, h), 64);
+#pragma unroll
+            for (int c = 0; c < G::CBW; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[c][e] *= arow[e];
+        }
 #pragma unroll
         for (int c = 0; c < G::CBW; ++c) {
             const int cb = w * G::CBW + c;
             if (cb < G::NCB) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc_o[c][e] *= arow[e];
                 const float* bp = o_lds + cb * 32 + r;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {

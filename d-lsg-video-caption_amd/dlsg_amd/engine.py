@@ -150,8 +150,10 @@ def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2
         g_o, b_o = m.obj_norm[1].weight, m.obj_norm[1].bias
         if fused_o2v and ops.o2v_supported(T, H):
             if nsplit is None:
+                # one resident workgroup per CU (148 KB of LDS each): split the objects of a clip only as far as needed to
+                # put ~256 workgroups on the chip; every extra split costs a (T x H) partial written and re-read.
                 tiles = (NO + 31) // 32
-                nsplit = max(1, min(tiles, (512 + B - 1) // B))
+                nsplit = max(1, min(tiles, 256 // max(B, 1)))
             ml = _empty(ref, B * T, 2)
             ops.o2v_fwd(y.view(B, NO, H), v.view(B, T, H), g_o, b_o, z, ml, ostats, S, scale, nsplit)
         else:
