@@ -240,12 +240,19 @@ class HipOps(object):
         if self.prof is not None:
             flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))
             if flops >= 2e9:     # only the heavy launches are timed, so the events do not perturb the step
-                big = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups) >= (512 if (a.flags & F_BF16X3) else 1000)
                 e0 = self._prof_begin()
         self._check(self.lib.dlsg_gemm(C.byref(a), self._stream()), 'dlsg_gemm')
         if e0 is not None:
-            x3 = 'bf16x3' if (a.flags & F_BF16X3) else 'f32'
-            self._prof_end('gemm_%s_mfma_%s' % (x3, '128x128' if big else '64x64'), e0, flops)
+            # same dispatch rule as dlsg_gemm (csrc/gemm.hip, csrc/gemm_bf16x3.hip)
+            x3 = bool(a.flags & F_BF16X3)
+            tiles_l = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups)
+            if M <= 64 and mode != GEMM_TN and N >= 64:
+                variant = 'skinny_64x32'
+            elif tiles_l >= (512 if x3 else 1000):
+                variant = '128x128'
+            else:
+                variant = '64x64'
+            self._prof_end('gemm_%s_mfma_%s' % ('bf16x3' if x3 else 'f32', variant), e0, flops)
 
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""
