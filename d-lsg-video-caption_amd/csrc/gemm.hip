@@ -28,10 +28,31 @@ struct TileGeom {
 };
 
 // Load one operand tile (ROWS x BK) into registers.  T=false: element (row,k) at base[row*ld + k];
-// T=true: element (row,k) at base[k*ld + row].  Out-of-range elements read as zero.
+// T=true: element (row,k) at base[k*ld + row].
+// Fast path (interior tile, 16-B aligned): unconditional float4 loads, no branches -- hipcc otherwise wraps every guarded
+// load in its own exec-mask branch and the loads of a tile no longer overlap.  Rows past the matrix edge are clamped to
+// the last valid row: they only feed output rows/columns that are never stored.
 template <int ROWS, bool T>
-__device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax,
-                                          int K, bool vec_ok, f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax,
+                                               f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
+    constexpr int NV = TileGeom<ROWS, T>::NV;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int f = threadIdx.x + NT * j;
+        const float* ptr;
+        if (!T) {
+            const int gr = min(row0 + (f >> 3), rmax - 1);
+            ptr = base + (int64_t)gr * ld + k0 + 4 * (f & 7);
+        } else {
+            ptr = base + (int64_t)(k0 + f / (ROWS / 4)) * ld + row0 + 4 * (f % (ROWS / 4));
+        }
+        regs[j] = *reinterpret_cast<const f32x4*>(ptr);
+    }
+}
+// Slow path: edge tiles / unaligned operands.  Out-of-range elements read as zero.
+template <int ROWS, bool T>
+__device__ __forceinline__ void load_tile_slow(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax,
+                                               int K, f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
     constexpr int NV = TileGeom<ROWS, T>::NV;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -52,16 +73,20 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_
             nvalid = (gk < K) ? min(max(rmax - gr, 0), 4) : 0;
         }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (nvalid == 4 && vec_ok) {
-            v = *reinterpret_cast<const f32x4*>(ptr);
-        } else {
-            if (nvalid > 0) v[0] = ptr[0];
-            if (nvalid > 1) v[1] = ptr[1];
-            if (nvalid > 2) v[2] = ptr[2];
-            if (nvalid > 3) v[3] = ptr[3];
-        }
+        if (nvalid > 0) v[0] = ptr[0];
+        if (nvalid > 1) v[1] = ptr[1];
+        if (nvalid > 2) v[2] = ptr[2];
+        if (nvalid > 3) v[3] = ptr[3];
         regs[j] = v;
     }
+}
+template <int ROWS, bool T>
+__device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax,
+                                          int K, bool vec_ok, f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
+    // wave-uniform choice per tile
+    const bool fast = vec_ok && (k0 + BK <= K) && (T ? (row0 + ROWS <= rmax) : (rmax > 0));
+    if (fast) load_tile_fast<ROWS, T>(base, ld, row0, k0, rmax, regs);
+    else load_tile_slow<ROWS, T>(base, ld, row0, k0, rmax, K, regs);
 }
 
 template <int ROWS, bool T>
@@ -205,12 +230,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs p) {
 // ------------------------------------------------------------------------------------------------ skinny GEMM (M <= 64)
 // The recurrent products of the path (BiLSTM / LSTMCell gates and their input gradients) have M = batch <= 64 rows:
 // every weight element is used once per launch, so they are weight-streaming and latency-bound, not MFMA-bound.
-// Block = 4 waves on one 64 x 32 output tile; the waves split K in 32-wide chunks (wave w takes chunks w, w+4, ...),
-// operands go straight from global memory to registers (no LDS staging: nothing is reused inside a block), the next
-// chunk's loads are in flight under the current chunk's 32 MFMAs, and the 4 partial tiles are summed through LDS.
+// Block = 4 waves on one 64 x 32 output tile, walking K in 128-wide super-chunks:
+//   * the activation chunk (64 x 128) and, for k-contiguous weights (NT), the weight chunk (32 x 128) are staged through
+//     LDS with fully coalesced loads (32 lanes x 16 B = one 512-B row segment); a lane-per-row gather straight into MFMA
+//     fragments was measured first: 64 cache lines per load instruction, address-coalescer bound (34 us vs 20 us);
+//   * n-contiguous weights (NN) are read straight into registers: lanes already run along n;
+//   * the 4 waves split the super-chunk's K (wave w owns k in [32w, 32w+32)), so a wave issues 32 fp32 MFMAs (or 12
+//     bf16 MFMAs on the split-bf16 path) per super-chunk; the next super-chunk's loads are in flight meanwhile;
+//   * the 4 partial tiles are summed through LDS in a fixed order (deterministic).
+constexpr int SK = 128;            // super-chunk depth
+constexpr int SLD = SK + 4;        // LDS row stride (floats): 16-B slot stride 33 = 1 mod 16
+
 template <bool BT>
 __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
-    __shared__ float red[4][2][16][64];
+    __shared__ __attribute__((aligned(16))) float lds[(64 + 32) * SLD];     // 50,688 B; reused for the final reduction
+    float* ldsA = lds;
+    float* ldsB = lds + 64 * SLD;
     const int z = blockIdx.y;
     const int gi = z % p.ngroups, bi = z / p.ngroups;
     const dlsg_gemm_group grp = p.g[gi];
@@ -222,7 +257,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const bool vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((grp.lda & 3) == 0);
-    const bool vecB = !BT && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
+    const bool vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
     const int col = n0 + r;
 
     f32x16 acc[2];
@@ -231,70 +266,122 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    float a_cur[2][16], b_cur[16], a_nxt[2][16], b_nxt[16];
+    f32x4 ra[8], rb[4];          // staged operands of the next super-chunk
+    float bdir[16];              // NN: this lane's 16 weight values of the next super-chunk
 
-    auto load_chunk = [&](int c, float (&fa)[2][16], float (&fb)[16]) {
-        const int k0 = c * 32 + 16 * h;
+    auto ld4s = [&](const float* ptr, int nvalid) {      // guarded (edge) load
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid > 0) v[0] = ptr[0];
+        if (nvalid > 1) v[1] = ptr[1];
+        if (nvalid > 2) v[2] = ptr[2];
+        if (nvalid > 3) v[3] = ptr[3];
+        return v;
+    };
+    auto load_super = [&](int k0) {
+        const bool fullk = k0 + SK <= K;                  // wave-uniform: branch-free loads on interior super-chunks
+        if (fullk && vecA) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int row = r + 32 * mi;
-            const float* ap = A + (int64_t)row * grp.lda + k0;
+            for (int j = 0; j < 8; ++j) {
+                const int f = threadIdx.x + NT * j;
+                const int row = min(f >> 5, M - 1);       // rows >= M feed output rows that are never stored
+                ra[j] = *reinterpret_cast<const f32x4*>(A + (int64_t)row * grp.lda + k0 + 4 * (f & 31));
+            }
+        } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = k0 + 4 * q;
-                if (row < M && vecA && k + 3 < K) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 4 * q);
-                    fa[mi][4 * q] = v[0]; fa[mi][4 * q + 1] = v[1]; fa[mi][4 * q + 2] = v[2]; fa[mi][4 * q + 3] = v[3];
-                } else {
+            for (int j = 0; j < 8; ++j) {
+                const int f = threadIdx.x + NT * j;
+                const int row = f >> 5, k = k0 + 4 * (f & 31);
+                ra[j] = ld4s(A + (int64_t)row * grp.lda + k, row < M ? min(max(K - k, 0), 4) : 0);
+            }
+        }
+        if (!BT) {
+            if (fullk && vecB) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) fa[mi][4 * q + i] = (row < M && k + i < K) ? ap[4 * q + i] : 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int f = threadIdx.x + NT * j;
+                    const int row = min(n0 + (f >> 5), N - 1);
+                    rb[j] = *reinterpret_cast<const f32x4*>(B + (int64_t)row * grp.ldb + k0 + 4 * (f & 31));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = threadIdx.x + NT * j;
+                    const int row = f >> 5, k = k0 + 4 * (f & 31);
+                    rb[j] = ld4s(B + (int64_t)(n0 + row) * grp.ldb + k, (n0 + row) < N ? min(max(K - k, 0), 4) : 0);
+                }
+            }
+        } else {
+            const int cc = min(col, N - 1);
+            if (fullk) {
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) bdir[s2] = B[(int64_t)(k0 + 32 * w + 16 * h + s2) * grp.ldb + cc];
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    const int k = k0 + 32 * w + 16 * h + s2;
+                    bdir[s2] = (k < K) ? B[(int64_t)k * grp.ldb + cc] : 0.f;
                 }
             }
         }
-        if (!BT) {      // B element (k, n) at B[n*ldb + k]
-            const float* bp = B + (int64_t)col * grp.ldb + k0;
+    };
+    auto store_super = [&]() {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = k0 + 4 * q;
-                if (col < N && vecB && k + 3 < K) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(bp + 4 * q);
-                    fb[4 * q] = v[0]; fb[4 * q + 1] = v[1]; fb[4 * q + 2] = v[2]; fb[4 * q + 3] = v[3];
-                } else {
+        for (int j = 0; j < 8; ++j) {
+            const int f = threadIdx.x + NT * j;
+            *reinterpret_cast<f32x4*>(ldsA + (f >> 5) * SLD + 4 * (f & 31)) = ra[j];
+        }
+        if (!BT) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) fb[4 * q + i] = (col < N && k + i < K) ? bp[4 * q + i] : 0.f;
-                }
-            }
-        } else {        // B element (k, n) at B[k*ldb + n]: lanes on consecutive n
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
-                const int k = k0 + s2;
-                fb[s2] = (col < N && k < K) ? B[(int64_t)k * grp.ldb + col] : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                const int f = threadIdx.x + NT * j;
+                *reinterpret_cast<f32x4*>(ldsB + (f >> 5) * SLD + 4 * (f & 31)) = rb[j];
             }
         }
     };
 
-    const int nchunks = (K + 31) / 32;
-    int c = w;
-    if (c < nchunks) load_chunk(c, a_cur, b_cur);
-    while (c < nchunks) {
-        const int cn = c + 4;
-        if (cn < nchunks) load_chunk(cn, a_nxt, b_nxt);
+    const int nsup = (K + SK - 1) / SK;
+    if (nsup > 0) load_super(0);
+    for (int sc = 0; sc < nsup; ++sc) {
+        store_super();
+        float bcur[16];
+        if (BT) {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) bcur[s2] = bdir[s2];
+        }
+        __syncthreads();
+        if (sc + 1 < nsup) load_super((sc + 1) * SK);
+        // fragments of this wave's 32-deep slice: lane half h owns k = 32w + 16h + s
+        float fa[2][16];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const float* ap = ldsA + (r + 32 * mi) * SLD + 32 * w + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 4 * q);
+                fa[mi][4 * q] = v[0]; fa[mi][4 * q + 1] = v[1]; fa[mi][4 * q + 2] = v[2]; fa[mi][4 * q + 3] = v[3];
+            }
+        }
+        if (!BT) {
+            const float* bp = ldsB + r * SLD + 32 * w + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+                bcur[4 * q] = v[0]; bcur[4 * q + 1] = v[1]; bcur[4 * q + 2] = v[2]; bcur[4 * q + 3] = v[3];
+            }
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 16; ++s2) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][s2], b_cur[s2], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1][s2], b_cur[s2], acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s2], bcur[s2], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][s2], bcur[s2], acc[1], 0, 0, 0);
         }
-        if (cn < nchunks) {
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) { a_cur[0][s2] = a_nxt[0][s2]; a_cur[1][s2] = a_nxt[1][s2]; b_cur[s2] = b_nxt[s2]; }
-        }
-        c = cn;
+        __syncthreads();
     }
-    // ---- sum the 4 waves' partial tiles through LDS; wave w finalises register group e in [4w, 4w+4)
+    // ---- sum the 4 waves' partial tiles through LDS (staging buffers are free now); wave w finalises e in [4w, 4w+4)
+    float* red = lds;               // [4][2][16][64] floats = 32 KB
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[w][mi][e][lane] = acc[mi][e];
+        for (int e = 0; e < 16; ++e) red[((w * 2 + mi) * 16 + e) * 64 + lane] = acc[mi][e];
     __syncthreads();
     const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && p.bias != nullptr;
     const bool do_tanh = p.flags & DLSG_GEMM_TANH;
@@ -307,7 +394,9 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
                 const int e = 4 * w + ee;
                 const int row = 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row >= M) continue;
-                float v = red[0][mi][e][lane] + red[1][mi][e][lane] + red[2][mi][e][lane] + red[3][mi][e][lane];
+                float v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) v += red[((ww * 2 + mi) * 16 + e) * 64 + lane];
                 v = p.alpha * v + bv;
                 float* cp = C + (int64_t)row * p.ldc + col;
                 if (accum) v += *cp;

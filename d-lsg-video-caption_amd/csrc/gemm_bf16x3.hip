@@ -56,10 +56,23 @@ struct Geom {
 
 // T=false: (row,k) at base[row*ld + k], one float4 = 4 consecutive k of a row.
 // T=true : (row,k) at base[k*ld + row], one float4 = 4 consecutive rows at one k.
+// Interior tiles take the branch-free path (see gemm.hip load_tile_fast); edge tiles / unaligned operands the guarded one.
 template <int ROWS, bool T>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax, int K,
                                           bool vec_ok, f32x4 (&regs)[Geom<ROWS, T>::NV]) {
     constexpr int NV = Geom<ROWS, T>::NV;
+    const bool fast = vec_ok && (k0 + BK <= K) && (T ? (row0 + ROWS <= rmax) : (rmax > 0));
+    if (fast) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int f = threadIdx.x + NT * j;
+            const float* ptr;
+            if (!T) ptr = base + (int64_t)min(row0 + (f >> 3), rmax - 1) * ld + k0 + 4 * (f & 7);
+            else ptr = base + (int64_t)(k0 + f / (ROWS / 4)) * ld + row0 + 4 * (f % (ROWS / 4));
+            regs[j] = *reinterpret_cast<const f32x4*>(ptr);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int f = threadIdx.x + NT * j;
@@ -77,14 +90,10 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_
             nvalid = (gk < K) ? min(max(rmax - gr, 0), 4) : 0;
         }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (nvalid == 4 && vec_ok) {
-            v = *reinterpret_cast<const f32x4*>(ptr);
-        } else {
-            if (nvalid > 0) v[0] = ptr[0];
-            if (nvalid > 1) v[1] = ptr[1];
-            if (nvalid > 2) v[2] = ptr[2];
-            if (nvalid > 3) v[3] = ptr[3];
-        }
+        if (nvalid > 0) v[0] = ptr[0];
+        if (nvalid > 1) v[1] = ptr[1];
+        if (nvalid > 2) v[2] = ptr[2];
+        if (nvalid > 3) v[3] = ptr[3];
         regs[j] = v;
     }
 }

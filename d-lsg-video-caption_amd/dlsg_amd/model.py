@@ -39,6 +39,8 @@ class _HipModel(nn.Module):
         # GEMM arithmetic: 'fp32' = exact fp32 MFMA everywhere; 'x3_bwd' = split-bf16 (3 bf16 MFMAs per product,
         # ~1e-5 relative error) for the backward products only; 'x3_all' = split-bf16 for forward and backward.
         self.gemm_precision = 'fp32'
+        self.two_streams = False   # fork/join of the two encoder branches: measured no gain (GEMM grids fill every CU)
+        self._side = None
 
     # ------------------------------------------------------------------ kernels handle
     @property
@@ -82,6 +84,23 @@ class _HipModel(nn.Module):
 
     def grad_views(self):
         return self._G
+
+    # ------------------------------------------------------------------ two-stream fork / join
+    def _fork(self, ref):
+        """Returns a side HIP stream ordered after the current one (None off-GPU).  Independent branches of the schedule
+        (object-stream encoder vs. BiLSTM motion pre-encoder) run concurrently: the recurrent part is ~50 small
+        latency-bound launches that hide under the other branch's large GEMMs.  Works inside hipGraph capture."""
+        if not ref.is_cuda or not self.two_streams:
+            return None
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=ref.device)
+        self._side.wait_stream(torch.cuda.current_stream())
+        return self._side
+
+    @staticmethod
+    def _join(side):
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
 
     def _gemm_flags(self, backward):
         from .hip import F_BF16X3
@@ -167,11 +186,18 @@ class CapGnnModel(_HipModel):
         B, T, F = frames.shape
         A = enc.a_feature_size
         f2 = frames.view(B * T, F)
-        obj = E.tun_fwd(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv, training, seed,
-                        E.SITE_PSL_OBJ, self.fused_o2v)
+        side = self._fork(frames)
+        if side is not None:
+            with torch.cuda.stream(side):
+                obj = E.tun_fwd(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv, training, seed,
+                                E.SITE_PSL_OBJ, self.fused_o2v)
+        else:
+            obj = E.tun_fwd(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv, training, seed,
+                            E.SITE_PSL_OBJ, self.fused_o2v)
         mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed)
         mot = E.tun_fwd(ops, enc.motion_encoder, 'encoder.motion_encoder', mot_in, regions, sv, training, seed,
                         E.SITE_PSL_MOT, self.fused_o2v)
+        self._join(side)
         return obj, mot
 
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
@@ -213,12 +239,17 @@ class CapGnnModel(_HipModel):
         dmot_in = E.tun_bwd(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, G, dmo, training, seed)
         if on_bucket:
             on_bucket('encoder.motion_encoder')
+        # the object-stream encoder backward (large GEMMs) runs beside the BiLSTM backward (small recurrent launches)
+        side = self._fork(frames)
+        if side is not None:
+            with torch.cuda.stream(side):
+                E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed)
         E.encvis_bwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, G, dmot_in, training, seed)
+        if side is None:
+            E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed)
+        self._join(side)
         if on_bucket:
-            on_bucket('encoder.motion_pre_encoder')
-        E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed)
-        if on_bucket:
-            on_bucket('encoder.obj_encoder')
+            on_bucket(('encoder.motion_pre_encoder', 'encoder.obj_encoder'))
 
     # ------------------------------------------------------------------ public forward
     def forward(self, visual_feats, region_feats, caption, max_words=None, teacher_forcing_ratio=1.0):
@@ -285,7 +316,7 @@ class CapBaseline1(_HipModel):
         ops.mean_rows_bwd(dgfeat, denc, accum=True)
         E.encvis_bwd(ops, self.encoder, 'encoder', frames.view(B * T, F), B, T, sv, G, denc.view(B * T, -1), training, seed)
         if on_bucket:
-            on_bucket('decoder'); on_bucket('encoder')
+            on_bucket(('decoder', 'encoder'))
 
     def forward(self, visual_feats, region_feats, caption, max_words=None, teacher_forcing_ratio=1.0):
         self.flatten_parameters_()
@@ -341,6 +372,7 @@ class Trainer(object):
         self.pg = process_group
         self.use_graphs = use_graphs
         self.device_coins = use_graphs if device_coins is None else device_coins
+        self.force_graph_cuts = False   # test hook: segment the capture at bucket boundaries even on one GPU
         self._works = []
         self._graphs = None
         # contiguous arena range of each backward bucket (named_parameters order == arena order)
@@ -355,11 +387,13 @@ class Trainer(object):
 
     # ------------------------------------------------------------------ collectives
     def _allreduce(self, key):
+        """key: a bucket name or a tuple of bucket names whose gradients are complete."""
         if self.world_size <= 1:
             return
         import torch.distributed as dist
-        lo, hi = self._ranges[key]
-        self._works.append(dist.all_reduce(self.model._gflat[lo:hi], group=self.pg, async_op=True))
+        for k in (key if isinstance(key, tuple) else (key,)):
+            lo, hi = self._ranges[k]
+            self._works.append(dist.all_reduce(self.model._gflat[lo:hi], group=self.pg, async_op=True))
 
     # ------------------------------------------------------------------ one step, as a schedule
     def _schedule(self, frames, regions, captions, cap_lens, coins, seed, dev_coins, on_bucket):
@@ -425,7 +459,7 @@ class Trainer(object):
             cur[0].capture_begin(pool=pool)
 
             def cut(key):
-                if self.world_size <= 1:
+                if self.world_size <= 1 and not self.force_graph_cuts:
                     return
                 cur[0].capture_end()
                 graphs.append((cur[0], key))
@@ -434,6 +468,7 @@ class Trainer(object):
 
             loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut)
             if self.world_size <= 1:
+                # single GPU: Adam is part of the (last) graph; with several ranks it follows the all-reduce waits
                 self.model.ops.adam(self.model._flat, self.model._gflat, self.m, self.v, self.lr, self.betas[0],
                                     self.betas[1], self.eps, 1, 1.0, hyper=st['hyper'])
             cur[0].capture_end()
