@@ -165,6 +165,8 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
     const float* B = grp.B + (int64_t)bi * p.bsb;
     float* C = grp.C + (int64_t)bi * p.bsc;
     const int K = grp.K;
+    const int Ng = grp.N > 0 ? grp.N : p.N;      // this group's output width
+    if (n0 >= Ng) return;
     const bool vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((grp.lda & 3) == 0);
     const bool vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
 
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
     const int nk = (K + BK - 1) / BK;
     if (nk > 0) {
         load_tile<BM, AT>(A, grp.lda, m0, 0, p.M, K, vecA, ra);
-        load_tile<BN, BT>(B, grp.ldb, n0, 0, p.N, K, vecB, rb);
+        load_tile<BN, BT>(B, grp.ldb, n0, 0, Ng, K, vecB, rb);
     }
     for (int kt = 0; kt < nk; ++kt) {
         store_tile<BM, AT>(a_hi, a_lo, ra);
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
         __syncthreads();
         if (kt + 1 < nk) {
             load_tile<BM, AT>(A, grp.lda, m0, (kt + 1) * BK, p.M, K, vecA, ra);
-            load_tile<BN, BT>(B, grp.ldb, n0, (kt + 1) * BK, p.N, K, vecB, rb);
+            load_tile<BN, BT>(B, grp.ldb, n0, (kt + 1) * BK, Ng, K, vecB, rb);
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {          // two 16-deep MFMA chunks per K tile; lane half h owns k = 16c + 8h + j
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WN + j * 32 + r;
-            if (col >= p.N) continue;
+            if (col >= Ng) continue;
             const float bv = use_bias ? p.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -281,8 +283,9 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
     const float* A = grp.A + (int64_t)bi * p.bsa;
     const float* B = grp.B + (int64_t)bi * p.bsb;
     float* C = grp.C + (int64_t)bi * p.bsc;
-    const int K = grp.K, M = p.M, N = p.N;
+    const int K = grp.K, M = p.M, N = grp.N > 0 ? grp.N : p.N;
     const int n0 = blockIdx.x * 32;
+    if (n0 >= N) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const bool vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((grp.lda & 3) == 0);

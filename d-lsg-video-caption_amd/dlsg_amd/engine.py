@@ -100,6 +100,27 @@ def gemm_tn_deep(ops, dy, x, gout, ref):
         ops.slab_reduce(slabs, gout, flags=F_ACCUM)
 
 
+def gemm_nn_multi(ops, dy, Ws, out, ref):
+    """out (M, sum Kin_i) = [dy @ W_0 | dy @ W_1 | ...] for several weight blocks sharing the same dy (e.g. W_ih and W_hh
+    of one cell): ONE grouped launch (groups have their own output width) writing column blocks of one slab set, ONE
+    slab_reduce.  dy (M, Nout), W_i (Nout, Kin_i)."""
+    M, Nn = dy.shape
+    widths = [W.shape[1] for W in Ws]
+    tot = sum(widths)
+    assert out.shape[1] == tot
+    ns = _nsplit_for(M, tot, 1)
+    ns = max(1, min(ns, 16 // len(Ws)))
+    bounds = _ksplit_bounds(Nn, ns)
+    slabs = _empty(ref, len(bounds), M, tot)
+    groups, c0 = [], 0
+    for W, wd in zip(Ws, widths):
+        for i, (k0, k1) in enumerate(bounds):
+            groups.append((dy[:, k0:k1], W[k0:k1, :], slabs[i][:, c0:c0 + wd]))
+        c0 += wd
+    ops.gemm(GEMM_NN, groups)
+    ops.slab_reduce(slabs, out)
+
+
 def lin(ops, x, W, out, bias=None, tanh=False, accum=False):
     ops.gemm(GEMM_NT, [(x, W, out)], flags=(F_TANH if tanh else 0) | (F_ACCUM if accum else 0), bias=bias)
 
@@ -400,8 +421,11 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     dout3 = dout.view(B, T, D2)
     gates, cst, hprev = s['gates'], s['cst'], s['hprev']
     dG = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
-    dhrec = [_empty(ref, B, H), _empty(ref, B, H)]
+    dhrec2 = _empty(ref, B, 2 * H)                       # [d h_prev of the forward dir | of the reverse dir]
+    dhrec = [dhrec2[:, :H], dhrec2[:, H:]]
     dcrec = [_empty(ref, B, H), _empty(ref, B, H)]
+    ns_r = max(1, min(_nsplit_for(B, 2 * H, 1), 8))
+    rb = _ksplit_bounds(4 * H, ns_r)
     for step in range(T - 1, -1, -1):
         tt = [step, T - 1 - step]
         tp = [step - 1, T - step]
@@ -412,8 +436,16 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
                             c_prev=cst[d][:, tp[d]] if step > 0 else None,
                             dh=dout3[:, t, d * H:(d + 1) * H], dh2=None if last else dhrec[d],
                             dc_next=None if last else dcrec[d], dc_prev=dcrec[d])
-            if step > 0:
-                gemm_nn_split(ops, dG[d][:, t], Whh[d], dhrec[d], ref)
+        if step > 0:
+            # recurrent gradient of both directions: one grouped launch, one reduction
+            slabs = _empty(ref, len(rb), B, 2 * H)
+            groups = []
+            for d in range(2):
+                dg = dG[d][:, tt[d]]
+                for i, (k0, k1) in enumerate(rb):
+                    groups.append((dg[:, k0:k1], Whh[d][k0:k1, :], slabs[i][:, d * H:(d + 1) * H]))
+            ops.gemm(GEMM_NN, groups)
+            ops.slab_reduce(slabs, dhrec2)
     de = _empty(ref, B * T, H)
     e = s['e']
     for d in range(2):
@@ -620,11 +652,13 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     dGQ = _empty(ref, L, B, 4 * Q)
     dGL = _empty(ref, L, B, 4 * D)
     dLH = _empty(ref, B, D)             # grad wrt the dropped lang h of the step being processed
-    dLHrec = _zeros(ref, B, D)          # contributions from step t+1 (query input + lang recurrent)
-    dQHrec = _zeros(ref, B, Q)
+    dQL = _empty(ref, B, Q + D)         # [dQHrec | query-input part of dLHrec] of the query cell
+    dQHrec = dQL[:, :Q]
     dQC = _zeros(ref, B, Q)
     dLC = _zeros(ref, B, D)
-    dXL = _empty(ref, B, ns * H + Q)    # grad wrt lang_lstm input [ctx.. | qcur]
+    dXLH = _empty(ref, B, ns * H + Q + D)   # [grad wrt lang_lstm input (ctx.. | qcur) | grad wrt its recurrent h]
+    dXL = dXLH[:, :ns * H + Q]
+    dLHrec = dXLH[:, ns * H + Q:]       # contributions from step t+1 to the dropped lang h (lang recurrent + query input)
     dCPRE = [_empty(ref, B, H) for _ in range(ns)]
     dQH = _empty(ref, B, Q)
     dKp = [torch.zeros_like(k) for k in s['Kp']]
@@ -644,10 +678,11 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
             ops.copy2d(dLHrec, dLH, accum=True)
         ops.lstm_pw_bwd(s['GL'][t], s['LC'][t + 1], dGL[t], B, D, c_prev=s['LC'][t], dh2=dLH, dc_next=dLC, dc_prev=dLC,
                         p=pd, site=site + SITE_LANG, seed=seed)
-        # input grads of the language cell
-        gemm_nn_split(ops, dGL[t], Wl_in, dXL, ref)
+        # input grads of the language cell: [dXL | dLHrec] = dGL[t] . [W_ih | W_hh] in one grouped launch
         if t > 0:
-            gemm_nn_split(ops, dGL[t], ll.weight_hh, dLHrec, ref)
+            gemm_nn_multi(ops, dGL[t], [Wl_in, ll.weight_hh], dXLH, ref)
+        else:
+            gemm_nn_split(ops, dGL[t], Wl_in, dXL, ref)
         for i, att in enumerate(atts):
             ln = att.output_layer[2]
             ops.rowln_bwd(dXL[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]], s['CPRE'][i][t], ln.weight, ln.bias, dCPRE[i],
@@ -662,8 +697,8 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
             ops.copy2d(dQHrec, dQH, accum=True)
         ops.lstm_pw_bwd(s['GQ'][t], s['QC'][t + 1], dGQ[t], B, Q, c_prev=s['QC'][t], dh=dQH, dc_next=dQC, dc_prev=dQC)
         if t > 0:
-            gemm_nn_split(ops, dGQ[t], ql.weight_hh, dQHrec, ref)
-            gemm_nn_split(ops, dGQ[t], ql.weight_ih[:, plan.q_lang[0]:plan.q_lang[1]], dLHrec, ref, accum=True)
+            gemm_nn_multi(ops, dGQ[t], [ql.weight_hh, ql.weight_ih[:, plan.q_lang[0]:plan.q_lang[1]]], dQL, ref)
+            ops.copy2d(dQL[:, Q:], dLHrec, accum=True)
     # ---- LayerNorm parameter grads of the per-step norms
     ln_grads(ops, part_q.view(L * nbB, 2, Q), G, 'decoder.query_lstm_layernorm', Q)
     att_names = ['decoder.context_att', 'decoder.context_att_2']

@@ -25,7 +25,7 @@ i32, i64, u32, u64, f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_floa
 
 
 class GemmGroup(C.Structure):
-    _fields_ = [('A', c_f32p), ('B', c_f32p), ('C', c_f32p), ('lda', i64), ('ldb', i64), ('K', i32), ('pad_', i32)]
+    _fields_ = [('A', c_f32p), ('B', c_f32p), ('C', c_f32p), ('lda', i64), ('ldb', i64), ('K', i32), ('N', i32)]
 
 
 class GemmArgs(C.Structure):
@@ -212,30 +212,32 @@ class HipOps(object):
         else:
             nb = 1
             a.bsa = a.bsb = a.bsc = 0
-        M, N = C0.shape[-2], C0.shape[-1]
+        M = C0.shape[-2]
+        N = max(g[2].shape[-1] for g in groups)          # groups may write column blocks of different widths
         a.mode, a.M, a.N, a.ldc = mode, M, N, C0.stride(-2)
         a.ngroups, a.nbatch, a.alpha = len(groups), nb, alpha
         a.flags = flags | self.extra_flags | (F_BIAS if bias is not None else 0)
         a.bias = _p(bias)
         assert len(groups) <= MAXG
         for i, (A, B, Cc) in enumerate(groups):
+            Ng = Cc.shape[-1]
             if mode == GEMM_TN:
                 K = A.shape[-2]
-                assert A.shape[-1] == M and B.shape[-2] == K and B.shape[-1] == N, (A.shape, B.shape, Cc.shape)
+                assert A.shape[-1] == M and B.shape[-2] == K and B.shape[-1] == Ng, (A.shape, B.shape, Cc.shape)
             elif mode == GEMM_NN:
                 K = A.shape[-1]
-                assert A.shape[-2] == M and B.shape[-2] == K and B.shape[-1] == N, (A.shape, B.shape, Cc.shape)
+                assert A.shape[-2] == M and B.shape[-2] == K and B.shape[-1] == Ng, (A.shape, B.shape, Cc.shape)
             else:
                 K = A.shape[-1]
-                assert A.shape[-2] == M and B.shape[-1] == K and B.shape[-2] == N, (A.shape, B.shape, Cc.shape)
+                assert A.shape[-2] == M and B.shape[-1] == K and B.shape[-2] == Ng, (A.shape, B.shape, Cc.shape)
             for t in (A, B, Cc):
                 assert t.dtype == torch.float32 and (t.stride(-1) == 1 or t.size(-1) == 1), (t.shape, t.stride())
-            assert Cc.stride(-2) == a.ldc and Cc.shape[-2:] == C0.shape[-2:]
+            assert Cc.stride(-2) == a.ldc and Cc.shape[-2] == M
             if batched:
                 assert (A.stride(0), B.stride(0), Cc.stride(0)) == (a.bsa, a.bsb, a.bsc)
             g = a.g[i]
             g.A, g.B, g.C = _p(A), _p(B), _p(Cc)
-            g.lda, g.ldb, g.K = A.stride(-2), B.stride(-2), K
+            g.lda, g.ldb, g.K, g.N = A.stride(-2), B.stride(-2), K, (Ng if Ng != N else 0)
         e0 = None
         if self.prof is not None:
             flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))

@@ -47,7 +47,8 @@ typedef struct {
     float* C;
     int64_t lda, ldb;
     int32_t K;
-    int32_t pad_;
+    int32_t N;   /* 0 = use args.N; otherwise this group's own output width (<= args.N): lets one launch write
+                    column blocks of different widths (e.g. dG.W_ih and dG.W_hh) */
 } dlsg_gemm_group;
 typedef struct {
     int32_t mode, M, N, ldc;
