@@ -277,6 +277,8 @@ __global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(const dlsg_lstm_pw_bwd
     float dh = a.dh ? a.dh[(int64_t)b * a.lddh + j] : 0.f;
     if (a.dh2) {
         float d2 = a.dh2[(int64_t)b * a.lddh2 + j];
+        if (a.dh3) d2 += a.dh3[(int64_t)b * a.lddh3 + j];
+        if (a.dh4) d2 += a.dh4[(int64_t)b * a.lddh4 + j];
         if (a.p > 0.f) d2 *= drop_scale(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), a.site, (uint64_t)b * H + j, a.p);
         dh += d2;
     }

@@ -651,7 +651,6 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
 
     dGQ = _empty(ref, L, B, 4 * Q)
     dGL = _empty(ref, L, B, 4 * D)
-    dLH = _empty(ref, B, D)             # grad wrt the dropped lang h of the step being processed
     dQL = _empty(ref, B, Q + D)         # [dQHrec | query-input part of dLHrec] of the query cell
     dQHrec = dQL[:, :Q]
     dQC = _zeros(ref, B, Q)
@@ -660,7 +659,6 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     dXL = dXLH[:, :ns * H + Q]
     dLHrec = dXLH[:, ns * H + Q:]       # contributions from step t+1 to the dropped lang h (lang recurrent + query input)
     dCPRE = [_empty(ref, B, H) for _ in range(ns)]
-    dQH = _empty(ref, B, Q)
     dKp = [torch.zeros_like(k) for k in s['Kp']]
     dVp = [torch.zeros_like(v) for v in s['Vp']]
     atts = _att_modules(dec)
@@ -672,11 +670,11 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     Wl_in = ll.weight_ih
     for t in range(L - 1, -1, -1):
         site = STEP_SITE * (t + 1)
-        # total grad on lang h_t (dropped): from the vocab head + from step t+1
-        ops.copy2d(dLHo[t], dLH)
-        if t < L - 1:
-            ops.copy2d(dLHrec, dLH, accum=True)
-        ops.lstm_pw_bwd(s['GL'][t], s['LC'][t + 1], dGL[t], B, D, c_prev=s['LC'][t], dh2=dLH, dc_next=dLC, dc_prev=dLC,
+        # total grad on lang h_t (dropped) = vocab head part + (step t+1) lang-recurrent part + query-input part; the
+        # three are summed inside the cell kernel (they share the dropout mask of h_t)
+        rec = t < L - 1
+        ops.lstm_pw_bwd(s['GL'][t], s['LC'][t + 1], dGL[t], B, D, c_prev=s['LC'][t], dh2=dLHo[t],
+                        dh3=dLHrec if rec else None, dh4=dQL[:, Q:] if rec else None, dc_next=dLC, dc_prev=dLC,
                         p=pd, site=site + SITE_LANG, seed=seed)
         # input grads of the language cell: [dXL | dLHrec] = dGL[t] . [W_ih | W_hh] in one grouped launch
         if t > 0:
@@ -691,14 +689,12 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
         dq = dXL[:, plan.l_q[0]:plan.l_q[1]]
         ops.decatt_bwd(s['Kp'], s['Vp'], s['QCUR'][t], s['ALPHA'][t], dCPRE, dKp, dVp, dq, scale, accum_dq=True,
                        dalpha=dalpha_tm[t] if dalpha_tm is not None else None)
-        ops.rowln_bwd(dq, s['QH'][t + 1], lnq.weight, lnq.bias, dQH, stats=s['ST_Q'][t], p1=pd, site1=site + SITE_QUERY,
-                      seed=seed, dgb_part=part_q[t])
-        if t < L - 1:
-            ops.copy2d(dQHrec, dQH, accum=True)
-        ops.lstm_pw_bwd(s['GQ'][t], s['QC'][t + 1], dGQ[t], B, Q, c_prev=s['QC'][t], dh=dQH, dc_next=dQC, dc_prev=dQC)
+        # dQH = LN-backward(dq) + recurrent part from step t+1 (accumulated in place into the dQHrec buffer)
+        ops.rowln_bwd(dq, s['QH'][t + 1], lnq.weight, lnq.bias, dQHrec, stats=s['ST_Q'][t], p1=pd, site1=site + SITE_QUERY,
+                      seed=seed, dgb_part=part_q[t], accum_dx=rec)
+        ops.lstm_pw_bwd(s['GQ'][t], s['QC'][t + 1], dGQ[t], B, Q, c_prev=s['QC'][t], dh=dQHrec, dc_next=dQC, dc_prev=dQC)
         if t > 0:
             gemm_nn_multi(ops, dGQ[t], [ql.weight_hh, ql.weight_ih[:, plan.q_lang[0]:plan.q_lang[1]]], dQL, ref)
-            ops.copy2d(dQL[:, Q:], dLHrec, accum=True)
     # ---- LayerNorm parameter grads of the per-step norms
     ln_grads(ops, part_q.view(L * nbB, 2, Q), G, 'decoder.query_lstm_layernorm', Q)
     att_names = ['decoder.context_att', 'decoder.context_att_2']

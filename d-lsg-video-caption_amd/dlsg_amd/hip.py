@@ -71,7 +71,8 @@ class LstmPwArgs(C.Structure):
 
 class LstmPwBwdArgs(C.Structure):
     _fields_ = [('gates', c_f32p), ('ldg', i64), ('c', c_f32p), ('ldc_', i64), ('c_prev', c_f32p), ('ldcp', i64), ('dh', c_f32p),
-                ('lddh', i64), ('dh2', c_f32p), ('lddh2', i64), ('dc_next', c_f32p), ('lddcn', i64),
+                ('lddh', i64), ('dh2', c_f32p), ('lddh2', i64), ('dh3', c_f32p), ('lddh3', i64), ('dh4', c_f32p), ('lddh4', i64),
+                ('dc_next', c_f32p), ('lddcn', i64),
                 ('dgates', c_f32p), ('lddg', i64), ('dc_prev', c_f32p), ('lddcp', i64), ('B', i32), ('H', i32), ('p', f32),
                 ('site', u32), ('seed', u64), ('seed_ptr', c_f32p)]
 
@@ -380,12 +381,14 @@ class HipOps(object):
         self._check(self.lib.dlsg_lstm_pw_fwd(C.byref(a), self._stream()), 'dlsg_lstm_pw_fwd')
 
     def lstm_pw_bwd(self, gates, c, dgates, B, H, c_prev=None, dh=None, dh2=None, dc_next=None, dc_prev=None, p=0.0,
-                    site=0, seed=0):
+                    site=0, seed=0, dh3=None, dh4=None):
         a = LstmPwBwdArgs()
         a.gates, a.ldg, a.c, a.ldc_ = _p(gates), gates.stride(0), _p(c), c.stride(0)
         a.c_prev, a.ldcp = _p(c_prev), (c_prev.stride(0) if c_prev is not None else 0)
         a.dh, a.lddh = _p(dh), (dh.stride(0) if dh is not None else 0)
         a.dh2, a.lddh2 = _p(dh2), (dh2.stride(0) if dh2 is not None else 0)
+        a.dh3, a.lddh3 = _p(dh3), (dh3.stride(0) if dh3 is not None else 0)
+        a.dh4, a.lddh4 = _p(dh4), (dh4.stride(0) if dh4 is not None else 0)
         a.dc_next, a.lddcn = _p(dc_next), (dc_next.stride(0) if dc_next is not None else 0)
         a.dgates, a.lddg = _p(dgates), dgates.stride(0)
         a.dc_prev, a.lddcp = _p(dc_prev), (dc_prev.stride(0) if dc_prev is not None else 0)

@@ -178,6 +178,8 @@ typedef struct {
     const float* c_prev; int64_t ldcp;
     const float* dh; int64_t lddh;             /* optional */
     const float* dh2; int64_t lddh2;           /* optional, goes through the dropout mask */
+    const float* dh3; int64_t lddh3;           /* optional, summed with dh2 before the mask */
+    const float* dh4; int64_t lddh4;           /* optional, summed with dh2 before the mask */
     const float* dc_next; int64_t lddcn;       /* optional */
     float* dgates; int64_t lddg;               /* (B,4H) pre-activation gate grads, row stride lddg */
     float* dc_prev; int64_t lddcp;

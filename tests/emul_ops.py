@@ -239,13 +239,18 @@ class EmulOps(object):
             gates.copy_(torch.cat([i, f, g, o], 1))
 
     def lstm_pw_bwd(self, gates, c, dgates, B, H, c_prev=None, dh=None, dh2=None, dc_next=None, dc_prev=None, p=0.0,
-                    site=0, seed=0):
+                    site=0, seed=0, dh3=None, dh4=None):
         self._count('lstm_pw_bwd')
         i, f, g, o = gates[:, :H], gates[:, H:2 * H], gates[:, 2 * H:3 * H], gates[:, 3 * H:]
         cp = c_prev if c_prev is not None else torch.zeros(B, H)
         d = torch.zeros(B, H) if dh is None else dh.clone()
         if dh2 is not None:
-            d = d + (dh2 * _mask(seed, site, B, H, p) if p > 0 else dh2)
+            d2 = dh2
+            if dh3 is not None:
+                d2 = d2 + dh3
+            if dh4 is not None:
+                d2 = d2 + dh4
+            d = d + (d2 * _mask(seed, site, B, H, p) if p > 0 else d2)
         tc = torch.tanh(c)
         dc = d * o * (1 - tc * tc)
         if dc_next is not None:
