@@ -274,9 +274,15 @@ __device__ __forceinline__ void split8(const float* x, bf16x8& hi, bf16x8& lo) {
     lo = __builtin_bit_cast(bf16x8, lv);
 }
 
+// LDS-staged 64 x 32 skinny kernel: same structure as skinny_kernel in gemm.hip, bf16x3 MFMAs (split in registers)
+constexpr int SK = 128;            // super-chunk depth
+constexpr int SLD = SK + 4;        // LDS row stride (floats): 16-B slot stride 33 = 1 mod 16
+
 template <bool BT>
 __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
-    __shared__ float red[4][2][16][64];
+    __shared__ __attribute__((aligned(16))) float lds[(64 + 32) * SLD];     // 50,688 B; reused for the final reduction
+    float* ldsA = lds;
+    float* ldsB = lds + 64 * SLD;
     const int z = blockIdx.y;
     const int gi = z % p.ngroups, bi = z / p.ngroups;
     const dlsg_gemm_group grp = p.g[gi];
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const bool vecA = ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && ((grp.lda & 3) == 0);
-    const bool vecB = !BT && ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
+    const bool vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
     const int col = n0 + r;
 
     f32x16 acc[2];
@@ -298,60 +304,116 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    float a_cur[2][16], b_cur[16], a_nxt[2][16], b_nxt[16];
+    f32x4 ra[8], rb[4];          // staged operands of the next super-chunk
+    float bdir[16];              // NN: this lane's 16 weight values of the next super-chunk
 
-    auto load_chunk = [&](int c, float (&fa)[2][16], float (&fb)[16]) {
-        const int k0 = c * 32 + 16 * h;
+    auto ld4s = [&](const float* ptr, int nvalid) {      // guarded (edge) load
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (nvalid > 0) v[0] = ptr[0];
+        if (nvalid > 1) v[1] = ptr[1];
+        if (nvalid > 2) v[2] = ptr[2];
+        if (nvalid > 3) v[3] = ptr[3];
+        return v;
+    };
+    auto load_super = [&](int k0) {
+        const bool fullk = k0 + SK <= K;                  // wave-uniform: branch-free loads on interior super-chunks
+        if (fullk && vecA) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int row = r + 32 * mi;
-            const float* ap = A + (int64_t)row * grp.lda + k0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = k0 + 4 * q;
-                if (row < M && vecA && k + 3 < K) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 4 * q);
-                    fa[mi][4 * q] = v[0]; fa[mi][4 * q + 1] = v[1]; fa[mi][4 * q + 2] = v[2]; fa[mi][4 * q + 3] = v[3];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fa[mi][4 * q + i] = (row < M && k + i < K) ? ap[4 * q + i] : 0.f;
-                }
-            }
-        }
-        if (!BT) {
-            const float* bp = B + (int64_t)col * grp.ldb + k0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = k0 + 4 * q;
-                if (col < N && vecB && k + 3 < K) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(bp + 4 * q);
-                    fb[4 * q] = v[0]; fb[4 * q + 1] = v[1]; fb[4 * q + 2] = v[2]; fb[4 * q + 3] = v[3];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) fb[4 * q + i] = (col < N && k + i < K) ? bp[4 * q + i] : 0.f;
-                }
+            for (int j = 0; j < 8; ++j) {
+                const int f = threadIdx.x + NT * j;
+                const int row = min(f >> 5, M - 1);       // rows >= M feed output rows that are never stored
+                ra[j] = *reinterpret_cast<const f32x4*>(A + (int64_t)row * grp.lda + k0 + 4 * (f & 31));
             }
         } else {
 #pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) {
-                const int k = k0 + s2;
-                fb[s2] = (col < N && k < K) ? B[(int64_t)k * grp.ldb + col] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int f = threadIdx.x + NT * j;
+                const int row = f >> 5, k = k0 + 4 * (f & 31);
+                ra[j] = ld4s(A + (int64_t)row * grp.lda + k, row < M ? min(max(K - k, 0), 4) : 0);
+            }
+        }
+        if (!BT) {
+            if (fullk && vecB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = threadIdx.x + NT * j;
+                    const int row = min(n0 + (f >> 5), N - 1);
+                    rb[j] = *reinterpret_cast<const f32x4*>(B + (int64_t)row * grp.ldb + k0 + 4 * (f & 31));
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = threadIdx.x + NT * j;
+                    const int row = f >> 5, k = k0 + 4 * (f & 31);
+                    rb[j] = ld4s(B + (int64_t)(n0 + row) * grp.ldb + k, (n0 + row) < N ? min(max(K - k, 0), 4) : 0);
+                }
+            }
+        } else {
+            const int cc = min(col, N - 1);
+            if (fullk) {
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) bdir[s2] = B[(int64_t)(k0 + 32 * w + 16 * h + s2) * grp.ldb + cc];
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2) {
+                    const int k = k0 + 32 * w + 16 * h + s2;
+                    bdir[s2] = (k < K) ? B[(int64_t)k * grp.ldb + cc] : 0.f;
+                }
+            }
+        }
+    };
+    auto store_super = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int f = threadIdx.x + NT * j;
+            *reinterpret_cast<f32x4*>(ldsA + (f >> 5) * SLD + 4 * (f & 31)) = ra[j];
+        }
+        if (!BT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int f = threadIdx.x + NT * j;
+                *reinterpret_cast<f32x4*>(ldsB + (f >> 5) * SLD + 4 * (f & 31)) = rb[j];
             }
         }
     };
 
-    const int nchunks = (K + 31) / 32;
-    int c = w;
-    if (c < nchunks) load_chunk(c, a_cur, b_cur);
-    while (c < nchunks) {
-        const int cn = c + 4;
-        if (cn < nchunks) load_chunk(cn, a_nxt, b_nxt);
+    const int nsup = (K + SK - 1) / SK;
+    if (nsup > 0) load_super(0);
+    for (int sc = 0; sc < nsup; ++sc) {
+        store_super();
+        float bcur[16];
+        if (BT) {
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) bcur[s2] = bdir[s2];
+        }
+        __syncthreads();
+        if (sc + 1 < nsup) load_super((sc + 1) * SK);
+        // fragments of this wave's 32-deep slice: lane half h owns k = 32w + 16h + s
+        float fa[2][16];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const float* ap = ldsA + (r + 32 * mi) * SLD + 32 * w + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap + 4 * q);
+                fa[mi][4 * q] = v[0]; fa[mi][4 * q + 1] = v[1]; fa[mi][4 * q + 2] = v[2]; fa[mi][4 * q + 3] = v[3];
+            }
+        }
+        if (!BT) {
+            const float* bp = ldsB + r * SLD + 32 * w + 16 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bp + 4 * q);
+                bcur[4 * q] = v[0]; bcur[4 * q + 1] = v[1]; bcur[4 * q + 2] = v[2]; bcur[4 * q + 3] = v[3];
+            }
+        }
+        // lane half h holds k = 32w + 16h + s, s < 16: two 8-deep bf16 MFMA chunks, split in registers
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             bf16x8 bh, bl, ah[2], al[2];
-            split8(&b_cur[8 * cc], bh, bl);
-            split8(&a_cur[0][8 * cc], ah[0], al[0]);
-            split8(&a_cur[1][8 * cc], ah[1], al[1]);
+            split8(&bcur[8 * cc], bh, bl);
+            split8(&fa[0][8 * cc], ah[0], al[0]);
+            split8(&fa[1][8 * cc], ah[1], al[1]);
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh, acc[mi], 0, 0, 0);
@@ -359,16 +421,14 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
                 acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh, acc[mi], 0, 0, 0);
             }
         }
-        if (cn < nchunks) {
-#pragma unroll
-            for (int s2 = 0; s2 < 16; ++s2) { a_cur[0][s2] = a_nxt[0][s2]; a_cur[1][s2] = a_nxt[1][s2]; b_cur[s2] = b_nxt[s2]; }
-        }
-        c = cn;
+        __syncthreads();
     }
+    // ---- sum the 4 waves' partial tiles through LDS (staging buffers are free now); wave w finalises e in [4w, 4w+4)
+    float* red = lds;               // [4][2][16][64] floats = 32 KB
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[w][mi][e][lane] = acc[mi][e];
+        for (int e = 0; e < 16; ++e) red[((w * 2 + mi) * 16 + e) * 64 + lane] = acc[mi][e];
     __syncthreads();
     const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && p.bias != nullptr;
     const bool do_tanh = p.flags & DLSG_GEMM_TANH;
@@ -381,7 +441,9 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
                 const int e = 4 * w + ee;
                 const int row = 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row >= M) continue;
-                float v = red[0][mi][e][lane] + red[1][mi][e][lane] + red[2][mi][e][lane] + red[3][mi][e][lane];
+                float v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) v += red[((ww * 2 + mi) * 16 + e) * 64 + lane];
                 v = p.alpha * v + bv;
                 float* cp = C + (int64_t)row * p.ldc + col;
                 if (accum) v += *cp;
