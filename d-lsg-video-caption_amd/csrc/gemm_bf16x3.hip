@@ -324,6 +324,15 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
                 const int row = min(f >> 5, M - 1);       // rows >= M feed output rows that are never stored
                 ra[j] = *reinterpret_cast<const f32x4*>(A + (int64_t)row * grp.lda + k0 + 4 * (f & 31));
             }
+        } else if (vecA && (K & 3) == 0 && K >= 4) {       // aligned tail: whole float4s, clamped address + select
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int f = threadIdx.x + NT * j;
+                const int row = min(f >> 5, M - 1), k = k0 + 4 * (f & 31);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(A + (int64_t)row * grp.lda + min(k, K - 4));
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                ra[j] = (k < K) ? v : zero;
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -339,6 +348,15 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
                     const int f = threadIdx.x + NT * j;
                     const int row = min(n0 + (f >> 5), N - 1);
                     rb[j] = *reinterpret_cast<const f32x4*>(B + (int64_t)row * grp.ldb + k0 + 4 * (f & 31));
+                }
+            } else if (vecB && (K & 3) == 0 && K >= 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int f = threadIdx.x + NT * j;
+                    const int row = min(n0 + (f >> 5), N - 1), k = k0 + 4 * (f & 31);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(B + (int64_t)row * grp.ldb + min(k, K - 4));
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    rb[j] = (k < K) ? v : zero;
                 }
             } else {
 #pragma unroll
@@ -357,7 +375,8 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
 #pragma unroll
                 for (int s2 = 0; s2 < 16; ++s2) {
                     const int k = k0 + 32 * w + 16 * h + s2;
-                    bdir[s2] = (k < K) ? B[(int64_t)k * grp.ldb + cc] : 0.f;
+                    const float v = B[(int64_t)min(k, K - 1) * grp.ldb + cc];      // clamped address + select: no branch
+                    bdir[s2] = (k < K) ? v : 0.f;
                 }
             }
         }

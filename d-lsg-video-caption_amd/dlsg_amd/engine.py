@@ -37,10 +37,11 @@ def _zeros(ref, *shape, dtype=torch.float32):
     return torch.zeros(*shape, dtype=dtype, device=ref.device)
 
 
-def _ksplit_bounds(K, nsplit):
-    """Split [0,K) into <= nsplit chunks whose boundaries are multiples of 32 (the GEMM K tile)."""
-    nsplit = max(1, min(nsplit, (K + 127) // 128))
-    step = ((K + nsplit - 1) // nsplit + 31) // 32 * 32
+def _ksplit_bounds(K, nsplit, align=32):
+    """Split [0,K) into <= nsplit chunks whose boundaries are multiples of `align`: 32 = the GEMM K tile, 128 = the
+    super-chunk of the skinny (M <= 64) kernel, whose partial tail chunks take the slower guarded-load path."""
+    nsplit = max(1, min(nsplit, K // 512))       # a split shorter than ~512 costs more in launch/tail than it hides
+    step = ((K + nsplit - 1) // nsplit + align - 1) // align * align
     out, k = [], 0
     while k < K:
         out.append((k, min(K, k + step)))
@@ -60,7 +61,7 @@ def seg_gemm_nt(ops, segs, M, N, ref):
     ns = _nsplit_for(M, N, len(segs))
     groups = []
     for x, W in segs:
-        for k0, k1 in _ksplit_bounds(x.shape[1], ns):
+        for k0, k1 in _ksplit_bounds(x.shape[1], ns, 128 if M <= 64 else 32):
             groups.append((x[:, k0:k1], W[:, k0:k1]))
     slabs = _empty(ref, len(groups), M, N)
     ops.gemm(GEMM_NT, [(a, b, slabs[i]) for i, (a, b) in enumerate(groups)])
@@ -72,7 +73,7 @@ def gemm_nn_split(ops, dy, W, out, ref, accum=False):
     M, Nn = dy.shape
     Kin = W.shape[1]
     ns = _nsplit_for(M, Kin, 1)
-    bounds = _ksplit_bounds(Nn, ns)
+    bounds = _ksplit_bounds(Nn, ns, 128 if M <= 64 else 32)
     if len(bounds) == 1:
         ops.gemm(GEMM_NN, [(dy, W, out)], flags=F_ACCUM if accum else 0)
         return
@@ -110,7 +111,7 @@ def gemm_nn_multi(ops, dy, Ws, out, ref):
     assert out.shape[1] == tot
     ns = _nsplit_for(M, tot, 1)
     ns = max(1, min(ns, 16 // len(Ws)))
-    bounds = _ksplit_bounds(Nn, ns)
+    bounds = _ksplit_bounds(Nn, ns, 128 if M <= 64 else 32)
     slabs = _empty(ref, len(bounds), M, tot)
     groups, c0 = [], 0
     for W, wd in zip(Ws, widths):
@@ -301,7 +302,7 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
     cst = [_empty(ref, B, T, H), _empty(ref, B, T, H)]
     gates = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
     ns = _nsplit_for(B, 4 * H, 2)
-    bounds = _ksplit_bounds(H, ns)
+    bounds = _ksplit_bounds(H, ns, 128 if B <= 64 else 32)
     for step in range(T):
         tt = [step, T - 1 - step]
         tp = [step - 1, T - step]                                # previous time index per direction
@@ -425,7 +426,7 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     dhrec = [dhrec2[:, :H], dhrec2[:, H:]]
     dcrec = [_empty(ref, B, H), _empty(ref, B, H)]
     ns_r = max(1, min(_nsplit_for(B, 2 * H, 1), 8))
-    rb = _ksplit_bounds(4 * H, ns_r)
+    rb = _ksplit_bounds(4 * H, ns_r, 128 if B <= 64 else 32)
     for step in range(T - 1, -1, -1):
         tt = [step, T - 1 - step]
         tp = [step - 1, T - step]
