@@ -7,7 +7,8 @@
 // (96 cycles) replace 8 fp32 MFMAs (512 cycles) per 32x32x16 block.  Selected per call with DLSG_GEMM_BF16X3; parity of
 // the whole model with it enabled is asserted in tests/test_gpu_parity.py (logits <= 1e-3, token ids bit-exact).
 //
-// Structure = gemm.hip: 256 threads as 2x2 waves, BMxBN block tile, BK = 32, global -> registers -> LDS with the next
+// Structure = gemm.hip: 256 threads as 2x2 waves, BMxBN block tile (64x64 with BK = 64, 128x128 with BK = 32: the 64-deep
+// K tile halves the barriers per MFMA and is worth +25-35 % on the model's shapes), global -> registers -> LDS with the next
 // K tile in flight.  LDS holds four bf16 planes (A_hi, A_lo, B_hi, B_lo):
 //   * k-contiguous operands : [row][32 + 8] (80-byte rows: 16-B slot stride 5 mod 16, conflict-free ds_read_b128)
 //   * m/n-contiguous operands (NN / TN): kept k-major, [k][rows + 32], written with 8-byte stores of 4 consecutive
@@ -19,9 +20,7 @@
 
 namespace {
 
-constexpr int BK = 32;
 constexpr int NT = 256;
-constexpr int LDP = BK + 8;   // bf16 elements per LDS row
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short short8 __attribute__((ext_vector_type(8)));
@@ -47,27 +46,30 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_
     lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(rres, bf16x2));
 }
 
-template <int ROWS, bool T>
+template <int ROWS, bool T, int BK>
 struct Geom {
     static constexpr int NV = ROWS * BK / 4 / NT;                     // float4 per thread per tile
+    static constexpr int LDP = BK + 8;                                // k-contiguous row stride (bf16): 16-B slot stride odd
     static constexpr int LDT = ROWS + 32;                             // k-major row stride (bf16)
     static constexpr int PLANE = T ? BK * LDT : ROWS * LDP;           // bf16 elements per plane
+    static constexpr int KQ = BK / 4;                                 // float4 per row of a k-contiguous tile
 };
 
 // T=false: (row,k) at base[row*ld + k], one float4 = 4 consecutive k of a row.
 // T=true : (row,k) at base[k*ld + row], one float4 = 4 consecutive rows at one k.
 // Interior tiles take the branch-free path (see gemm.hip load_tile_fast); edge tiles / unaligned operands the guarded one.
-template <int ROWS, bool T>
+template <int ROWS, bool T, int BK>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax, int K,
-                                          bool vec_ok, f32x4 (&regs)[Geom<ROWS, T>::NV]) {
-    constexpr int NV = Geom<ROWS, T>::NV;
+                                          bool vec_ok, f32x4 (&regs)[Geom<ROWS, T, BK>::NV]) {
+    constexpr int NV = Geom<ROWS, T, BK>::NV;
+    constexpr int KQ = Geom<ROWS, T, BK>::KQ;
     const bool fast = vec_ok && (k0 + BK <= K) && (T ? (row0 + ROWS <= rmax) : (rmax > 0));
     if (fast) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int f = threadIdx.x + NT * j;
             const float* ptr;
-            if (!T) ptr = base + (int64_t)min(row0 + (f >> 3), rmax - 1) * ld + k0 + 4 * (f & 7);
+            if (!T) ptr = base + (int64_t)min(row0 + f / KQ, rmax - 1) * ld + k0 + 4 * (f % KQ);
             else ptr = base + (int64_t)(k0 + f / (ROWS / 4)) * ld + row0 + 4 * (f % (ROWS / 4));
             regs[j] = *reinterpret_cast<const f32x4*>(ptr);
         }
@@ -79,7 +81,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_
         int gr, gk, nvalid;
         const float* ptr;
         if (!T) {
-            const int row = f >> 3, kq = f & 7;
+            const int row = f / KQ, kq = f % KQ;
             gr = row0 + row; gk = k0 + 4 * kq;
             ptr = base + (int64_t)gr * ld + gk;
             nvalid = (gr < rmax) ? min(max(K - gk, 0), 4) : 0;
@@ -98,14 +100,16 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_
     }
 }
 
-template <int ROWS, bool T>
+template <int ROWS, bool T, int BK>
 __device__ __forceinline__ void store_tile(unsigned short* __restrict__ hi_p, unsigned short* __restrict__ lo_p,
-                                           const f32x4 (&regs)[Geom<ROWS, T>::NV]) {
-    constexpr int NV = Geom<ROWS, T>::NV;
+                                           const f32x4 (&regs)[Geom<ROWS, T, BK>::NV]) {
+    constexpr int NV = Geom<ROWS, T, BK>::NV;
+    constexpr int KQ = Geom<ROWS, T, BK>::KQ;
+    constexpr int LDP = Geom<ROWS, T, BK>::LDP;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int f = threadIdx.x + NT * j;
-        const int off = T ? (f / (ROWS / 4)) * Geom<ROWS, T>::LDT + 4 * (f % (ROWS / 4)) : (f >> 3) * LDP + 4 * (f & 7);
+        const int off = T ? (f / (ROWS / 4)) * Geom<ROWS, T, BK>::LDT + 4 * (f % (ROWS / 4)) : (f / KQ) * LDP + 4 * (f % KQ);
         uint32_t h0, l0, h1, l1;
         split2(regs[j][0], regs[j][1], h0, l0);
         split2(regs[j][2], regs[j][3], h1, l1);
@@ -115,8 +119,9 @@ __device__ __forceinline__ void store_tile(unsigned short* __restrict__ hi_p, un
 }
 
 // MFMA 32x32x16 operand fragment of the 32-row subtile starting at `rowbase`, chunk c (k = 16c + 8h + j, j < 8)
-template <int ROWS, bool T>
+template <int ROWS, bool T, int BK>
 __device__ __forceinline__ bf16x8 ld_frag(const unsigned short* __restrict__ plane, int rowbase, int c, int lane) {
+    constexpr int LDP = Geom<ROWS, T, BK>::LDP;
     if (!T) {
         const int r = lane & 31, h = lane >> 5;
         const short8 v = *reinterpret_cast<const short8*>(plane + (rowbase + r) * LDP + 16 * c + 8 * h);
@@ -124,7 +129,7 @@ __device__ __forceinline__ bf16x8 ld_frag(const unsigned short* __restrict__ pla
     } else {
         // 16-lane group g: rows rowbase + 16*(g&1) + i, k half h = g>>1.  Lane 4q+p of a group addresses k row q,
         // rows 4p..4p+3 of the 4 x 16 block; it receives the 4 k values of its own row (i = lane & 15).
-        constexpr int LDT = Geom<ROWS, T>::LDT;
+        constexpr int LDT = Geom<ROWS, T, BK>::LDT;
         const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
         const int kb = 16 * c + 8 * (g >> 1);
         const unsigned short* a0 = plane + (kb + q) * LDT + rowbase + 16 * (g & 1) + 4 * pp;
@@ -136,12 +141,12 @@ __device__ __forceinline__ bf16x8 ld_frag(const unsigned short* __restrict__ pla
     }
 }
 
-template <int BM, int BN, bool AT, bool BT>
+template <int BM, int BN, bool AT, bool BT, int BK>
 __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
-    using GA = Geom<BM, AT>;
-    using GB = Geom<BN, BT>;
+    using GA = Geom<BM, AT, BK>;
+    using GB = Geom<BN, BT, BK>;
     __shared__ __attribute__((aligned(16))) unsigned short lds[2 * GA::PLANE + 2 * GB::PLANE];
     unsigned short* a_hi = lds;
     unsigned short* a_lo = lds + GA::PLANE;
@@ -185,29 +190,29 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
     f32x4 ra[GA::NV], rb[GB::NV];
     const int nk = (K + BK - 1) / BK;
     if (nk > 0) {
-        load_tile<BM, AT>(A, grp.lda, m0, 0, p.M, K, vecA, ra);
-        load_tile<BN, BT>(B, grp.ldb, n0, 0, Ng, K, vecB, rb);
+        load_tile<BM, AT, BK>(A, grp.lda, m0, 0, p.M, K, vecA, ra);
+        load_tile<BN, BT, BK>(B, grp.ldb, n0, 0, Ng, K, vecB, rb);
     }
     for (int kt = 0; kt < nk; ++kt) {
-        store_tile<BM, AT>(a_hi, a_lo, ra);
-        store_tile<BN, BT>(b_hi, b_lo, rb);
+        store_tile<BM, AT, BK>(a_hi, a_lo, ra);
+        store_tile<BN, BT, BK>(b_hi, b_lo, rb);
         __syncthreads();
         if (kt + 1 < nk) {
-            load_tile<BM, AT>(A, grp.lda, m0, (kt + 1) * BK, p.M, K, vecA, ra);
-            load_tile<BN, BT>(B, grp.ldb, n0, (kt + 1) * BK, Ng, K, vecB, rb);
+            load_tile<BM, AT, BK>(A, grp.lda, m0, (kt + 1) * BK, p.M, K, vecA, ra);
+            load_tile<BN, BT, BK>(B, grp.ldb, n0, (kt + 1) * BK, Ng, K, vecB, rb);
         }
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {          // two 16-deep MFMA chunks per K tile; lane half h owns k = 16c + 8h + j
+        for (int c = 0; c < BK / 16; ++c) {    // 16-deep MFMA chunks of the K tile; lane half h owns k = 16c + 8h + j
             bf16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                fah[i] = ld_frag<BM, AT>(a_hi, wm * WM + i * 32, c, lane);
-                fal[i] = ld_frag<BM, AT>(a_lo, wm * WM + i * 32, c, lane);
+                fah[i] = ld_frag<BM, AT, BK>(a_hi, wm * WM + i * 32, c, lane);
+                fal[i] = ld_frag<BM, AT, BK>(a_lo, wm * WM + i * 32, c, lane);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                fbh[j] = ld_frag<BN, BT>(b_hi, wn * WN + j * 32, c, lane);
-                fbl[j] = ld_frag<BN, BT>(b_lo, wn * WN + j * 32, c, lane);
+                fbh[j] = ld_frag<BN, BT, BK>(b_hi, wn * WN + j * 32, c, lane);
+                fbl[j] = ld_frag<BN, BT, BK>(b_lo, wn * WN + j * 32, c, lane);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
         }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 int launch(const dlsg_gemm_args* a, hipStream_t st) {
     KArgs k;
     k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
@@ -252,9 +257,9 @@ int launch(const dlsg_gemm_args* a, hipStream_t st) {
     const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
     dim3 grid(tiles, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
     switch (a->mode) {
-        case 0: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, false>), grid, block, 0, st, k); break;
-        case 1: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, true>), grid, block, 0, st, k); break;
-        case 2: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, true, true>), grid, block, 0, st, k); break;
+        case 0: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, false, BK>), grid, block, 0, st, k); break;
+        case 1: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, false, true, BK>), grid, block, 0, st, k); break;
+        case 2: hipLaunchKernelGGL((gemm_x3_kernel<BM, BN, true, true, BK>), grid, block, 0, st, k); break;
         default: return DLSG_EINVAL;
     }
     DLSG_CHECK_LAUNCH();
@@ -490,9 +495,10 @@ int launch_skinny_x3(const dlsg_gemm_args* a, hipStream_t st) {
 int dlsg_gemm_bf16x3_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     const int64_t z = (int64_t)a->ngroups * a->nbatch;
     const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
-    if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64>(a, st);
-    if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128>(a, st);
+    if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64, 64>(a, st);
+    if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128, 32>(a, st);
     if (a->M <= 64 && a->mode != 2 && a->N >= 64) return launch_skinny_x3(a, st);
-    if (tilesL >= 512) return launch<128, 128>(a, st);
-    return launch<64, 64>(a, st);
+    // measured (tools/gemm_bench.py): the 128x128 tile wins only once it fills the chip several times over
+    if (tilesL >= 1000) return launch<128, 128, 32>(a, st);
+    return launch<64, 64, 64>(a, st);
 }

@@ -251,7 +251,7 @@ class HipOps(object):
             tiles_l = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups)
             if M <= 64 and mode != GEMM_TN and N >= 64:
                 variant = 'skinny_64x32'
-            elif tiles_l >= (512 if x3 else 1000):
+            elif tiles_l >= 1000:
                 variant = '128x128'
             else:
                 variant = '64x64'
