@@ -16,15 +16,15 @@
 
 namespace {
 
-constexpr int BK = 32;
 constexpr int NT = 256;
 
-template <int ROWS, bool T>
+template <int ROWS, bool T, int BK>
 struct TileGeom {
     // float4 count per tile and per thread
     static constexpr int NV = ROWS * BK / 4 / NT;
     static constexpr int LD = T ? (ROWS + 4) : (BK + 4);
     static constexpr int ELEMS = T ? BK * (ROWS + 4) : ROWS * (BK + 4);
+    static constexpr int KQ = BK / 4;
 };
 
 // Load one operand tile (ROWS x BK) into registers.  T=false: element (row,k) at base[row*ld + k];
@@ -32,17 +32,17 @@ struct TileGeom {
 // Fast path (interior tile, 16-B aligned): unconditional float4 loads, no branches -- hipcc otherwise wraps every guarded
 // load in its own exec-mask branch and the loads of a tile no longer overlap.  Rows past the matrix edge are clamped to
 // the last valid row: they only feed output rows/columns that are never stored.
-template <int ROWS, bool T>
+template <int ROWS, bool T, int BK>
 __device__ __forceinline__ void load_tile_fast(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax,
-                                               f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
-    constexpr int NV = TileGeom<ROWS, T>::NV;
+                                               f32x4 (&regs)[TileGeom<ROWS, T, BK>::NV]) {
+    constexpr int NV = TileGeom<ROWS, T, BK>::NV;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int f = threadIdx.x + NT * j;
         const float* ptr;
         if (!T) {
-            const int gr = min(row0 + (f >> 3), rmax - 1);
-            ptr = base + (int64_t)gr * ld + k0 + 4 * (f & 7);
+            const int gr = min(row0 + f / (BK / 4), rmax - 1);
+            ptr = base + (int64_t)gr * ld + k0 + 4 * (f % (BK / 4));
         } else {
             ptr = base + (int64_t)(k0 + f / (ROWS / 4)) * ld + row0 + 4 * (f % (ROWS / 4));
         }
@@ -50,17 +50,17 @@ __device__ __forceinline__ void load_tile_fast(const float* __restrict__ base, i
     }
 }
 // Slow path: edge tiles / unaligned operands.  Out-of-range elements read as zero.
-template <int ROWS, bool T>
+template <int ROWS, bool T, int BK>
 __device__ __forceinline__ void load_tile_slow(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax,
-                                               int K, f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
-    constexpr int NV = TileGeom<ROWS, T>::NV;
+                                               int K, f32x4 (&regs)[TileGeom<ROWS, T, BK>::NV]) {
+    constexpr int NV = TileGeom<ROWS, T, BK>::NV;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int f = threadIdx.x + NT * j;
         int gr, gk, nvalid;
         const float* ptr;
         if (!T) {
-            const int row = f >> 3, kq = f & 7;
+            const int row = f / (BK / 4), kq = f % (BK / 4);
             gr = row0 + row;
             gk = k0 + 4 * kq;
             ptr = base + (int64_t)gr * ld + gk;
@@ -80,25 +80,25 @@ __device__ __forceinline__ void load_tile_slow(const float* __restrict__ base, i
         regs[j] = v;
     }
 }
-template <int ROWS, bool T>
+template <int ROWS, bool T, int BK>
 __device__ __forceinline__ void load_tile(const float* __restrict__ base, int64_t ld, int row0, int k0, int rmax,
-                                          int K, bool vec_ok, f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
+                                          int K, bool vec_ok, f32x4 (&regs)[TileGeom<ROWS, T, BK>::NV]) {
     // wave-uniform choice per tile
     const bool fast = vec_ok && (k0 + BK <= K) && (T ? (row0 + ROWS <= rmax) : (rmax > 0));
-    if (fast) load_tile_fast<ROWS, T>(base, ld, row0, k0, rmax, regs);
-    else load_tile_slow<ROWS, T>(base, ld, row0, k0, rmax, K, regs);
+    if (fast) load_tile_fast<ROWS, T, BK>(base, ld, row0, k0, rmax, regs);
+    else load_tile_slow<ROWS, T, BK>(base, ld, row0, k0, rmax, K, regs);
 }
 
-template <int ROWS, bool T>
-__device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 (&regs)[TileGeom<ROWS, T>::NV]) {
-    constexpr int NV = TileGeom<ROWS, T>::NV;
-    constexpr int LD = TileGeom<ROWS, T>::LD;
+template <int ROWS, bool T, int BK>
+__device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 (&regs)[TileGeom<ROWS, T, BK>::NV]) {
+    constexpr int NV = TileGeom<ROWS, T, BK>::NV;
+    constexpr int LD = TileGeom<ROWS, T, BK>::LD;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int f = threadIdx.x + NT * j;
         int off;
         if (!T) {
-            off = (f >> 3) * LD + 4 * (f & 7);
+            off = (f / (BK / 4)) * LD + 4 * (f % (BK / 4));
         } else {
             off = (f / (ROWS / 4)) * LD + 4 * (f % (ROWS / 4));
         }
@@ -106,19 +106,19 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 
     }
 }
 
-// Fragment of 16 k-values for one 32-row subtile: element s <-> k = 16h + s.
-template <int ROWS, bool T>
-__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rowbase, int r, int h, float (&a)[16]) {
-    constexpr int LD = TileGeom<ROWS, T>::LD;
+// Fragment of 16 k-values for one 32-row subtile: element s <-> k = kbase + 16h + s.
+template <int ROWS, bool T, int BK>
+__device__ __forceinline__ void read_frag(const float* __restrict__ lds, int rowbase, int kbase, int r, int h, float (&a)[16]) {
+    constexpr int LD = TileGeom<ROWS, T, BK>::LD;
     if (!T) {
-        const float* p = lds + (rowbase + r) * LD + 16 * h;
+        const float* p = lds + (rowbase + r) * LD + kbase + 16 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(p + 4 * q);
             a[4 * q + 0] = v[0]; a[4 * q + 1] = v[1]; a[4 * q + 2] = v[2]; a[4 * q + 3] = v[3];
         }
     } else {
-        const float* p = lds + (16 * h) * LD + rowbase + r;
+        const float* p = lds + (kbase + 16 * h) * LD + rowbase + r;
 #pragma unroll
         for (int s = 0; s < 16; ++s) a[s] = p[s * LD];
     }
@@ -132,12 +132,12 @@ struct KArgs {
     dlsg_gemm_group g[DLSG_GEMM_MAXG];
 };
 
-template <int BM, int BN, bool AT, bool BT>
+template <int BM, int BN, bool AT, bool BT, int BK>
 __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs p) {
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
-    using GA = TileGeom<BM, AT>;
-    using GB = TileGeom<BN, BT>;
+    using GA = TileGeom<BM, AT, BK>;
+    using GB = TileGeom<BN, BT, BK>;
     __shared__ __attribute__((aligned(16))) float lds[GA::ELEMS + GB::ELEMS];
     float* ldsA = lds;
     float* ldsB = lds + GA::ELEMS;
@@ -180,29 +180,32 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs p) {
     f32x4 ra[GA::NV], rb[GB::NV];
     const int nk = (K + BK - 1) / BK;
     if (nk > 0) {
-        load_tile<BM, AT>(A, grp.lda, m0, 0, p.M, K, vecA, ra);
-        load_tile<BN, BT>(B, grp.ldb, n0, 0, Ng, K, vecB, rb);
+        load_tile<BM, AT, BK>(A, grp.lda, m0, 0, p.M, K, vecA, ra);
+        load_tile<BN, BT, BK>(B, grp.ldb, n0, 0, Ng, K, vecB, rb);
     }
     for (int kt = 0; kt < nk; ++kt) {
-        store_tile<BM, AT>(ldsA, ra);
-        store_tile<BN, BT>(ldsB, rb);
+        store_tile<BM, AT, BK>(ldsA, ra);
+        store_tile<BN, BT, BK>(ldsB, rb);
         __syncthreads();
         if (kt + 1 < nk) {
-            load_tile<BM, AT>(A, grp.lda, m0, (kt + 1) * BK, p.M, K, vecA, ra);
-            load_tile<BN, BT>(B, grp.ldb, n0, (kt + 1) * BK, Ng, K, vecB, rb);
+            load_tile<BM, AT, BK>(A, grp.lda, m0, (kt + 1) * BK, p.M, K, vecA, ra);
+            load_tile<BN, BT, BK>(B, grp.ldb, n0, (kt + 1) * BK, Ng, K, vecB, rb);
         }
-        float fa[TM][16], fb[TN][16];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) read_frag<BM, AT>(ldsA, wm * WM + i * 32, r, h, fa[i]);
+        for (int sub = 0; sub < BK / 32; ++sub) {      // 32-deep slices of the K tile
+            float fa[TM][16], fb[TN][16];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) read_frag<BN, BT>(ldsB, wn * WN + j * 32, r, h, fb[j]);
+            for (int i = 0; i < TM; ++i) read_frag<BM, AT, BK>(ldsA, wm * WM + i * 32, 32 * sub, r, h, fa[i]);
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+            for (int j = 0; j < TN; ++j) read_frag<BN, BT, BK>(ldsB, wn * WN + j * 32, 32 * sub, r, h, fb[j]);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int s = 0; s < 16; ++s)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        }
         __syncthreads();
     }
 
@@ -440,7 +443,7 @@ int launch_skinny(const dlsg_gemm_args* a, hipStream_t st) {
     return DLSG_OK;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 int launch(const dlsg_gemm_args* a, hipStream_t st) {
     KArgs k;
     k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
@@ -449,9 +452,9 @@ int launch(const dlsg_gemm_args* a, hipStream_t st) {
     const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
     dim3 grid(tiles, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
     switch (a->mode) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, block, 0, st, k); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), grid, block, 0, st, k); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, block, 0, st, k); break;
+        case 0: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, BK>), grid, block, 0, st, k); break;
+        case 1: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true, BK>), grid, block, 0, st, k); break;
+        case 2: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, BK>), grid, block, 0, st, k); break;
         default: return DLSG_EINVAL;
     }
     DLSG_CHECK_LAUNCH();
@@ -490,13 +493,13 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     const int64_t z = (int64_t)a->ngroups * a->nbatch;
     const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
     if (a->flags & DLSG_GEMM_BF16X3) return dlsg_gemm_bf16x3_dispatch(a, st);
-    if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64>(a, st);
-    if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128>(a, st);
+    if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64, 64>(a, st);
+    if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128, 32>(a, st);
     // M <= 64, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernel
     if (a->M <= 64 && a->mode != 2 && a->N >= 64) return launch_skinny(a, st);
     // measured on MI355X (tools/gemm_bench.py): the 128x128 tile only wins once it fills the chip several times over
-    if (tilesL >= 1000) return launch<128, 128>(a, st);
-    return launch<64, 64>(a, st);
+    if (tilesL >= 1000) return launch<128, 128, 32>(a, st);
+    return launch<64, 64, 64>(a, st);
 }
 
 extern "C" int dlsg_slab_reduce(const float* slabs, int nslab, int64_t slab_stride, const float* bias, float* out,
