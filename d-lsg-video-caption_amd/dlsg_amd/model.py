@@ -341,6 +341,40 @@ class CapBaseline1(_HipModel):
         return out[0], 0, 0, 0
 
 
+class GreedyGraph(object):
+    """hipGraph-captured greedy inference (BASELINE configs[4]: 'hipGraph-captured decode step'): encoder + the 26
+    decode steps (argmax and embedding gather stay on device) are captured once for a batch shape and replayed; the
+    ids are identical to the eager `model(frames, regions, None)` path with beam_size 1."""
+
+    def __init__(self, model, frames, regions):
+        self.model = model
+        model.flatten_parameters_()
+        dev = frames.device
+        self.frames, self.regions = frames.clone(), regions.clone()
+        L = model.decoder.max_words
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            model._engine_forward(self.frames, self.regions, None, L, [False] * L, False, 0, {})     # warm-up
+            side.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            self.graph.capture_begin()
+            sv = {}
+            model._engine_forward(self.frames, self.regions, None, L, [False] * L, False, 0, sv)
+            self.ids = sv['dec']['IDS'][1:].t().contiguous()
+            self.graph.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+
+    @torch.no_grad()
+    def __call__(self, frames, regions):
+        if frames.data_ptr() != self.frames.data_ptr():
+            self.frames.copy_(frames, non_blocking=True)
+        if regions.data_ptr() != self.regions.data_ptr():
+            self.regions.copy_(regions, non_blocking=True)
+        self.graph.replay()
+        return self.ids
+
+
 # ================================================================================================ fast training path
 def ss_epsilon(epoch, ss_factor=20):
     """scheduled-sampling probability, run_gun.py:136"""

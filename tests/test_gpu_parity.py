@@ -250,3 +250,16 @@ def test_segmented_graph_capture_as_used_with_several_ranks():
         res.append((losses, net._flat.cpu().clone()))
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
+
+
+def test_hipgraph_greedy_inference_ids_bit_exact():
+    """BASELINE configs[4]: the graph-captured greedy decode returns the reference's token ids."""
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    net.update_beam_size(1)
+    gg = dlsg_amd.GreedyGraph(net, frames, regions)
+    ids = gg(frames, regions)
+    torch.cuda.synchronize()
+    assert np.array_equal(ids.cpu().numpy(), g['greedy_ids'])
+    ids2 = gg(frames.flip(0).contiguous(), regions.flip(0).contiguous())        # new inputs through the static buffers
+    torch.cuda.synchronize()
+    assert np.array_equal(ids2.cpu().numpy(), g['greedy_ids'][::-1])

@@ -32,3 +32,15 @@ for prec in ('fp32', 'x3_all'):
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         print('gemm=%s beam=%d batch=%d: %.1f ms / batch, %.0f clips/s, ids %s' % (prec, k, B, dt * 1e3, B / dt, tuple(ids.shape)))
+
+net.gemm_precision = 'fp32'
+net.update_beam_size(1)
+gg = dlsg_amd.GreedyGraph(net, frames, regions)
+gg(frames, regions)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    ids = gg(frames, regions)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 10
+print('gemm=fp32 greedy hipGraph replay batch=%d: %.1f ms / batch, %.0f clips/s' % (B, dt * 1e3, B / dt))
