@@ -226,7 +226,8 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
         __syncthreads();
     }
 
-    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && p.bias != nullptr;
+    const float* biasp = grp.bias ? grp.bias : p.bias;
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && biasp != nullptr;
     const bool do_tanh = p.flags & DLSG_GEMM_TANH;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) {
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WN + j * 32 + r;
             if (col >= Ng) continue;
-            const float bv = use_bias ? p.bias[col] : 0.f;
+            const float bv = use_bias ? biasp[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -454,10 +455,11 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) red[((w * 2 + mi) * 16 + e) * 64 + lane] = acc[mi][e];
     __syncthreads();
-    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && p.bias != nullptr;
+    const float* biasp = grp.bias ? grp.bias : p.bias;
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && biasp != nullptr;
     const bool do_tanh = p.flags & DLSG_GEMM_TANH;
     if (col < N) {
-        const float bv = use_bias ? p.bias[col] : 0.f;
+        const float bv = use_bias ? biasp[col] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

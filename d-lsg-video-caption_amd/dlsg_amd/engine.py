@@ -149,7 +149,18 @@ def ln_grads(ops, part, G, prefix, n):
 
 
 # ================================================================================================ TUN encoder
-def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2v=True, nsplit=None):
+def region_projections(ops, mods, regions):
+    """y_i = tanh(obj_embed_i(regions)) for every stream in ONE grouped launch (layer.py:184 runs once per stream on the
+    same regions): the two 1664-tile grids of the batch-64 step pack into the chip's 768 workgroup slots in 5 rounds
+    instead of 3 + 3, and the second stream finds the region panel in L2."""
+    B, T, O, R = regions.shape
+    r2 = regions.view(B * T * O, R)
+    ys = [_empty(regions, B * T * O, m.obj_embed.weight.shape[0]) for m in mods]
+    ops.gemm(GEMM_NT, [(r2, m.obj_embed.weight, y, m.obj_embed.bias) for m, y in zip(mods, ys)], flags=F_TANH)
+    return ys
+
+
+def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2v=True, nsplit=None, y=None):
     """EncoderVisualGraphTUN.forward (models/layer.py:172-201).  visual: (B*T, Hin) view."""
     B, T, O, R = regions.shape
     H = m.visual_norm[1].weight.numel()
@@ -166,8 +177,9 @@ def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2
     s.update(visual=visual, v_pre=v_pre, v=v, st_v=st_v)
     if O >= 5:
         NO = T * O
-        y = _empty(ref, B * NO, H)
-        lin(ops, regions.view(B * NO, R), m.obj_embed.weight, y, m.obj_embed.bias, tanh=True)
+        if y is None:
+            y = _empty(ref, B * NO, H)
+            lin(ops, regions.view(B * NO, R), m.obj_embed.weight, y, m.obj_embed.bias, tanh=True)
         z = _empty(ref, B * T, H); ostats = _empty(ref, B * NO, 2); S = _empty(ref, B, NO, T)
         scale = 1.0 / math.sqrt(R)
         g_o, b_o = m.obj_norm[1].weight, m.obj_norm[1].bias

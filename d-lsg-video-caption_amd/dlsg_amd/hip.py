@@ -25,7 +25,8 @@ i32, i64, u32, u64, f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_floa
 
 
 class GemmGroup(C.Structure):
-    _fields_ = [('A', c_f32p), ('B', c_f32p), ('C', c_f32p), ('lda', i64), ('ldb', i64), ('K', i32), ('N', i32)]
+    _fields_ = [('A', c_f32p), ('B', c_f32p), ('C', c_f32p), ('lda', i64), ('ldb', i64), ('K', i32), ('N', i32),
+                ('bias', c_f32p)]
 
 
 class GemmArgs(C.Structure):
@@ -203,9 +204,9 @@ class HipOps(object):
 
     # ------------------------------------------------------------------ GEMM
     def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None):
-        """groups: list of (A, B, C) views (2-d, or 3-d batched with identical batch strides across groups)."""
+        """groups: list of (A, B, C[, bias]) views (2-d, or 3-d batched with identical batch strides across groups)."""
         a = GemmArgs()
-        A0, B0, C0 = groups[0]
+        A0, B0, C0 = groups[0][:3]
         batched = A0.dim() == 3
         if batched:
             nb = C0.size(0)
@@ -217,10 +218,12 @@ class HipOps(object):
         N = max(g[2].shape[-1] for g in groups)          # groups may write column blocks of different widths
         a.mode, a.M, a.N, a.ldc = mode, M, N, C0.stride(-2)
         a.ngroups, a.nbatch, a.alpha = len(groups), nb, alpha
-        a.flags = flags | self.extra_flags | (F_BIAS if bias is not None else 0)
+        gbias = any(len(g) > 3 and g[3] is not None for g in groups)
+        a.flags = flags | self.extra_flags | (F_BIAS if (bias is not None or gbias) else 0)
         a.bias = _p(bias)
         assert len(groups) <= MAXG
-        for i, (A, B, Cc) in enumerate(groups):
+        for i, grp_ in enumerate(groups):
+            A, B, Cc = grp_[:3]
             Ng = Cc.shape[-1]
             if mode == GEMM_TN:
                 K = A.shape[-2]
@@ -239,6 +242,7 @@ class HipOps(object):
             g = a.g[i]
             g.A, g.B, g.C = _p(A), _p(B), _p(Cc)
             g.lda, g.ldb, g.K, g.N = A.stride(-2), B.stride(-2), K, (Ng if Ng != N else 0)
+            g.bias = _p(grp_[3]) if len(grp_) > 3 else None
         e0 = None
         if self.prof is not None:
             flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))

@@ -186,17 +186,20 @@ class CapGnnModel(_HipModel):
         B, T, F = frames.shape
         A = enc.a_feature_size
         f2 = frames.view(B * T, F)
+        ys = [None, None]
+        if regions.shape[2] >= 5 and enc.obj_encoder.obj_embed.weight.shape == enc.motion_encoder.obj_embed.weight.shape:
+            ys = E.region_projections(ops, [enc.obj_encoder, enc.motion_encoder], regions)
         side = self._fork(frames)
         if side is not None:
             with torch.cuda.stream(side):
                 obj = E.tun_fwd(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv, training, seed,
-                                E.SITE_PSL_OBJ, self.fused_o2v)
+                                E.SITE_PSL_OBJ, self.fused_o2v, y=ys[0])
         else:
             obj = E.tun_fwd(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv, training, seed,
-                            E.SITE_PSL_OBJ, self.fused_o2v)
+                            E.SITE_PSL_OBJ, self.fused_o2v, y=ys[0])
         mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed)
         mot = E.tun_fwd(ops, enc.motion_encoder, 'encoder.motion_encoder', mot_in, regions, sv, training, seed,
-                        E.SITE_PSL_MOT, self.fused_o2v)
+                        E.SITE_PSL_MOT, self.fused_o2v, y=ys[1])
         self._join(side)
         return obj, mot
 

@@ -49,6 +49,7 @@ typedef struct {
     int32_t K;
     int32_t N;   /* 0 = use args.N; otherwise this group's own output width (<= args.N): lets one launch write
                     column blocks of different widths (e.g. dG.W_ih and dG.W_hh) */
+    const float* bias; /* optional per-group bias (overrides args.bias when DLSG_GEMM_BIAS is set) */
 } dlsg_gemm_group;
 typedef struct {
     int32_t mode, M, N, ldc;

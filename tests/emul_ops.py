@@ -60,7 +60,9 @@ class EmulOps(object):
     # ------------------------------------------------------------------ GEMM
     def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None):
         self._count('gemm')
-        for A, B, C in groups:
+        for grp_ in groups:
+            A, B, C = grp_[:3]
+            gb = grp_[3] if len(grp_) > 3 else None
             if mode == GEMM_NT:
                 r = A @ B.transpose(-1, -2)
             elif mode == GEMM_NN:
@@ -68,7 +70,9 @@ class EmulOps(object):
             else:
                 r = A.transpose(-1, -2) @ B
             r = alpha * r
-            if bias is not None:
+            if gb is not None:
+                r = r + gb
+            elif bias is not None:
                 r = r + bias
             if flags & F_ACCUM:
                 r = r + C
