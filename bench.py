@@ -216,11 +216,13 @@ def main():
             tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
             if os.path.exists(tpath):
                 try:
-                    traffic = json.load(open(tpath)).get(gk)
+                    traffic = (json.load(open(tpath)).get(gk) or {}).get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
             out['roofline'] = {'kernel': gk + (' (3 x v_mfma_f32_32x32x16_bf16 per product; peak = 2500/3)' if is_x3
                                                else ' (v_mfma_f32_32x32x2_f32)'),
+                               'traffic_note': 'HBM bytes/launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes) '
+                                               'when that file has this kernel at this launch shape, else null',
                                'bound': 'mfma', 'achieved': round(ach, 2),
                                'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'launches_timed': g['launches'],

@@ -259,7 +259,8 @@ class HipOps(object):
                 variant = '128x128'
             else:
                 variant = '64x64'
-            self._prof_end('gemm_%s_mfma_%s' % ('bf16x3' if x3 else 'f32', variant), e0, flops)
+            # one key per kernel symbol (arithmetic, tile, operand layout), as rocprofv3 --stats lists them
+            self._prof_end('gemm_%s_mfma_%s_%s' % ('bf16x3' if x3 else 'f32', variant, ('nt', 'nn', 'tn')[mode]), e0, flops)
 
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""

@@ -361,7 +361,7 @@ class GreedyGraph(object):
             model._engine_forward(self.frames, self.regions, None, L, [False] * L, False, 0, {})     # warm-up
             side.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            self.graph.capture_begin()
+            self.graph.capture_begin(capture_error_mode='thread_local')
             sv = {}
             model._engine_forward(self.frames, self.regions, None, L, [False] * L, False, 0, sv)
             self.ids = sv['dec']['IDS'][1:].t().contiguous()
@@ -465,6 +465,12 @@ class Trainer(object):
         self.t += 1
         if self.use_graphs:
             return self._step_graphs(frames, regions, captions, cap_lens, coins, seed)
+        return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
+
+    def _eager_step(self, frames, regions, captions, cap_lens, coins, seed, counted=False):
+        model, ops = self.model, self.model.ops
+        if not counted:
+            self.t += 1
         dev_coins = None
         if self.device_coins:
             dev_coins = torch.tensor([int(c) for c in coins], dtype=torch.int32).to(captions.device)
@@ -492,8 +498,9 @@ class Trainer(object):
             self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], None)
             side.synchronize()
             pool = torch.cuda.graph_pool_handle()
+            # thread-local capture mode: calls made by other threads (e.g. the RCCL watchdog) cannot invalidate the capture
             cur = [torch.cuda.CUDAGraph()]
-            cur[0].capture_begin(pool=pool)
+            cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
 
             def cut(key):
                 if self.world_size <= 1 and not self.force_graph_cuts:
@@ -501,7 +508,7 @@ class Trainer(object):
                 cur[0].capture_end()
                 graphs.append((cur[0], key))
                 cur[0] = torch.cuda.CUDAGraph()
-                cur[0].capture_begin(pool=pool)
+                cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
 
             loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut)
             if self.world_size <= 1:
@@ -516,7 +523,14 @@ class Trainer(object):
     def _step_graphs(self, frames, regions, captions, cap_lens, coins, seed):
         model, ops = self.model, self.model.ops
         if self._graphs is None:
-            self._capture(frames, regions, captions, cap_lens)
+            try:
+                self._capture(frames, regions, captions, cap_lens)
+            except Exception as e:      # never lose the run to a capture problem: fall back to kernel-by-kernel launches
+                import warnings
+                warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                self.use_graphs, self._graphs = False, None
+                return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
         st = self._static
         for k, src in (('frames', frames), ('regions', regions), ('captions', captions), ('lens', cap_lens)):
             if src.data_ptr() != st[k].data_ptr():

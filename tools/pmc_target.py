@@ -16,10 +16,11 @@ dev = 'cuda'
 # 1. region projection, batch 64: (B*T*O=26624, 2048) x (1024, 2048)^T, tanh epilogue (layer.py:184)
 A = torch.randn(26624, 2048, device=dev); W = torch.randn(1024, 2048, device=dev); b = torch.randn(1024, device=dev)
 C = torch.empty(26624, 1024, device=dev)
+W2 = torch.randn(1024, 2048, device=dev); b2 = torch.randn(1024, device=dev); C2 = torch.empty(26624, 1024, device=dev)
+for _ in range(3):      # as the step launches it: both streams' projections as two groups of one launch
+    ops.gemm(GEMM_NT, [(A, W, C, b), (A, W2, C2, b2)], flags=F_TANH)
 for _ in range(3):
-    ops.gemm(GEMM_NT, [(A, W, C)], bias=b, flags=F_TANH)
-for _ in range(3):
-    ops.gemm(GEMM_NT, [(A, W, C)], bias=b, flags=F_TANH | F_BF16X3)
+    ops.gemm(GEMM_NT, [(A, W, C, b), (A, W2, C2, b2)], flags=F_TANH | F_BF16X3)
 # 2. its weight gradient (TN, 26624 deep, 8 row groups -> slabs)
 dY = torch.randn(26624, 1024, device=dev)
 slabs = torch.empty(8, 1024, 2048, device=dev)
