@@ -159,12 +159,16 @@ def test_train_mode_matches_emulated_masks():
     assert d <= 2e-5 + 2e-3 * outs[0][1].abs().max().item(), d
 
 
-def test_oracle_parity_on_fresh_inputs():
-    """Not a fixture: new seed, oracle (CPU torch restatement) vs HIP, batch 5."""
+@pytest.mark.parametrize('shape', [dict(B=5, T=26, L=26, O=16, P=8), dict(B=1, T=26, L=26, O=16, P=8),
+                                   dict(B=3, T=20, L=12, O=5, P=5), dict(B=2, T=32, L=7, O=9, P=3)])
+def test_oracle_parity_on_fresh_inputs(shape):
+    """Not fixtures: new seeds and odd shapes (batch 1, 20 or 32 frames, 5 or 9 regions, short captions); the oracle
+    (CPU torch restatement, pinned by the goldens) against the HIP path: logits, greedy ids, loss and every gradient."""
     from oracle import torch_ref as R
     from dlsg_amd.synth import synth_state_dict, synth_batch
     from helpers import small_args
-    args = small_args()
+    B, T, L = shape['B'], shape['T'], shape['L']
+    args = small_args(num_obj=shape['O'], num_proposals=shape['P'], max_frames=T, max_words=L)
     vocab = dlsg_amd.make_vocab(50)
     torch.manual_seed(0)
     net = dlsg_amd.CapGnnModel(args, vocab).eval()
@@ -172,11 +176,31 @@ def test_oracle_parity_on_fresh_inputs():
     net.load_state_dict(sd)
     orc = R.CapGnnModelRef(args, vocab).eval()
     orc.load_state_dict(sd)
-    frames, regions, caps, lens = synth_batch(args, 50, 5, 123)
+    frames, regions, caps, lens = synth_batch(args, 50, B, 123)
+    lens = lens.clamp(max=L)
+    want = orc(frames, regions, caps, L, 1.0)[0]
+    loss_ref = R.ragged_ce(want, caps, lens)
+    loss_ref.backward()
+    orc.update_beam_size(1)
     with torch.no_grad():
-        want = orc(frames, regions, caps, 26, 1.0)[0]
-        got = net.cuda()(frames.cuda(), regions.cuda(), caps.cuda(), 26, 1.0)[0].cpu()
-    assert (want - got).abs().max().item() <= LOGIT_TOL
+        ids_ref = orc(frames, regions, None)[0]
+    net = net.cuda()
+    with torch.no_grad():
+        got = net(frames.cuda(), regions.cuda(), caps.cuda(), L, 1.0)[0].cpu()
+        net.update_beam_size(1)
+        ids = net(frames.cuda(), regions.cuda(), None)[0].cpu()
+    assert (want.detach() - got).abs().max().item() <= LOGIT_TOL
+    assert torch.equal(ids, ids_ref)
+    tr = dlsg_amd.Trainer(net, lr=0.0)
+    loss = tr.step(frames.cuda(), regions.cuda(), caps.cuda(), lens, 1.0, max_len=L)
+    assert abs(float(loss) - float(loss_ref)) <= 1e-4
+    G = net.grad_views()
+    for (k, p) in orc.named_parameters():
+        if p.grad is None:
+            continue
+        ref = p.grad
+        err = (G[k].cpu() - ref).abs().max().item()
+        assert err <= 2e-5 + 2e-3 * ref.abs().max().item(), (k, err, ref.abs().max().item())
 
 
 @pytest.mark.parametrize('train_mode', [False, True])
