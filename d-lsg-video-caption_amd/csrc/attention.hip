@@ -444,6 +444,10 @@ extern "C" int dlsg_struct_size(int which) {
         case 5: return (int)sizeof(dlsg_decatt_bwd_args);
         case 6: return (int)sizeof(dlsg_lstm_pw_args);
         case 7: return (int)sizeof(dlsg_lstm_pw_bwd_args);
+        case 8: return (int)sizeof(dlsg_dec_mid_args);
+        case 9: return (int)sizeof(dlsg_dec_tail_args);
+        case 10: return (int)sizeof(dlsg_dec_mid_bwd_args);
+        case 11: return (int)sizeof(dlsg_decatt_cache_grads_args);
         default: return -1;
     }
 }

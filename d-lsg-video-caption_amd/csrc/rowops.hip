@@ -278,7 +278,10 @@ __global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(const dlsg_lstm_pw_bwd
     if (a.dh2) {
         float d2 = a.dh2[(int64_t)b * a.lddh2 + j];
         if (a.dh3) d2 += a.dh3[(int64_t)b * a.lddh3 + j];
-        if (a.dh4) d2 += a.dh4[(int64_t)b * a.lddh4 + j];
+        if (a.dh4) {
+            const int ns4 = a.dh4_nslab > 1 ? a.dh4_nslab : 1;
+            for (int k = 0; k < ns4; ++k) d2 += a.dh4[k * a.dh4_slab_stride + (int64_t)b * a.lddh4 + j];
+        }
         if (a.p > 0.f) d2 *= drop_scale(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), a.site, (uint64_t)b * H + j, a.p);
         dh += d2;
     }

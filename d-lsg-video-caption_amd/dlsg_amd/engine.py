@@ -123,6 +123,26 @@ def gemm_nn_multi(ops, dy, Ws, out, ref):
     ops.slab_reduce(slabs, out)
 
 
+def gemm_nn_multi_slabs(ops, dy, Ws, width, ref):
+    """gemm_nn_multi without the reduction: returns the slab stack (S, M, width) whose sum over S is
+    [dy @ W_0 | dy @ W_1 | ...] in the leading columns (the consumer kernel sums the slabs while it reads them)."""
+    M, Nn = dy.shape
+    widths = [W.shape[1] for W in Ws]
+    tot = sum(widths)
+    assert tot <= width
+    ns = _nsplit_for(M, tot, 1)
+    ns = max(1, min(ns, 16 // len(Ws)))
+    bounds = _ksplit_bounds(Nn, ns, 128 if M <= 64 else 32)
+    slabs = _empty(ref, len(bounds), M, width)
+    groups, c0 = [], 0
+    for W, wd in zip(Ws, widths):
+        for i, (k0, k1) in enumerate(bounds):
+            groups.append((dy[:, k0:k1], W[k0:k1, :], slabs[i][:, c0:c0 + wd]))
+        c0 += wd
+    ops.gemm(GEMM_NN, groups)
+    return slabs
+
+
 def lin(ops, x, W, out, bias=None, tanh=False, accum=False):
     ops.gemm(GEMM_NT, [(x, W, out)], flags=(F_TANH if tanh else 0) | (F_ACCUM if accum else 0), bias=bias)
 
@@ -538,39 +558,35 @@ def dec_step(ops, dec, s, t, ref, training, seed, B, word_dropout=True):
     if t > 0 or s.get('warm', False):
         segs += [(s['LHP'][t], ql.weight_ih[:, plan.q_lang[0]:plan.q_lang[1]]), (s['QH'][t], ql.weight_hh)]
     slabs = seg_gemm_nt(ops, segs, B, 4 * Q, ref)
-    ops.lstm_pw_fwd(slabs, s['QC'][t + 1], B, Q, addend=s['gq'], b_ih=ql.bias_ih, b_hh=ql.bias_hh, c_prev=s['QC'][t],
-                    h=s['QH'][t + 1], gates=s['GQ'][t])
-    lnq = dec.query_lstm_layernorm
-    ops.rowln_fwd(s['QH'][t + 1], lnq.weight, lnq.bias, s['QCUR'][t], s['ST_Q'][t], p1=pd, site1=site + SITE_QUERY,
-                  seed=seed)
-    # ---- attention over the cached proposals
+    # ---- cell pointwise -> LN -> attention over the cached proposals -> tanh -> LN: one launch per step
     ns = plan.ns
-    scale = 1.0 / math.sqrt(H)
-    ops.decatt_fwd(s['Kp'], s['Vp'], s['QCUR'][t], [s['CPRE'][i][t] for i in range(ns)], s['ALPHA'][t], scale)
-    for i, att in enumerate(_att_modules(dec)):
-        ln = att.output_layer[2]
-        ops.rowln_fwd(s['CPRE'][i][t], ln.weight, ln.bias, s['CTX'][i][t], s['ST_C'][i][t], pre_tanh=1,
-                      p1=att.dropout if training else 0.0, site1=site + SITE_ATT1 + i, seed=seed)
+    lnq = dec.query_lstm_layernorm
+    atts = _att_modules(dec)
+    ops.dec_mid_fwd(slabs, s['gq'], ql.bias_ih, ql.bias_hh, s['QC'][t], s['QC'][t + 1], s['QH'][t + 1], s['GQ'][t],
+                    (lnq.weight, lnq.bias), s['QCUR'][t], s['ST_Q'][t], pd, site + SITE_QUERY, s['Kp'], s['Vp'],
+                    [(a.output_layer[2].weight, a.output_layer[2].bias) for a in atts],
+                    [s['CPRE'][i][t] for i in range(ns)], [s['CTX'][i][t] for i in range(ns)],
+                    [s['ST_C'][i][t] for i in range(ns)], s['ALPHA'][t],
+                    [a.dropout if training else 0.0 for a in atts], [site + SITE_ATT1 + i for i in range(ns)],
+                    1.0 / math.sqrt(H), seed=seed)
     # ---- language LSTM
     segs = [(s['CTX'][i][t], ll.weight_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]]) for i in range(ns)]
     segs.append((s['QCUR'][t], ll.weight_ih[:, plan.l_q[0]:plan.l_q[1]]))
     if t > 0 or s.get('warm', False):
         segs.append((s['LHP'][t], ll.weight_hh))
     slabs = seg_gemm_nt(ops, segs, B, 4 * D, ref)
-    ops.lstm_pw_fwd(slabs, s['LC'][t + 1], B, D, b_ih=ll.bias_ih, b_hh=ll.bias_hh, c_prev=s['LC'][t], h2=s['LHP'][t + 1],
-                    gates=s['GL'][t], p=pd, site=site + SITE_LANG, seed=seed)
+    lnl = dec.lang_lstm_layernorm
+    ops.dec_tail_fwd(slabs, ll.bias_ih, ll.bias_hh, s['LC'][t], s['LC'][t + 1], s['LHP'][t + 1], s['GL'][t],
+                     (lnl.weight, lnl.bias), s['DOUT'][t], s['ST_L'][t], pd, site + SITE_LANG, seed=seed)
 
 
 def dec_logits(ops, dec, s, t0, t1):
-    """logits of steps [t0,t1): tanh(LN(lang_h)) -> word_restore (models/layer.py:599-600)."""
+    """logits of steps [t0,t1): word_restore of tanh(LN(lang_h)) (models/layer.py:599-600); dec_step left the LN output in DOUT."""
     plan = s['plan']
     D = plan.D
     B = s['LHP'].shape[1]
     V = dec.vocab_size
     n = (t1 - t0) * B
-    lnl = dec.lang_lstm_layernorm
-    x = s['LHP'][t0 + 1:t1 + 1].view(n, D)
-    ops.rowln_fwd(x, lnl.weight, lnl.bias, s['DOUT'][t0:t1].view(n, D), s['ST_L'][t0:t1].view(n, 2), post_tanh=1)
     lin(ops, s['DOUT'][t0:t1].view(n, D), dec.word_restore.weight, s['LOGITS'][t0:t1].view(n, V), dec.word_restore.bias)
 
 
@@ -665,55 +681,50 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
 
     dGQ = _empty(ref, L, B, 4 * Q)
     dGL = _empty(ref, L, B, 4 * D)
-    dQL = _empty(ref, B, Q + D)         # [dQHrec | query-input part of dLHrec] of the query cell
-    dQHrec = dQL[:, :Q]
     dQC = _zeros(ref, B, Q)
     dLC = _zeros(ref, B, D)
-    dXLH = _empty(ref, B, ns * H + Q + D)   # [grad wrt lang_lstm input (ctx.. | qcur) | grad wrt its recurrent h]
-    dXL = dXLH[:, :ns * H + Q]
-    dLHrec = dXLH[:, ns * H + Q:]       # contributions from step t+1 to the dropped lang h (lang recurrent + query input)
-    dCPRE = [_empty(ref, B, H) for _ in range(ns)]
-    dKp = [torch.zeros_like(k) for k in s['Kp']]
-    dVp = [torch.zeros_like(v) for v in s['Vp']]
+    dLHrec = _empty(ref, B, D)           # recurrent part of d lang_h, written by step t+1's fused kernel
+    P = s['Kp'][0].shape[1]
+    dCPRE = [_empty(ref, L, B, H) for _ in range(ns)]       # kept per step: contracted into dV' after the loop
+    dS = _empty(ref, L, B, ns * P)                           # score grads per step: contracted into dK'
     atts = _att_modules(dec)
-    nbB = ops.rowln_bwd_nblk(B)
-    part_q = _zeros(ref, L, nbB, 2, Q)
-    part_c = [_zeros(ref, L, nbB, 2, H) for _ in range(ns)]
+    part_q = _empty(ref, L, B, 2, Q)
+    part_c = [_empty(ref, L, B, 2, H) for _ in range(ns)]
     lnq = dec.query_lstm_layernorm
+    lnc_g = [att.output_layer[2].weight for att in atts]
+    p_att = [att.dropout if training else 0.0 for att in atts]
     scale = 1.0 / math.sqrt(H)
     Wl_in = ll.weight_ih
+    Wq_rec = [ql.weight_hh, ql.weight_ih[:, plan.q_lang[0]:plan.q_lang[1]]]
+    wx = ns * H + Q + D
+    ql_slabs = None                       # slabs of [d query_h(recurrent) | d lang_h(query-input part)] from step t+1
     for t in range(L - 1, -1, -1):
         site = STEP_SITE * (t + 1)
-        # total grad on lang h_t (dropped) = vocab head part + (step t+1) lang-recurrent part + query-input part; the
-        # three are summed inside the cell kernel (they share the dropout mask of h_t)
+        # language cell: total grad on lang h_t (dropped) = vocab head part + (step t+1) lang-recurrent part +
+        # query-input part; the three are summed inside the cell kernel (they share the dropout mask of h_t)
         rec = t < L - 1
         ops.lstm_pw_bwd(s['GL'][t], s['LC'][t + 1], dGL[t], B, D, c_prev=s['LC'][t], dh2=dLHo[t],
-                        dh3=dLHrec if rec else None, dh4=dQL[:, Q:] if rec else None, dc_next=dLC, dc_prev=dLC,
+                        dh3=dLHrec if rec else None, dh4=ql_slabs[:, :, Q:] if rec else None, dc_next=dLC, dc_prev=dLC,
                         p=pd, site=site + SITE_LANG, seed=seed)
-        # input grads of the language cell: [dXL | dLHrec] = dGL[t] . [W_ih | W_hh] in one grouped launch
+        # input grads of the language cell: slabs of dGL[t] . [W_ih | W_hh] from one grouped launch ...
+        xl_slabs = gemm_nn_multi_slabs(ops, dGL[t], [Wl_in, ll.weight_hh] if t > 0 else [Wl_in], wx, ref)
+        # ... consumed by ONE launch: slab sum -> output_layer LN bwd -> attention bwd -> query LN bwd -> query cell bwd
+        ops.dec_mid_bwd(xl_slabs, dLHrec if t > 0 else None, [s['CPRE'][i][t] for i in range(ns)],
+                        [s['ST_C'][i][t] for i in range(ns)], lnc_g, [part_c[i][t] for i in range(ns)],
+                        [dCPRE[i][t] for i in range(ns)], p_att, [site + SITE_ATT1 + i for i in range(ns)], s['Kp'], s['Vp'],
+                        s['ALPHA'][t], dalpha_tm[t] if dalpha_tm is not None else None, dS[t], s['QH'][t + 1], s['ST_Q'][t],
+                        lnq.weight, part_q[t], pd, site + SITE_QUERY, ql_slabs[:, :, :Q] if rec else None, s['GQ'][t],
+                        s['QC'][t + 1], s['QC'][t], dQC, dGQ[t], scale, seed=seed)
         if t > 0:
-            gemm_nn_multi(ops, dGL[t], [Wl_in, ll.weight_hh], dXLH, ref)
-        else:
-            gemm_nn_split(ops, dGL[t], Wl_in, dXL, ref)
-        for i, att in enumerate(atts):
-            ln = att.output_layer[2]
-            ops.rowln_bwd(dXL[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]], s['CPRE'][i][t], ln.weight, ln.bias, dCPRE[i],
-                          stats=s['ST_C'][i][t], pre_tanh=1, p1=att.dropout if training else 0.0,
-                          site1=site + SITE_ATT1 + i, seed=seed, dgb_part=part_c[i][t])
-        dq = dXL[:, plan.l_q[0]:plan.l_q[1]]
-        ops.decatt_bwd(s['Kp'], s['Vp'], s['QCUR'][t], s['ALPHA'][t], dCPRE, dKp, dVp, dq, scale, accum_dq=True,
-                       dalpha=dalpha_tm[t] if dalpha_tm is not None else None)
-        # dQH = LN-backward(dq) + recurrent part from step t+1 (accumulated in place into the dQHrec buffer)
-        ops.rowln_bwd(dq, s['QH'][t + 1], lnq.weight, lnq.bias, dQHrec, stats=s['ST_Q'][t], p1=pd, site1=site + SITE_QUERY,
-                      seed=seed, dgb_part=part_q[t], accum_dx=rec)
-        ops.lstm_pw_bwd(s['GQ'][t], s['QC'][t + 1], dGQ[t], B, Q, c_prev=s['QC'][t], dh=dQHrec, dc_next=dQC, dc_prev=dQC)
-        if t > 0:
-            gemm_nn_multi(ops, dGQ[t], [ql.weight_hh, ql.weight_ih[:, plan.q_lang[0]:plan.q_lang[1]]], dQL, ref)
+            ql_slabs = gemm_nn_multi_slabs(ops, dGQ[t], Wq_rec, Q + D, ref)
+    dKp = [torch.empty_like(k) for k in s['Kp']]
+    dVp = [torch.empty_like(v) for v in s['Vp']]
+    ops.decatt_cache_grads(s['ALPHA'], dS, s['QCUR'], dCPRE, dKp, dVp)
     # ---- LayerNorm parameter grads of the per-step norms
-    ln_grads(ops, part_q.view(L * nbB, 2, Q), G, 'decoder.query_lstm_layernorm', Q)
+    ln_grads(ops, part_q.view(L * B, 2, Q), G, 'decoder.query_lstm_layernorm', Q)
     att_names = ['decoder.context_att', 'decoder.context_att_2']
     for i in range(ns):
-        ln_grads(ops, part_c[i].view(L * nbB, 2, H), G, att_names[i] + '.output_layer.2', H)
+        ln_grads(ops, part_c[i].view(L * B, 2, H), G, att_names[i] + '.output_layer.2', H)
     # ---- weight gradients: one (L*B)-deep TN GEMM per weight block
     dgq2, dgl2 = dGQ.view(n, 4 * Q), dGL.view(n, 4 * D)
     Gq_ih, Gl_ih = G['decoder.query_lstm.weight_ih'], G['decoder.lang_lstm.weight_ih']

@@ -73,9 +73,44 @@ class LstmPwArgs(C.Structure):
 class LstmPwBwdArgs(C.Structure):
     _fields_ = [('gates', c_f32p), ('ldg', i64), ('c', c_f32p), ('ldc_', i64), ('c_prev', c_f32p), ('ldcp', i64), ('dh', c_f32p),
                 ('lddh', i64), ('dh2', c_f32p), ('lddh2', i64), ('dh3', c_f32p), ('lddh3', i64), ('dh4', c_f32p), ('lddh4', i64),
+                ('dh4_nslab', i32), ('pad4_', i32), ('dh4_slab_stride', i64),
                 ('dc_next', c_f32p), ('lddcn', i64),
                 ('dgates', c_f32p), ('lddg', i64), ('dc_prev', c_f32p), ('lddcp', i64), ('B', i32), ('H', i32), ('p', f32),
                 ('site', u32), ('seed', u64), ('seed_ptr', c_f32p)]
+
+
+class DecMidArgs(C.Structure):
+    _fields_ = [('slabs', c_f32p), ('nslab', i32), ('pad_', i32), ('slab_stride', i64), ('addend', c_f32p), ('ldadd', i64),
+                ('b_ih', c_f32p), ('b_hh', c_f32p), ('c_prev', c_f32p), ('c', c_f32p), ('h', c_f32p), ('gates', c_f32p),
+                ('lnq_g', c_f32p), ('lnq_b', c_f32p), ('qcur', c_f32p), ('st_q', c_f32p), ('p_q', f32), ('site_q', u32),
+                ('Kp', C.c_void_p * 2), ('Vp', C.c_void_p * 2), ('lnc_g', C.c_void_p * 2), ('lnc_b', C.c_void_p * 2),
+                ('cpre', C.c_void_p * 2), ('ctx', C.c_void_p * 2), ('st_c', C.c_void_p * 2), ('alpha', c_f32p),
+                ('p_att', f32 * 2), ('site_att', u32 * 2), ('B', i32), ('Q', i32), ('H', i32), ('P', i32), ('nstream', i32),
+                ('scale', f32), ('eps', f32), ('seed', u64), ('seed_ptr', c_f32p)]
+
+
+class DecTailArgs(C.Structure):
+    _fields_ = [('slabs', c_f32p), ('nslab', i32), ('pad_', i32), ('slab_stride', i64), ('b_ih', c_f32p), ('b_hh', c_f32p),
+                ('c_prev', c_f32p), ('c', c_f32p), ('hd', c_f32p), ('gates', c_f32p), ('ln_g', c_f32p), ('ln_b', c_f32p),
+                ('dout', c_f32p), ('st_l', c_f32p), ('p', f32), ('site', u32), ('B', i32), ('D', i32), ('eps', f32),
+                ('seed', u64), ('seed_ptr', c_f32p)]
+
+
+class DecMidBwdArgs(C.Structure):
+    _fields_ = [('slabs', c_f32p), ('nslab', i32), ('write_rec', i32), ('slab_stride', i64), ('dlh_rec', c_f32p),
+                ('cpre', C.c_void_p * 2), ('st_c', C.c_void_p * 2), ('lnc_g', C.c_void_p * 2), ('part_c', C.c_void_p * 2),
+                ('dcpre', C.c_void_p * 2), ('p_att', f32 * 2), ('site_att', u32 * 2), ('Kp', C.c_void_p * 2),
+                ('Vp', C.c_void_p * 2), ('alpha', c_f32p), ('dalpha', c_f32p), ('ds', c_f32p), ('qh', c_f32p),
+                ('st_q', c_f32p), ('lnq_g', c_f32p), ('part_q', c_f32p), ('p_q', f32), ('site_q', u32),
+                ('rec_slabs', c_f32p), ('rec_nslab', i32), ('pad_', i32), ('rec_slab_stride', i64), ('rec_ld', i64),
+                ('gates', c_f32p), ('c', c_f32p), ('c_prev', c_f32p), ('dc', c_f32p), ('dgates', c_f32p),
+                ('B', i32), ('Q', i32), ('H', i32), ('D', i32), ('P', i32), ('nstream', i32), ('scale', f32), ('pad2_', f32),
+                ('seed', u64), ('seed_ptr', c_f32p)]
+
+
+class DecattCacheGradsArgs(C.Structure):
+    _fields_ = [('alpha', c_f32p), ('ds', c_f32p), ('qcur', c_f32p), ('dcpre', C.c_void_p * 2), ('dKp', C.c_void_p * 2),
+                ('dVp', C.c_void_p * 2), ('L', i32), ('B', i32), ('Q', i32), ('H', i32), ('P', i32), ('nstream', i32)]
 
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
@@ -84,7 +119,8 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
-           'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows']
+           'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
+           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads']
 
 
 def load_library(path=LIB_PATH):
@@ -126,6 +162,10 @@ def load_library(path=LIB_PATH):
         'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
         'dlsg_permute_tb': [vp, vp, i32, i32, i32, vp],
         'dlsg_gather_rows': [vp, i64, vp, vp, i64, i32, i32, vp],
+        'dlsg_dec_mid_fwd': [P(DecMidArgs), vp],
+        'dlsg_dec_tail_fwd': [P(DecTailArgs), vp],
+        'dlsg_dec_mid_bwd': [P(DecMidBwdArgs), vp],
+        'dlsg_decatt_cache_grads': [P(DecattCacheGradsArgs), vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -135,11 +175,17 @@ def load_library(path=LIB_PATH):
     return lib
 
 
-STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs]
+STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
+           DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs]
 
 
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chkc(t):
+    if not t.is_contiguous():
+        raise ValueError('fused decoder-step kernels take dense row-major buffers')
 
 
 def _seed(seed):
@@ -366,6 +412,89 @@ class HipOps(object):
         b.dq, b.lddq, b.accum_dq = _p(dq), dq.stride(0), int(accum_dq)
         self._check(self.lib.dlsg_decatt_bwd(C.byref(b), self._stream()), 'dlsg_decatt_bwd')
 
+    # ------------------------------------------------------------------ fused decoder step
+    def dec_mid_fwd(self, slabs, addend, b_ih, b_hh, c_prev, c, h, gates, lnq, qcur, st_q, p_q, site_q, Kp, Vp, lnc, cpre,
+                    ctx, st_c, alpha, p_att, site_att, scale, seed=0, eps=1e-5):
+        """query cell pointwise -> LN(+dropout) -> attention over Kp/Vp (per stream) -> tanh -> LN(+dropout); one launch.
+        lnq = (gamma, beta); lnc = [(gamma, beta)] per stream."""
+        a = DecMidArgs()
+        a.slabs, a.nslab, a.slab_stride = _p(slabs), slabs.size(0), slabs.stride(0)
+        a.addend, a.ldadd = _p(addend), (addend.stride(0) if addend is not None else 0)
+        a.b_ih, a.b_hh, a.c_prev, a.c, a.h, a.gates = _p(b_ih), _p(b_hh), _p(c_prev), _p(c), _p(h), _p(gates)
+        a.lnq_g, a.lnq_b, a.qcur, a.st_q, a.p_q, a.site_q = _p(lnq[0]), _p(lnq[1]), _p(qcur), _p(st_q), p_q, site_q
+        ns = len(Kp)
+        for i in range(ns):
+            _chkc(Kp[i]); _chkc(Vp[i]); _chkc(cpre[i]); _chkc(ctx[i])
+            a.Kp[i], a.Vp[i] = Kp[i].data_ptr(), Vp[i].data_ptr()
+            a.lnc_g[i], a.lnc_b[i] = lnc[i][0].data_ptr(), lnc[i][1].data_ptr()
+            a.cpre[i], a.ctx[i], a.st_c[i] = cpre[i].data_ptr(), ctx[i].data_ptr(), st_c[i].data_ptr()
+            a.p_att[i], a.site_att[i] = p_att[i], site_att[i]
+        for t in (c, h, gates, qcur, alpha):
+            _chkc(t)
+        a.alpha = _p(alpha)
+        a.B, a.Q, a.H, a.P, a.nstream = c.size(0), c.size(1), Vp[0].size(2), Kp[0].size(1), ns
+        a.scale, a.eps = scale, eps
+        a.seed, a.seed_ptr = _seed(seed)
+        self._check(self.lib.dlsg_dec_mid_fwd(C.byref(a), self._stream()), 'dlsg_dec_mid_fwd')
+
+    def dec_tail_fwd(self, slabs, b_ih, b_hh, c_prev, c, hd, gates, ln, dout, st_l, p, site, seed=0, eps=1e-5):
+        """language cell pointwise (+dropout on h) -> tanh(LN(h)); one launch."""
+        a = DecTailArgs()
+        a.slabs, a.nslab, a.slab_stride = _p(slabs), slabs.size(0), slabs.stride(0)
+        a.b_ih, a.b_hh, a.c_prev, a.c, a.hd, a.gates = _p(b_ih), _p(b_hh), _p(c_prev), _p(c), _p(hd), _p(gates)
+        for t in (c, hd, gates, dout):
+            _chkc(t)
+        a.ln_g, a.ln_b, a.dout, a.st_l, a.p, a.site = _p(ln[0]), _p(ln[1]), _p(dout), _p(st_l), p, site
+        a.B, a.D, a.eps = c.size(0), c.size(1), eps
+        a.seed, a.seed_ptr = _seed(seed)
+        self._check(self.lib.dlsg_dec_tail_fwd(C.byref(a), self._stream()), 'dlsg_dec_tail_fwd')
+
+    def dec_mid_bwd(self, slabs, dlh_rec, cpre, st_c, lnc_g, part_c, dcpre, p_att, site_att, Kp, Vp, alpha, dalpha, ds, qh,
+                    st_q, lnq_g, part_q, p_q, site_q, rec_slabs, gates, c, c_prev, dc, dgates, scale, seed=0):
+        """backward of dec_mid_fwd for one word step (see include/dlsg.h).  slabs (S,B,ns*H+Q+D); dlh_rec (B,D) or None;
+        rec_slabs (S',B,Q) view of the query cell's input-gradient slabs of step t+1, or None."""
+        a = DecMidBwdArgs()
+        ns = len(Kp)
+        B, Q = c.shape
+        H, P = Vp[0].size(2), Kp[0].size(1)
+        D = slabs.size(2) - ns * H - Q
+        _chkc(slabs)
+        a.slabs, a.nslab, a.slab_stride = _p(slabs), slabs.size(0), slabs.stride(0)
+        a.write_rec, a.dlh_rec = int(dlh_rec is not None), _p(dlh_rec)
+        for i in range(ns):
+            for t in (cpre[i], part_c[i], dcpre[i], Kp[i], Vp[i]):
+                _chkc(t)
+            a.cpre[i], a.st_c[i], a.lnc_g[i] = cpre[i].data_ptr(), st_c[i].data_ptr(), lnc_g[i].data_ptr()
+            a.part_c[i], a.dcpre[i] = part_c[i].data_ptr(), dcpre[i].data_ptr()
+            a.p_att[i], a.site_att[i] = p_att[i], site_att[i]
+            a.Kp[i], a.Vp[i] = Kp[i].data_ptr(), Vp[i].data_ptr()
+        for t in (alpha, ds, qh, part_q, gates, c, dc, dgates) + ((dlh_rec,) if dlh_rec is not None else ()):
+            _chkc(t)
+        a.alpha, a.dalpha, a.ds = _p(alpha), _p(dalpha), _p(ds)
+        a.qh, a.st_q, a.lnq_g, a.part_q, a.p_q, a.site_q = _p(qh), _p(st_q), _p(lnq_g), _p(part_q), p_q, site_q
+        if rec_slabs is not None:
+            a.rec_slabs, a.rec_nslab = _p(rec_slabs), rec_slabs.size(0)
+            a.rec_slab_stride, a.rec_ld = rec_slabs.stride(0), rec_slabs.stride(1)
+        a.gates, a.c, a.c_prev, a.dc, a.dgates = _p(gates), _p(c), _p(c_prev), _p(dc), _p(dgates)
+        a.B, a.Q, a.H, a.D, a.P, a.nstream, a.scale = B, Q, H, D, P, ns, scale
+        a.seed, a.seed_ptr = _seed(seed)
+        self._check(self.lib.dlsg_dec_mid_bwd(C.byref(a), self._stream()), 'dlsg_dec_mid_bwd')
+
+    def decatt_cache_grads(self, alpha, ds, qcur, dcpre, dKp, dVp):
+        """dK'[s] = sum_t ds_t (x) q_cur_t, dV'[s] = sum_t alpha_t (x) dcpre_t  (time-major (L,B,.) inputs)."""
+        a = DecattCacheGradsArgs()
+        L, B, Q = qcur.shape
+        ns = len(dKp)
+        for t in (alpha, ds, qcur):
+            _chkc(t)
+        a.alpha, a.ds, a.qcur = _p(alpha), _p(ds), _p(qcur)
+        for i in range(ns):
+            for t in (dcpre[i], dKp[i], dVp[i]):
+                _chkc(t)
+            a.dcpre[i], a.dKp[i], a.dVp[i] = dcpre[i].data_ptr(), dKp[i].data_ptr(), dVp[i].data_ptr()
+        a.L, a.B, a.Q, a.H, a.P, a.nstream = L, B, Q, dVp[0].size(2), dKp[0].size(1), ns
+        self._check(self.lib.dlsg_decatt_cache_grads(C.byref(a), self._stream()), 'dlsg_decatt_cache_grads')
+
     # ------------------------------------------------------------------ LSTM pointwise
     def lstm_pw_fwd(self, slabs, c, B, H, addend=None, b_ih=None, b_hh=None, c_prev=None, h=None, h2=None, gates=None,
                     p=0.0, site=0, seed=0):
@@ -393,7 +522,10 @@ class HipOps(object):
         a.dh, a.lddh = _p(dh), (dh.stride(0) if dh is not None else 0)
         a.dh2, a.lddh2 = _p(dh2), (dh2.stride(0) if dh2 is not None else 0)
         a.dh3, a.lddh3 = _p(dh3), (dh3.stride(0) if dh3 is not None else 0)
-        a.dh4, a.lddh4 = _p(dh4), (dh4.stride(0) if dh4 is not None else 0)
+        if dh4 is not None and dh4.dim() == 3:      # slab stack (S,B,H): summed inside the kernel
+            a.dh4, a.lddh4, a.dh4_nslab, a.dh4_slab_stride = _p(dh4), dh4.stride(1), dh4.size(0), dh4.stride(0)
+        else:
+            a.dh4, a.lddh4 = _p(dh4), (dh4.stride(0) if dh4 is not None else 0)
         a.dc_next, a.lddcn = _p(dc_next), (dc_next.stride(0) if dc_next is not None else 0)
         a.dgates, a.lddg = _p(dgates), dgates.stride(0)
         a.dc_prev, a.lddcp = _p(dc_prev), (dc_prev.stride(0) if dc_prev is not None else 0)

@@ -18,7 +18,8 @@ extern "C" {
 #define DLSG_ABI_VERSION 1
 int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
- * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args): lets a binding verify its struct layout without a GPU. */
+ * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args): lets a binding verify its
+ * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
 /* ---------------------------------------------------------------- GEMM (fp32-in / fp32-acc MFMA 32x32x2)
@@ -154,6 +155,86 @@ typedef struct {
 } dlsg_decatt_bwd_args;
 int dlsg_decatt_bwd(const dlsg_decatt_bwd_args* a, void* stream);
 
+/* ---------------------------------------------------------------- fused decoder step (Decoder.decode, layer.py:569-602)
+ * One workgroup per batch row; everything between the two gate GEMMs of a word step in ONE launch:
+ *   query LSTM cell pointwise (sums the gate GEMM's slabs) -> query_lstm_layernorm (+dropout) -> attention over the
+ *   cached K', V' of every stream (scores, softmax over P, weighted V') -> tanh -> output_layer LayerNorm (+dropout).
+ * Replaces dlsg_lstm_pw_fwd + dlsg_rowln_fwd + dlsg_decatt_fwd + 2 x dlsg_rowln_fwd of the unfused schedule. */
+typedef struct {
+    /* query cell */
+    const float* slabs; int32_t nslab; int32_t pad_; int64_t slab_stride;     /* (S,B,4Q) gate partial sums */
+    const float* addend; int64_t ldadd;          /* (B,4Q) global-feature gate part */
+    const float* b_ih; const float* b_hh;
+    const float* c_prev;                         /* (B,Q) */
+    float* c; float* h; float* gates;            /* (B,Q), (B,Q) raw h, (B,4Q) activated gates */
+    const float* lnq_g; const float* lnq_b;      /* query_lstm_layernorm */
+    float* qcur; float* st_q;                    /* (B,Q) dropout(LN(h)), (B,2) */
+    float p_q; uint32_t site_q;
+    /* attention streams */
+    const float* Kp[2]; const float* Vp[2];      /* (B,P,Q), (B,P,H) */
+    const float* lnc_g[2]; const float* lnc_b[2];/* output_layer.2 of each AttentionShare */
+    float* cpre[2]; float* ctx[2]; float* st_c[2];   /* (B,H) pre-tanh context, (B,H) output, (B,2) */
+    float* alpha;                                /* (B, nstream*P) */
+    float p_att[2]; uint32_t site_att[2];
+    int32_t B, Q, H, P, nstream;
+    float scale, eps;
+    uint64_t seed; const uint64_t* seed_ptr;
+} dlsg_dec_mid_args;
+int dlsg_dec_mid_fwd(const dlsg_dec_mid_args* a, void* stream);
+/* language LSTM cell pointwise (+dropout on h) -> tanh(lang_lstm_layernorm(h)) for the vocab projection. */
+typedef struct {
+    const float* slabs; int32_t nslab; int32_t pad_; int64_t slab_stride;     /* (S,B,4D) */
+    const float* b_ih; const float* b_hh;
+    const float* c_prev; float* c; float* hd; float* gates;    /* (B,D) ..., hd = dropout(h) (next state), (B,4D) */
+    const float* ln_g; const float* ln_b;
+    float* dout; float* st_l;                   /* (B,D) tanh(LN(hd)), (B,2) */
+    float p; uint32_t site;
+    int32_t B, D;
+    float eps;
+    uint64_t seed; const uint64_t* seed_ptr;
+} dlsg_dec_tail_args;
+int dlsg_dec_tail_fwd(const dlsg_dec_tail_args* a, void* stream);
+/* Backward of dlsg_dec_mid_fwd for one word step, one workgroup per batch row.  Consumes the slabs of the language
+ * cell's input-gradient GEMM directly (their sum is [d ctx_0 | d ctx_1 | d q_cur | d lang_h(recurrent)]), runs the
+ * output_layer LayerNorm backward of each stream, the attention backward (score / softmax / context), the
+ * query_lstm_layernorm backward and the query cell backward.  The gradients of the cached K', V' are NOT accumulated
+ * here: the step leaves d(pre-tanh context) and d(score) in per-step buffers and dlsg_decatt_cache_grads contracts them
+ * over the word loop afterwards (no read-modify-write of the (B,P,Q)+(B,P,H) caches per word).
+ * Replaces dlsg_slab_reduce + 2 x dlsg_rowln_bwd + dlsg_decatt_bwd + dlsg_rowln_bwd + dlsg_lstm_pw_bwd. */
+typedef struct {
+    const float* slabs; int32_t nslab; int32_t write_rec; int64_t slab_stride;   /* (S,B,ns*H+Q+D), rows dense */
+    float* dlh_rec;                      /* (B,D) out when write_rec: sum of the last D columns */
+    const float* cpre[2]; const float* st_c[2]; const float* lnc_g[2];
+    float* part_c[2];                    /* (B,2,H) per-row dgamma | dbeta of each output_layer LayerNorm */
+    float* dcpre[2];                     /* (B,H) out */
+    float p_att[2]; uint32_t site_att[2];
+    const float* Kp[2]; const float* Vp[2];
+    const float* alpha; const float* dalpha;     /* (B,ns*P); dalpha optional */
+    float* ds;                           /* (B,ns*P) out */
+    const float* qh; const float* st_q; const float* lnq_g;
+    float* part_q;                       /* (B,2,Q) */
+    float p_q; uint32_t site_q;
+    const float* rec_slabs; int32_t rec_nslab; int32_t pad_; int64_t rec_slab_stride; int64_t rec_ld;
+                                         /* (S',B,>=Q): recurrent d h_query from step t+1, NULL at the last step */
+    const float* gates; const float* c; const float* c_prev;   /* (B,4Q), (B,Q), (B,Q) */
+    float* dc;                           /* (B,Q) in/out: cell-state gradient */
+    float* dgates;                       /* (B,4Q) out */
+    int32_t B, Q, H, D, P, nstream;
+    float scale; float pad2_;
+    uint64_t seed; const uint64_t* seed_ptr;
+} dlsg_dec_mid_bwd_args;
+int dlsg_dec_mid_bwd(const dlsg_dec_mid_bwd_args* a, void* stream);
+/* dK'[s][b,p,:] = sum_t ds[t,b,s*P+p] * q_cur[t,b,:],  dV'[s][b,p,:] = sum_t alpha[t,b,s*P+p] * dcpre[s][t,b,:]
+ * (time-major (L,B,.) inputs; outputs written, not accumulated). */
+typedef struct {
+    const float* alpha; const float* ds;         /* (L,B,ns*P) */
+    const float* qcur;                           /* (L,B,Q) */
+    const float* dcpre[2];                       /* (L,B,H) */
+    float* dKp[2]; float* dVp[2];                /* (B,P,Q), (B,P,H) */
+    int32_t L, B, Q, H, P, nstream;
+} dlsg_decatt_cache_grads_args;
+int dlsg_decatt_cache_grads(const dlsg_decatt_cache_grads_args* a, void* stream);
+
 /* ---------------------------------------------------------------- LSTM cell pointwise (nn.LSTM layer.py:52, nn.LSTMCell :571,593)
  * gates = sum_s slabs[s] (+ addend) (+ b_ih + b_hh), PyTorch gate order i,f,g,o;
  * c = f*c_prev + i*g; h = o*tanh(c).  Saves activated gates (B,4H) for backward.  h is written to up to two
@@ -181,6 +262,7 @@ typedef struct {
     const float* dh2; int64_t lddh2;           /* optional, goes through the dropout mask */
     const float* dh3; int64_t lddh3;           /* optional, summed with dh2 before the mask */
     const float* dh4; int64_t lddh4;           /* optional, summed with dh2 before the mask */
+    int32_t dh4_nslab; int32_t pad4_; int64_t dh4_slab_stride;   /* dh4_nslab > 1: dh4 is a slab stack, summed on the fly */
     const float* dc_next; int64_t lddcn;       /* optional */
     float* dgates; int64_t lddg;               /* (B,4H) pre-activation gate grads, row stride lddg */
     float* dc_prev; int64_t lddcp;

@@ -220,6 +220,54 @@ class EmulOps(object):
         dq.copy_(acc)
 
     # ------------------------------------------------------------------ LSTM pointwise
+    def dec_mid_fwd(self, slabs, addend, b_ih, b_hh, c_prev, c, h, gates, lnq, qcur, st_q, p_q, site_q, Kp, Vp, lnc, cpre,
+                    ctx, st_c, alpha, p_att, site_att, scale, seed=0, eps=1e-5):
+        # the fused launch is, by definition, the unfused chain
+        B, Q = c.shape
+        self.lstm_pw_fwd(slabs, c, B, Q, addend=addend, b_ih=b_ih, b_hh=b_hh, c_prev=c_prev, h=h, gates=gates)
+        self.rowln_fwd(h, lnq[0], lnq[1], qcur, st_q, p1=p_q, site1=site_q, seed=seed, eps=eps)
+        self.decatt_fwd(Kp, Vp, qcur, cpre, alpha, scale)
+        for i in range(len(Kp)):
+            self.rowln_fwd(cpre[i], lnc[i][0], lnc[i][1], ctx[i], st_c[i], pre_tanh=1, p1=p_att[i], site1=site_att[i],
+                           seed=seed, eps=eps)
+
+    def dec_tail_fwd(self, slabs, b_ih, b_hh, c_prev, c, hd, gates, ln, dout, st_l, p, site, seed=0, eps=1e-5):
+        B, D = c.shape
+        self.lstm_pw_fwd(slabs, c, B, D, b_ih=b_ih, b_hh=b_hh, c_prev=c_prev, h2=hd, gates=gates, p=p, site=site, seed=seed)
+        self.rowln_fwd(hd, ln[0], ln[1], dout, st_l, post_tanh=1, eps=eps)
+
+    def dec_mid_bwd(self, slabs, dlh_rec, cpre, st_c, lnc_g, part_c, dcpre, p_att, site_att, Kp, Vp, alpha, dalpha, ds, qh,
+                    st_q, lnq_g, part_q, p_q, site_q, rec_slabs, gates, c, c_prev, dc, dgates, scale, seed=0):
+        ns = len(Kp)
+        B, Q = c.shape
+        H, P = Vp[0].shape[2], Kp[0].shape[1]
+        dx = slabs.sum(0)
+        if dlh_rec is not None:
+            dlh_rec.copy_(dx[:, ns * H + Q:])
+        for i in range(ns):
+            self.rowln_bwd(dx[:, i * H:(i + 1) * H], cpre[i], lnc_g[i], None, dcpre[i], stats=st_c[i], pre_tanh=1, p1=p_att[i],
+                           site1=site_att[i], seed=seed, dgb_part=part_c[i])
+        dq = dx[:, ns * H:ns * H + Q].clone()
+        for i in range(ns):
+            w = alpha[:, i * P:(i + 1) * P]
+            dw = (Vp[i] @ dcpre[i].unsqueeze(2)).squeeze(2)
+            if dalpha is not None:
+                dw = dw + dalpha[:, i * P:(i + 1) * P]
+            dsi = w * (dw - (w * dw).sum(1, keepdim=True)) * scale
+            ds[:, i * P:(i + 1) * P] = dsi
+            dq = dq + (dsi.unsqueeze(1) @ Kp[i]).squeeze(1)
+        dh = torch.zeros(B, Q)
+        self.rowln_bwd(dq, qh, lnq_g, None, dh, stats=st_q, p1=p_q, site1=site_q, seed=seed, dgb_part=part_q)
+        if rec_slabs is not None:
+            dh = dh + rec_slabs.sum(0)
+        self.lstm_pw_bwd(gates, c, dgates, B, Q, c_prev=c_prev, dh=dh, dc_next=dc, dc_prev=dc)
+
+    def decatt_cache_grads(self, alpha, ds, qcur, dcpre, dKp, dVp):
+        P = dKp[0].shape[1]
+        for i in range(len(dKp)):
+            dKp[i].copy_(torch.einsum('tbp,tbq->bpq', ds[:, :, i * P:(i + 1) * P], qcur))
+            dVp[i].copy_(torch.einsum('tbp,tbh->bph', alpha[:, :, i * P:(i + 1) * P], dcpre[i]))
+
     def lstm_pw_fwd(self, slabs, c, B, H, addend=None, b_ih=None, b_hh=None, c_prev=None, h=None, h2=None, gates=None,
                     p=0.0, site=0, seed=0):
         self._count('lstm_pw_fwd')
@@ -253,7 +301,7 @@ class EmulOps(object):
             if dh3 is not None:
                 d2 = d2 + dh3
             if dh4 is not None:
-                d2 = d2 + dh4
+                d2 = d2 + (dh4.sum(0) if dh4.dim() == 3 else dh4)
             d = d + (d2 * _mask(seed, site, B, H, p) if p > 0 else d2)
         tc = torch.tanh(c)
         dc = d * o * (1 - tc * tc)

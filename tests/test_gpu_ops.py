@@ -373,6 +373,81 @@ def test_lstm_pointwise(hip, dims):
     both(hip, build, run, ['c', 'h', 'h2', 'gates', 'dg', 'dcp', 'c0', 'g0'], tol=1e-5, name='lstm_pw %s' % (dims,))
 
 
+@pytest.mark.parametrize('dims', [(3, 48, 32, 40, 5, 2), (64, 1024, 1024, 1024, 8, 2), (5, 96, 64, 80, 3, 1), (2, 600, 520, 300, 32, 2)])
+def test_dec_step_fused_fwd(hip, dims):
+    """dec_mid_fwd / dec_tail_fwd against the unfused chain they replace (the emulator composes the unfused ops)."""
+    B, Q, H, D, P, ns = dims
+
+    def build(g):
+        d = dict(slabs=rnd(g, 3, B, 4 * Q), add=rnd(g, B, 2, 4 * Q), bi=rnd(g, 4 * Q), bh=rnd(g, 4 * Q), cp=rnd(g, B, Q),
+                 c=torch.zeros(B, Q), h=torch.zeros(B, Q), gates=torch.zeros(B, 4 * Q), gq=rnd(g, Q), bq=rnd(g, Q),
+                 qcur=torch.zeros(B, Q), stq=torch.zeros(B, 2), alpha=torch.zeros(B, ns * P),
+                 slabs2=rnd(g, 2, B, 4 * D), bi2=rnd(g, 4 * D), bh2=rnd(g, 4 * D), cp2=rnd(g, B, D), c2=torch.zeros(B, D),
+                 hd=torch.zeros(B, D), gates2=torch.zeros(B, 4 * D), gl=rnd(g, D), bl=rnd(g, D), dout=torch.zeros(B, D),
+                 stl=torch.zeros(B, 2))
+        for s in range(ns):
+            d['K%d' % s] = rnd(g, B, P, Q, scale=0.2); d['V%d' % s] = rnd(g, B, P, H)
+            d['g%d' % s] = rnd(g, H); d['b%d' % s] = rnd(g, H)
+            d['cpre%d' % s] = torch.zeros(B, H); d['ctx%d' % s] = torch.zeros(B, H); d['stc%d' % s] = torch.zeros(B, 2)
+        return d
+
+    def run(ops, t):
+        R = range(ns)
+        ops.dec_mid_fwd(t['slabs'], t['add'][:, 1], t['bi'], t['bh'], t['cp'], t['c'], t['h'], t['gates'], (t['gq'], t['bq']),
+                        t['qcur'], t['stq'], 0.3, 11, [t['K%d' % s] for s in R], [t['V%d' % s] for s in R],
+                        [(t['g%d' % s], t['b%d' % s]) for s in R], [t['cpre%d' % s] for s in R], [t['ctx%d' % s] for s in R],
+                        [t['stc%d' % s] for s in R], t['alpha'], [0.2, 0.4][:ns], [21, 22][:ns], 0.3, seed=5)
+        ops.dec_tail_fwd(t['slabs2'], t['bi2'], t['bh2'], t['cp2'], t['c2'], t['hd'], t['gates2'], (t['gl'], t['bl']),
+                         t['dout'], t['stl'], 0.3, 31, seed=5)
+    outs = ['c', 'h', 'gates', 'qcur', 'stq', 'alpha', 'c2', 'hd', 'gates2', 'dout', 'stl']
+    outs += [k % s for s in range(ns) for k in ('cpre%d', 'ctx%d', 'stc%d')]
+    both(hip, build, run, outs, tol=3e-5, name='dec_step %s' % (dims,))
+
+
+@pytest.mark.parametrize('dims', [(3, 48, 32, 40, 5, 2, 3), (64, 1024, 1024, 1024, 8, 2, 5), (5, 96, 64, 80, 3, 1, 1),
+                                  (2, 600, 520, 300, 32, 2, 6)])
+@pytest.mark.parametrize('last', [False, True])
+def test_dec_step_fused_bwd(hip, dims, last):
+    """dec_mid_bwd (+ slab-stack dh4 of lstm_pw_bwd, + decatt_cache_grads) against the unfused backward chain.
+    last=True: the final word step (no recurrent inputs); write_rec is exercised by last=False."""
+    B, Q, H, D, P, ns, S = dims
+    L = 4
+
+    def build(g):
+        d = dict(slabs=rnd(g, S, B, ns * H + Q + D), rec=rnd(g, 3, B, Q + D), dlh=torch.zeros(B, D), alpha=torch.softmax(rnd(g, B, ns, P), 2).reshape(B, ns * P),
+                 dalpha=rnd(g, B, ns * P), ds=torch.zeros(B, ns * P), qh=rnd(g, B, Q), gq=rnd(g, Q), partq=torch.zeros(B, 2, Q),
+                 gates=torch.sigmoid(rnd(g, B, 4 * Q)), c=rnd(g, B, Q), cp=rnd(g, B, Q), dc=rnd(g, B, Q), dg=torch.zeros(B, 4 * Q),
+                 gl=torch.sigmoid(rnd(g, B, 4 * D)), lc=rnd(g, B, D), lcp=rnd(g, B, D), dlho=rnd(g, B, D), dlc=rnd(g, B, D),
+                 dgl=torch.zeros(B, 4 * D), dlh3=rnd(g, B, D),
+                 A=torch.softmax(rnd(g, L, B, ns, P), 3).reshape(L, B, ns * P), DS=rnd(g, L, B, ns * P), QC=rnd(g, L, B, Q))
+        qh = d['qh']
+        d['stq'] = torch.cat([qh.mean(1, keepdim=True), 1 / torch.sqrt(qh.var(1, unbiased=False, keepdim=True) + 1e-5)], 1)
+        for s in range(ns):
+            d['K%d' % s] = rnd(g, B, P, Q, scale=0.2); d['V%d' % s] = rnd(g, B, P, H)
+            d['g%d' % s] = rnd(g, H); d['cpre%d' % s] = rnd(g, B, H)
+            y = torch.tanh(d['cpre%d' % s])
+            d['stc%d' % s] = torch.cat([y.mean(1, keepdim=True), 1 / torch.sqrt(y.var(1, unbiased=False, keepdim=True) + 1e-5)], 1)
+            d['partc%d' % s] = torch.zeros(B, 2, H); d['dcpre%d' % s] = torch.zeros(B, H)
+            d['DC%d' % s] = rnd(g, L, B, H); d['dK%d' % s] = torch.zeros(B, P, Q); d['dV%d' % s] = torch.zeros(B, P, H)
+        return d
+
+    def run(ops, t):
+        R = range(ns)
+        rec = None if last else t['rec']
+        ops.lstm_pw_bwd(t['gl'], t['lc'], t['dgl'], B, D, c_prev=t['lcp'], dh2=t['dlho'], dh3=None if last else t['dlh3'],
+                        dh4=None if last else rec[:, :, Q:], dc_next=t['dlc'], dc_prev=t['dlc'], p=0.3, site=9, seed=5)
+        ops.dec_mid_bwd(t['slabs'], None if last else t['dlh'], [t['cpre%d' % s] for s in R], [t['stc%d' % s] for s in R],
+                        [t['g%d' % s] for s in R], [t['partc%d' % s] for s in R], [t['dcpre%d' % s] for s in R], [0.2, 0.4][:ns],
+                        [21, 22][:ns], [t['K%d' % s] for s in R], [t['V%d' % s] for s in R], t['alpha'],
+                        t['dalpha'] if last else None, t['ds'], t['qh'], t['stq'], t['gq'], t['partq'], 0.3, 11,
+                        None if last else rec[:, :, :Q], t['gates'], t['c'], t['cp'], t['dc'], t['dg'], 0.3, seed=5)
+        ops.decatt_cache_grads(t['A'], t['DS'], t['QC'], [t['DC%d' % s] for s in R], [t['dK%d' % s] for s in R],
+                               [t['dV%d' % s] for s in R])
+    outs = ['dgl', 'dlc', 'ds', 'partq', 'dc', 'dg'] + ([] if last else ['dlh'])
+    outs += [k % s for s in range(ns) for k in ('partc%d', 'dcpre%d', 'dK%d', 'dV%d')]
+    both(hip, build, run, outs, tol=3e-5, name='dec_step_bwd %s' % (dims,))
+
+
 def test_movers_embed_argmax(hip):
     def build(g):
         lg = rnd(g, 9, 1000)

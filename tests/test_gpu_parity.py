@@ -193,7 +193,7 @@ def test_oracle_parity_on_fresh_inputs(shape):
     assert torch.equal(ids, ids_ref)
     tr = dlsg_amd.Trainer(net, lr=0.0)
     loss = tr.step(frames.cuda(), regions.cuda(), caps.cuda(), lens, 1.0, max_len=L)
-    assert abs(float(loss) - float(loss_ref)) <= 1e-4
+    assert abs(float(loss) - float(loss_ref.detach())) <= 1e-4
     G = net.grad_views()
     for (k, p) in orc.named_parameters():
         if p.grad is None:
