@@ -164,8 +164,7 @@ class Grads(object):
 def ln_grads(ops, part, G, prefix, n):
     """fold rowln_bwd partials (nblk, 2, n) into the LayerNorm weight/bias gradients."""
     p2 = part.view(-1, 2 * n)
-    ops.colsum(p2[:, :n], G[prefix + '.weight'], accum=True)
-    ops.colsum(p2[:, n:], G[prefix + '.bias'], accum=True)
+    ops.colsum2(p2, G[prefix + '.weight'], G[prefix + '.bias'], split=n, accum=True)
 
 
 # ================================================================================================ TUN encoder
@@ -487,8 +486,7 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
         ops.gemm(GEMM_NN, [(dg2, Wih[d], de)], flags=F_ACCUM if d else 0)
         ops.gemm(GEMM_TN, [(dg2, e, G[name + '.lstm.weight_ih_l0' + sfx[d]])], flags=F_ACCUM)
         ops.gemm(GEMM_TN, [(dg2, hprev[d].view(B * T, H), G[name + '.lstm.weight_hh_l0' + sfx[d]])], flags=F_ACCUM)
-        ops.colsum(dg2, G[name + '.lstm.bias_ih_l0' + sfx[d]], accum=True)
-        ops.colsum(dg2, G[name + '.lstm.bias_hh_l0' + sfx[d]], accum=True)
+        ops.colsum2(dg2, G[name + '.lstm.bias_ih_l0' + sfx[d]], G[name + '.lstm.bias_hh_l0' + sfx[d]], accum=True)
     ops.gemm(GEMM_TN, [(de, frames2d, G[name + '.linear_embed.weight'])], flags=F_ACCUM)
     ops.colsum(de, G[name + '.linear_embed.bias'], accum=True)
 
@@ -734,14 +732,12 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     dgq_sum = _empty(ref, B, 4 * Q)
     ops.slab_reduce(dGQ, dgq_sum)
     ops.gemm(GEMM_TN, [(dgq_sum, s['gfeat'], Gq_ih[:, plan.q_glob[0]:plan.q_glob[1]])], flags=F_ACCUM)
-    ops.colsum(dgq2, G['decoder.query_lstm.bias_ih'], accum=True)
-    ops.colsum(dgq2, G['decoder.query_lstm.bias_hh'], accum=True)
+    ops.colsum2(dgq2, G['decoder.query_lstm.bias_ih'], G['decoder.query_lstm.bias_hh'], accum=True)
     for i in range(ns):
         ops.gemm(GEMM_TN, [(dgl2, s['CTX'][i].view(n, H), Gl_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]])], flags=F_ACCUM)
     ops.gemm(GEMM_TN, [(dgl2, s['QCUR'].view(n, Q), Gl_ih[:, plan.l_q[0]:plan.l_q[1]])], flags=F_ACCUM)
     ops.gemm(GEMM_TN, [(dgl2, s['LHP'][:L].view(n, D), G['decoder.lang_lstm.weight_hh'])], flags=F_ACCUM)
-    ops.colsum(dgl2, G['decoder.lang_lstm.bias_ih'], accum=True)
-    ops.colsum(dgl2, G['decoder.lang_lstm.bias_hh'], accum=True)
+    ops.colsum2(dgl2, G['decoder.lang_lstm.bias_ih'], G['decoder.lang_lstm.bias_hh'], accum=True)
     # ---- word embedding rows
     dWE = _empty(ref, n, W)
     ops.gemm(GEMM_NN, [(dgq2, ql.weight_ih[:, plan.q_word[0]:plan.q_word[1]], dWE)])

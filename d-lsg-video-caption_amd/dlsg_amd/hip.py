@@ -115,7 +115,7 @@ class DecattCacheGradsArgs(C.Structure):
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
-           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd',
+           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
@@ -140,6 +140,7 @@ def load_library(path=LIB_PATH):
         'dlsg_rowln_bwd': [P(RowLnBwdArgs), vp],
         'dlsg_rowln_bwd_nblk': [i32],
         'dlsg_colsum': [vp, i64, i32, i32, vp, i32, vp],
+        'dlsg_colsum2': [vp, i64, i32, i32, vp, vp, i32, i32, i32, vp],
         'dlsg_o2v_workspace_bytes': [i32, i32, i32, i32],
         'dlsg_o2v_fwd': [P(O2VArgs), vp],
         'dlsg_softmax_fwd': [vp, vp, vp, i64, i32, i32, vp],
@@ -356,6 +357,14 @@ class HipOps(object):
         _chk2(part)
         self._check(self.lib.dlsg_colsum(_p(part), i64(part.stride(0)), part.size(0), part.size(1), _p(out), int(accum),
                                          self._stream()), 'dlsg_colsum')
+
+    def colsum2(self, part, out_a, out_b, split=None, accum=False):
+        """one pass, two destinations: split=k -> columns [0,k) to out_a and [k,n) to out_b; split=None -> every column
+        to both out_a and out_b."""
+        _chk2(part)
+        self._check(self.lib.dlsg_colsum2(_p(part), i64(part.stride(0)), part.size(0), part.size(1), _p(out_a), _p(out_b),
+                                          0 if split is None else split, int(split is None), int(accum), self._stream()),
+                    'dlsg_colsum2')
 
     def softmax_fwd(self, x, y, outer, n, inner, mask=None):
         self._check(self.lib.dlsg_softmax_fwd(_p(x), _p(mask), _p(y), i64(outer), n, inner, self._stream()), 'softmax_fwd')

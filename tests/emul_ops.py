@@ -160,6 +160,13 @@ class EmulOps(object):
         r = part.sum(0)
         out.copy_(r + out if accum else r)
 
+    def colsum2(self, part, out_a, out_b, split=None, accum=False):
+        self._count('colsum')
+        r = part.sum(0)
+        ra, rb = (r, r) if split is None else (r[:split], r[split:])
+        out_a.copy_(ra + out_a if accum else ra)
+        out_b.copy_(rb + out_b if accum else rb)
+
     def softmax_fwd(self, x, y, outer, n, inner, mask=None):
         self._count('softmax')
         xv = x.reshape(outer, n, inner)

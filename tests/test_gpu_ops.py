@@ -207,6 +207,21 @@ def test_colsum_tall_chunked(hip):
     both(hip, build, run, ['cs', 'cs2'], tol=1e-4, name='colsum tall')
 
 
+@pytest.mark.parametrize('rows', [1, 63, 1664, 5000])
+def test_colsum_two_destinations(hip, rows):
+    def build(g):
+        return dict(part=rnd(g, rows, 2048), ga=rnd(g, 1024), gb=rnd(g, 1024), b1=rnd(g, 2048), b2=rnd(g, 2048),
+                    odd=rnd(g, rows, 131), o1=rnd(g, 60), o2=rnd(g, 70), o3=rnd(g, 130), o4=rnd(g, 130), w=rnd(g, 200), w2=rnd(g, 56))
+
+    def run(ops, t):
+        ops.colsum2(t['part'], t['ga'], t['gb'], split=1024, accum=True)          # LayerNorm gamma | beta partials
+        ops.colsum2(t['part'], t['b1'], t['b2'], accum=False)                      # bias_ih / bias_hh
+        ops.colsum2(t['odd'][:, 1:], t['o1'], t['o2'], split=60, accum=True)       # unaligned -> scalar fallback
+        ops.colsum2(t['odd'][:, 1:], t['o3'], t['o4'], accum=True)
+        ops.colsum2(t['part'][:, 256:512], t['w'], t['w2'], split=200, accum=False)  # aligned, uneven split
+    both(hip, build, run, ['ga', 'gb', 'b1', 'b2', 'o1', 'o2', 'o3', 'o4', 'w', 'w2'], tol=1e-4, name='colsum2 %d' % rows)
+
+
 def test_select_embed(hip):
     def build(g):
         lg = rnd(g, 6, 50)
