@@ -278,17 +278,39 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ LSTM pointwise
-__global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(const dlsg_lstm_pw_args a) {
+// blockIdx.z selects one of up to two descriptors: the two directions of a BiLSTM step run as one launch.
+struct PwFwdSet { dlsg_lstm_pw_args a[2]; };
+struct PwBwdSet { dlsg_lstm_pw_bwd_args a[2]; };
+
+__global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(const PwFwdSet set) {
+    const dlsg_lstm_pw_args& a = set.a[blockIdx.z];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (j >= a.H) return;
     const int H = a.H;
-    float pre[4];
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    // slab partial sums: all four gates of a slab pair are loaded before any add (independent loads in flight)
+    const float* sp = a.slabs + (int64_t)b * 4 * H + j;
+    int k = 0;
+    for (; k + 2 <= a.nslab; k += 2) {
+        float t[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) t[u][g] = sp[(k + u) * a.slab_stride + g * H];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] += t[u][g];
+    }
+    if (k < a.nslab) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] += sp[k * a.slab_stride + g * H];
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int col = g * H + j;
-        float s = 0.f;
-        for (int k = 0; k < a.nslab; ++k) s += a.slabs[k * a.slab_stride + (int64_t)b * 4 * H + col];
+        float s = pre[g];
         if (a.addend) s += a.addend[(int64_t)b * a.ldadd + col];
         if (a.b_ih) s += a.b_ih[col];
         if (a.b_hh) s += a.b_hh[col];
@@ -311,7 +333,8 @@ __global__ __launch_bounds__(256) void lstm_pw_fwd_kernel(const dlsg_lstm_pw_arg
     }
 }
 
-__global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(const dlsg_lstm_pw_bwd_args a) {
+__global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(const PwBwdSet set) {
+    const dlsg_lstm_pw_bwd_args& a = set.a[blockIdx.z];
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (j >= a.H) return;
@@ -321,8 +344,8 @@ __global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(const dlsg_lstm_pw_bwd
     const float c = a.c[(int64_t)b * a.ldc_ + j];
     const float cp = a.c_prev ? a.c_prev[(int64_t)b * a.ldcp + j] : 0.f;
     float dh = a.dh ? a.dh[(int64_t)b * a.lddh + j] : 0.f;
-    if (a.dh2) {
-        float d2 = a.dh2[(int64_t)b * a.lddh2 + j];
+    if (a.dh2 || a.dh3 || a.dh4) {
+        float d2 = a.dh2 ? a.dh2[(int64_t)b * a.lddh2 + j] : 0.f;
         if (a.dh3) d2 += a.dh3[(int64_t)b * a.lddh3 + j];
         if (a.dh4) {
             const int ns4 = a.dh4_nslab > 1 ? a.dh4_nslab : 1;
@@ -663,20 +686,28 @@ extern "C" int dlsg_softmax_bwd(const float* y, const float* dy, float* dx, int6
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
-extern "C" int dlsg_lstm_pw_fwd(const dlsg_lstm_pw_args* a, void* stream) {
-    if (!a || a->H < 1) return DLSG_EINVAL;
-    if (a->B == 0) return DLSG_OK;
-    hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3((a->H + 255) / 256, a->B), dim3(256), 0, ST(stream), *a);
+extern "C" int dlsg_lstm_pw_fwd_n(const dlsg_lstm_pw_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > 2 || a[0].H < 1) return DLSG_EINVAL;
+    if (count == 2 && (a[1].H != a[0].H || a[1].B != a[0].B)) return DLSG_EINVAL;
+    if (a[0].B == 0) return DLSG_OK;
+    PwFwdSet set;
+    for (int i = 0; i < 2; ++i) set.a[i] = a[i < count ? i : 0];
+    hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3((a[0].H + 255) / 256, a[0].B, count), dim3(256), 0, ST(stream), set);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
-extern "C" int dlsg_lstm_pw_bwd(const dlsg_lstm_pw_bwd_args* a, void* stream) {
-    if (!a || a->H < 1) return DLSG_EINVAL;
-    if (a->B == 0) return DLSG_OK;
-    hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3((a->H + 255) / 256, a->B), dim3(256), 0, ST(stream), *a);
+extern "C" int dlsg_lstm_pw_fwd(const dlsg_lstm_pw_args* a, void* stream) { return dlsg_lstm_pw_fwd_n(a, 1, stream); }
+extern "C" int dlsg_lstm_pw_bwd_n(const dlsg_lstm_pw_bwd_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > 2 || a[0].H < 1) return DLSG_EINVAL;
+    if (count == 2 && (a[1].H != a[0].H || a[1].B != a[0].B)) return DLSG_EINVAL;
+    if (a[0].B == 0) return DLSG_OK;
+    PwBwdSet set;
+    for (int i = 0; i < 2; ++i) set.a[i] = a[i < count ? i : 0];
+    hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3((a[0].H + 255) / 256, a[0].B, count), dim3(256), 0, ST(stream), set);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
+extern "C" int dlsg_lstm_pw_bwd(const dlsg_lstm_pw_bwd_args* a, void* stream) { return dlsg_lstm_pw_bwd_n(a, 1, stream); }
 extern "C" int dlsg_mean_rows_fwd(const float* x, float* out, int64_t ldo, int B, int P, int H, void* stream) {
     if (B == 0) return DLSG_OK;
     hipLaunchKernelGGL(mean_rows_fwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, ST(stream), x, out, ldo, P, H);

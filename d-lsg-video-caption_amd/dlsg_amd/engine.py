@@ -347,14 +347,16 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
                 for i, (k0, k1) in enumerate(bounds):
                     groups.append((hp[:, k0:k1], Whh[d][:, k0:k1], slabs[d * len(bounds) + i]))
             ops.gemm(GEMM_NT, groups)
+        calls = []
         for d in range(2):
             t = tt[d]
             nxt = t + 1 if d == 0 else t - 1
             h2 = hprev[d][:, nxt] if 0 <= nxt < T else None
-            ops.lstm_pw_fwd(slabs[d * len(bounds):(d + 1) * len(bounds)] if slabs is not None else None,
-                            cst[d][:, t], B, H, addend=xg[d].view(B, T, 4 * H)[:, t], b_ih=bih[d], b_hh=bhh[d],
-                            c_prev=cst[d][:, tp[d]] if step > 0 else None, h=out[:, t, d * H:(d + 1) * H], h2=h2,
-                            gates=gates[d][:, t])
+            calls.append(dict(slabs=slabs[d * len(bounds):(d + 1) * len(bounds)] if slabs is not None else None,
+                              c=cst[d][:, t], B=B, H=H, addend=xg[d].view(B, T, 4 * H)[:, t], b_ih=bih[d], b_hh=bhh[d],
+                              c_prev=cst[d][:, tp[d]] if step > 0 else None, h=out[:, t, d * H:(d + 1) * H], h2=h2,
+                              gates=gates[d][:, t]))
+        ops.lstm_pw_fwd_multi(calls)            # both directions: one launch
     out2 = out.view(B * T, 2 * H)
     pd = m.p_drop if training else 0.0
     s.update(e=e, out=out2, hprev=hprev, cst=cst, gates=gates, pd=pd)
@@ -454,23 +456,22 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     dout3 = dout.view(B, T, D2)
     gates, cst, hprev = s['gates'], s['cst'], s['hprev']
     dG = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
-    dhrec2 = _empty(ref, B, 2 * H)                       # [d h_prev of the forward dir | of the reverse dir]
-    dhrec = [dhrec2[:, :H], dhrec2[:, H:]]
     dcrec = [_empty(ref, B, H), _empty(ref, B, H)]
     ns_r = max(1, min(_nsplit_for(B, 2 * H, 1), 8))
     rb = _ksplit_bounds(4 * H, ns_r, 128 if B <= 64 else 32)
+    slabs = None                       # (S, B, 2H): slabs of [d h_prev of the forward dir | of the reverse dir]
     for step in range(T - 1, -1, -1):
         tt = [step, T - 1 - step]
         tp = [step - 1, T - step]
         last = step == T - 1
-        for d in range(2):
-            t = tt[d]
-            ops.lstm_pw_bwd(gates[d][:, t], cst[d][:, t], dG[d][:, t], B, H,
-                            c_prev=cst[d][:, tp[d]] if step > 0 else None,
-                            dh=dout3[:, t, d * H:(d + 1) * H], dh2=None if last else dhrec[d],
-                            dc_next=None if last else dcrec[d], dc_prev=dcrec[d])
+        # both directions in one launch; the recurrent gradient is read straight from the GEMM's slabs
+        ops.lstm_pw_bwd_multi([dict(gates=gates[d][:, tt[d]], c=cst[d][:, tt[d]], dgates=dG[d][:, tt[d]], B=B, H=H,
+                                    c_prev=cst[d][:, tp[d]] if step > 0 else None,
+                                    dh=dout3[:, tt[d], d * H:(d + 1) * H],
+                                    dh4=None if last else slabs[:, :, d * H:(d + 1) * H],
+                                    dc_next=None if last else dcrec[d], dc_prev=dcrec[d]) for d in range(2)])
         if step > 0:
-            # recurrent gradient of both directions: one grouped launch, one reduction
+            # recurrent gradient of both directions: one grouped launch
             slabs = _empty(ref, len(rb), B, 2 * H)
             groups = []
             for d in range(2):
@@ -478,7 +479,6 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
                 for i, (k0, k1) in enumerate(rb):
                     groups.append((dg[:, k0:k1], Whh[d][k0:k1, :], slabs[i][:, d * H:(d + 1) * H]))
             ops.gemm(GEMM_NN, groups)
-            ops.slab_reduce(slabs, dhrec2)
     de = _empty(ref, B * T, H)
     e = s['e']
     for d in range(2):

@@ -117,7 +117,7 @@ class DecattCacheGradsArgs(C.Structure):
 SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
            'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
-           'dlsg_lstm_pw_bwd', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
+           'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads']
@@ -149,6 +149,8 @@ def load_library(path=LIB_PATH):
         'dlsg_decatt_bwd': [P(DecAttBwdArgs), vp],
         'dlsg_lstm_pw_fwd': [P(LstmPwArgs), vp],
         'dlsg_lstm_pw_bwd': [P(LstmPwBwdArgs), vp],
+        'dlsg_lstm_pw_fwd_n': [P(LstmPwArgs), i32, vp],
+        'dlsg_lstm_pw_bwd_n': [P(LstmPwBwdArgs), i32, vp],
         'dlsg_mean_rows_fwd': [vp, vp, i64, i32, i32, i32, vp],
         'dlsg_mean_rows_bwd': [vp, i64, vp, i32, i32, i32, i32, vp],
         'dlsg_embed_fwd': [vp, vp, vp, i64, i32, i32, f32, u64, u32, i64, vp, vp],
@@ -505,9 +507,9 @@ class HipOps(object):
         self._check(self.lib.dlsg_decatt_cache_grads(C.byref(a), self._stream()), 'dlsg_decatt_cache_grads')
 
     # ------------------------------------------------------------------ LSTM pointwise
-    def lstm_pw_fwd(self, slabs, c, B, H, addend=None, b_ih=None, b_hh=None, c_prev=None, h=None, h2=None, gates=None,
-                    p=0.0, site=0, seed=0):
-        a = LstmPwArgs()
+    @staticmethod
+    def _pw_fwd_args(a, slabs, c, B, H, addend=None, b_ih=None, b_hh=None, c_prev=None, h=None, h2=None, gates=None,
+                     p=0.0, site=0, seed=0):
         if slabs is not None:
             a.slabs, a.nslab, a.slab_stride = _p(slabs), slabs.size(0), slabs.stride(0)
         else:
@@ -521,11 +523,22 @@ class HipOps(object):
         a.gates, a.ldg = _p(gates), (gates.stride(0) if gates is not None else 0)
         a.B, a.H, a.p, a.site = B, H, p, site
         a.seed, a.seed_ptr = _seed(seed)
+
+    def lstm_pw_fwd(self, slabs, c, B, H, **kw):
+        a = LstmPwArgs()
+        self._pw_fwd_args(a, slabs, c, B, H, **kw)
         self._check(self.lib.dlsg_lstm_pw_fwd(C.byref(a), self._stream()), 'dlsg_lstm_pw_fwd')
 
-    def lstm_pw_bwd(self, gates, c, dgates, B, H, c_prev=None, dh=None, dh2=None, dc_next=None, dc_prev=None, p=0.0,
-                    site=0, seed=0, dh3=None, dh4=None):
-        a = LstmPwBwdArgs()
+    def lstm_pw_fwd_multi(self, calls):
+        """calls: 1 or 2 dicts of lstm_pw_fwd arguments (same B, H) -> one launch (both directions of a BiLSTM step)."""
+        arr = (LstmPwArgs * len(calls))()
+        for a, kw in zip(arr, calls):
+            self._pw_fwd_args(a, **kw)
+        self._check(self.lib.dlsg_lstm_pw_fwd_n(arr, len(calls), self._stream()), 'dlsg_lstm_pw_fwd_n')
+
+    @staticmethod
+    def _pw_bwd_args(a, gates, c, dgates, B, H, c_prev=None, dh=None, dh2=None, dc_next=None, dc_prev=None, p=0.0,
+                     site=0, seed=0, dh3=None, dh4=None):
         a.gates, a.ldg, a.c, a.ldc_ = _p(gates), gates.stride(0), _p(c), c.stride(0)
         a.c_prev, a.ldcp = _p(c_prev), (c_prev.stride(0) if c_prev is not None else 0)
         a.dh, a.lddh = _p(dh), (dh.stride(0) if dh is not None else 0)
@@ -540,7 +553,17 @@ class HipOps(object):
         a.dc_prev, a.lddcp = _p(dc_prev), (dc_prev.stride(0) if dc_prev is not None else 0)
         a.B, a.H, a.p, a.site = B, H, p, site
         a.seed, a.seed_ptr = _seed(seed)
+
+    def lstm_pw_bwd(self, gates, c, dgates, B, H, **kw):
+        a = LstmPwBwdArgs()
+        self._pw_bwd_args(a, gates, c, dgates, B, H, **kw)
         self._check(self.lib.dlsg_lstm_pw_bwd(C.byref(a), self._stream()), 'dlsg_lstm_pw_bwd')
+
+    def lstm_pw_bwd_multi(self, calls):
+        arr = (LstmPwBwdArgs * len(calls))()
+        for a, kw in zip(arr, calls):
+            self._pw_bwd_args(a, **kw)
+        self._check(self.lib.dlsg_lstm_pw_bwd_n(arr, len(calls), self._stream()), 'dlsg_lstm_pw_bwd_n')
 
     # ------------------------------------------------------------------ movers
     def mean_rows_fwd(self, x, out):

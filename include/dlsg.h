@@ -257,6 +257,8 @@ typedef struct {
     const uint64_t* seed_ptr;
 } dlsg_lstm_pw_args;
 int dlsg_lstm_pw_fwd(const dlsg_lstm_pw_args* a, void* stream);
+/* `count` (1 or 2) descriptors of equal B, H in one launch: the two directions of a BiLSTM step */
+int dlsg_lstm_pw_fwd_n(const dlsg_lstm_pw_args* a, int count, void* stream);
 /* backward: dh (B,H) [+ dh2 through dropout], dc_next -> dgates (B,4H pre-activation grads), dc_prev */
 typedef struct {
     const float* gates; int64_t ldg;           /* activated gates from forward, row stride ldg */
@@ -275,6 +277,7 @@ typedef struct {
     const uint64_t* seed_ptr;
 } dlsg_lstm_pw_bwd_args;
 int dlsg_lstm_pw_bwd(const dlsg_lstm_pw_bwd_args* a, void* stream);
+int dlsg_lstm_pw_bwd_n(const dlsg_lstm_pw_bwd_args* a, int count, void* stream);
 
 /* ---------------------------------------------------------------- small data movement on the path
  * mean over P proposals (layer.py:407-410): out[b, off + h] = mean_p x[b,p,h]; and its backward (accumulating) */

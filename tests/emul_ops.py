@@ -275,6 +275,14 @@ class EmulOps(object):
             dKp[i].copy_(torch.einsum('tbp,tbq->bpq', ds[:, :, i * P:(i + 1) * P], qcur))
             dVp[i].copy_(torch.einsum('tbp,tbh->bph', alpha[:, :, i * P:(i + 1) * P], dcpre[i]))
 
+    def lstm_pw_fwd_multi(self, calls):
+        for kw in calls:
+            self.lstm_pw_fwd(**kw)
+
+    def lstm_pw_bwd_multi(self, calls):
+        for kw in calls:
+            self.lstm_pw_bwd(**kw)
+
     def lstm_pw_fwd(self, slabs, c, B, H, addend=None, b_ih=None, b_hh=None, c_prev=None, h=None, h2=None, gates=None,
                     p=0.0, site=0, seed=0):
         self._count('lstm_pw_fwd')
@@ -303,8 +311,8 @@ class EmulOps(object):
         i, f, g, o = gates[:, :H], gates[:, H:2 * H], gates[:, 2 * H:3 * H], gates[:, 3 * H:]
         cp = c_prev if c_prev is not None else torch.zeros(B, H)
         d = torch.zeros(B, H) if dh is None else dh.clone()
-        if dh2 is not None:
-            d2 = dh2
+        if dh2 is not None or dh3 is not None or dh4 is not None:
+            d2 = dh2 if dh2 is not None else torch.zeros(B, H)
             if dh3 is not None:
                 d2 = d2 + dh3
             if dh4 is not None:

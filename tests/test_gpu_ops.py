@@ -388,6 +388,33 @@ def test_lstm_pointwise(hip, dims):
     both(hip, build, run, ['c', 'h', 'h2', 'gates', 'dg', 'dcp', 'c0', 'g0'], tol=1e-5, name='lstm_pw %s' % (dims,))
 
 
+@pytest.mark.parametrize('dims', [(3, 48), (64, 1024), (7, 100)])
+def test_lstm_pointwise_two_directions_one_launch(hip, dims):
+    B, H = dims
+
+    def build(g):
+        d = {}
+        for k in range(2):
+            d.update({'slabs%d' % k: rnd(g, 3 + k, B, 4 * H), 'add%d' % k: rnd(g, B, 5, 4 * H), 'bi%d' % k: rnd(g, 4 * H),
+                      'bh%d' % k: rnd(g, 4 * H), 'cp%d' % k: rnd(g, B, H), 'c%d' % k: torch.zeros(B, H),
+                      'h%d' % k: torch.zeros(B, 2 * H), 'h2%d' % k: torch.zeros(B, H), 'gates%d' % k: torch.zeros(B, 4 * H),
+                      'dh%d' % k: rnd(g, B, H), 'rec%d' % k: rnd(g, 4, B, 2 * H), 'dcn%d' % k: rnd(g, B, H),
+                      'dg%d' % k: torch.zeros(B, 4 * H), 'dcp%d' % k: torch.zeros(B, H)})
+        return d
+
+    def run(ops, t):
+        ops.lstm_pw_fwd_multi([dict(slabs=t['slabs%d' % k], c=t['c%d' % k], B=B, H=H, addend=t['add%d' % k][:, 2 + k],
+                                    b_ih=t['bi%d' % k], b_hh=t['bh%d' % k], c_prev=t['cp%d' % k] if k else None,
+                                    h=t['h%d' % k][:, k * H:(k + 1) * H], h2=t['h2%d' % k], gates=t['gates%d' % k])
+                               for k in range(2)])
+        ops.lstm_pw_bwd_multi([dict(gates=t['gates%d' % k], c=t['c%d' % k], dgates=t['dg%d' % k], B=B, H=H,
+                                    c_prev=t['cp%d' % k] if k else None, dh=t['dh%d' % k],
+                                    dh4=t['rec%d' % k][:, :, k * H:(k + 1) * H], dc_next=t['dcn%d' % k], dc_prev=t['dcp%d' % k])
+                               for k in range(2)])
+    outs = [n + str(k) for k in range(2) for n in ('c', 'h', 'h2', 'gates', 'dg', 'dcp')]
+    both(hip, build, run, outs, tol=1e-5, name='lstm_pw pair %s' % (dims,))
+
+
 @pytest.mark.parametrize('dims', [(3, 48, 32, 40, 5, 2), (64, 1024, 1024, 1024, 8, 2), (5, 96, 64, 80, 3, 1), (2, 600, 520, 300, 32, 2)])
 def test_dec_step_fused_fwd(hip, dims):
     """dec_mid_fwd / dec_tail_fwd against the unfused chain they replace (the emulator composes the unfused ops)."""
