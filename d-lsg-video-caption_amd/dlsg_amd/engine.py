@@ -210,6 +210,7 @@ def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2
                 nsplit = max(1, min(tiles, 256 // max(B, 1)))
             ml = _empty(ref, B * T, 2)
             ops.o2v_fwd(y.view(B, NO, H), v.view(B, T, H), g_o, b_o, z, ml, ostats, S, scale, nsplit)
+            s.update(ml=ml, o2v_nsplit=nsplit)
         else:
             o = _empty(ref, B * NO, H)
             ops.rowln_fwd(y, g_o, b_o, o, ostats)
@@ -277,25 +278,33 @@ def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed):
         ln_grads(ops, part, G, name + '.obj_visual_norm.1', H)
         g_o, b_o = m.obj_norm[1].weight, m.obj_norm[1].bias
         y, v, S, scale = s['y'], s['v'], s['S'], s['scale']
-        o = _empty(ref, B * NO, H)
-        ops.rowln_fwd(y, g_o, b_o, o, None)
-        o3, dz3, v3 = o.view(B, NO, H), dz.view(B, T, H), v.view(B, T, H)
-        Pm = _empty(ref, B, NO, T)
-        ops.softmax_fwd(S, Pm, B, NO, T)
-        dP = _empty(ref, B, NO, T)
-        ops.gemm(GEMM_NT, [(o3, dz3, dP)])
-        dS = _empty(ref, B, NO, T)
-        ops.softmax_bwd(Pm, dP, dS, B, NO, T)
-        do = _empty(ref, B * NO, H)
-        ops.gemm(GEMM_NN, [(Pm, dz3, do.view(B, NO, H))])
-        ops.gemm(GEMM_NN, [(dS, v3, do.view(B, NO, H))], alpha=scale, flags=F_ACCUM)
-        dv = _empty(ref, B * T, H)
-        ops.copy2d(dz, dv)
-        ops.gemm(GEMM_TN, [(dS, o3, dv.view(B, T, H))], alpha=scale, flags=F_ACCUM)
-        nb = ops.rowln_bwd_nblk(B * NO)
-        part = _empty(ref, nb, 2, H)
-        dy = o   # reuse the scratch: rowln_bwd reads y/stats, not o
-        ops.rowln_bwd(do, y, g_o, b_o, dy, stats=s['ostats'], pre_tanh=2, dgb_part=part)
+        if 'ml' in s:
+            # fused backward of the graph: two passes over y (scores, apply) instead of ten launches
+            dy = _empty(ref, B * NO, H)
+            dv = _empty(ref, B * T, H)
+            part = _empty(ref, B, 2, H)
+            ops.o2v_bwd(y.view(B, NO, H), s['ostats'], g_o, b_o, v.view(B, T, H), s['z'].view(B, T, H), dz.view(B, T, H), S,
+                        s['ml'], dy.view(B, NO, H), dv.view(B, T, H), part, scale, s['o2v_nsplit'])
+        else:
+            o = _empty(ref, B * NO, H)
+            ops.rowln_fwd(y, g_o, b_o, o, None)
+            o3, dz3, v3 = o.view(B, NO, H), dz.view(B, T, H), v.view(B, T, H)
+            Pm = _empty(ref, B, NO, T)
+            ops.softmax_fwd(S, Pm, B, NO, T)
+            dP = _empty(ref, B, NO, T)
+            ops.gemm(GEMM_NT, [(o3, dz3, dP)])
+            dS = _empty(ref, B, NO, T)
+            ops.softmax_bwd(Pm, dP, dS, B, NO, T)
+            do = _empty(ref, B * NO, H)
+            ops.gemm(GEMM_NN, [(Pm, dz3, do.view(B, NO, H))])
+            ops.gemm(GEMM_NN, [(dS, v3, do.view(B, NO, H))], alpha=scale, flags=F_ACCUM)
+            dv = _empty(ref, B * T, H)
+            ops.copy2d(dz, dv)
+            ops.gemm(GEMM_TN, [(dS, o3, dv.view(B, T, H))], alpha=scale, flags=F_ACCUM)
+            nb = ops.rowln_bwd_nblk(B * NO)
+            part = _empty(ref, nb, 2, H)
+            dy = o   # reuse the scratch: rowln_bwd reads y/stats, not o
+            ops.rowln_bwd(do, y, g_o, b_o, dy, stats=s['ostats'], pre_tanh=2, dgb_part=part)
         ln_grads(ops, part, G, name + '.obj_norm.1', H)
         gemm_tn_deep(ops, dy, regions.view(B * NO, R), G[name + '.obj_embed.weight'], ref)
         ops.colsum(dy, G[name + '.obj_embed.bias'], accum=True)

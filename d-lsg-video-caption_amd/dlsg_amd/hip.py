@@ -53,6 +53,12 @@ class O2VArgs(C.Structure):
                 ('NO', i32), ('H', i32), ('nsplit', i32), ('scale', f32), ('eps', f32)]
 
 
+class O2VBwdArgs(C.Structure):
+    _fields_ = [(n, c_f32p) for n in ('y', 'ostats', 'g_obj', 'b_obj', 'v', 'z', 'dz', 'S', 'ml', 'pd', 'm12', 'dy', 'dv',
+                                      'part')] + [('B', i32), ('T', i32), ('NO', i32), ('H', i32), ('nsplit', i32),
+                                                  ('scale', f32)]
+
+
 class DecAttArgs(C.Structure):
     _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
                 ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
@@ -120,7 +126,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
-           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads']
+           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd']
 
 
 def load_library(path=LIB_PATH):
@@ -169,6 +175,7 @@ def load_library(path=LIB_PATH):
         'dlsg_dec_tail_fwd': [P(DecTailArgs), vp],
         'dlsg_dec_mid_bwd': [P(DecMidBwdArgs), vp],
         'dlsg_decatt_cache_grads': [P(DecattCacheGradsArgs), vp],
+        'dlsg_o2v_bwd': [P(O2VBwdArgs), vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -179,7 +186,7 @@ def load_library(path=LIB_PATH):
 
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
-           DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs]
+           DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs]
 
 
 def _p(t):
@@ -392,6 +399,24 @@ class HipOps(object):
         self._check(self.lib.dlsg_o2v_fwd(C.byref(a), self._stream()), 'dlsg_o2v_fwd')
         # algorithmic bytes: read y once + read v + write z
         self._prof_end('o2v_graph_fwd', e0, 4.0 * B * (NO * H + 2 * T * H))
+
+    def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, part, scale, nsplit):
+        """backward of o2v_fwd: dz (B,T,H) -> dy (B,NO,H), dv (B,T,H), part (B,2,H) (obj_norm dgamma | dbeta per clip)."""
+        B, NO, H = y.shape
+        T = v.shape[1]
+        for t in (y, ostats, v, z, dz, S, ml, dy, dv, part):
+            _chkc(t)
+        pd = torch.empty(B, NO, 64, dtype=torch.float32, device=y.device)
+        m12 = torch.empty(B, NO, 2, dtype=torch.float32, device=y.device)
+        a = O2VBwdArgs()
+        a.y, a.ostats, a.g_obj, a.b_obj, a.v, a.z, a.dz, a.S, a.ml = _p(y), _p(ostats), _p(g_obj), _p(b_obj), _p(v), _p(z), \
+            _p(dz), _p(S), _p(ml)
+        a.pd, a.m12, a.dy, a.dv, a.part = _p(pd), _p(m12), _p(dy), _p(dv), _p(part)
+        a.B, a.T, a.NO, a.H, a.nsplit, a.scale = B, T, NO, H, nsplit, scale
+        e0 = self._prof_begin()
+        self._check(self.lib.dlsg_o2v_bwd(C.byref(a), self._stream()), 'dlsg_o2v_bwd')
+        # algorithmic bytes: y read by both passes is counted once (SURVEY.md 8d convention) + dy written + dz, v, dv
+        self._prof_end('o2v_graph_bwd', e0, 4.0 * B * (2 * NO * H + 3 * T * H))
 
     # ------------------------------------------------------------------ decoder attention
     def _decatt_args(self, Kp, Vp, q, c, alpha, scale):

@@ -18,7 +18,8 @@ extern "C" {
 #define DLSG_ABI_VERSION 1
 int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
- * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args): lets a binding verify its
+ * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
+ * 12 o2v_bwd_args): lets a binding verify its
  * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
@@ -126,8 +127,22 @@ typedef struct {
 } dlsg_o2v_args;
 int64_t dlsg_o2v_workspace_bytes(int B, int T, int H, int nsplit);
 int dlsg_o2v_fwd(const dlsg_o2v_args* a, void* stream);
-/* The backward of the graph runs through dlsg_softmax_fwd/bwd on the saved scores S (P = softmax_n(S),
- * dS = P*(dP - sum_n P dP)) and batched dlsg_gemm products; see engine.py tun_bwd. */
+/* Backward of the fused graph in two passes over y (see attention.hip): given dz (B,T,H) it writes
+ *   dy (B,NO,H)  grad wrt the obj_embed pre-activation (through obj_norm's LayerNorm and the tanh of the GEMM epilogue),
+ *   dv (B,T,H)   grad wrt the frame nodes v (includes the residual dz),
+ *   part (B,2,H) per-clip dgamma | dbeta of obj_norm (fold with dlsg_colsum2).
+ * y, ostats, S, ml, z are the forward's inputs / outputs; pd (B,NO,64) and m12 (B,NO,2) are workspaces.
+ * Same support as the forward (T <= 32, H in {64,512,1024}); otherwise the caller runs the unfused chain
+ * (dlsg_softmax_fwd/bwd on S + batched dlsg_gemm + dlsg_rowln_bwd; engine.py tun_bwd). */
+typedef struct {
+    const float* y; const float* ostats; const float* g_obj; const float* b_obj;
+    const float* v; const float* z; const float* dz; const float* S; const float* ml;
+    float* pd; float* m12;
+    float* dy; float* dv; float* part;
+    int32_t B, T, NO, H, nsplit;
+    float scale;
+} dlsg_o2v_bwd_args;
+int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------- softmax along the middle axis of (outer, n, inner)
  * LatentPSL softmax over frames (sublayer.py:192: outer=B, n=T, inner=P), SelfAttention row softmax

@@ -200,6 +200,24 @@ class EmulOps(object):
         ml.copy_(torch.stack([m.reshape(-1), l.reshape(-1)], 1))
         ostats.copy_(torch.cat([mean.reshape(-1, 1), rstd.reshape(-1, 1)], 1))
 
+    def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, part, scale, nsplit, eps=1e-5):
+        self._count('o2v_bwd')
+        B, NO, H = y.shape
+        mean = y.mean(2, keepdim=True)
+        rstd = 1.0 / torch.sqrt(((y - mean) ** 2).mean(2, keepdim=True) + eps)
+        xh = (y - mean) * rstd
+        o = xh * g_obj + b_obj
+        P = torch.softmax(S, 1)                                   # over the objects, per frame
+        dP = o @ dz.transpose(1, 2)                               # (B,NO,T)
+        dS = P * (dP - (P * dP).sum(1, keepdim=True))
+        do = P @ dz + scale * (dS @ v)
+        dv.copy_(dz + scale * (dS.transpose(1, 2) @ o))
+        part[:, 0] = (do * xh).sum(1)
+        part[:, 1] = do.sum(1)
+        gx = do * g_obj
+        d = rstd * (gx - gx.mean(2, keepdim=True) - xh * (gx * xh).mean(2, keepdim=True))
+        dy.copy_(d * (1 - y * y))
+
     # ------------------------------------------------------------------ decoder attention
     def decatt_fwd(self, Kp, Vp, q, c, alpha, scale):
         self._count('decatt_fwd')

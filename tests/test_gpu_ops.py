@@ -326,6 +326,26 @@ def test_o2v_fused(hip, case):
     both(hip, build, run, ['z', 'os', 'S', 'lse'], tol=3e-5, name='o2v %s' % (case,))
 
 
+@pytest.mark.parametrize('case', O2V_CASES)
+def test_o2v_fused_backward(hip, case):
+    """dlsg_o2v_bwd (scores pass + apply pass) against the closed-form backward of the graph; forward state (S, ml,
+    ostats, z) comes from each side's own forward."""
+    B, T, O, H, ns = case
+    NO = T * O
+
+    def build(g):
+        return dict(y=torch.tanh(rnd(g, B, NO, H)), v=rnd(g, B, T, H), go=1 + 0.2 * rnd(g, H), bo=0.2 * rnd(g, H),
+                    z=torch.zeros(B * T, H), ml=torch.zeros(B * T, 2), os=torch.zeros(B * NO, 2), S=torch.zeros(B, NO, T),
+                    dz=rnd(g, B, T, H), dy=torch.zeros(B, NO, H), dv=torch.zeros(B, T, H), part=torch.zeros(B, 2, H))
+
+    def run(ops, t):
+        sc = 1.0 / math.sqrt(H / 4.0)
+        ops.o2v_fwd(t['y'], t['v'], t['go'], t['bo'], t['z'], t['ml'], t['os'], t['S'], sc, ns)
+        ops.o2v_bwd(t['y'], t['os'], t['go'], t['bo'], t['v'], t['z'].view(B, T, H), t['dz'], t['S'], t['ml'], t['dy'], t['dv'],
+                    t['part'], sc, ns)
+    both(hip, build, run, ['dy', 'dv', 'part'], tol=5e-5, name='o2v bwd %s' % (case,))
+
+
 def test_o2v_online_softmax_rescale_branch(hip):
     """Force the running max to jump at a late tile (guide 5.4 rule 26): one object aligned with one frame."""
     B, T, O, H = 2, 26, 16, 64
