@@ -472,27 +472,49 @@ __global__ __launch_bounds__(AP_THREADS) void o2v_bwd_apply_kernel(const dlsg_o2
 #pragma unroll
     for (int e = 0; e < 16; ++e) accv[e] = 0.f;
 
-    for (int n0 = 0; n0 < NO; n0 += 64) {
-        __syncthreads();                        // previous tile fully consumed (also orders the dzv fill on the first pass)
-        for (int f = threadIdx.x; f < 64 * 16; f += AP_THREADS) {
+    // next tile's y / pd rows travel in registers while the current tile is on the matrix cores
+    f32x4 yq[4], pq[4];
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = threadIdx.x + AP_THREADS * j;
             const int row = f >> 4, c4 = f & 15, n = n0 + row;
-            f32x4 yv = {0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            yq[j] = zero; pq[j] = zero;
             if (n < NO) {
-                yv = *reinterpret_cast<const f32x4*>(a.y + ((int64_t)b * NO + n) * H + h0 + 4 * c4);
-                pv = *reinterpret_cast<const f32x4*>(a.pd + ((int64_t)b * NO + n) * 64 + 4 * c4);
+                yq[j] = *reinterpret_cast<const f32x4*>(a.y + ((int64_t)b * NO + n) * H + h0 + 4 * c4);
+                pq[j] = *reinterpret_cast<const f32x4*>(a.pd + ((int64_t)b * NO + n) * 64 + 4 * c4);
             }
-            *reinterpret_cast<f32x4*>(yl + row * AP_LD + 4 * c4) = yv;
-            *reinterpret_cast<f32x4*>(pdl + row * AP_LD + 4 * c4) = pv;
         }
+    };
+    float st4[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch_stats = [&](int n0) {
         if (threadIdx.x < 64) {
             const int n = n0 + threadIdx.x;
             const bool v = n < NO;
-            sm[threadIdx.x * 4 + 0] = v ? a.ostats[2 * ((int64_t)b * NO + n)] : 0.f;
-            sm[threadIdx.x * 4 + 1] = v ? a.ostats[2 * ((int64_t)b * NO + n) + 1] : 0.f;
-            sm[threadIdx.x * 4 + 2] = v ? a.m12[2 * ((int64_t)b * NO + n)] : 0.f;
-            sm[threadIdx.x * 4 + 3] = v ? a.m12[2 * ((int64_t)b * NO + n) + 1] : 0.f;
+            st4[0] = v ? a.ostats[2 * ((int64_t)b * NO + n)] : 0.f;
+            st4[1] = v ? a.ostats[2 * ((int64_t)b * NO + n) + 1] : 0.f;
+            st4[2] = v ? a.m12[2 * ((int64_t)b * NO + n)] : 0.f;
+            st4[3] = v ? a.m12[2 * ((int64_t)b * NO + n) + 1] : 0.f;
+        }
+    };
+    fetch(0);
+    fetch_stats(0);
+    for (int n0 = 0; n0 < NO; n0 += 64) {
+        __syncthreads();                        // previous tile fully consumed (also orders the dzv fill on the first pass)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = threadIdx.x + AP_THREADS * j;
+            const int row = f >> 4, c4 = f & 15;
+            *reinterpret_cast<f32x4*>(yl + row * AP_LD + 4 * c4) = yq[j];
+            *reinterpret_cast<f32x4*>(pdl + row * AP_LD + 4 * c4) = pq[j];
+        }
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sm[threadIdx.x * 4 + i] = st4[i];
         }
         __syncthreads();
+        if (n0 + 64 < NO) { fetch(n0 + 64); fetch_stats(n0 + 64); }
         // ---- do[n][col] = sum_k pd[n][k] * dzv[k][col]   (lane half h owns k in [32h, 32h+32))
         f32x16 acc;
 #pragma unroll

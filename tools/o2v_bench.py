@@ -35,4 +35,20 @@ for O in (16, 36):
             gb = 4.0 * B * (NO * H + 2 * T * H) / 1e9
             res.append('ns%d: %.3f ms %.0f GB/s (%.1f%%)' % (ns, ms, gb / ms * 1e3, gb / ms * 1e3 / 80))
         print('O=%d B=%d  %s' % (O, B, '  '.join(res)))
-        del y, v, z, S
+        # backward (scores pass + apply pass); bytes = y read once + dy written + dz, v read + dv written
+        dz = torch.randn(B, T, H, device='cuda'); dy = torch.empty(B, NO, H, device='cuda')
+        dv = torch.empty(B, T, H, device='cuda'); part = torch.empty(B, 2, H, device='cuda')
+        ns = max(1, min(tiles, 256 // B))
+        for _ in range(2):
+            ops.o2v_bwd(y, st, g, b_, v, z.view(B, T, H), dz, S, ml, dy, dv, part, 1 / math.sqrt(2048), ns)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ops.o2v_bwd(y, st, g, b_, v, z.view(B, T, H), dz, S, ml, dy, dv, part, 1 / math.sqrt(2048), ns)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        gb = 4.0 * B * (2 * NO * H + 3 * T * H) / 1e9
+        print('          backward ns%d: %.3f ms %.0f GB/s (%.1f%%)' % (ns, ms, gb / ms * 1e3, gb / ms * 1e3 / 80))
+        del y, v, z, S, dz, dy, dv
