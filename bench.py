@@ -235,6 +235,13 @@ def main():
                                                'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                                'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
                                                'avg_launch_ms': round(o['ms_total'] / o['launches'], 4)}
+        ob = prof.get('o2v_graph_bwd')
+        if ob and ob['ms_total'] > 0:
+            ach = ob['work_total'] / (ob['ms_total'] * 1e-3) / 1e9
+            out['roofline_graph_attention_bwd'] = {'kernel': 'o2v_bwd_scores_kernel + o2v_bwd_apply_kernel', 'bound': 'hbm',
+                                                   'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                                   'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+                                                   'avg_launch_ms': round(ob['ms_total'] / ob['launches'], 4)}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         out['dtype_note'] = {'fp32': 'all products on fp32-input MFMA (exact fp32)',
