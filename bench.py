@@ -98,6 +98,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=64, help='clips per GPU (BASELINE configs[1]: 64)')
     ap.add_argument('--shape', default='msvd', choices=['msvd', 'msrvtt'])
+    ap.add_argument('--no-pass', action='store_true', help='skip the isolated graph-attention pass measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-mode', action='store_true', help='dropout off (not the reported configuration)')
     ap.add_argument('--gemm', default='x3_bwd', choices=['fp32', 'x3_bwd', 'x3_all'],
@@ -242,6 +243,18 @@ def main():
                                                    'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                                    'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
                                                    'avg_launch_ms': round(ob['ms_total'] / ob['launches'], 4)}
+        if world == 1 and not a.no_pass:
+            # the graph-attention pass (object->frame graph x2, LatentPSL x2, self-attention core, decoder
+            # attention over cached K',V' x 26 steps) in isolation, 1024 clips in flight, algorithmic bytes 8.79 MB/clip
+            from dlsg_amd.passbench import run_graph_attention_pass
+            torch.cuda.empty_cache()
+            pr = run_graph_attention_pass(net.ops, B=1024)
+            out['roofline_graph_attention_pass'] = {'kernel': 'o2v + latent_psl_fwd + sa_core_fwd + decatt_fwd x 26 (forward pass of '
+                                                              'SURVEY.md 8d in isolation, 1024 clips)', 'bound': 'hbm',
+                                                    'achieved': pr['achieved_GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                                    'frac': round(pr['achieved_GBps'] / PEAK_HBM_GBS, 4), 'traffic': None,
+                                                    'clips_per_s': pr['clips_per_s'], 'ms': pr['ms'], 'parts_ms': pr['parts_ms'],
+                                                    'bytes_per_clip': pr['bytes_per_clip']}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         out['dtype_note'] = {'fp32': 'all products on fp32-input MFMA (exact fp32)',

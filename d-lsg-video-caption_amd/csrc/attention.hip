@@ -770,6 +770,8 @@ extern "C" int dlsg_struct_size(int which) {
         case 10: return (int)sizeof(dlsg_dec_mid_bwd_args);
         case 11: return (int)sizeof(dlsg_decatt_cache_grads_args);
         case 12: return (int)sizeof(dlsg_o2v_bwd_args);
+        case 13: return (int)sizeof(dlsg_latent_psl_args);
+        case 14: return (int)sizeof(dlsg_sa_core_args);
         default: return -1;
     }
 }

@@ -1,0 +1,286 @@
+// The two small per-clip graphs of the encoder, each as ONE launch with one workgroup per clip (a4, a6):
+//   * latent_psl_fwd : LatentPSL (reference models/sublayer.py:189-198): logits = ov . theta^T, softmax over the frames,
+//                      u = adj^T ov, Dropout(LayerNorm(tanh(u))).  Unfused it is two batched GEMMs whose output tiles are
+//                      26 x 8 (a 64 x 64 MFMA tile is 95 % padding), a softmax and a LayerNorm launch.
+//   * sa_core_fwd    : the 26 x 26 core of SelfAttention (sublayer.py:69-78): logits = K Q^T * scale, softmax over the
+//                      Q index, out = w V.  Unfused: batched GEMM + softmax + batched GEMM.
+// Both are HBM-bound in isolation (0.14 MB and 0.85 MB per clip); the unfused launches ran them at 0.3 / 0.6 TB/s.
+#include <mutex>
+
+#include "common.hpp"
+#include "dlsg.h"
+
+using namespace dlsg;
+
+namespace {
+
+constexpr int PSL_THREADS = 1024;
+constexpr int PSL_MAXT = 32, PSL_MAXP = 32;
+
+__device__ __forceinline__ int crow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------ LatentPSL forward
+__global__ __launch_bounds__(PSL_THREADS) void latent_psl_fwd_kernel(const dlsg_latent_psl_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float lgs[PSL_MAXT][PSL_MAXP + 1];       // logits, then adj
+    __shared__ float red[16 * 8];
+    const int b = blockIdx.x;
+    const int T = a.T, P = a.P, H = a.H;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
+    float* ovl = smem;                                   // [T][H]
+    // ---- frame nodes of the clip -> LDS (read once from HBM)
+    {
+        const float* src = a.ov + (int64_t)b * T * H;
+        for (int i = threadIdx.x * 4; i < T * H; i += PSL_THREADS * 4)
+            *reinterpret_cast<f32x4*>(ovl + i) = *reinterpret_cast<const f32x4*>(src + i);
+    }
+    __syncthreads();
+    // ---- logits[t][p] = ov[t] . theta[p]: a wave keeps theta[p] in registers and walks a slice of the frames
+    {
+        const int nw = P <= 16 ? 16 / P : 1;             // waves per proposal
+        for (int task = w; task < P * nw; task += PSL_THREADS / 64) {
+            const int p = task / nw, part = task % nw;
+            const int t0 = (T * part) / nw, t1 = (T * (part + 1)) / nw;
+            const float* th = a.theta + (int64_t)p * H;
+            for (int t = t0; t < t1; ++t) {
+                float acc = 0.f;
+                for (int j = lane * 4; j < H; j += 256) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(ovl + t * H + j);
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(th + j);
+                    acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) lgs[t][p] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- softmax over the frames, per proposal
+    if (threadIdx.x < P) {
+        const int p = threadIdx.x;
+        float m = -INFINITY;
+        for (int t = 0; t < T; ++t) m = fmaxf(m, lgs[t][p]);
+        float l = 0.f;
+        for (int t = 0; t < T; ++t) l += __expf(lgs[t][p] - m);
+        const float inv = 1.f / l;
+        for (int t = 0; t < T; ++t) {
+            const float v = __expf(lgs[t][p] - m) * inv;
+            lgs[t][p] = v;
+            a.adj[((int64_t)b * T + t) * P + p] = v;
+        }
+    }
+    __syncthreads();
+    // ---- u[p][h] = sum_t adj[t][p] ov[t][h];  psl = Dropout(LayerNorm(tanh(u))), proposals in chunks of 8
+    for (int p0 = 0; p0 < P; p0 += 8) {
+        float y[8][2];                                   // up to two columns per thread (H <= 2048)
+        float s8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s8[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int h = threadIdx.x + c * PSL_THREADS;
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            if (h < H) {
+                for (int t = 0; t < T; ++t) {
+                    const float x = ovl[t * H + h];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += ((p0 + i < P) ? lgs[t][p0 + i] : 0.f) * x;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (p0 + i < P) a.u[((int64_t)b * P + p0 + i) * H + h] = acc[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { y[i][c] = (h < H) ? tanhf(acc[i]) : 0.f; s8[i] += y[i][c]; }
+        }
+        // LayerNorm statistics of the 8 rows at once
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s8[i] = wave_sum(s8[i]);
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[16 * i + w] = s8[i];
+        __syncthreads();
+        float mean[8], q8[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) r += red[16 * i + k];
+            mean[i] = r / H;
+            q8[i] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (threadIdx.x + c * PSL_THREADS < H) { const float d = y[i][c] - mean[i]; q8[i] += d * d; }
+            q8[i] = wave_sum(q8[i]);
+        }
+        __syncthreads();
+        if (lane == 0)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[16 * i + w] = q8[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (p0 + i >= P) continue;
+            float r = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) r += red[16 * i + k];
+            const float rstd = rsqrtf(r / H + a.eps);
+            const int64_t row = (int64_t)b * P + p0 + i;
+            if (threadIdx.x == 0) { a.stats[2 * row] = mean[i]; a.stats[2 * row + 1] = rstd; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int h = threadIdx.x + c * PSL_THREADS;
+                if (h < H) {
+                    float v = (y[i][c] - mean[i]) * rstd * a.gamma[h] + a.beta[h];
+                    if (a.p > 0.f) v *= drop_scale(seed, a.site, (uint64_t)row * H + h, a.p);
+                    a.out[row * H + h] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ self-attention core
+// Workgroup = 8 waves, one clip.  Scores: K and Q are walked in 512-column chunks staged in LDS; wave w contracts its
+// 64-column slice on the f32 matrix cores (A = K rows, B = Q rows), the 8 partial 32 x 32 tiles are summed through LDS
+// (as in the o2v kernel).  Softmax along the Q index = across lanes of the C layout.  out = w V on the VALU: one thread
+// per 4 columns, V rows read once with 16-B loads, w broadcast from LDS.
+constexpr int SA_THREADS = 512;
+constexpr int SA_CH = 512;
+constexpr int SA_LD = SA_CH + 4;
+constexpr int SA_LDS_FLOATS = 2 * 32 * SA_LD + 4 * 16 * 64;
+
+__global__ __launch_bounds__(SA_THREADS) void sa_core_fwd_kernel(const dlsg_sa_core_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float wl[32][33];
+    float* kl = smem;                       // [32][SA_LD]
+    float* ql = smem + 32 * SA_LD;
+    float* red = smem + 2 * 32 * SA_LD;     // [4][16][64]
+    const int b = blockIdx.x;
+    const int T = a.T, D = a.D;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const float* Kb = a.K + (int64_t)b * T * D;
+    const float* Qb = a.Q + (int64_t)b * T * D;
+    const float* Vb = a.V + (int64_t)b * T * D;
+
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    for (int c0 = 0; c0 < D; c0 += SA_CH) {
+        const int cw = min(SA_CH, D - c0);              // multiple of 64
+        __syncthreads();
+        for (int f = threadIdx.x; f < 32 * (SA_CH / 4); f += SA_THREADS) {
+            const int row = f / (SA_CH / 4), c4 = f % (SA_CH / 4);
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+            if (row < T && 4 * c4 < cw) {
+                kv = *reinterpret_cast<const f32x4*>(Kb + (int64_t)row * D + c0 + 4 * c4);
+                qv = *reinterpret_cast<const f32x4*>(Qb + (int64_t)row * D + c0 + 4 * c4);
+            }
+            *reinterpret_cast<f32x4*>(kl + row * SA_LD + 4 * c4) = kv;
+            *reinterpret_cast<f32x4*>(ql + row * SA_LD + 4 * c4) = qv;
+        }
+        __syncthreads();
+        // wave w: columns [64w, 64w+64) of the chunk; lane half h owns 32 of them
+        if (64 * w < cw) {
+            const float* ap = kl + r * SA_LD + 64 * w + 32 * h;
+            const float* bp = ql + r * SA_LD + 64 * w + 32 * h;
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 4 * s4);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 4 * s4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], b4[i], sacc, 0, 0, 0);
+            }
+        }
+    }
+    // ---- sum the 8 partial tiles (C layout: lane column = Q index j, registers = K index i)
+    if (w >= 4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[((w - 4) * 16 + e) * 64 + lane] = sacc[e];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float t = sacc[e] + red[(w * 16 + e) * 64 + lane];
+            red[(w * 16 + e) * 64 + lane] = t;
+        }
+    }
+    __syncthreads();
+    // ---- softmax over j (lanes of one half); wave w finishes registers 2w, 2w+1
+#pragma unroll
+    for (int ee = 0; ee < 2; ++ee) {
+        const int e = 2 * w + ee;
+        float sv = red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane] + red[(2 * 16 + e) * 64 + lane] +
+                   red[(3 * 16 + e) * 64 + lane];
+        sv *= a.scale;
+        const int i = crow(e, h);
+        if (a.mask && i < T && r < T && !(a.mask[((int64_t)b * T + i) * T + r] > 0.f)) sv = -9e15f;
+        if (r >= T) sv = -INFINITY;
+        float m = sv;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const float ex = __expf(sv - m);
+        float l = ex;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
+        const float wv = ex / l;
+        wl[i][r] = wv;
+        if (i < T && r < T) a.w[((int64_t)b * T + i) * T + r] = wv;
+    }
+    __syncthreads();
+    // ---- out[i][cols] = sum_j w[i][j] V[j][cols]
+    for (int c = threadIdx.x * 4; c < D; c += SA_THREADS * 4) {
+        f32x4 acc[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < T; ++j) {
+            const f32x4 v4 = *reinterpret_cast<const f32x4*>(Vb + (int64_t)j * D + c);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] += wl[i][j] * v4;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (i < T) *reinterpret_cast<f32x4*>(a.out + ((int64_t)b * T + i) * D + c) = acc[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream) {
+    if (!a || a->T < 1 || a->T > PSL_MAXT || a->P < 1 || a->P > PSL_MAXP || a->H < 4 || a->H > 2 * PSL_THREADS || a->H % 4)
+        return DLSG_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->ov) | reinterpret_cast<uintptr_t>(a->theta)) & 15) return DLSG_EINVAL;
+    if (a->B == 0) return DLSG_OK;
+    const int lds_bytes = a->T * a->H * 4;
+    if (lds_bytes > 140 * 1024) return DLSG_EINVAL;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&latent_psl_fwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+    });
+    hipLaunchKernelGGL(latent_psl_fwd_kernel, dim3(a->B), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+extern "C" int dlsg_sa_core_fwd(const dlsg_sa_core_args* a, void* stream) {
+    if (!a || a->T < 1 || a->T > 32 || a->D < 64 || a->D % 64) return DLSG_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->K) | reinterpret_cast<uintptr_t>(a->Q) | reinterpret_cast<uintptr_t>(a->V) |
+         reinterpret_cast<uintptr_t>(a->out)) & 15)
+        return DLSG_EINVAL;
+    if (a->B == 0) return DLSG_OK;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_core_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SA_LDS_FLOATS * 4);
+    });
+    hipLaunchKernelGGL(sa_core_fwd_kernel, dim3(a->B), dim3(SA_THREADS), SA_LDS_FLOATS * 4, reinterpret_cast<hipStream_t>(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}

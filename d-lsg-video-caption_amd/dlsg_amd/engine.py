@@ -229,16 +229,19 @@ def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2
         return ov
     # LatentPSL (models/sublayer.py:189-198)
     theta = m.v2l_layer.theta
-    lg = _empty(ref, B, T, P)
-    ops.gemm(GEMM_NT, [(ov.view(B, T, H), theta.unsqueeze(0).expand(B, P, H), lg)])
     adj = _empty(ref, B, T, P)
-    ops.softmax_fwd(lg, adj, B, T, P)
     u = _empty(ref, B * P, H)
-    ops.gemm(GEMM_TN, [(adj, ov.view(B, T, H), u.view(B, P, H))])
     psl = _empty(ref, B * P, H); st_p = _empty(ref, B * P, 2)
     ln = m.v2l_layer.out_norm[1]
     pd = 0.3 if training else 0.0
-    ops.rowln_fwd(u, ln.weight, ln.bias, psl, st_p, pre_tanh=1, p1=pd, site1=psl_site, seed=seed)
+    if ops.latent_psl_supported(T, P, H):
+        ops.latent_psl_fwd(ov.view(B, T, H), theta, ln.weight, ln.bias, adj, u, psl, st_p, p=pd, site=psl_site, seed=seed)
+    else:
+        lg = _empty(ref, B, T, P)
+        ops.gemm(GEMM_NT, [(ov.view(B, T, H), theta.unsqueeze(0).expand(B, P, H), lg)])
+        ops.softmax_fwd(lg, adj, B, T, P)
+        ops.gemm(GEMM_TN, [(adj, ov.view(B, T, H), u.view(B, P, H))])
+        ops.rowln_fwd(u, ln.weight, ln.bias, psl, st_p, pre_tanh=1, p1=pd, site1=psl_site, seed=seed)
     s.update(adj=adj, u=u, st_p=st_p, pd=pd, psl_site=psl_site)
     return psl.view(B, P, H)
 
@@ -386,12 +389,15 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
     Kp, Qp, Vp = _empty(ref, B * T, D2), _empty(ref, B * T, D2), _empty(ref, B * T, D2)
     ops.gemm(GEMM_NT, [(x, sa.K.weight, Kp), (x, sa.Q.weight, Qp), (x, sa.V.weight, Vp)])
     scale = 1.0 / math.sqrt(sa.attention_size)
-    lg = _empty(ref, B, T, T)
-    ops.gemm(GEMM_NT, [(Kp.view(B, T, D2), Qp.view(B, T, D2), lg)], alpha=scale)
     w = _empty(ref, B, T, T)
-    ops.softmax_fwd(lg, w, B * T, T, 1)
     att = _empty(ref, B * T, D2)
-    ops.gemm(GEMM_NN, [(w, Vp.view(B, T, D2), att.view(B, T, D2))])
+    if ops.sa_core_supported(T, D2):
+        ops.sa_core_fwd(Kp.view(B, T, D2), Qp.view(B, T, D2), Vp.view(B, T, D2), w, att.view(B, T, D2), scale)
+    else:
+        lg = _empty(ref, B, T, T)
+        ops.gemm(GEMM_NT, [(Kp.view(B, T, D2), Qp.view(B, T, D2), lg)], alpha=scale)
+        ops.softmax_fwd(lg, w, B * T, T, 1)
+        ops.gemm(GEMM_NN, [(w, Vp.view(B, T, D2), att.view(B, T, D2))])
     so = _empty(ref, B * T, H)
     lin(ops, att, sa.output_layer[0].weight, so)
     psa = sa.dropout if training else 0.0

@@ -59,6 +59,16 @@ class O2VBwdArgs(C.Structure):
                                                   ('scale', f32)]
 
 
+class LatentPslArgs(C.Structure):
+    _fields_ = [(n, c_f32p) for n in ('ov', 'theta', 'gamma', 'beta', 'adj', 'u', 'out', 'stats')] + \
+               [('B', i32), ('T', i32), ('P', i32), ('H', i32), ('p', f32), ('site', u32), ('eps', f32), ('pad_', f32),
+                ('seed', u64), ('seed_ptr', c_f32p)]
+
+
+class SaCoreArgs(C.Structure):
+    _fields_ = [(n, c_f32p) for n in ('K', 'Q', 'V', 'mask', 'w', 'out')] + [('B', i32), ('T', i32), ('D', i32), ('scale', f32)]
+
+
 class DecAttArgs(C.Structure):
     _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
                 ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
@@ -126,7 +136,8 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
-           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd']
+           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
+           'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd']
 
 
 def load_library(path=LIB_PATH):
@@ -176,6 +187,8 @@ def load_library(path=LIB_PATH):
         'dlsg_dec_mid_bwd': [P(DecMidBwdArgs), vp],
         'dlsg_decatt_cache_grads': [P(DecattCacheGradsArgs), vp],
         'dlsg_o2v_bwd': [P(O2VBwdArgs), vp],
+        'dlsg_latent_psl_fwd': [P(LatentPslArgs), vp],
+        'dlsg_sa_core_fwd': [P(SaCoreArgs), vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -186,7 +199,8 @@ def load_library(path=LIB_PATH):
 
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
-           DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs]
+           DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
+           SaCoreArgs]
 
 
 def _p(t):
@@ -417,6 +431,36 @@ class HipOps(object):
         self._check(self.lib.dlsg_o2v_bwd(C.byref(a), self._stream()), 'dlsg_o2v_bwd')
         # algorithmic bytes: y read by both passes is counted once (SURVEY.md 8d convention) + dy written + dz, v, dv
         self._prof_end('o2v_graph_bwd', e0, 4.0 * B * (2 * NO * H + 3 * T * H))
+
+    # ------------------------------------------------------------------ small per-clip graphs of the encoder
+    def latent_psl_supported(self, T, P, H):
+        return T <= 32 and P <= 32 and H % 4 == 0 and H <= 2048 and T * H * 4 <= 140 * 1024
+
+    def latent_psl_fwd(self, ov, theta, gamma, beta, adj, u, out, stats, p=0.0, site=0, seed=0, eps=1e-5):
+        """ov (B,T,H), theta (P,H) -> adj (B,T,P), u (B*P,H) pre-activation, out (B*P,H), stats (B*P,2); one launch."""
+        B, T, H = ov.shape
+        P = theta.shape[0]
+        for t in (ov, theta, adj, u, out, stats):
+            _chkc(t)
+        a = LatentPslArgs()
+        a.ov, a.theta, a.gamma, a.beta, a.adj, a.u, a.out, a.stats = _p(ov), _p(theta), _p(gamma), _p(beta), _p(adj), _p(u), \
+            _p(out), _p(stats)
+        a.B, a.T, a.P, a.H, a.p, a.site, a.eps = B, T, P, H, p, site, eps
+        a.seed, a.seed_ptr = _seed(seed)
+        self._check(self.lib.dlsg_latent_psl_fwd(C.byref(a), self._stream()), 'dlsg_latent_psl_fwd')
+
+    def sa_core_supported(self, T, D):
+        return T <= 32 and D % 64 == 0
+
+    def sa_core_fwd(self, K, Q, V, w, out, scale, mask=None):
+        """K, Q, V (B,T,D) -> w (B,T,T) = softmax_j(K_i.Q_j*scale), out (B,T,D) = w V; one launch."""
+        B, T, D = K.shape
+        for t in (K, Q, V, w, out):
+            _chkc(t)
+        a = SaCoreArgs()
+        a.K, a.Q, a.V, a.mask, a.w, a.out = _p(K), _p(Q), _p(V), _p(mask), _p(w), _p(out)
+        a.B, a.T, a.D, a.scale = B, T, D, scale
+        self._check(self.lib.dlsg_sa_core_fwd(C.byref(a), self._stream()), 'dlsg_sa_core_fwd')
 
     # ------------------------------------------------------------------ decoder attention
     def _decatt_args(self, Kp, Vp, q, c, alpha, scale):

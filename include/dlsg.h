@@ -19,7 +19,7 @@ extern "C" {
 int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
- * 12 o2v_bwd_args): lets a binding verify its
+ * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args): lets a binding verify its
  * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
@@ -143,6 +143,29 @@ typedef struct {
     float scale;
 } dlsg_o2v_bwd_args;
 int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream);
+
+/* ---------------------------------------------------------------- LatentPSL forward (sublayer.py:189-198), one launch
+ * adj (B,T,P) = softmax over the frames of ov . theta^T;  u (B*P,H) = adj^T ov;  out = Dropout(LayerNorm(tanh(u))).
+ * T <= 32, P <= 32, H <= 2048 (multiple of 4), T*H*4 <= 140 KB of LDS; otherwise the caller runs the unfused chain
+ * (2 x dlsg_gemm + dlsg_softmax_fwd + dlsg_rowln_fwd), which is also what the backward consumes (adj, u, stats). */
+typedef struct {
+    const float* ov; const float* theta; const float* gamma; const float* beta;
+    float* adj; float* u; float* out; float* stats;
+    int32_t B, T, P, H;
+    float p; uint32_t site; float eps; float pad_;
+    uint64_t seed; const uint64_t* seed_ptr;
+} dlsg_latent_psl_args;
+int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream);
+
+/* ---------------------------------------------------------------- SelfAttention 26x26 core (sublayer.py:69-78), one launch
+ * w (B,T,T) = softmax_j(K_i . Q_j * scale) (optional mask (B,T,T): mask <= 0 -> -9e15 as sublayer.py:70-72);
+ * out (B,T,D) = w V.  T <= 32, D a multiple of 64; otherwise dlsg_gemm + dlsg_softmax_fwd + dlsg_gemm. */
+typedef struct {
+    const float* K; const float* Q; const float* V; const float* mask;
+    float* w; float* out;
+    int32_t B, T, D; float scale;
+} dlsg_sa_core_args;
+int dlsg_sa_core_fwd(const dlsg_sa_core_args* a, void* stream);
 
 /* ---------------------------------------------------------------- softmax along the middle axis of (outer, n, inner)
  * LatentPSL softmax over frames (sublayer.py:192: outer=B, n=T, inner=P), SelfAttention row softmax

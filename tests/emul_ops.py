@@ -218,6 +218,27 @@ class EmulOps(object):
         d = rstd * (gx - gx.mean(2, keepdim=True) - xh * (gx * xh).mean(2, keepdim=True))
         dy.copy_(d * (1 - y * y))
 
+    def latent_psl_supported(self, T, P, H):
+        return self.fused_supported and T <= 32 and P <= 32 and H % 4 == 0
+
+    def latent_psl_fwd(self, ov, theta, gamma, beta, adj, u, out, stats, p=0.0, site=0, seed=0, eps=1e-5):
+        B, T, H = ov.shape
+        P = theta.shape[0]
+        lg = ov @ theta.t()                                     # (B,T,P)
+        adj.copy_(torch.softmax(lg, 1))
+        u.copy_((adj.transpose(1, 2) @ ov).reshape(B * P, H))
+        self.rowln_fwd(u, gamma, beta, out, stats, pre_tanh=1, p1=p, site1=site, seed=seed, eps=eps)
+
+    def sa_core_supported(self, T, D):
+        return self.fused_supported and T <= 32 and D % 64 == 0
+
+    def sa_core_fwd(self, K, Q, V, w, out, scale, mask=None):
+        lg = (K @ Q.transpose(1, 2)) * scale
+        if mask is not None:
+            lg = torch.where(mask > 0, lg, torch.full_like(lg, -9e15))
+        w.copy_(torch.softmax(lg, 2))
+        out.copy_(w @ V)
+
     # ------------------------------------------------------------------ decoder attention
     def decatt_fwd(self, Kp, Vp, q, c, alpha, scale):
         self._count('decatt_fwd')

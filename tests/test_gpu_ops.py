@@ -346,6 +346,34 @@ def test_o2v_fused_backward(hip, case):
     both(hip, build, run, ['dy', 'dv', 'part'], tol=5e-5, name='o2v bwd %s' % (case,))
 
 
+@pytest.mark.parametrize('dims', [(3, 26, 8, 64), (64, 26, 8, 1024), (2, 26, 5, 1024), (2, 32, 32, 96), (1, 7, 3, 2048),
+                                  (5, 20, 17, 512)])
+def test_latent_psl_fused_forward(hip, dims):
+    B, T, P, H = dims
+
+    def build(g):
+        return dict(ov=rnd(g, B, T, H), th=rnd(g, P, H, scale=0.1), ga=1 + 0.2 * rnd(g, H), be=0.2 * rnd(g, H),
+                    adj=torch.zeros(B, T, P), u=torch.zeros(B * P, H), out=torch.zeros(B * P, H), st=torch.zeros(B * P, 2))
+
+    def run(ops, t):
+        ops.latent_psl_fwd(t['ov'], t['th'], t['ga'], t['be'], t['adj'], t['u'], t['out'], t['st'], p=0.3, site=77, seed=9)
+    both(hip, build, run, ['adj', 'u', 'out', 'st'], tol=3e-5, name='latent_psl %s' % (dims,))
+
+
+@pytest.mark.parametrize('dims', [(3, 26, 128), (64, 26, 2048), (2, 32, 576), (2, 7, 64), (4, 20, 1024)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_self_attention_core_fused_forward(hip, dims, masked):
+    B, T, D = dims
+
+    def build(g):
+        return dict(K=rnd(g, B, T, D, scale=0.3), Q=rnd(g, B, T, D, scale=0.3), V=rnd(g, B, T, D),
+                    mask=(torch.rand(B, T, T, generator=g) > 0.3).float(), w=torch.zeros(B, T, T), out=torch.zeros(B, T, D))
+
+    def run(ops, t):
+        ops.sa_core_fwd(t['K'], t['Q'], t['V'], t['w'], t['out'], 1.0 / math.sqrt(D / 8.0), mask=t['mask'] if masked else None)
+    both(hip, build, run, ['w', 'out'], tol=3e-5, name='sa_core %s' % (dims,))
+
+
 def test_o2v_online_softmax_rescale_branch(hip):
     """Force the running max to jump at a late tile (guide 5.4 rule 26): one object aligned with one frame."""
     B, T, O, H = 2, 26, 16, 64
