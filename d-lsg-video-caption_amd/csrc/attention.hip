@@ -772,6 +772,8 @@ extern "C" int dlsg_struct_size(int which) {
         case 12: return (int)sizeof(dlsg_o2v_bwd_args);
         case 13: return (int)sizeof(dlsg_latent_psl_args);
         case 14: return (int)sizeof(dlsg_sa_core_args);
+        case 15: return (int)sizeof(dlsg_beam_select_args);
+        case 16: return (int)sizeof(dlsg_gather_multi_args);
         default: return -1;
     }
 }

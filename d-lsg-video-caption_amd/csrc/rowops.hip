@@ -580,6 +580,105 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restric
     for (int j = threadIdx.x; j < V; j += blockDim.x) y[j] = x[j] - lse;
 }
 
+// ------------------------------------------------------------------------------------------------ beam search step
+// One workgroup per batch item, one wave per live beam (BeamSearch.search, allennlp_beamsearch.py:140-260 with
+// per_node_beam_size == beam_size): log-softmax of the beam's logits row, its top-k classes (a finished beam offers
+// <end> at log-prob 0 and nothing else), then the top-k of the k*k summed candidates, back-pointers and the row
+// indices that reorder the recurrent state.  Ties resolve to the lower index.
+constexpr int BEAM_MAXK = 8;
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(i, o, 64);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+__global__ __launch_bounds__(64 * BEAM_MAXK) void beam_select_kernel(const dlsg_beam_select_args a) {
+    __shared__ float cand_lp[BEAM_MAXK * BEAM_MAXK];
+    __shared__ int cand_cls[BEAM_MAXK * BEAM_MAXK];
+    const int b = blockIdx.x, k = a.k, V = a.V;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nbeam = a.first ? 1 : k;                      // step 0: the k rows of a group are identical, use row 0
+    if (w < nbeam) {
+        const int64_t row = (int64_t)b * k + w;
+        const float* x = a.logits + row * a.ld;
+        const bool ended = !a.first && a.last[row] == a.end;
+        const float base = a.first ? 0.f : a.last_lp[row];
+        if (ended) {
+            if (lane < k) {
+                cand_lp[w * k + lane] = lane == 0 ? base : -INFINITY;
+                cand_cls[w * k + lane] = lane == 0 ? a.end : (lane - 1 < a.end ? lane - 1 : lane);
+            }
+        } else {
+            float m = -INFINITY;
+            for (int j = lane; j < V; j += 64) m = fmaxf(m, x[j]);
+            m = wave_max(m);
+            float sum = 0.f;
+            for (int j = lane; j < V; j += 64) sum += expf(x[j] - m);
+            sum = wave_sum(sum);
+            const float lse = logf(sum) + m;
+            int chosen[BEAM_MAXK];
+            for (int c = 0; c < k; ++c) {
+                float bv = -INFINITY;
+                int bi = 0x7fffffff;
+                for (int j = lane; j < V; j += 64) {
+                    bool taken = false;
+                    for (int q = 0; q < c; ++q) taken = taken || (chosen[q] == j);
+                    const float v = x[j];
+                    if (!taken && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
+                }
+                wave_argmax(bv, bi);
+                chosen[c] = bi;
+                if (lane == 0) {
+                    cand_lp[w * k + c] = (bv - lse) + base;
+                    cand_cls[w * k + c] = bi;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        const int n = nbeam * k;
+        float v = lane < n ? cand_lp[lane] : -INFINITY;
+        int idx = lane < n ? lane : 0x7fffffff;
+        int n_end = 0;
+        for (int c = 0; c < k; ++c) {
+            float bv = v;
+            int bi = idx;
+            wave_argmax(bv, bi);
+            if (lane == bi) v = -INFINITY, idx = 0x7fffffff;        // remove the winner (it can win only once)
+            if (bi == 0x7fffffff) bi = c < n ? c : 0;               // fewer than k finite candidates: any slot, log-prob -inf
+            const int cls = cand_cls[bi];
+            if (lane == 0) {
+                const int64_t o = (int64_t)b * k + c;
+                a.pred[o] = cls;
+                a.new_lp[o] = bv;
+                a.back[o] = bi / k;
+                a.rows[o] = (int64_t)b * k + bi / k;
+            }
+            n_end += cls == a.end;
+        }
+        if (lane == 0 && a.ended_count) atomicAdd(a.ended_count, n_end);
+    }
+}
+
+// dst_i[r, :] = src_i[rows[r], :] for up to four (src, dst, width) triples in one launch (blockIdx.y selects)
+__global__ void gather_rows_multi_kernel(const dlsg_gather_multi_args a) {
+    const int i = blockIdx.y, r = blockIdx.x;
+    const int n = a.n[i];
+    const float* s = a.src[i] + a.rows[r] * (int64_t)n;
+    float* d = a.dst[i] + (int64_t)r * n;
+    if ((n & 3) == 0) {
+        for (int j = threadIdx.x * 4; j < n; j += blockDim.x * 4)
+            *reinterpret_cast<f32x4*>(d + j) = *reinterpret_cast<const f32x4*>(s + j);
+    } else {
+        for (int j = threadIdx.x; j < n; j += blockDim.x) d[j] = s[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             int64_t n, float lr, float b1, float b2, float eps, float bc1, float bc2s, float gscale,
@@ -796,6 +895,20 @@ extern "C" int dlsg_ce_ragged(const float* logits, const int64_t* targets, const
 extern "C" int dlsg_log_softmax(const float* logits, float* out, int rows, int V, void* stream) {
     if (rows == 0) return DLSG_OK;
     hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(256), 0, ST(stream), logits, out, V);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_beam_select(const dlsg_beam_select_args* a, void* stream) {
+    if (!a || a->k < 1 || a->k > BEAM_MAXK || a->V < a->k) return DLSG_EINVAL;
+    if (a->B == 0) return DLSG_OK;
+    hipLaunchKernelGGL(beam_select_kernel, dim3(a->B), dim3(64 * a->k), 0, ST(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_gather_rows_multi(const dlsg_gather_multi_args* a, void* stream) {
+    if (!a || a->count < 1 || a->count > 4) return DLSG_EINVAL;
+    if (a->nrows == 0) return DLSG_OK;
+    hipLaunchKernelGGL(gather_rows_multi_kernel, dim3(a->nrows, a->count), dim3(256), 0, ST(stream), *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -4,8 +4,9 @@ BeamSearch.search models/allennlp_beamsearch.py:51-294 with per_node_beam_size =
 The decode step runs on the HIP kernels with all B*k beams as one batch (the reference loops over the k beams,
 layer.py:521-551; rows are independent so the values are the same).  The step-invariant tensors (K', V', the
 global-feature gates) are expanded once instead of being re-gathered by back-pointer every step; only the four
-LSTM states are reordered.  Candidate selection (top-k over the vocabulary and over the k*k continuations) is
-bookkeeping on small tensors and uses torch.topk / gather on the device.
+LSTM states are reordered (one gather launch, ping-pong slots).  Candidate selection -- log-softmax, top-k over the
+vocabulary per beam, top-k over the k*k continuations, back-pointers -- is one HIP launch per step (`beam_select`);
+the host does not synchronise inside the loop except for the early-exit test every 4th step.
 """
 import torch
 
@@ -49,57 +50,67 @@ def beam_infer(model, visual_feats, region_feats):
     s['gq'] = _expand_rows(s['gq'], k)
     R = B * k
     E.dec_alloc(dec, s, frames, R, L)
-    ids = s['IDS']
-    ids[0].fill_(dec.vocab('<start>'))
+    dev = frames.device
+    # recurrent state: two physical slots per step.  Step t reads slot 2t and writes slot 2t+1; the reorder by
+    # back-pointer gathers slot 2t+1 into slot 2t+2, so nothing is gathered in place and nothing is copied back.
+    state_keys = ['LHP', 'QH', 'QC', 'LC']
+    big = {key: torch.zeros(2 * L + 2, R, s[key].shape[2], dtype=torch.float32, device=dev) for key in state_keys}
     Emb = dec.word_embed.weight
-    ops.embed_fwd(Emb, ids[0], s['WE'][0])                       # beam_step applies no word dropout (layer.py:537)
-    logp = torch.empty(R, V, dtype=torch.float32, device=frames.device)
+    preds = torch.empty(L, R, dtype=torch.int64, device=dev)       # chosen classes per step, (B,k) flattened
+    backs = torch.zeros(L, R, dtype=torch.int64, device=dev)
+    rows = torch.empty(R, dtype=torch.int64, device=dev)
+    lps = torch.zeros(2, R, dtype=torch.float32, device=dev)       # running log-probs, ping-pong
+    ended = torch.zeros(L, dtype=torch.int32, device=dev)          # number of <end> among the classes chosen at step t
+    start = torch.full((R,), dec.vocab('<start>'), dtype=torch.int64, device=dev)
 
-    def step(t):
+    def step(t, words):
+        for key in state_keys:
+            s[key] = big[key][t:]                                  # index t -> slot 2t, index t+1 -> slot 2t+1
+        ops.embed_fwd(Emb, words, s['WE'][t])                      # beam_step applies no word dropout (layer.py:537)
         E.dec_step(ops, dec, s, t, frames, False, seed, R)
         E.dec_logits(ops, dec, s, t, t + 1)
-        ops.log_softmax(s['LOGITS'][t], logp)
 
-    step(0)
-    start_lp = logp.view(B, k, V)[:, 0]                          # all k rows of a group are identical at step 0
-    top_lp, top_cls = start_lp.topk(k)
-    if k == 1 and bool((top_cls == end).all()):
-        return top_cls, sv['dec_gsrc'][0], sv['dec_gsrc'][-1], []
-    last_lp = top_lp
-    preds, backs = [top_cls], []
-    after_end = torch.full((R, V), float('-inf'), device=frames.device)
-    after_end[:, end] = 0.0
-    base = (torch.arange(B, device=frames.device) * k).unsqueeze(1)
-    state_keys = ['LHP', 'QH', 'QC', 'LC']
-    tmp = {key: torch.empty_like(s[key][0]) for key in state_keys}
+    # the reference tests `all beams ended` on the host before every step (allennlp_beamsearch.py:168); here the count of
+    # <end> tokens is kept on the device and read every CHECK steps, and the result is cut to the step the reference
+    # would have stopped at (steps after that only append <end> at log-prob 0 and change nothing before them)
+    CHECK = 4
+    step(0, start)
+    ops.beam_select(s['LOGITS'][0], start, lps[0], preds[0], lps[1], backs[0], rows, k, end, first=True, ended_count=ended[0:1])
+    n_steps, done = L, 1
+    if k == 1 and int(ended[0]) == R:
+        return preds[0].view(B, k), sv['dec_gsrc'][0], sv['dec_gsrc'][-1], []
     for t in range(1, L):
-        last = preds[-1].reshape(R)
-        if bool((last == end).all()):
-            break
-        ids[t].copy_(last)
-        ops.embed_fwd(Emb, ids[t], s['WE'][t])
-        step(t)
-        cleaned = torch.where((last == end).unsqueeze(-1), after_end, logp)
-        node_lp, node_cls = cleaned.topk(k)
-        summed = (node_lp + last_lp.reshape(R, 1)).reshape(B, k * k)
-        best_lp, best_idx = summed.topk(k)
-        preds.append(node_cls.reshape(B, k * k).gather(1, best_idx))
-        last_lp = best_lp
-        back = (best_idx / k).type(torch.int64)                   # allennlp_beamsearch.py:242
-        backs.append(back)
-        rows = (base + back).reshape(R)
-        for key in state_keys:                                    # reorder the recurrent state of slot t+1
-            ops.gather_rows(s[key][t + 1], rows, tmp[key])
-            ops.copy2d(tmp[key], s[key][t + 1])
-    if not backs:
-        all_preds = preds[0].unsqueeze(2)
+        if t % CHECK == 0:
+            cnt = ended[:t].tolist()
+            hit = [i for i, c in enumerate(cnt) if c == R]
+            if hit:
+                n_steps = hit[0] + 1
+                break
+        # state of step t: slot 2t <- slot 2t-1, rows reordered by the parents chosen at step t-1
+        ops.gather_rows_multi([big[key][2 * t - 1] for key in state_keys], rows, [big[key][2 * t] for key in state_keys])
+        step(t, preds[t - 1])
+        cur, nxt = lps[t % 2], lps[(t + 1) % 2]
+        ops.beam_select(s['LOGITS'][t], preds[t - 1], cur, preds[t], nxt, backs[t], rows, k, end, ended_count=ended[t:t + 1])
+        done = t + 1
     else:
-        rec = [preds[-1].unsqueeze(2)]
-        cur = backs[-1]
-        for t in range(len(preds) - 2, 0, -1):
-            rec.append(preds[t].gather(1, cur).unsqueeze(2))
-            cur = backs[t - 1].gather(1, cur)
-        rec.append(preds[0].gather(1, cur).unsqueeze(2))
+        cnt = ended.tolist()
+        hit = [i for i, c in enumerate(cnt[:L - 1]) if c == R]
+        if hit:
+            n_steps = hit[0] + 1
+    # ---- back-trace over the steps the reference would have run (allennlp_beamsearch.py:272-292)
+    P = preds[:n_steps].view(n_steps, B, k)
+    Bk = backs[:n_steps].view(n_steps, B, k)
+    # once every beam has ended, further steps keep the log-probs and their order, so the last buffer is the reference's
+    last_lp = lps[done % 2].view(B, k)
+    if n_steps == 1:
+        all_preds = P[0].unsqueeze(2)
+    else:
+        rec = [P[n_steps - 1].unsqueeze(2)]
+        cur = Bk[n_steps - 1]
+        for t in range(n_steps - 2, 0, -1):
+            rec.append(P[t].gather(1, cur).unsqueeze(2))
+            cur = Bk[t].gather(1, cur)
+        rec.append(P[0].gather(1, cur).unsqueeze(2))
         all_preds = torch.cat(list(reversed(rec)), 2)
     best = last_lp.topk(1)[1].squeeze(1)                          # layer.py:456-460
     out = torch.stack([all_preds[i, best[i], :] for i in range(B)])

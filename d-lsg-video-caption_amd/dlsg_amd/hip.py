@@ -69,6 +69,17 @@ class SaCoreArgs(C.Structure):
     _fields_ = [(n, c_f32p) for n in ('K', 'Q', 'V', 'mask', 'w', 'out')] + [('B', i32), ('T', i32), ('D', i32), ('scale', f32)]
 
 
+class BeamSelectArgs(C.Structure):
+    _fields_ = [('logits', c_f32p), ('ld', i64), ('last', c_f32p), ('last_lp', c_f32p), ('pred', c_f32p), ('new_lp', c_f32p),
+                ('back', c_f32p), ('rows', c_f32p), ('ended_count', c_f32p), ('B', i32), ('k', i32), ('V', i32), ('end', i32),
+                ('first', i32), ('pad_', i32)]
+
+
+class GatherMultiArgs(C.Structure):
+    _fields_ = [('src', C.c_void_p * 4), ('dst', C.c_void_p * 4), ('n', i32 * 4), ('rows', c_f32p), ('nrows', i32),
+                ('count', i32)]
+
+
 class DecAttArgs(C.Structure):
     _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
                 ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
@@ -137,7 +148,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
-           'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd']
+           'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi']
 
 
 def load_library(path=LIB_PATH):
@@ -189,6 +200,8 @@ def load_library(path=LIB_PATH):
         'dlsg_o2v_bwd': [P(O2VBwdArgs), vp],
         'dlsg_latent_psl_fwd': [P(LatentPslArgs), vp],
         'dlsg_sa_core_fwd': [P(SaCoreArgs), vp],
+        'dlsg_beam_select': [P(BeamSelectArgs), vp],
+        'dlsg_gather_rows_multi': [P(GatherMultiArgs), vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -200,7 +213,7 @@ def load_library(path=LIB_PATH):
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
-           SaCoreArgs]
+           SaCoreArgs, BeamSelectArgs, GatherMultiArgs]
 
 
 def _p(t):
@@ -431,6 +444,26 @@ class HipOps(object):
         self._check(self.lib.dlsg_o2v_bwd(C.byref(a), self._stream()), 'dlsg_o2v_bwd')
         # algorithmic bytes: y read by both passes is counted once (SURVEY.md 8d convention) + dy written + dz, v, dv
         self._prof_end('o2v_graph_bwd', e0, 4.0 * B * (2 * NO * H + 3 * T * H))
+
+    # ------------------------------------------------------------------ beam search
+    def beam_select(self, logits, last, last_lp, pred, new_lp, back, rows, k, end, first=False, ended_count=None):
+        """one beam-search step for every batch item (see include/dlsg.h): logits (B*k,V) -> pred/new_lp/back/rows (B*k)."""
+        a = BeamSelectArgs()
+        R, V = logits.shape
+        a.logits, a.ld = _p(logits), logits.stride(0)
+        a.last, a.last_lp = _p(last), _p(last_lp)
+        a.pred, a.new_lp, a.back, a.rows, a.ended_count = _p(pred), _p(new_lp), _p(back), _p(rows), _p(ended_count)
+        a.B, a.k, a.V, a.end, a.first = R // k, k, V, end, int(first)
+        self._check(self.lib.dlsg_beam_select(C.byref(a), self._stream()), 'dlsg_beam_select')
+
+    def gather_rows_multi(self, srcs, rows, dsts):
+        """dsts[i][r] = srcs[i][rows[r]] for up to 4 dense (R, n_i) arrays in one launch."""
+        a = GatherMultiArgs()
+        for i, (sr, ds) in enumerate(zip(srcs, dsts)):
+            _chkc(sr); _chkc(ds)
+            a.src[i], a.dst[i], a.n[i] = sr.data_ptr(), ds.data_ptr(), sr.shape[1]
+        a.rows, a.nrows, a.count = _p(rows), rows.numel(), len(srcs)
+        self._check(self.lib.dlsg_gather_rows_multi(C.byref(a), self._stream()), 'dlsg_gather_rows_multi')
 
     # ------------------------------------------------------------------ small per-clip graphs of the encoder
     def latent_psl_supported(self, T, P, H):

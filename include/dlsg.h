@@ -19,7 +19,8 @@ extern "C" {
 int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
- * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args): lets a binding verify its
+ * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args, 15 beam_select_args,
+ * 16 gather_multi_args): lets a binding verify its
  * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
@@ -354,6 +355,26 @@ int dlsg_permute_tb(const float* src, float* dst, int T, int B, int n, void* str
 int dlsg_ce_ragged(const float* logits, const int64_t* targets, const int64_t* lens, float* dlogits, float* row_loss,
                    float* loss, int B, int L, int V, int time_major, void* stream);
 int dlsg_log_softmax(const float* logits, float* out, int rows, int V, void* stream);
+/* One beam-search step for every batch item (BeamSearch.search, allennlp_beamsearch.py:140-260, per-node k == k):
+ * log-softmax + per-beam top-k over the vocabulary + top-k over the k*k summed candidates, in one launch.
+ * logits (B*k, V) rows (ld floats apart); last (B*k) the tokens fed to this step (a beam whose last token is `end`
+ * offers only `end` at log-prob 0); last_lp (B*k) running log-probs.  first != 0: step 0 (only beam 0 of each group).
+ * Out: pred (B*k) int64 chosen classes, new_lp (B*k), back (B*k) int64 parent beam, rows (B*k) int64 = b*k + back (the
+ * gather indices for the recurrent state), ended_count += number of chosen `end` tokens (optional device counter). */
+typedef struct {
+    const float* logits; int64_t ld;
+    const int64_t* last; const float* last_lp;
+    int64_t* pred; float* new_lp; int64_t* back; int64_t* rows;
+    int32_t* ended_count;
+    int32_t B, k, V, end, first, pad_;
+} dlsg_beam_select_args;
+int dlsg_beam_select(const dlsg_beam_select_args* a, void* stream);
+/* dst_i[r,:] = src_i[rows[r],:] (dense rows of n[i] floats) for count <= 4 arrays in one launch */
+typedef struct {
+    const float* src[4]; float* dst[4]; int32_t n[4];
+    const int64_t* rows; int32_t nrows, count;
+} dlsg_gather_multi_args;
+int dlsg_gather_rows_multi(const dlsg_gather_multi_args* a, void* stream);
 /* torch.optim.Adam semantics (no weight decay, no amsgrad); step = 1-based step count; grad_scale folds 1/world */
 int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step,
               float grad_scale, const float* hyper, void* stream);

@@ -218,6 +218,34 @@ class EmulOps(object):
         d = rstd * (gx - gx.mean(2, keepdim=True) - xh * (gx * xh).mean(2, keepdim=True))
         dy.copy_(d * (1 - y * y))
 
+    def beam_select(self, logits, last, last_lp, pred, new_lp, back, rows, k, end, first=False, ended_count=None):
+        # allennlp_beamsearch.py:114-129 (first step) and :140-260 (later steps) on one step's logits
+        R, V = logits.shape
+        B = R // k
+        logp = torch.log_softmax(logits, 1)
+        if first:
+            lp, cls = logp.view(B, k, V)[:, 0].topk(k)
+            pred.copy_(cls.reshape(R)); new_lp.copy_(lp.reshape(R)); back.zero_()
+            rows.copy_((torch.arange(B).unsqueeze(1) * k).expand(B, k).reshape(R))
+        else:
+            after_end = torch.full((R, V), float('-inf'))
+            after_end[:, end] = 0.0
+            cleaned = torch.where((last == end).unsqueeze(-1), after_end, logp)
+            node_lp, node_cls = cleaned.topk(k)
+            summed = (node_lp + last_lp.reshape(R, 1)).reshape(B, k * k)
+            best_lp, best_idx = summed.topk(k)
+            pred.copy_(node_cls.reshape(B, k * k).gather(1, best_idx).reshape(R))
+            new_lp.copy_(best_lp.reshape(R))
+            bk = (best_idx / k).type(torch.int64)
+            back.copy_(bk.reshape(R))
+            rows.copy_((torch.arange(B).unsqueeze(1) * k + bk).reshape(R))
+        if ended_count is not None:
+            ended_count += int((pred == end).sum())
+
+    def gather_rows_multi(self, srcs, rows, dsts):
+        for sr, ds in zip(srcs, dsts):
+            ds.copy_(sr[rows])
+
     def latent_psl_supported(self, T, P, H):
         return self.fused_supported and T <= 32 and P <= 32 and H % 4 == 0
 

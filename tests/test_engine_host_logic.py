@@ -114,6 +114,29 @@ def test_beam5_ids(tag):
     assert np.array_equal(ids.numpy(), g['beam5_ids'])
 
 
+@pytest.mark.parametrize('bias', [4.0, 7.0, 30.0])
+@pytest.mark.parametrize('k', [5, 3])
+def test_beam_early_exit_matches_oracle(bias, k):
+    """<end> made likely: beams finish at different steps (the finished-beam rule, allennlp_beamsearch.py:147-150,186-190)
+    and the search stops early (:168) -- the output is shorter than max_words; compared with the oracle's beam search."""
+    from oracle import torch_ref as R
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    sd = {kk: v.clone() for kk, v in net.state_dict().items()}
+    sd['decoder.word_restore.bias'][net.decoder.vocab('<end>')] += bias
+    net.load_state_dict(sd)
+    args, vocab, _, _ = load_case('small_msvd')
+    orc = R.CapGnnModelRef(args, vocab).eval()
+    orc.load_state_dict(sd)
+    orc.update_beam_size(k)
+    net.update_beam_size(k)
+    with torch.no_grad():
+        want = orc(frames, regions, None)[0]
+        got = net(frames, regions, None)[0]
+    assert got.shape == want.shape and torch.equal(got, want), (got.shape, want.shape)
+    if bias >= 30.0:
+        assert got.shape[1] < 26
+
+
 @pytest.mark.parametrize('tag', ['small_msvd', 'small_baseline1'])
 def test_device_coin_path_matches_host_coin_path(tag):
     """select_embed (coins applied on device, graph-invariant launch sequence) == the host-branching path."""

@@ -538,6 +538,30 @@ def test_dec_step_fused_bwd(hip, dims, last):
     both(hip, build, run, outs, tol=3e-5, name='dec_step_bwd %s' % (dims,))
 
 
+@pytest.mark.parametrize('dims', [(7, 5, 1000), (128, 5, 1000), (3, 3, 50), (4, 8, 10007), (2, 1, 40)])
+@pytest.mark.parametrize('first', [False, True])
+def test_beam_select_and_state_gather(hip, dims, first):
+    B, k, V = dims
+    R = B * k
+    end = 2
+
+    def build(g):
+        last = torch.randint(3, V, (R,), generator=g)
+        last[torch.rand(R, generator=g) < 0.4] = end               # finished beams, including whole groups
+        last[:k] = end
+        return dict(lg=rnd(g, R, V + 3, scale=3.0), last=last, lp=-torch.rand(R, generator=g) * 5,
+                    pred=torch.zeros(R, dtype=torch.int64), nlp=torch.zeros(R), back=torch.zeros(R, dtype=torch.int64),
+                    rows=torch.zeros(R, dtype=torch.int64), cnt=torch.zeros(1, dtype=torch.int32),
+                    s0=rnd(g, R, 64), s1=rnd(g, R, 100), s2=rnd(g, R, 1024), s3=rnd(g, R, 7),
+                    d0=torch.zeros(R, 64), d1=torch.zeros(R, 100), d2=torch.zeros(R, 1024), d3=torch.zeros(R, 7))
+
+    def run(ops, t):
+        ops.beam_select(t['lg'][:, 1:V + 1], t['last'], t['lp'], t['pred'], t['nlp'], t['back'], t['rows'], k, end, first=first,
+                        ended_count=t['cnt'])
+        ops.gather_rows_multi([t['s%d' % i] for i in range(4)], t['rows'], [t['d%d' % i] for i in range(4)])
+    both(hip, build, run, ['pred', 'nlp', 'back', 'rows', 'cnt', 'd0', 'd1', 'd2', 'd3'], tol=1e-5, name='beam_select %s' % (dims,))
+
+
 def test_movers_embed_argmax(hip):
     def build(g):
         lg = rnd(g, 9, 1000)

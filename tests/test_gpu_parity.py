@@ -74,6 +74,29 @@ def test_beam5_ids_bit_exact(tag):
     assert np.array_equal(ids.cpu().numpy(), g['beam5_ids'])
 
 
+@pytest.mark.parametrize('bias', [4.0, 7.0, 30.0])
+@pytest.mark.parametrize('k', [5, 3])
+def test_beam_early_exit_and_finished_beams(bias, k):
+    """<end> made likely: beams finish at different steps and the search stops before max_words; the fused beam_select
+    kernel + deferred early-exit test against the oracle's beam search (ids and output length)."""
+    from oracle import torch_ref as R
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    sd = {kk: v.clone().cpu() for kk, v in net.state_dict().items()}
+    sd['decoder.word_restore.bias'][net.decoder.vocab('<end>')] += bias
+    net.load_state_dict(sd)
+    args, vocab, _, _ = load_case('small_msvd')
+    orc = R.CapGnnModelRef(args, vocab).eval()
+    orc.load_state_dict(sd)
+    orc.update_beam_size(k)
+    net.update_beam_size(k)
+    with torch.no_grad():
+        want = orc(frames.cpu(), regions.cpu(), None)[0]
+        got = net(frames, regions, None)[0].cpu()
+    assert got.shape == want.shape and torch.equal(got, want), (got.shape, want.shape)
+    if bias >= 30.0:
+        assert got.shape[1] < 26
+
+
 @pytest.mark.parametrize('tag', SMALL)
 def test_autograd_gradients(tag):
     net, g, frames, regions, caps, lens, kind = build(tag)
