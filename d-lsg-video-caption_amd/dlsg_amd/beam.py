@@ -32,6 +32,9 @@ def beam_infer(model, visual_feats, region_feats):
         regions = region_feats.contiguous().float()
         obj, mot = model._encode(frames, regions, False, seed, sv)
         mems, sv['dec_gsrc'] = [obj, mot], [obj, mot]
+    elif hasattr(model, '_motion_nodes'):
+        mot = model._motion_nodes(frames, region_feats.contiguous().float(), False, seed, sv)
+        mems, sv['dec_gsrc'] = [mot], [mot]
     else:
         B0, T, F = frames.shape
         enc = E.encvis_fwd(ops, model.encoder, 'encoder', frames.view(B0 * T, F), B0, T, sv, False, seed)

@@ -254,23 +254,27 @@ def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed):
     P = m.v2l_layer.theta.shape[0]
     ref = regions
     name = pfx
-    ln = m.v2l_layer.out_norm[1]
-    nb = ops.rowln_bwd_nblk(B * P)
-    part = _empty(ref, nb, 2, H)
-    du = _empty(ref, B * P, H)
-    ops.rowln_bwd(dpsl.reshape(B * P, H), s['u'], ln.weight, ln.bias, du, stats=s['st_p'], pre_tanh=1, p1=s['pd'],
-                  site1=s['psl_site'], seed=seed, dgb_part=part)
-    ln_grads(ops, part, G, name + '.v2l_layer.out_norm.1', H)
-    ov, adj, theta = s['ov'], s['adj'], m.v2l_layer.theta
-    du3 = du.view(B, P, H)
-    dadj = _empty(ref, B, T, P)
-    ops.gemm(GEMM_NT, [(ov.view(B, T, H), du3, dadj)])
-    dov = _empty(ref, B * T, H)
-    ops.gemm(GEMM_NN, [(adj, du3, dov.view(B, T, H))])
-    dlg = _empty(ref, B, T, P)
-    ops.softmax_bwd(adj, dadj, dlg, B, T, P)
-    ops.gemm(GEMM_NN, [(dlg, theta.unsqueeze(0).expand(B, P, H), dov.view(B, T, H))], flags=F_ACCUM)
-    ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[name + '.v2l_layer.theta'])], flags=F_ACCUM)
+    if m.baseline:
+        # baseline streams return the frame nodes ov themselves (layer.py:197-198): dpsl is d(ov), (B,T,H)
+        dov = dpsl.reshape(B * T, H)
+    else:
+        ln = m.v2l_layer.out_norm[1]
+        nb = ops.rowln_bwd_nblk(B * P)
+        part = _empty(ref, nb, 2, H)
+        du = _empty(ref, B * P, H)
+        ops.rowln_bwd(dpsl.reshape(B * P, H), s['u'], ln.weight, ln.bias, du, stats=s['st_p'], pre_tanh=1, p1=s['pd'],
+                      site1=s['psl_site'], seed=seed, dgb_part=part)
+        ln_grads(ops, part, G, name + '.v2l_layer.out_norm.1', H)
+        ov, adj, theta = s['ov'], s['adj'], m.v2l_layer.theta
+        du3 = du.view(B, P, H)
+        dadj = _empty(ref, B, T, P)
+        ops.gemm(GEMM_NT, [(ov.view(B, T, H), du3, dadj)])
+        dov = _empty(ref, B * T, H)
+        ops.gemm(GEMM_NN, [(adj, du3, dov.view(B, T, H))])
+        dlg = _empty(ref, B, T, P)
+        ops.softmax_bwd(adj, dadj, dlg, B, T, P)
+        ops.gemm(GEMM_NN, [(dlg, theta.unsqueeze(0).expand(B, P, H), dov.view(B, T, H))], flags=F_ACCUM)
+        ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[name + '.v2l_layer.theta'])], flags=F_ACCUM)
     if O >= 5:
         NO = T * O
         lnv = m.obj_visual_norm[1]

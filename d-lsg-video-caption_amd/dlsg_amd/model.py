@@ -344,6 +344,78 @@ class CapBaseline1(_HipModel):
         return out[0], 0, 0, 0
 
 
+class CapBaselineModel(_HipModel):
+    """models/model.py:76-91: CapGnnEncoder(baseline=True) -- the TUN streams return their frame nodes instead of latent
+    proposals -- and a baseline Decoder (one attention) on the motion stream only.  The reference also runs the object
+    stream and drops its output; that work is skipped here (no output or gradient depends on it), and the 24 parameters
+    the reference leaves without a gradient (object stream, LatentPSL of the motion stream, linear_baseline, ...) are
+    reported as unused."""
+
+    @property
+    def unused_parameters(self):
+        names = ['decoder.context_layernorm.weight', 'decoder.context_layernorm.bias', 'linear_baseline.weight',
+                 'linear_baseline.bias']
+        for n, _ in self.encoder.obj_encoder.named_parameters():
+            names.append('encoder.obj_encoder.' + n)
+        me = 'encoder.motion_encoder.'
+        names += [me + 'att_l2l_norm.weight', me + 'att_l2l_norm.bias', me + 'v2l_layer.theta',
+                  me + 'v2l_layer.out_norm.1.weight', me + 'v2l_layer.out_norm.1.bias']
+        if not self.encoder.motion_encoder.has_obj:
+            names += [me + 'obj_visual_norm.1.weight', me + 'obj_visual_norm.1.bias']
+        return frozenset(names)
+
+    def __init__(self, args, vocab):
+        super().__init__()
+        self.use_visual_gan = args.use_visual_gan
+        self.encoder = CapGnnEncoder(args, baseline=True)
+        self.linear_baseline = nn.Linear(args.visual_hidden_size * 2, args.visual_hidden_size)
+        self.decoder = Decoder(args, vocab, multi_modal=False, baseline=True)
+
+    def update_beam_size(self, beam_size):
+        self.decoder.update_beam_size(beam_size)
+
+    def _motion_nodes(self, frames, regions, training, seed, sv):
+        ops, enc = self.ops, self.encoder
+        B, T, F = frames.shape
+        f2 = frames.view(B * T, F)
+        mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed)
+        mot = E.tun_fwd(ops, enc.motion_encoder, 'encoder.motion_encoder', mot_in, regions, sv, training, seed,
+                        E.SITE_PSL_MOT, self.fused_o2v)
+        return mot.view(B, T, -1)
+
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
+        ops = self.ops
+        ops.extra_flags = self._gemm_flags(False)
+        frames = frames.contiguous().float()
+        regions = regions.contiguous().float()
+        mot = self._motion_nodes(frames, regions, training, seed, sv)
+        sv['frames'], sv['regions'] = frames, regions
+        sv['dec_gsrc'] = [mot]
+        s = E.dec_fwd(ops, self.decoder, [mot], sv, captions, L, coins, training, seed, dev_coins)
+        B = frames.shape[0]
+        logits = torch.empty(B, L, self.decoder.vocab_size, dtype=torch.float32, device=frames.device)
+        ops.permute_tb(s['LOGITS'], logits)
+        return logits, mot, mot, torch.empty(0, device=frames.device)
+
+    def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed, on_bucket=None):
+        ops, enc = self.ops, self.encoder
+        ops.extra_flags = self._gemm_flags(True)
+        G = self._G
+        ops.fill(self._gflat, 0.0)
+        frames, regions = sv['frames'], sv['regions']
+        B, T, F = frames.shape
+        dmems, dgfeat = E.dec_bwd(ops, self.decoder, sv, G, dlogits_tm, seed, training, None)
+        dmo = dmems[0]
+        ops.mean_rows_bwd(dgfeat, dmo, accum=True)
+        dmot_in = E.tun_bwd(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, G, dmo, training, seed)
+        E.encvis_bwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', frames.view(B * T, F), B, T, sv, G, dmot_in,
+                     training, seed)
+        if on_bucket:
+            on_bucket(('decoder', 'linear_baseline', 'encoder.obj_encoder', 'encoder.motion_pre_encoder', 'encoder.motion_encoder'))
+
+    forward = CapBaseline1.forward
+
+
 class GreedyGraph(object):
     """hipGraph-captured greedy inference (BASELINE configs[4]: 'hipGraph-captured decode step'): encoder + the 26
     decode steps (argmax and embedding gather stay on device) are captured once for a batch shape and replayed; the

@@ -434,6 +434,28 @@ class CapBaseline1Ref(nn.Module):
         self.decoder.beam_size = k
 
 
+class CapBaselineModelRef(nn.Module):
+    """models/model.py:76-91 -- CapGnnEncoder(baseline=True): the TUN streams return the frame nodes `ov` instead of the
+    latent proposals; the decoder (baseline, one attention) runs on the motion stream only.  `obj_proposals` is computed by
+    the reference and discarded; `linear_baseline` is constructed and never used."""
+    def __init__(self, args, vocab):
+        super().__init__()
+        self.use_visual_gan = args.use_visual_gan
+        self.encoder = CapGnnEncoderP(args, baseline=True)
+        self.linear_baseline = nn.Linear(args.visual_hidden_size * 2, args.visual_hidden_size)
+        self.decoder = DecoderP(args, vocab, multi_modal=False, baseline=True)
+        self.rng = random
+
+    def forward(self, visual_feats, region_feats, caption, max_words=None, teacher_forcing_ratio=1.0):
+        _, mot = capgnn_encoder(self.encoder, visual_feats, region_feats, self.training, None)
+        outs, _ = decoder_forward(self.decoder, mot, caption, max_words, teacher_forcing_ratio, None,
+                                  self.training, self.rng)
+        return outs, 0, 0, 0
+
+    def update_beam_size(self, k):
+        self.decoder.beam_size = k
+
+
 # --------------------------------------------------------------------------------------------
 # caller-side step (run_gun.py:153-160,181-198,233-234)
 # --------------------------------------------------------------------------------------------

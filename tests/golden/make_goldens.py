@@ -170,6 +170,8 @@ if __name__ == '__main__':
     run_case('small_noobj', small_args(num_obj=4), V=50, B=2, seed=13, store_weights=True, store_inter=True)
     run_case('small_baseline1', small_args(), V=50, B=3, seed=14, store_weights=True, store_inter=False,
              model_cls='CapBaseline1')
+    run_case('small_baselinemodel', small_args(), V=50, B=3, seed=15, store_weights=True, store_inter=False,
+             model_cls='CapBaselineModel')
     sa_mask_case()
     run_case('full_msvd_b2', msvd_shaped(), V=1000, B=2, seed=21, store_weights=False, store_inter=False)
     run_case('full_msrvtt_b2', msrvtt_shaped(), V=10000, B=2, seed=22, store_weights=False, store_inter=False,

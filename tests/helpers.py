@@ -23,6 +23,7 @@ CASES = {
     'small_msrvtt': (lambda: small_args(num_obj=6, num_proposals=5, decode_hidden_size=80, dataset='msr-vtt'), 'capgnn'),
     'small_noobj': (lambda: small_args(num_obj=4), 'capgnn'),
     'small_baseline1': (lambda: small_args(), 'baseline1'),
+    'small_baselinemodel': (lambda: small_args(), 'baselinemodel'),
     'full_msvd_b2': (lambda: msvd_shaped(), 'capgnn'),
     'full_msrvtt_b2': (lambda: msrvtt_shaped(), 'capgnn'),
 }

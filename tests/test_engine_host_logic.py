@@ -11,13 +11,14 @@ import dlsg_amd
 from emul_ops import EmulOps
 from helpers import load_case, weights_and_inputs
 
-SMALL = ['small_msvd', 'small_msrvtt', 'small_noobj', 'small_baseline1']
+SMALL = ['small_msvd', 'small_msrvtt', 'small_noobj', 'small_baseline1', 'small_baselinemodel']
+MODELS = {'capgnn': dlsg_amd.CapGnnModel, 'baseline1': dlsg_amd.CapBaseline1, 'baselinemodel': dlsg_amd.CapBaselineModel}
 
 
 def build(tag, fused=True):
     args, vocab, g, kind = load_case(tag)
     torch.manual_seed(0)
-    net = (dlsg_amd.CapGnnModel if kind == 'capgnn' else dlsg_amd.CapBaseline1)(args, vocab).eval()
+    net = MODELS[kind](args, vocab).eval()
     net.set_ops(EmulOps(fused_supported=fused))
     sd, frames, regions, caps, lens = weights_and_inputs(net, g, args)
     net.load_state_dict(sd, strict=True)

@@ -11,13 +11,13 @@ import torch
 from oracle import torch_ref as R
 from helpers import load_case, weights_and_inputs
 
-SMALL = ['small_msvd', 'small_msrvtt', 'small_noobj', 'small_baseline1']
+SMALL = ['small_msvd', 'small_msrvtt', 'small_noobj', 'small_baseline1', 'small_baselinemodel']
 
 
 def build(tag):
     args, vocab, g, kind = load_case(tag)
     torch.manual_seed(0)
-    net = (R.CapGnnModelRef if kind == 'capgnn' else R.CapBaseline1Ref)(args, vocab).eval()
+    net = {'capgnn': R.CapGnnModelRef, 'baseline1': R.CapBaseline1Ref, 'baselinemodel': R.CapBaselineModelRef}[kind](args, vocab).eval()
     sd, frames, regions, caps, lens = weights_and_inputs(net, g, args)
     net.load_state_dict(sd, strict=True)
     return net, g, frames, regions, caps, lens, kind
