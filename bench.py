@@ -111,13 +111,21 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import dlsg_amd
     from dlsg_amd.synth import synth_state_dict, synth_batch
+    # test hooks (tests/test_gpu_bench_two_ranks.py): a 1-GPU box can rehearse the N>1 code path with both ranks on device 0
+    # over gloo; the driver's runs use neither variable (one rank per GPU, backend nccl = RCCL)
+    if os.environ.get('DLSG_BENCH_ALL_RANKS_ON_DEVICE0') == '1':
+        local = 0
+    backend = os.environ.get('DLSG_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
 
     if a.shape == 'msvd':
