@@ -242,17 +242,24 @@ class CapGnnModel(_HipModel):
         dmot_in = E.tun_bwd(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, G, dmo, training, seed)
         if on_bucket:
             on_bucket('encoder.motion_encoder')
-        # the object-stream encoder backward (large GEMMs) runs beside the BiLSTM backward (small recurrent launches)
+        # optional second stream: the object-stream encoder backward (large GEMMs) beside the BiLSTM backward
         side = self._fork(frames)
         if side is not None:
             with torch.cuda.stream(side):
                 E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed)
         E.encvis_bwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, G, dmot_in, training, seed)
         if side is None:
+            # the 151 MB motion_pre_encoder bucket travels while the object stream's backward (its largest GEMMs) runs;
+            # only the small obj_encoder bucket is exposed at the end of the step
+            if on_bucket:
+                on_bucket('encoder.motion_pre_encoder')
             E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed)
-        self._join(side)
-        if on_bucket:
-            on_bucket(('encoder.motion_pre_encoder', 'encoder.obj_encoder'))
+            if on_bucket:
+                on_bucket('encoder.obj_encoder')
+        else:
+            self._join(side)
+            if on_bucket:
+                on_bucket(('encoder.motion_pre_encoder', 'encoder.obj_encoder'))
 
     # ------------------------------------------------------------------ public forward
     def forward(self, visual_feats, region_feats, caption, max_words=None, teacher_forcing_ratio=1.0):
