@@ -1,5 +1,5 @@
 """Target for rocprofv3 --kernel-trace --stats: N eager train steps (kernel by kernel) in one arithmetic policy.
-usage: python3 tools/profile_step.py [x3_bwd|fp32|x3_all] [steps] [batch]"""
+usage: python3 tools/profile_step.py [x3_bwd|fp32|x3_all] [steps] [batch] [msvd|msrvtt]"""
 import os
 import random
 import sys
@@ -13,14 +13,16 @@ from dlsg_amd.synth import synth_state_dict, synth_batch  # noqa: E402
 mode = sys.argv[1] if len(sys.argv) > 1 else 'x3_bwd'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-args = dlsg_amd.msvd_shaped()
-vocab = dlsg_amd.make_vocab(1000)
+shape = sys.argv[4] if len(sys.argv) > 4 else 'msvd'
+args = dlsg_amd.msvd_shaped() if shape == 'msvd' else dlsg_amd.msrvtt_shaped()
+V = 1000 if shape == 'msvd' else 10000
+vocab = dlsg_amd.make_vocab(V)
 torch.manual_seed(0)
 net = dlsg_amd.CapGnnModel(args, vocab)
 net.load_state_dict(synth_state_dict(net.state_dict(), 0))
 net = net.cuda().train()
 net.gemm_precision = mode
-frames, regions, caps, lens = synth_batch(args, 1000, B, 1)
+frames, regions, caps, lens = synth_batch(args, V, B, 1)
 frames, regions, caps, lens = frames.cuda(), regions.cuda(), caps.cuda(), lens.cuda()
 tr = dlsg_amd.Trainer(net, use_graphs=False)
 random.seed(12)
