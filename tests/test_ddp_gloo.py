@@ -74,3 +74,40 @@ def test_two_rank_step_equals_mean_of_shard_gradients(tmp_path):
     tr2.t = 1
     net2.ops.adam(net2._flat, net2._gflat, tr2.m, tr2.v, tr2.lr, 0.5, 0.9, 1e-8, 1, 0.5)
     assert np.abs(net2._flat.numpy() - f0).max() <= 1e-6
+
+
+def _worker_torch_ddp(rank, world, port, out_dir):
+    for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'd-lsg-video-caption_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import torch_ref as R
+    from torch.nn.parallel import DistributedDataParallel
+    net, frames, regions, caps, lens = _build()
+    ddp = DistributedDataParallel(net, find_unused_parameters=True)      # run_gun.py:63-64
+    opt = torch.optim.Adam(ddp.parameters(), lr=1.6e-4, betas=(0.5, 0.9))
+    sl = slice(rank * 2, rank * 2 + 2)
+    opt.zero_grad()
+    outs = ddp(frames[sl], regions[sl], caps[sl], 26, 1.0)[0]             # run_gun.py:183
+    loss = R.ragged_ce(outs, caps[sl], lens[sl])                           # run_gun.py:189-198
+    loss.backward()
+    opt.step()
+    np.save(os.path.join(out_dir, 'ddp_flat%d.npy' % rank), net._flat.detach().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_reference_style_loop_with_torch_ddp_wrapper_and_adam(tmp_path):
+    """The reference's own loop shape (run_gun.py:63-64,183-198,233-234): DistributedDataParallel(model) +
+    loss.backward() + torch.optim.Adam, with the model's autograd bridge underneath -- must equal the Trainer path."""
+    port = _free_port()
+    mp.spawn(_worker_torch_ddp, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    f0, f1 = np.load(tmp_path / 'ddp_flat0.npy'), np.load(tmp_path / 'ddp_flat1.npy')
+    assert np.array_equal(f0, f1)
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    t0 = np.load(tmp_path / 'flat0.npy')
+    assert np.abs(t0 - f0).max() <= 2e-6
