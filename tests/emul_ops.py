@@ -122,7 +122,7 @@ class EmulOps(object):
     def rowln_bwd_nblk(self, rows):
         if rows <= 256:
             return max(rows, 1)
-        return 256 if rows <= 4096 else 1024
+        return min((rows + 1) // 2, 1024) if rows <= 4096 else 1024
 
     def rowln_bwd(self, dy, x, gamma, beta, dx, stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0,
                   site1=0, p2=0.0, site2=0, seed=0, eps=1e-5, dgb_part=None, accum_dx=False):

@@ -11,13 +11,14 @@ from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN  # noqa: E402
 ops = HipOps()
 dev = 'cuda'
 SHAPES = [('NT', 1664, 1024, 6144, 1), ('NT', 1664, 1024, 2048, 2), ('NT', 1664, 4096, 1024, 2), ('NT', 1664, 2048, 2048, 3),
-          ('NT', 1664, 1000, 1024, 1), ('NT', 1664, 1024, 2048, 1), ('NN', 1664, 1024, 4096, 1), ('NN', 1664, 2048, 2048, 1)]
+          ('NT', 1664, 1000, 1024, 1), ('NT', 1664, 1024, 2048, 1), ('NN', 1664, 1024, 4096, 1), ('NN', 1664, 2048, 2048, 1),
+          ('TN', 4096, 1024, 1664, 1), ('TN', 2048, 2048, 1664, 1), ('TN', 1024, 6144, 1664, 1), ('TN', 4096, 300, 1664, 1)]
 MODE = {'NT': GEMM_NT, 'NN': GEMM_NN, 'TN': GEMM_TN}
 
 
 def run(mode, M, N, K, G, force, ks, x3=0):
     g = torch.Generator().manual_seed(0)
-    A = torch.randn(M, K, generator=g).to(dev)
+    A = (torch.randn(M, K, generator=g) if mode != 'TN' else torch.randn(K, M, generator=g)).to(dev)
     Bs = [(torch.randn(N, K, generator=g) if mode == 'NT' else torch.randn(K, N, generator=g)).to(dev) for _ in range(G)]
     out = torch.empty(G, M, N, device=dev)
     slabs = torch.empty(G, ks, M, N, device=dev)
@@ -29,7 +30,10 @@ def run(mode, M, N, K, G, force, ks, x3=0):
         for gi in range(G):
             for i, (k0, k1) in enumerate(kb):
                 dst = out[gi] if len(kb) == 1 else slabs[gi][i]
-                groups.append((A[:, k0:k1], Bs[gi][:, k0:k1] if mode == 'NT' else Bs[gi][k0:k1], dst))
+                if mode == 'TN':
+                    groups.append((A[k0:k1], Bs[gi][k0:k1], dst))
+                else:
+                    groups.append((A[:, k0:k1], Bs[gi][:, k0:k1] if mode == 'NT' else Bs[gi][k0:k1], dst))
         ops.gemm(MODE[mode], groups, flags=force | x3)
         if len(kb) > 1:
             for gi in range(G):
@@ -47,7 +51,7 @@ def run(mode, M, N, K, G, force, ks, x3=0):
     return ms, 2.0 * M * N * K * G / ms / 1e9
 
 
-for x3, nm in ((0, 'fp32'), (1024, 'bf16x3')):
+for x3, nm in ((1024, 'bf16x3'),):
     for mode, M, N, K, G in SHAPES:
         line = '%s %-2s %5d %5d %5d G%d |' % (nm, mode, M, N, K, G)
         for force, ks in ((256, 1), (512, 1), (512, 2), (512, 3), (512, 4), (512, 5), (512, 8), (256, 2)):
