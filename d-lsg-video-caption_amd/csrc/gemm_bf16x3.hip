@@ -240,7 +240,7 @@ __device__ __forceinline__ void gemm_x3_body(const KArgs& p) {
             for (int e = 0; e < 16; ++e) {
                 const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row >= p.M) continue;
-                float* cp = C + (int64_t)row * p.ldc + col;
+                float* cp = C + (int64_t)row * (grp.ldc ? grp.ldc : (int64_t)p.ldc) + col;
                 float v = p.alpha * acc[i][j][e] + bv;
                 if (accum) v += *cp;
                 if (do_tanh) v = tanhf(v);
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
 #pragma unroll
                 for (int ww = 0; ww < 4; ++ww) v += red[((ww * 2 + mi) * 16 + e) * 64 + lane];
                 v = p.alpha * v + bv;
-                float* cp = C + (int64_t)row * p.ldc + col;
+                float* cp = C + (int64_t)row * (grp.ldc ? grp.ldc : (int64_t)p.ldc) + col;
                 if (accum) v += *cp;
                 if (do_tanh) v = tanhf(v);
                 *cp = v;

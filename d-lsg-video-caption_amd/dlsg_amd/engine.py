@@ -143,6 +143,18 @@ def gemm_nn_multi_slabs(ops, dy, Ws, width, ref):
     return slabs
 
 
+def tn_grouped(ops, items):
+    """Weight gradients gout_i += dy_i^T x_i for several (dy, x, gout) triples: one grouped launch per distinct output
+    height (dy width) instead of one launch each.  A 4096 x 1024 gradient block is 256 tiles of 128 x 128 -- one per CU,
+    nothing to hide latency behind; seven of them in one launch fill every CU three deep and run on the large tile."""
+    by_m = {}
+    for dy, x, gout in items:
+        by_m.setdefault(dy.shape[1], []).append((dy, x, gout))
+    for grp in by_m.values():
+        for i in range(0, len(grp), 16):
+            ops.gemm(GEMM_TN, grp[i:i + 16], flags=F_ACCUM)
+
+
 def lin(ops, x, W, out, bias=None, tanh=False, accum=False):
     ops.gemm(GEMM_NT, [(x, W, out)], flags=(F_TANH if tanh else 0) | (F_ACCUM if accum else 0), bias=bias)
 
@@ -500,11 +512,11 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
             ops.gemm(GEMM_NN, groups)
     de = _empty(ref, B * T, H)
     e = s['e']
+    tn_grouped(ops, [(dG[d].view(B * T, 4 * H), src, G[name + '.lstm.' + wn + sfx[d]])
+                     for d in range(2) for src, wn in ((e, 'weight_ih_l0'), (hprev[d].view(B * T, H), 'weight_hh_l0'))])
     for d in range(2):
         dg2 = dG[d].view(B * T, 4 * H)
         ops.gemm(GEMM_NN, [(dg2, Wih[d], de)], flags=F_ACCUM if d else 0)
-        ops.gemm(GEMM_TN, [(dg2, e, G[name + '.lstm.weight_ih_l0' + sfx[d]])], flags=F_ACCUM)
-        ops.gemm(GEMM_TN, [(dg2, hprev[d].view(B * T, H), G[name + '.lstm.weight_hh_l0' + sfx[d]])], flags=F_ACCUM)
         ops.colsum2(dg2, G[name + '.lstm.bias_ih_l0' + sfx[d]], G[name + '.lstm.bias_hh_l0' + sfx[d]], accum=True)
     ops.gemm(GEMM_TN, [(de, frames2d, G[name + '.linear_embed.weight'])], flags=F_ACCUM)
     ops.colsum(de, G[name + '.linear_embed.bias'], accum=True)
@@ -745,17 +757,17 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     # ---- weight gradients: one (L*B)-deep TN GEMM per weight block
     dgq2, dgl2 = dGQ.view(n, 4 * Q), dGL.view(n, 4 * D)
     Gq_ih, Gl_ih = G['decoder.query_lstm.weight_ih'], G['decoder.lang_lstm.weight_ih']
-    ops.gemm(GEMM_TN, [(dgq2, s['LHP'][:L].view(n, D), Gq_ih[:, plan.q_lang[0]:plan.q_lang[1]])], flags=F_ACCUM)
-    ops.gemm(GEMM_TN, [(dgq2, s['WE'][:L].view(n, W), Gq_ih[:, plan.q_word[0]:plan.q_word[1]])], flags=F_ACCUM)
-    ops.gemm(GEMM_TN, [(dgq2, s['QH'][:L].view(n, Q), G['decoder.query_lstm.weight_hh'])], flags=F_ACCUM)
     dgq_sum = _empty(ref, B, 4 * Q)
     ops.slab_reduce(dGQ, dgq_sum)
+    lhp, qh = s['LHP'][:L].view(n, D), s['QH'][:L].view(n, Q)
+    tn_grouped(ops, [(dgq2, lhp, Gq_ih[:, plan.q_lang[0]:plan.q_lang[1]]),
+                     (dgq2, s['WE'][:L].view(n, W), Gq_ih[:, plan.q_word[0]:plan.q_word[1]]),
+                     (dgq2, qh, G['decoder.query_lstm.weight_hh'])] +
+               [(dgl2, s['CTX'][i].view(n, H), Gl_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]]) for i in range(ns)] +
+               [(dgl2, s['QCUR'].view(n, Q), Gl_ih[:, plan.l_q[0]:plan.l_q[1]]),
+                (dgl2, lhp, G['decoder.lang_lstm.weight_hh'])])
     ops.gemm(GEMM_TN, [(dgq_sum, s['gfeat'], Gq_ih[:, plan.q_glob[0]:plan.q_glob[1]])], flags=F_ACCUM)
     ops.colsum2(dgq2, G['decoder.query_lstm.bias_ih'], G['decoder.query_lstm.bias_hh'], accum=True)
-    for i in range(ns):
-        ops.gemm(GEMM_TN, [(dgl2, s['CTX'][i].view(n, H), Gl_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]])], flags=F_ACCUM)
-    ops.gemm(GEMM_TN, [(dgl2, s['QCUR'].view(n, Q), Gl_ih[:, plan.l_q[0]:plan.l_q[1]])], flags=F_ACCUM)
-    ops.gemm(GEMM_TN, [(dgl2, s['LHP'][:L].view(n, D), G['decoder.lang_lstm.weight_hh'])], flags=F_ACCUM)
     ops.colsum2(dgl2, G['decoder.lang_lstm.bias_ih'], G['decoder.lang_lstm.bias_hh'], accum=True)
     # ---- word embedding rows
     dWE = _empty(ref, n, W)

@@ -26,7 +26,7 @@ i32, i64, u32, u64, f32 = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_floa
 
 class GemmGroup(C.Structure):
     _fields_ = [('A', c_f32p), ('B', c_f32p), ('C', c_f32p), ('lda', i64), ('ldb', i64), ('K', i32), ('N', i32),
-                ('bias', c_f32p)]
+                ('bias', c_f32p), ('ldc', i64)]
 
 
 class GemmArgs(C.Structure):
@@ -319,13 +319,14 @@ class HipOps(object):
                 assert A.shape[-2] == M and B.shape[-1] == K and B.shape[-2] == Ng, (A.shape, B.shape, Cc.shape)
             for t in (A, B, Cc):
                 assert t.dtype == torch.float32 and (t.stride(-1) == 1 or t.size(-1) == 1), (t.shape, t.stride())
-            assert Cc.stride(-2) == a.ldc and Cc.shape[-2] == M
+            assert Cc.shape[-2] == M
             if batched:
                 assert (A.stride(0), B.stride(0), Cc.stride(0)) == (a.bsa, a.bsb, a.bsc)
             g = a.g[i]
             g.A, g.B, g.C = _p(A), _p(B), _p(Cc)
             g.lda, g.ldb, g.K, g.N = A.stride(-2), B.stride(-2), K, (Ng if Ng != N else 0)
             g.bias = _p(grp_[3]) if len(grp_) > 3 else None
+            g.ldc = Cc.stride(-2) if Cc.stride(-2) != a.ldc else 0
         e0 = None
         if self.prof is not None:
             flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))

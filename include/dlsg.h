@@ -53,6 +53,8 @@ typedef struct {
     int32_t N;   /* 0 = use args.N; otherwise this group's own output width (<= args.N): lets one launch write
                     column blocks of different widths (e.g. dG.W_ih and dG.W_hh) */
     const float* bias; /* optional per-group bias (overrides args.bias when DLSG_GEMM_BIAS is set) */
+    int64_t ldc;       /* 0 = args.ldc; otherwise this group's own output row stride (groups writing into different arrays,
+                          e.g. the weight-gradient blocks of one LSTM cell in one launch) */
 } dlsg_gemm_group;
 typedef struct {
     int32_t mode, M, N, ldc;
