@@ -155,6 +155,17 @@ def tn_grouped(ops, items):
             ops.gemm(GEMM_TN, grp[i:i + 16], flags=F_ACCUM)
 
 
+def gemm_bucketed(ops, mode, groups, flags=0):
+    """groups (A, B, C) of one mode launched together whenever their output heights agree (the two attention streams,
+    the three projections of the self-attention, ...): one launch per distinct C row count."""
+    by_m = {}
+    for g in groups:
+        by_m.setdefault(g[2].shape[-2], []).append(g)
+    for grp in by_m.values():
+        for i in range(0, len(grp), 16):
+            ops.gemm(mode, grp[i:i + 16], flags=flags)
+
+
 def lin(ops, x, W, out, bias=None, tanh=False, accum=False):
     ops.gemm(GEMM_NT, [(x, W, out)], flags=(F_TANH if tanh else 0) | (F_ACCUM if accum else 0), bias=bias)
 
@@ -471,9 +482,8 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
         ops.gemm(GEMM_NN, [(dK, sa.K.weight, dx)])
         ops.gemm(GEMM_NN, [(dQ, sa.Q.weight, dx)], flags=F_ACCUM)
         ops.gemm(GEMM_NN, [(dV, sa.V.weight, dx)], flags=F_ACCUM)
-        ops.gemm(GEMM_TN, [(dK, x, G[name + '.self_attention.K.weight'])], flags=F_ACCUM)
-        ops.gemm(GEMM_TN, [(dQ, x, G[name + '.self_attention.Q.weight'])], flags=F_ACCUM)
-        ops.gemm(GEMM_TN, [(dV, x, G[name + '.self_attention.V.weight'])], flags=F_ACCUM)
+        tn_grouped(ops, [(dK, x, G[name + '.self_attention.K.weight']), (dQ, x, G[name + '.self_attention.Q.weight']),
+                         (dV, x, G[name + '.self_attention.V.weight'])])
         nb = ops.rowln_bwd_nblk(B * T)
         part = _empty(ref, nb, 2, D2)
         ops.rowln_bwd(dx, out2, ln.weight, ln.bias, dout, stats=s['st_l'], pe=s['pe'], p1=s['pd'], site1=SITE_LSTM,
@@ -561,16 +571,18 @@ def dec_prepare(ops, dec, mems, sv, training, seed):
     Wq = dec.query_lstm.weight_ih
     gq = _empty(ref, B, 4 * Q)
     lin(ops, gfeat, Wq[:, plan.q_glob[0]:plan.q_glob[1]], gq)
-    Kc, Vc, Kp, Vp = [], [], [], []
-    for att, mem in zip(_att_modules(dec), mems):
-        Bm, P, _ = mem.shape
-        m2 = mem.reshape(Bm * P, H)
-        K = _empty(ref, Bm * P, H); V = _empty(ref, Bm * P, H)
-        ops.gemm(GEMM_NT, [(m2, att.K.weight, K), (m2, att.V.weight, V)])
-        kp = _empty(ref, Bm * P, Q); vp = _empty(ref, Bm * P, H)
-        ops.gemm(GEMM_NN, [(K, att.Q.weight, kp)])                     # K' = K W_Q
-        lin(ops, V, att.output_layer[0].weight, vp)                    # V' = V W_O^T
-        Kc.append(K); Vc.append(V); Kp.append(kp.view(Bm, P, Q)); Vp.append(vp.view(Bm, P, H))
+    atts = _att_modules(dec)
+    m2s = [mem.reshape(mem.shape[0] * mem.shape[1], H) for mem in mems]
+    Kc = [_empty(ref, m2.shape[0], H) for m2 in m2s]
+    Vc = [_empty(ref, m2.shape[0], H) for m2 in m2s]
+    kps = [_empty(ref, m2.shape[0], Q) for m2 in m2s]
+    vps = [_empty(ref, m2.shape[0], H) for m2 in m2s]
+    # both streams per launch: K = m W_K^T, V = m W_V^T;  K' = K W_Q;  V' = V W_O^T
+    gemm_bucketed(ops, GEMM_NT, [g for att, m2, K, V in zip(atts, m2s, Kc, Vc) for g in ((m2, att.K.weight, K), (m2, att.V.weight, V))])
+    gemm_bucketed(ops, GEMM_NN, [(K, att.Q.weight, kp) for att, K, kp in zip(atts, Kc, kps)])
+    gemm_bucketed(ops, GEMM_NT, [(V, att.output_layer[0].weight, vp) for att, V, vp in zip(atts, Vc, vps)])
+    Kp = [kp.view(mem.shape[0], mem.shape[1], Q) for kp, mem in zip(kps, mems)]
+    Vp = [vp.view(mem.shape[0], mem.shape[1], H) for vp, mem in zip(vps, mems)]
     s.update(plan=plan, gfeat=gfeat, gq=gq, K=Kc, V=Vc, Kp=Kp, Vp=Vp, mems=mems)
     return s
 
@@ -778,23 +790,22 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     dgfeat = _empty(ref, B, plan.G)
     gemm_nn_split(ops, dgq_sum, ql.weight_ih[:, plan.q_glob[0]:plan.q_glob[1]], dgfeat, ref)
     # ---- attention caches: K' = K W_Q, V' = V W_O^T, K = m W_K^T, V = m W_V^T
-    dmems = []
-    for i, att in enumerate(atts):
-        nm = att_names[i]
-        mem = s['mems'][i]
-        Bm, P, _ = mem.shape
-        m2 = mem.reshape(Bm * P, H)
-        dkp, dvp = dKp[i].view(Bm * P, Q), dVp[i].view(Bm * P, H)
-        K, Vv = s['K'][i], s['V'][i]
-        ops.gemm(GEMM_TN, [(K, dkp, G[nm + '.Q.weight'])], flags=F_ACCUM)                     # dW_Q = K^T dK'
-        ops.gemm(GEMM_TN, [(dvp, Vv, G[nm + '.output_layer.0.weight'])], flags=F_ACCUM)       # dW_O = dV'^T V
-        dK = _empty(ref, Bm * P, H); dV = _empty(ref, Bm * P, H)
-        ops.gemm(GEMM_NT, [(dkp, att.Q.weight, dK)])                                           # dK = dK' W_Q^T
-        ops.gemm(GEMM_NN, [(dvp, att.output_layer[0].weight, dV)])                             # dV = dV' W_O
-        ops.gemm(GEMM_TN, [(dK, m2, G[nm + '.K.weight'])], flags=F_ACCUM)
-        ops.gemm(GEMM_TN, [(dV, m2, G[nm + '.V.weight'])], flags=F_ACCUM)
-        dm = _empty(ref, Bm * P, H)
-        ops.gemm(GEMM_NN, [(dK, att.K.weight, dm)])
-        ops.gemm(GEMM_NN, [(dV, att.V.weight, dm)], flags=F_ACCUM)
-        dmems.append(dm.view(Bm, P, H))
+    m2s = [mem.reshape(mem.shape[0] * mem.shape[1], H) for mem in s['mems']]
+    dkps = [dKp[i].view(m2s[i].shape[0], Q) for i in range(ns)]
+    dvps = [dVp[i].view(m2s[i].shape[0], H) for i in range(ns)]
+    dKs = [_empty(ref, m2.shape[0], H) for m2 in m2s]
+    dVs = [_empty(ref, m2.shape[0], H) for m2 in m2s]
+    dms = [_empty(ref, m2.shape[0], H) for m2 in m2s]
+    R = range(ns)
+    # every product once for all streams: dW_Q = K^T dK', dW_O = dV'^T V | dK = dK' W_Q^T | dV = dV' W_O |
+    # dW_K = dK^T m, dW_V = dV^T m | dm = dK W_K (+ dV W_V)
+    tn_grouped(ops, [g for i in R for g in ((s['K'][i], dkps[i], G[att_names[i] + '.Q.weight']),
+                                            (dvps[i], s['V'][i], G[att_names[i] + '.output_layer.0.weight']))])
+    gemm_bucketed(ops, GEMM_NT, [(dkps[i], atts[i].Q.weight, dKs[i]) for i in R])
+    gemm_bucketed(ops, GEMM_NN, [(dvps[i], atts[i].output_layer[0].weight, dVs[i]) for i in R])
+    tn_grouped(ops, [g for i in R for g in ((dKs[i], m2s[i], G[att_names[i] + '.K.weight']),
+                                            (dVs[i], m2s[i], G[att_names[i] + '.V.weight']))])
+    gemm_bucketed(ops, GEMM_NN, [(dKs[i], atts[i].K.weight, dms[i]) for i in R])
+    gemm_bucketed(ops, GEMM_NN, [(dVs[i], atts[i].V.weight, dms[i]) for i in R], flags=F_ACCUM)
+    dmems = [dms[i].view(s['mems'][i].shape) for i in R]
     return dmems, dgfeat
