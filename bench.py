@@ -257,10 +257,16 @@ def main():
             from dlsg_amd.passbench import run_graph_attention_pass
             torch.cuda.empty_cache()
             pr = run_graph_attention_pass(net.ops, B=1024)
+            ptraffic = None
+            try:
+                ptraffic = (json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get('graph_attention_pass_1024') or {}).get(
+                    'hbm_bytes_per_launch')
+            except Exception:
+                ptraffic = None
             out['roofline_graph_attention_pass'] = {'kernel': 'o2v + latent_psl_fwd + sa_core_fwd + decatt_fwd x 26 (forward pass of '
                                                               'SURVEY.md 8d in isolation, 1024 clips)', 'bound': 'hbm',
                                                     'achieved': pr['achieved_GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                                    'frac': round(pr['achieved_GBps'] / PEAK_HBM_GBS, 4), 'traffic': None,
+                                                    'frac': round(pr['achieved_GBps'] / PEAK_HBM_GBS, 4), 'traffic': ptraffic,
                                                     'clips_per_s': pr['clips_per_s'], 'ms': pr['ms'], 'parts_ms': pr['parts_ms'],
                                                     'bytes_per_clip': pr['bytes_per_clip']}
         if world == 1 and not a.no_cpu_baseline:
