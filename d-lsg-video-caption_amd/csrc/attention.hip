@@ -774,6 +774,7 @@ extern "C" int dlsg_struct_size(int which) {
         case 14: return (int)sizeof(dlsg_sa_core_args);
         case 15: return (int)sizeof(dlsg_beam_select_args);
         case 16: return (int)sizeof(dlsg_gather_multi_args);
+        case 17: return (int)sizeof(dlsg_sa_core_bwd_args);
         default: return -1;
     }
 }

@@ -250,6 +250,125 @@ __global__ __launch_bounds__(SA_THREADS) void sa_core_fwd_kernel(const dlsg_sa_c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ self-attention core backward
+// Given d(out) (B,T,D) and the saved softmax weights w (B,T,T): dw = d(out) V^T on the matrix cores (same chunked
+// product as the forward's scores), softmax backward across the lanes of the C layout, then three column-parallel
+// VALU passes   dV = w^T d(out),   dK = scale * dlg Q,   dQ = scale * dlg^T K.
+// Replaces two batched GEMMs + softmax_bwd + two more batched GEMMs whose 26 x 26 x D products each launched
+// thousands of nearly empty 64 x 64 tiles.
+__global__ __launch_bounds__(SA_THREADS) void sa_core_bwd_kernel(const dlsg_sa_core_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float wl[32][33];            // w[i][j]
+    __shared__ float gl[32][33];            // scale * dlogits[i][j]
+    float* al = smem;                       // [32][SA_LD]  d(out) rows
+    float* vl = smem + 32 * SA_LD;          //              V rows
+    float* red = smem + 2 * 32 * SA_LD;     // [4][16][64]
+    const int b = blockIdx.x;
+    const int T = a.T, D = a.D;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t base = (int64_t)b * T * D;
+    const float* Gb = a.dout + base;
+    const float* Kb = a.K + base;
+    const float* Qb = a.Q + base;
+    const float* Vb = a.V + base;
+
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+    for (int c0 = 0; c0 < D; c0 += SA_CH) {
+        const int cw = min(SA_CH, D - c0);
+        __syncthreads();
+        for (int f = threadIdx.x; f < 32 * (SA_CH / 4); f += SA_THREADS) {
+            const int row = f / (SA_CH / 4), c4 = f % (SA_CH / 4);
+            f32x4 gv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (row < T && 4 * c4 < cw) {
+                gv = *reinterpret_cast<const f32x4*>(Gb + (int64_t)row * D + c0 + 4 * c4);
+                vv = *reinterpret_cast<const f32x4*>(Vb + (int64_t)row * D + c0 + 4 * c4);
+            }
+            *reinterpret_cast<f32x4*>(al + row * SA_LD + 4 * c4) = gv;
+            *reinterpret_cast<f32x4*>(vl + row * SA_LD + 4 * c4) = vv;
+        }
+        __syncthreads();
+        if (64 * w < cw) {
+            const float* ap = al + r * SA_LD + 64 * w + 32 * h;
+            const float* bp = vl + r * SA_LD + 64 * w + 32 * h;
+#pragma unroll
+            for (int s4 = 0; s4 < 8; ++s4) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 4 * s4);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 4 * s4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], b4[i], sacc, 0, 0, 0);
+            }
+        }
+    }
+    if (w >= 4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[((w - 4) * 16 + e) * 64 + lane] = sacc[e];
+    }
+    __syncthreads();
+    if (w < 4) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float t = sacc[e] + red[(w * 16 + e) * 64 + lane];
+            red[(w * 16 + e) * 64 + lane] = t;
+        }
+    }
+    __syncthreads();
+    // ---- softmax backward per row i (lanes of one half = j); wave w finishes registers 2w, 2w+1
+#pragma unroll
+    for (int ee = 0; ee < 2; ++ee) {
+        const int e = 2 * w + ee;
+        const float dw = red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane] + red[(2 * 16 + e) * 64 + lane] +
+                         red[(3 * 16 + e) * 64 + lane];
+        const int i = crow(e, h);
+        const float wv = (i < T && r < T) ? a.w[((int64_t)b * T + i) * T + r] : 0.f;
+        float dot = wv * dw;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+        wl[i][r] = wv;
+        gl[i][r] = wv * (dw - dot) * a.scale;
+    }
+    __syncthreads();
+    // ---- column-parallel passes: one thread per 4 columns
+    for (int c = threadIdx.x * 4; c < D; c += SA_THREADS * 4) {
+        f32x4 acc[32];
+        // dV[j] = sum_i w[i][j] d(out)[i]
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < T; ++i) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(Gb + (int64_t)i * D + c);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] += wl[i][j] * x;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < T) *reinterpret_cast<f32x4*>(a.dV + base + (int64_t)j * D + c) = acc[j];
+        // dK[i] = sum_j g[i][j] Q[j]
+#pragma unroll
+        for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < T; ++j) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(Qb + (int64_t)j * D + c);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] += gl[i][j] * x;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            if (i < T) *reinterpret_cast<f32x4*>(a.dK + base + (int64_t)i * D + c) = acc[i];
+        // dQ[j] = sum_i g[i][j] K[i]
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < T; ++i) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(Kb + (int64_t)i * D + c);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] += gl[i][j] * x;
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j)
+            if (j < T) *reinterpret_cast<f32x4*>(a.dQ + base + (int64_t)j * D + c) = acc[j];
+    }
+}
+
 }  // namespace
 
 extern "C" int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream) {
@@ -281,6 +400,23 @@ extern "C" int dlsg_sa_core_fwd(const dlsg_sa_core_args* a, void* stream) {
                                   SA_LDS_FLOATS * 4);
     });
     hipLaunchKernelGGL(sa_core_fwd_kernel, dim3(a->B), dim3(SA_THREADS), SA_LDS_FLOATS * 4, reinterpret_cast<hipStream_t>(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+extern "C" int dlsg_sa_core_bwd(const dlsg_sa_core_bwd_args* a, void* stream) {
+    if (!a || a->T < 1 || a->T > 32 || a->D < 64 || a->D % 64) return DLSG_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a->K) | reinterpret_cast<uintptr_t>(a->Q) | reinterpret_cast<uintptr_t>(a->V) |
+         reinterpret_cast<uintptr_t>(a->dout) | reinterpret_cast<uintptr_t>(a->dK) | reinterpret_cast<uintptr_t>(a->dQ) |
+         reinterpret_cast<uintptr_t>(a->dV)) & 15)
+        return DLSG_EINVAL;
+    if (a->B == 0) return DLSG_OK;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_core_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  SA_LDS_FLOATS * 4);
+    });
+    hipLaunchKernelGGL(sa_core_bwd_kernel, dim3(a->B), dim3(SA_THREADS), SA_LDS_FLOATS * 4, reinterpret_cast<hipStream_t>(stream), *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -469,15 +469,18 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
         datt = _empty(ref, B * T, D2)
         ops.gemm(GEMM_NN, [(dso, sa.output_layer[0].weight, datt)])
         datt3 = datt.view(B, T, D2)
-        dw = _empty(ref, B, T, T)
-        ops.gemm(GEMM_NT, [(datt3, Vp.view(B, T, D2), dw)])
-        dV = _empty(ref, B * T, D2)
-        ops.gemm(GEMM_TN, [(w, datt3, dV.view(B, T, D2))])
-        dlg = _empty(ref, B, T, T)
-        ops.softmax_bwd(w, dw, dlg, B * T, T, 1)
-        dK = _empty(ref, B * T, D2); dQ = _empty(ref, B * T, D2)
-        ops.gemm(GEMM_NN, [(dlg, Qp.view(B, T, D2), dK.view(B, T, D2))], alpha=scale)
-        ops.gemm(GEMM_TN, [(dlg, Kp.view(B, T, D2), dQ.view(B, T, D2))], alpha=scale)
+        dK = _empty(ref, B * T, D2); dQ = _empty(ref, B * T, D2); dV = _empty(ref, B * T, D2)
+        if ops.sa_core_supported(T, D2):
+            ops.sa_core_bwd(w, Kp.view(B, T, D2), Qp.view(B, T, D2), Vp.view(B, T, D2), datt3, dK.view(B, T, D2),
+                            dQ.view(B, T, D2), dV.view(B, T, D2), scale)
+        else:
+            dw = _empty(ref, B, T, T)
+            ops.gemm(GEMM_NT, [(datt3, Vp.view(B, T, D2), dw)])
+            ops.gemm(GEMM_TN, [(w, datt3, dV.view(B, T, D2))])
+            dlg = _empty(ref, B, T, T)
+            ops.softmax_bwd(w, dw, dlg, B * T, T, 1)
+            ops.gemm(GEMM_NN, [(dlg, Qp.view(B, T, D2), dK.view(B, T, D2))], alpha=scale)
+            ops.gemm(GEMM_TN, [(dlg, Kp.view(B, T, D2), dQ.view(B, T, D2))], alpha=scale)
         dx = _empty(ref, B * T, D2)
         ops.gemm(GEMM_NN, [(dK, sa.K.weight, dx)])
         ops.gemm(GEMM_NN, [(dQ, sa.Q.weight, dx)], flags=F_ACCUM)

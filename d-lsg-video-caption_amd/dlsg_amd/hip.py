@@ -80,6 +80,11 @@ class GatherMultiArgs(C.Structure):
                 ('count', i32)]
 
 
+class SaCoreBwdArgs(C.Structure):
+    _fields_ = [(n, c_f32p) for n in ('w', 'K', 'Q', 'V', 'dout', 'dK', 'dQ', 'dV')] + [('B', i32), ('T', i32), ('D', i32),
+                                                                                          ('scale', f32)]
+
+
 class DecAttArgs(C.Structure):
     _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
                 ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
@@ -148,7 +153,8 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
-           'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi']
+           'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
+           'dlsg_sa_core_bwd']
 
 
 def load_library(path=LIB_PATH):
@@ -202,6 +208,7 @@ def load_library(path=LIB_PATH):
         'dlsg_sa_core_fwd': [P(SaCoreArgs), vp],
         'dlsg_beam_select': [P(BeamSelectArgs), vp],
         'dlsg_gather_rows_multi': [P(GatherMultiArgs), vp],
+        'dlsg_sa_core_bwd': [P(SaCoreBwdArgs), vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -213,7 +220,7 @@ def load_library(path=LIB_PATH):
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
-           SaCoreArgs, BeamSelectArgs, GatherMultiArgs]
+           SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs]
 
 
 def _p(t):
@@ -495,6 +502,16 @@ class HipOps(object):
         a.K, a.Q, a.V, a.mask, a.w, a.out = _p(K), _p(Q), _p(V), _p(mask), _p(w), _p(out)
         a.B, a.T, a.D, a.scale = B, T, D, scale
         self._check(self.lib.dlsg_sa_core_fwd(C.byref(a), self._stream()), 'dlsg_sa_core_fwd')
+
+    def sa_core_bwd(self, w, K, Q, V, dout, dK, dQ, dV, scale):
+        """backward of sa_core_fwd: dout (B,T,D) + saved w (B,T,T) -> dK, dQ, dV (B,T,D); one launch."""
+        B, T, D = K.shape
+        for t in (w, K, Q, V, dout, dK, dQ, dV):
+            _chkc(t)
+        a = SaCoreBwdArgs()
+        a.w, a.K, a.Q, a.V, a.dout, a.dK, a.dQ, a.dV = _p(w), _p(K), _p(Q), _p(V), _p(dout), _p(dK), _p(dQ), _p(dV)
+        a.B, a.T, a.D, a.scale = B, T, D, scale
+        self._check(self.lib.dlsg_sa_core_bwd(C.byref(a), self._stream()), 'dlsg_sa_core_bwd')
 
     # ------------------------------------------------------------------ decoder attention
     def _decatt_args(self, Kp, Vp, q, c, alpha, scale):

@@ -20,7 +20,7 @@ int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
  * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args, 15 beam_select_args,
- * 16 gather_multi_args): lets a binding verify its
+ * 16 gather_multi_args, 17 sa_core_bwd_args): lets a binding verify its
  * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
@@ -169,6 +169,13 @@ typedef struct {
     int32_t B, T, D; float scale;
 } dlsg_sa_core_args;
 int dlsg_sa_core_fwd(const dlsg_sa_core_args* a, void* stream);
+/* backward of the core: dout (B,T,D) and the saved w -> dK, dQ, dV (B,T,D), all dense (row stride D). */
+typedef struct {
+    const float* w; const float* K; const float* Q; const float* V; const float* dout;
+    float* dK; float* dQ; float* dV;
+    int32_t B, T, D; float scale;
+} dlsg_sa_core_bwd_args;
+int dlsg_sa_core_bwd(const dlsg_sa_core_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------- softmax along the middle axis of (outer, n, inner)
  * LatentPSL softmax over frames (sublayer.py:192: outer=B, n=T, inner=P), SelfAttention row softmax

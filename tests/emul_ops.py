@@ -267,6 +267,13 @@ class EmulOps(object):
         w.copy_(torch.softmax(lg, 2))
         out.copy_(w @ V)
 
+    def sa_core_bwd(self, w, K, Q, V, dout, dK, dQ, dV, scale):
+        dw = dout @ V.transpose(1, 2)
+        dV.copy_(w.transpose(1, 2) @ dout)
+        dlg = w * (dw - (w * dw).sum(2, keepdim=True))
+        dK.copy_(scale * (dlg @ Q))
+        dQ.copy_(scale * (dlg.transpose(1, 2) @ K))
+
     # ------------------------------------------------------------------ decoder attention
     def decatt_fwd(self, Kp, Vp, q, c, alpha, scale):
         self._count('decatt_fwd')

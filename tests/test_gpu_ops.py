@@ -375,6 +375,22 @@ def test_self_attention_core_fused_forward(hip, dims, masked):
     both(hip, build, run, ['w', 'out'], tol=3e-5, name='sa_core %s' % (dims,))
 
 
+@pytest.mark.parametrize('dims', [(3, 26, 128), (64, 26, 2048), (2, 32, 576), (2, 7, 64), (4, 20, 1024)])
+def test_self_attention_core_fused_backward(hip, dims):
+    B, T, D = dims
+
+    def build(g):
+        return dict(K=rnd(g, B, T, D, scale=0.3), Q=rnd(g, B, T, D, scale=0.3), V=rnd(g, B, T, D), dout=rnd(g, B, T, D),
+                    w=torch.zeros(B, T, T), out=torch.zeros(B, T, D), dK=torch.zeros(B, T, D), dQ=torch.zeros(B, T, D),
+                    dV=torch.zeros(B, T, D))
+
+    def run(ops, t):
+        sc = 1.0 / math.sqrt(D / 8.0)
+        ops.sa_core_fwd(t['K'], t['Q'], t['V'], t['w'], t['out'], sc)
+        ops.sa_core_bwd(t['w'], t['K'], t['Q'], t['V'], t['dout'], t['dK'], t['dQ'], t['dV'], sc)
+    both(hip, build, run, ['dK', 'dQ', 'dV'], tol=3e-5, name='sa_core bwd %s' % (dims,))
+
+
 def test_o2v_online_softmax_rescale_branch(hip):
     """Force the running max to jump at a late tile (guide 5.4 rule 26): one object aligned with one frame."""
     B, T, O, H = 2, 26, 16, 64
