@@ -611,6 +611,9 @@ class Trainer(object):
                 self.use_graphs, self._graphs = False, None
                 return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
         st = self._static
+        if (frames.shape, regions.shape, captions.shape) != (st['frames'].shape, st['regions'].shape, st['captions'].shape):
+            # a batch of another shape (the short last batch of an epoch): the captured graphs are for one shape only
+            return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
         for k, src in (('frames', frames), ('regions', regions), ('captions', captions), ('lens', cap_lens)):
             if src.data_ptr() != st[k].data_ptr():
                 st[k].copy_(src, non_blocking=True)
