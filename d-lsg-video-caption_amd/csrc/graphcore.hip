@@ -369,6 +369,138 @@ __global__ __launch_bounds__(SA_THREADS) void sa_core_bwd_kernel(const dlsg_sa_c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LatentPSL backward
+// One workgroup per clip, P <= 8 proposals.  d(out) (P x H) -> LayerNorm + tanh backward -> du (LDS) ->
+// dadj = ov du^T (wave dot products) -> softmax backward over the frames -> dov = adj du + dlg theta (written once),
+// per-clip partials of dtheta = dlg^T ov and of the LayerNorm's dgamma | dbeta.
+// Replaces rowln_bwd + two batched GEMMs + softmax_bwd + two more GEMMs (six launches on 26 x 8 tiles).
+constexpr int PB_MAXP = 8;
+__global__ __launch_bounds__(PSL_THREADS) void latent_psl_bwd_kernel(const dlsg_latent_psl_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float adjl[PSL_MAXT][PB_MAXP + 1];
+    __shared__ float dlgl[PSL_MAXT][PB_MAXP + 1];      // dadj, then dlogits
+    __shared__ float red[16 * 16];
+    const int b = blockIdx.x;
+    const int T = a.T, P = a.P, H = a.H;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
+    float* ovl = smem;                       // [T][H]
+    float* dul = smem + T * H;               // [PB_MAXP][H]
+    {
+        const float* src = a.ov + (int64_t)b * T * H;
+        for (int i = threadIdx.x * 4; i < T * H; i += PSL_THREADS * 4)
+            *reinterpret_cast<f32x4*>(ovl + i) = *reinterpret_cast<const f32x4*>(src + i);
+        for (int i = threadIdx.x; i < T * P; i += PSL_THREADS) adjl[i / P][i % P] = a.adj[(int64_t)b * T * P + i];
+    }
+    // ---- LayerNorm (+ dropout, tanh) backward of the P rows, statistics of all rows reduced together
+    float yv[PB_MAXP][2], gv[PB_MAXP][2], xh[PB_MAXP][2];
+    float sums[2 * PB_MAXP];
+#pragma unroll
+    for (int i = 0; i < 2 * PB_MAXP; ++i) sums[i] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int h = threadIdx.x + c * PSL_THREADS;
+        float dgam = 0.f, dbet = 0.f;
+#pragma unroll
+        for (int p = 0; p < PB_MAXP; ++p) {
+            yv[p][c] = 0.f; gv[p][c] = 0.f; xh[p][c] = 0.f;
+            if (p < P && h < H) {
+                const int64_t row = (int64_t)b * P + p;
+                const float y = tanhf(a.u[row * H + h]);
+                const float mean = a.stats[2 * row], rstd = a.stats[2 * row + 1];
+                float g = a.dout[row * H + h];
+                if (a.p > 0.f) g *= drop_scale(seed, a.site, (uint64_t)row * H + h, a.p);
+                const float x = (y - mean) * rstd;
+                dgam += g * x;
+                dbet += g;
+                const float gx = g * a.gamma[h];
+                yv[p][c] = y; gv[p][c] = gx; xh[p][c] = x;
+                sums[2 * p] += gx;
+                sums[2 * p + 1] += gx * x;
+            }
+        }
+        if (h < H) {
+            a.part[(int64_t)b * 2 * H + h] = dgam;
+            a.part[(int64_t)b * 2 * H + H + h] = dbet;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * PB_MAXP; ++i) sums[i] = wave_sum(sums[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 2 * PB_MAXP; ++i) red[16 * i + w] = sums[i];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PB_MAXP; ++p) {
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { m1 += red[16 * (2 * p) + k]; m2 += red[16 * (2 * p + 1) + k]; }
+        m1 /= H; m2 /= H;
+        const float rstd = p < P ? a.stats[2 * ((int64_t)b * P + p) + 1] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int h = threadIdx.x + c * PSL_THREADS;
+            if (h < H) dul[p * H + h] = (p < P) ? rstd * (gv[p][c] - m1 - xh[p][c] * m2) * (1.f - yv[p][c] * yv[p][c]) : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- dadj[t][p] = ov[t] . du[p]: a wave keeps du[p] in registers and walks a slice of the frames
+    {
+        const int nw = P <= 16 ? 16 / P : 1;
+        for (int task = w; task < P * nw; task += PSL_THREADS / 64) {
+            const int p = task / nw, part = task % nw;
+            const int t0 = (T * part) / nw, t1 = (T * (part + 1)) / nw;
+            for (int t = t0; t < t1; ++t) {
+                float acc = 0.f;
+                for (int j = lane * 4; j < H; j += 256) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(ovl + t * H + j);
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(dul + p * H + j);
+                    acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) dlgl[t][p] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- softmax backward over the frames, per proposal
+    if (threadIdx.x < P) {
+        const int p = threadIdx.x;
+        float dot = 0.f;
+        for (int t = 0; t < T; ++t) dot += adjl[t][p] * dlgl[t][p];
+        for (int t = 0; t < T; ++t) dlgl[t][p] = adjl[t][p] * (dlgl[t][p] - dot);
+    }
+    __syncthreads();
+    // ---- dov[t][h] = sum_p adj[t][p] du[p][h] + dlg[t][p] theta[p][h];  dtheta[p][h] = sum_t dlg[t][p] ov[t][h]
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int h = threadIdx.x + c * PSL_THREADS;
+        if (h >= H) continue;
+        float du[PB_MAXP], th[PB_MAXP], dth[PB_MAXP];
+#pragma unroll
+        for (int p = 0; p < PB_MAXP; ++p) {
+            du[p] = p < P ? dul[p * H + h] : 0.f;
+            th[p] = p < P ? a.theta[(int64_t)p * H + h] : 0.f;
+            dth[p] = 0.f;
+        }
+        for (int t = 0; t < T; ++t) {
+            const float x = ovl[t * H + h];
+            float o = 0.f;
+#pragma unroll
+            for (int p = 0; p < PB_MAXP; ++p) {
+                const float ad = p < P ? adjl[t][p] : 0.f, dl = p < P ? dlgl[t][p] : 0.f;
+                o += ad * du[p] + dl * th[p];
+                dth[p] += dl * x;
+            }
+            a.dov[((int64_t)b * T + t) * H + h] = o;
+        }
+#pragma unroll
+        for (int p = 0; p < PB_MAXP; ++p)
+            if (p < P) a.dtheta_part[((int64_t)b * P + p) * H + h] = dth[p];
+    }
+}
+
 }  // namespace
 
 extern "C" int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream) {
@@ -417,6 +549,23 @@ extern "C" int dlsg_sa_core_bwd(const dlsg_sa_core_bwd_args* a, void* stream) {
                                   SA_LDS_FLOATS * 4);
     });
     hipLaunchKernelGGL(sa_core_bwd_kernel, dim3(a->B), dim3(SA_THREADS), SA_LDS_FLOATS * 4, reinterpret_cast<hipStream_t>(stream), *a);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+extern "C" int dlsg_latent_psl_bwd(const dlsg_latent_psl_bwd_args* a, void* stream) {
+    if (!a || a->T < 1 || a->T > PSL_MAXT || a->P < 1 || a->P > PB_MAXP || a->H < 4 || a->H > 2 * PSL_THREADS || a->H % 4)
+        return DLSG_EINVAL;
+    if (reinterpret_cast<uintptr_t>(a->ov) & 15) return DLSG_EINVAL;
+    if (a->B == 0) return DLSG_OK;
+    const int lds_bytes = (a->T + PB_MAXP) * a->H * 4;
+    if (lds_bytes > 150 * 1024) return DLSG_EINVAL;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&latent_psl_bwd_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    });
+    hipLaunchKernelGGL(latent_psl_bwd_kernel, dim3(a->B), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

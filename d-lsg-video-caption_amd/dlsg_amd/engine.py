@@ -282,22 +282,30 @@ def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed):
         dov = dpsl.reshape(B * T, H)
     else:
         ln = m.v2l_layer.out_norm[1]
-        nb = ops.rowln_bwd_nblk(B * P)
-        part = _empty(ref, nb, 2, H)
-        du = _empty(ref, B * P, H)
-        ops.rowln_bwd(dpsl.reshape(B * P, H), s['u'], ln.weight, ln.bias, du, stats=s['st_p'], pre_tanh=1, p1=s['pd'],
-                      site1=s['psl_site'], seed=seed, dgb_part=part)
-        ln_grads(ops, part, G, name + '.v2l_layer.out_norm.1', H)
         ov, adj, theta = s['ov'], s['adj'], m.v2l_layer.theta
-        du3 = du.view(B, P, H)
-        dadj = _empty(ref, B, T, P)
-        ops.gemm(GEMM_NT, [(ov.view(B, T, H), du3, dadj)])
         dov = _empty(ref, B * T, H)
-        ops.gemm(GEMM_NN, [(adj, du3, dov.view(B, T, H))])
-        dlg = _empty(ref, B, T, P)
-        ops.softmax_bwd(adj, dadj, dlg, B, T, P)
-        ops.gemm(GEMM_NN, [(dlg, theta.unsqueeze(0).expand(B, P, H), dov.view(B, T, H))], flags=F_ACCUM)
-        ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[name + '.v2l_layer.theta'])], flags=F_ACCUM)
+        if ops.latent_psl_bwd_supported(T, P, H):
+            part = _empty(ref, B, 2, H)
+            dth = _empty(ref, B, P * H)
+            ops.latent_psl_bwd(dpsl.reshape(B * P, H), s['u'], s['st_p'], ln.weight, adj, ov.view(B, T, H), theta, dov,
+                               dth.view(B, P, H), part, p=s['pd'], site=s['psl_site'], seed=seed)
+            ln_grads(ops, part, G, name + '.v2l_layer.out_norm.1', H)
+            ops.colsum(dth, G[name + '.v2l_layer.theta'].view(P * H), accum=True)
+        else:
+            nb = ops.rowln_bwd_nblk(B * P)
+            part = _empty(ref, nb, 2, H)
+            du = _empty(ref, B * P, H)
+            ops.rowln_bwd(dpsl.reshape(B * P, H), s['u'], ln.weight, ln.bias, du, stats=s['st_p'], pre_tanh=1, p1=s['pd'],
+                          site1=s['psl_site'], seed=seed, dgb_part=part)
+            ln_grads(ops, part, G, name + '.v2l_layer.out_norm.1', H)
+            du3 = du.view(B, P, H)
+            dadj = _empty(ref, B, T, P)
+            ops.gemm(GEMM_NT, [(ov.view(B, T, H), du3, dadj)])
+            ops.gemm(GEMM_NN, [(adj, du3, dov.view(B, T, H))])
+            dlg = _empty(ref, B, T, P)
+            ops.softmax_bwd(adj, dadj, dlg, B, T, P)
+            ops.gemm(GEMM_NN, [(dlg, theta.unsqueeze(0).expand(B, P, H), dov.view(B, T, H))], flags=F_ACCUM)
+            ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[name + '.v2l_layer.theta'])], flags=F_ACCUM)
     if O >= 5:
         NO = T * O
         lnv = m.obj_visual_norm[1]

@@ -85,6 +85,11 @@ class SaCoreBwdArgs(C.Structure):
                                                                                           ('scale', f32)]
 
 
+class LatentPslBwdArgs(C.Structure):
+    _fields_ = [(n, c_f32p) for n in ('dout', 'u', 'stats', 'gamma', 'adj', 'ov', 'theta', 'dov', 'dtheta_part', 'part')] + \
+               [('B', i32), ('T', i32), ('P', i32), ('H', i32), ('p', f32), ('site', u32), ('seed', u64), ('seed_ptr', c_f32p)]
+
+
 class DecAttArgs(C.Structure):
     _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
                 ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
@@ -154,7 +159,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
-           'dlsg_sa_core_bwd']
+           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd']
 
 
 def load_library(path=LIB_PATH):
@@ -209,6 +214,7 @@ def load_library(path=LIB_PATH):
         'dlsg_beam_select': [P(BeamSelectArgs), vp],
         'dlsg_gather_rows_multi': [P(GatherMultiArgs), vp],
         'dlsg_sa_core_bwd': [P(SaCoreBwdArgs), vp],
+        'dlsg_latent_psl_bwd': [P(LatentPslBwdArgs), vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -220,7 +226,8 @@ def load_library(path=LIB_PATH):
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
-           SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs]
+           SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs,
+           LatentPslBwdArgs]
 
 
 def _p(t):
@@ -489,6 +496,22 @@ class HipOps(object):
         a.B, a.T, a.P, a.H, a.p, a.site, a.eps = B, T, P, H, p, site, eps
         a.seed, a.seed_ptr = _seed(seed)
         self._check(self.lib.dlsg_latent_psl_fwd(C.byref(a), self._stream()), 'dlsg_latent_psl_fwd')
+
+    def latent_psl_bwd_supported(self, T, P, H):
+        return T <= 32 and P <= 8 and H % 4 == 0 and H <= 2048 and (T + 8) * H * 4 <= 150 * 1024
+
+    def latent_psl_bwd(self, dout, u, stats, gamma, adj, ov, theta, dov, dtheta_part, part, p=0.0, site=0, seed=0):
+        """backward of latent_psl_fwd: dout (B*P,H) -> dov (B*T,H), dtheta_part (B,P,H), part (B,2,H); one launch."""
+        B, T, H = ov.shape
+        P = theta.shape[0]
+        for t in (dout, u, stats, adj, ov, theta, dov, dtheta_part, part):
+            _chkc(t)
+        a = LatentPslBwdArgs()
+        a.dout, a.u, a.stats, a.gamma, a.adj, a.ov, a.theta = _p(dout), _p(u), _p(stats), _p(gamma), _p(adj), _p(ov), _p(theta)
+        a.dov, a.dtheta_part, a.part = _p(dov), _p(dtheta_part), _p(part)
+        a.B, a.T, a.P, a.H, a.p, a.site = B, T, P, H, p, site
+        a.seed, a.seed_ptr = _seed(seed)
+        self._check(self.lib.dlsg_latent_psl_bwd(C.byref(a), self._stream()), 'dlsg_latent_psl_bwd')
 
     def sa_core_supported(self, T, D):
         return T <= 32 and D % 64 == 0

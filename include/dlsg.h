@@ -20,7 +20,7 @@ int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
  * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args, 15 beam_select_args,
- * 16 gather_multi_args, 17 sa_core_bwd_args): lets a binding verify its
+ * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args): lets a binding verify its
  * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
@@ -159,6 +159,18 @@ typedef struct {
     uint64_t seed; const uint64_t* seed_ptr;
 } dlsg_latent_psl_args;
 int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream);
+/* backward (P <= 8, (T+8)*H*4 <= 150 KB of LDS): dout (B*P,H) -> dov (B*T,H) written, dtheta_part (B,P,H) and
+ * part (B,2,H) = per-clip partials of dtheta and of out_norm's dgamma | dbeta (fold with dlsg_colsum / dlsg_colsum2).
+ * u, stats, adj are the forward's outputs; p/site/seed the forward's dropout. */
+typedef struct {
+    const float* dout; const float* u; const float* stats; const float* gamma;
+    const float* adj; const float* ov; const float* theta;
+    float* dov; float* dtheta_part; float* part;
+    int32_t B, T, P, H;
+    float p; uint32_t site;
+    uint64_t seed; const uint64_t* seed_ptr;
+} dlsg_latent_psl_bwd_args;
+int dlsg_latent_psl_bwd(const dlsg_latent_psl_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------- SelfAttention 26x26 core (sublayer.py:69-78), one launch
  * w (B,T,T) = softmax_j(K_i . Q_j * scale) (optional mask (B,T,T): mask <= 0 -> -9e15 as sublayer.py:70-72);

@@ -257,6 +257,22 @@ class EmulOps(object):
         u.copy_((adj.transpose(1, 2) @ ov).reshape(B * P, H))
         self.rowln_fwd(u, gamma, beta, out, stats, pre_tanh=1, p1=p, site1=site, seed=seed, eps=eps)
 
+    def latent_psl_bwd_supported(self, T, P, H):
+        return self.fused_supported and T <= 32 and P <= 8 and H % 4 == 0
+
+    def latent_psl_bwd(self, dout, u, stats, gamma, adj, ov, theta, dov, dtheta_part, part, p=0.0, site=0, seed=0):
+        B, T, H = ov.shape
+        P = theta.shape[0]
+        du = torch.zeros(B * P, H)
+        full = torch.zeros(B * P, 2, H)
+        self.rowln_bwd(dout, u, gamma, None, du, stats=stats, pre_tanh=1, p1=p, site1=site, seed=seed, dgb_part=full)
+        part.copy_(full.view(B, P, 2, H).sum(1))
+        du3 = du.view(B, P, H)
+        dadj = ov @ du3.transpose(1, 2)                               # (B,T,P)
+        dlg = adj * (dadj - (adj * dadj).sum(1, keepdim=True))
+        dov.copy_((adj @ du3 + dlg @ theta).reshape(B * T, H))
+        dtheta_part.copy_(dlg.transpose(1, 2) @ ov)
+
     def sa_core_supported(self, T, D):
         return self.fused_supported and T <= 32 and D % 64 == 0
 

@@ -375,6 +375,22 @@ def test_self_attention_core_fused_forward(hip, dims, masked):
     both(hip, build, run, ['w', 'out'], tol=3e-5, name='sa_core %s' % (dims,))
 
 
+@pytest.mark.parametrize('dims', [(3, 26, 8, 64), (64, 26, 8, 1024), (2, 26, 5, 1024), (2, 32, 8, 96), (1, 7, 3, 2048), (5, 20, 1, 512)])
+def test_latent_psl_fused_backward(hip, dims):
+    B, T, P, H = dims
+
+    def build(g):
+        return dict(ov=rnd(g, B, T, H), th=rnd(g, P, H, scale=0.1), ga=1 + 0.2 * rnd(g, H), be=0.2 * rnd(g, H),
+                    adj=torch.zeros(B, T, P), u=torch.zeros(B * P, H), out=torch.zeros(B * P, H), st=torch.zeros(B * P, 2),
+                    dout=rnd(g, B * P, H), dov=torch.zeros(B * T, H), dth=torch.zeros(B, P, H), part=torch.zeros(B, 2, H))
+
+    def run(ops, t):
+        ops.latent_psl_fwd(t['ov'], t['th'], t['ga'], t['be'], t['adj'], t['u'], t['out'], t['st'], p=0.3, site=77, seed=9)
+        ops.latent_psl_bwd(t['dout'], t['u'], t['st'], t['ga'], t['adj'], t['ov'], t['th'], t['dov'], t['dth'], t['part'], p=0.3,
+                           site=77, seed=9)
+    both(hip, build, run, ['dov', 'dth', 'part'], tol=3e-5, name='latent_psl bwd %s' % (dims,))
+
+
 @pytest.mark.parametrize('dims', [(3, 26, 128), (64, 26, 2048), (2, 32, 576), (2, 7, 64), (4, 20, 1024)])
 def test_self_attention_core_fused_backward(hip, dims):
     B, T, D = dims
