@@ -327,3 +327,30 @@ def test_hipgraph_greedy_inference_ids_bit_exact():
     ids2 = gg(frames.flip(0).contiguous(), regions.flip(0).contiguous())        # new inputs through the static buffers
     torch.cuda.synchronize()
     assert np.array_equal(ids2.cpu().numpy(), g['greedy_ids'][::-1])
+
+
+def test_full_size_batch64_clips_are_independent_and_deterministic():
+    """Size-independent properties at the bench configuration (MSVD-shaped, batch 64): the forward is deterministic
+    (bit-identical on a second run) and a clip's logits / greedy ids do not depend on which other clips share its batch
+    (same clip alone, in a batch of 3, in the batch of 64): catches any cross-clip indexing at full size."""
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    args = dlsg_amd.msvd_shaped()
+    vocab = dlsg_amd.make_vocab(1000)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab).eval()
+    net.load_state_dict(synth_state_dict(net.state_dict(), 3))
+    net = net.cuda()
+    frames, regions, caps, lens = synth_batch(args, 1000, 64, 5)
+    frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
+    with torch.no_grad():
+        full = net(frames, regions, caps, 26, 1.0)[0]
+        again = net(frames, regions, caps, 26, 1.0)[0]
+        assert torch.equal(full, again)
+        net.update_beam_size(1)
+        ids_full = net(frames, regions, None)[0]
+        for sel in ([0], [63], [5, 17, 40]):
+            idx = torch.tensor(sel, device='cuda')
+            part = net(frames[idx].contiguous(), regions[idx].contiguous(), caps[idx].contiguous(), 26, 1.0)[0]
+            assert (part - full[idx]).abs().max().item() <= 5e-5, sel
+            ids_part = net(frames[idx].contiguous(), regions[idx].contiguous(), None)[0]
+            assert torch.equal(ids_part, ids_full[idx]), sel
