@@ -354,3 +354,34 @@ def test_full_size_batch64_clips_are_independent_and_deterministic():
             assert (part - full[idx]).abs().max().item() <= 5e-5, sel
             ids_part = net(frames[idx].contiguous(), regions[idx].contiguous(), None)[0]
             assert torch.equal(ids_part, ids_full[idx]), sel
+
+
+@pytest.mark.parametrize('mode', ['fp32', 'x3_bwd'])
+def test_full_size_gradient_is_token_weighted_mean_of_shard_gradients(mode):
+    """Property at the bench configuration (batch 64, MSVD-shaped, dropout off): the ragged CrossEntropy is a mean over
+    sum(cap_lens) rows, so grad(batch) = (n_A grad(A) + n_B grad(B)) / (n_A + n_B) for any split of the batch.  Exercises
+    every backward kernel at full size with no oracle in the loop."""
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    args = dlsg_amd.msvd_shaped()
+    vocab = dlsg_amd.make_vocab(1000)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab).eval()
+    net.load_state_dict(synth_state_dict(net.state_dict(), 4))
+    net = net.cuda()
+    net.gemm_precision = mode
+    frames, regions, caps, lens = synth_batch(args, 1000, 64, 6)
+    frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
+    tr = dlsg_amd.Trainer(net, lr=0.0)
+
+    def grad(sl):
+        loss = tr.step(frames[sl].contiguous(), regions[sl].contiguous(), caps[sl].contiguous(), lens[sl], 1.0)
+        return float(loss), net._gflat.clone(), int(lens[sl].clamp(max=26).sum())
+    lf, gf, nf = grad(slice(0, 64))
+    la, ga, na = grad(slice(0, 23))
+    lb, gb, nb = grad(slice(23, 64))
+    assert na + nb == nf
+    assert abs(lf - (na * la + nb * lb) / nf) <= 2e-5
+    want = (na * ga + nb * gb) / nf
+    scale = gf.abs().max().item()
+    tol = 2e-5 if mode == 'fp32' else 3e-4
+    assert (gf - want).abs().max().item() <= tol * scale + 1e-7, ((gf - want).abs().max().item(), scale)
