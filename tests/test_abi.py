@@ -45,3 +45,18 @@ def test_product_path_fails_loudly_without_gpu():
     net = dlsg_amd.CapGnnModel(small_args(), dlsg_amd.make_vocab(50))
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 26, 112), torch.zeros(1, 26, 16, 32), torch.zeros(1, 26, dtype=torch.long))
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md is the reference-side binding guide: every symbol include/dlsg.h declares must appear in it."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, 'include', 'dlsg.h')).read()
+    doc = open(os.path.join(root, 'INTEGRATION.md')).read()
+    names = sorted(set(re.findall(r'\b(dlsg_[a-z0-9_]+)\s*\(', header)))
+    missing = []
+    for n in names:
+        stem = re.sub(r'_(fwd|bwd)$', '', n)
+        if n not in doc and (stem + '_fwd/bwd') not in doc:
+            missing.append(n)
+    assert not missing, missing
