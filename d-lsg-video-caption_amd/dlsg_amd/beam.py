@@ -20,6 +20,15 @@ def _expand_rows(t, k):
 
 @torch.no_grad()
 def beam_infer(model, visual_feats, region_feats):
+    """Beam search as the reference runs it (early exit tested every 4th step on the host)."""
+    return beam_finish(model, *beam_device(model, visual_feats, region_feats, early_exit=True))
+
+
+@torch.no_grad()
+def beam_device(model, visual_feats, region_feats, early_exit=True):
+    """Everything of the search that runs on the device.  early_exit=False: no host synchronisation at all (all L steps
+    are launched; beam_finish cuts the result to the step the reference would have stopped at) -- this form is what
+    BeamGraph captures into a hipGraph.  Returns the tensors beam_finish needs."""
     model.flatten_parameters_()
     ops, dec = model.ops, model.decoder
     ops.extra_flags = model._gemm_flags(False)
@@ -79,15 +88,11 @@ def beam_infer(model, visual_feats, region_feats):
     CHECK = 4
     step(0, start)
     ops.beam_select(s['LOGITS'][0], start, lps[0], preds[0], lps[1], backs[0], rows, k, end, first=True, ended_count=ended[0:1])
-    n_steps, done = L, 1
-    if k == 1 and int(ended[0]) == R:
-        return preds[0].view(B, k), sv['dec_gsrc'][0], sv['dec_gsrc'][-1], []
+    done = 1
     for t in range(1, L):
-        if t % CHECK == 0:
+        if early_exit and t % CHECK == 0:
             cnt = ended[:t].tolist()
-            hit = [i for i, c in enumerate(cnt) if c == R]
-            if hit:
-                n_steps = hit[0] + 1
+            if any(c == R for c in cnt):
                 break
         # state of step t: slot 2t <- slot 2t-1, rows reordered by the parents chosen at step t-1
         ops.gather_rows_multi([big[key][2 * t - 1] for key in state_keys], rows, [big[key][2 * t] for key in state_keys])
@@ -95,11 +100,20 @@ def beam_infer(model, visual_feats, region_feats):
         cur, nxt = lps[t % 2], lps[(t + 1) % 2]
         ops.beam_select(s['LOGITS'][t], preds[t - 1], cur, preds[t], nxt, backs[t], rows, k, end, ended_count=ended[t:t + 1])
         done = t + 1
-    else:
-        cnt = ended.tolist()
-        hit = [i for i, c in enumerate(cnt[:L - 1]) if c == R]
-        if hit:
-            n_steps = hit[0] + 1
+    extras = (sv['dec_gsrc'][0], sv['dec_gsrc'][-1]) if hasattr(model, '_encode') else None
+    return preds, backs, lps, ended, done, B, k, R, L, extras
+
+
+def beam_finish(model, preds, backs, lps, ended, done, B, k, R, L, extras):
+    """Host side of the search: where the reference would have stopped (allennlp_beamsearch.py:168), the back-trace
+    (:272-292) and the choice of the best beam (layer.py:456-460)."""
+    cnt = ended[:done].tolist()
+    n_steps = done
+    hit = [i for i, c in enumerate(cnt[:L - 1]) if c == R]
+    if hit:
+        n_steps = min(done, hit[0] + 1)
+    if k == 1 and cnt[0] == R:
+        n_steps = 1
     # ---- back-trace over the steps the reference would have run (allennlp_beamsearch.py:272-292)
     P = preds[:n_steps].view(n_steps, B, k)
     Bk = backs[:n_steps].view(n_steps, B, k)
@@ -117,6 +131,6 @@ def beam_infer(model, visual_feats, region_feats):
         all_preds = torch.cat(list(reversed(rec)), 2)
     best = last_lp.topk(1)[1].squeeze(1)                          # layer.py:456-460
     out = torch.stack([all_preds[i, best[i], :] for i in range(B)])
-    if hasattr(model, '_encode'):
-        return out, sv['dec_gsrc'][0], sv['dec_gsrc'][1], []
+    if extras is not None:
+        return out, extras[0], extras[1], []
     return out, 0, 0, 0

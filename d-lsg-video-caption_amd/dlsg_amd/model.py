@@ -457,6 +457,39 @@ class GreedyGraph(object):
         return self.ids
 
 
+class BeamGraph(object):
+    """hipGraph-captured beam search (BASELINE configs[4]): encoder + all max_words beam steps (decode step, `beam_select`,
+    state reorder) captured once for a batch shape; a replay has no host synchronisation, the early stop of the reference is
+    applied afterwards (`beam.beam_finish`).  Ids are identical to `model(frames, regions, None)` with the same beam size."""
+
+    def __init__(self, model, frames, regions):
+        from .beam import beam_device
+        self.model = model
+        model.flatten_parameters_()
+        dev = frames.device
+        self.frames, self.regions = frames.clone(), regions.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            beam_device(model, self.frames, self.regions, early_exit=False)                       # warm-up
+            side.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            self.graph.capture_begin(capture_error_mode='thread_local')
+            self.state = beam_device(model, self.frames, self.regions, early_exit=False)
+            self.graph.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
+
+    @torch.no_grad()
+    def __call__(self, frames, regions):
+        from .beam import beam_finish
+        if frames.data_ptr() != self.frames.data_ptr():
+            self.frames.copy_(frames, non_blocking=True)
+        if regions.data_ptr() != self.regions.data_ptr():
+            self.regions.copy_(regions, non_blocking=True)
+        self.graph.replay()
+        return beam_finish(self.model, *self.state)
+
+
 # ================================================================================================ fast training path
 def ss_epsilon(epoch, ss_factor=20):
     """scheduled-sampling probability, run_gun.py:136"""

@@ -329,6 +329,21 @@ def test_hipgraph_greedy_inference_ids_bit_exact():
     assert np.array_equal(ids2.cpu().numpy(), g['greedy_ids'][::-1])
 
 
+@pytest.mark.parametrize('tag', ['small_msvd', 'small_baselinemodel', 'full_msvd_b2'])
+def test_hipgraph_beam_search_ids_bit_exact(tag):
+    """BeamGraph (whole beam search replayed from a hipGraph, no host sync inside) == the eager beam search == the golden
+    beam-5 ids of the reference; a second replay on other inputs follows the inputs."""
+    net, g, frames, regions, caps, lens, kind = build(tag)
+    net.update_beam_size(5)
+    bg = dlsg_amd.BeamGraph(net, frames, regions)
+    ids = bg(frames, regions)[0]
+    assert np.array_equal(ids.cpu().numpy(), g['beam5_ids'])
+    f2, r2 = torch.flip(frames, [0]).contiguous(), torch.flip(regions, [0]).contiguous()
+    with torch.no_grad():
+        want = net(f2, r2, None)[0]
+    assert torch.equal(bg(f2, r2)[0], want)
+
+
 def test_full_size_batch64_clips_are_independent_and_deterministic():
     """Size-independent properties at the bench configuration (MSVD-shaped, batch 64): the forward is deterministic
     (bit-identical on a second run) and a clip's logits / greedy ids do not depend on which other clips share its batch

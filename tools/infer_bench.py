@@ -44,3 +44,14 @@ for _ in range(10):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 10
 print('gemm=fp32 greedy hipGraph replay batch=%d: %.1f ms / batch, %.0f clips/s' % (B, dt * 1e3, B / dt))
+
+net.update_beam_size(5)
+bg = dlsg_amd.BeamGraph(net, frames, regions)
+bg(frames, regions)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    ids = bg(frames, regions)[0]
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 10
+print('gemm=fp32 beam=5 hipGraph replay batch=%d: %.1f ms / batch, %.0f clips/s' % (B, dt * 1e3, B / dt))
