@@ -30,6 +30,7 @@ struct KArgs {
     int64_t bsa, bsb, bsc;
     float alpha;
     const float* bias;
+    const int32_t* skip_if;
     dlsg_gemm_group g[DLSG_GEMM_MAXG];
 };
 
@@ -163,6 +164,7 @@ __device__ __forceinline__ void gemm_x3_body(const KArgs& p) {
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
+    if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
     const int z = blockIdx.y;
     const int gi = z % p.ngroups, bi = z / p.ngroups;
     const dlsg_gemm_group grp = p.g[gi];
@@ -261,7 +263,7 @@ template <int BM, int BN, int BK>
 int launch(const dlsg_gemm_args* a, hipStream_t st) {
     KArgs k;
     k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
-    k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias;
+    k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias; k.skip_if = a->skip_if;
     for (int i = 0; i < a->ngroups; ++i) k.g[i] = a->g[i];
     const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
     dim3 grid(tiles, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[(64 + 32) * SLD];     // 50,688 B; reused for the final reduction
     float* ldsA = lds;
     float* ldsB = lds + 64 * SLD;
+    if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
     const int z = blockIdx.y;
     const int gi = z % p.ngroups, bi = z / p.ngroups;
     const dlsg_gemm_group grp = p.g[gi];
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(NT) void skinny_x3_kernel(const KArgs p) {
 int launch_skinny_x3(const dlsg_gemm_args* a, hipStream_t st) {
     KArgs k;
     k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
-    k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias;
+    k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias; k.skip_if = a->skip_if;
     for (int i = 0; i < a->ngroups; ++i) k.g[i] = a->g[i];
     dim3 grid((a->N + 31) / 32, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
     if (a->mode == 0) hipLaunchKernelGGL((skinny_x3_kernel<false>), grid, block, 0, st, k);

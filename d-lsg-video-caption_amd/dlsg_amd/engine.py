@@ -166,8 +166,8 @@ def gemm_bucketed(ops, mode, groups, flags=0):
             ops.gemm(mode, grp[i:i + 16], flags=flags)
 
 
-def lin(ops, x, W, out, bias=None, tanh=False, accum=False):
-    ops.gemm(GEMM_NT, [(x, W, out)], flags=(F_TANH if tanh else 0) | (F_ACCUM if accum else 0), bias=bias)
+def lin(ops, x, W, out, bias=None, tanh=False, accum=False, skip_if=None):
+    ops.gemm(GEMM_NT, [(x, W, out)], flags=(F_TANH if tanh else 0) | (F_ACCUM if accum else 0), bias=bias, skip_if=skip_if)
 
 
 class Grads(object):
@@ -632,14 +632,16 @@ def dec_step(ops, dec, s, t, ref, training, seed, B, word_dropout=True):
                      (lnl.weight, lnl.bias), s['DOUT'][t], s['ST_L'][t], pd, site + SITE_LANG, seed=seed)
 
 
-def dec_logits(ops, dec, s, t0, t1):
-    """logits of steps [t0,t1): word_restore of tanh(LN(lang_h)) (models/layer.py:599-600); dec_step left the LN output in DOUT."""
+def dec_logits(ops, dec, s, t0, t1, skip_if=None):
+    """logits of steps [t0,t1): word_restore of tanh(LN(lang_h)) (models/layer.py:599-600); dec_step left the LN output in DOUT.
+    skip_if: device flag -- the launch is a no-op when it is set (teacher-forced step of a replayed graph)."""
     plan = s['plan']
     D = plan.D
     B = s['LHP'].shape[1]
     V = dec.vocab_size
     n = (t1 - t0) * B
-    lin(ops, s['DOUT'][t0:t1].view(n, D), dec.word_restore.weight, s['LOGITS'][t0:t1].view(n, V), dec.word_restore.bias)
+    lin(ops, s['DOUT'][t0:t1].view(n, D), dec.word_restore.weight, s['LOGITS'][t0:t1].view(n, V), dec.word_restore.bias,
+        skip_if=skip_if)
 
 
 def dec_alloc(dec, s, ref, B, L):
@@ -685,10 +687,13 @@ def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed, dev_coins=No
         ops.embed_fwd(E, ids[0], s['WE'][0], p=pw, seed=seed, site=SITE_WORD, row0=0)
         for t in range(L):
             dec_step(ops, dec, s, t, ref, training, seed, B)
-            dec_logits(ops, dec, s, t, t + 1)
             if t + 1 < L:
+                # the step's logits are needed now only if the next word is sampled from them: on a teacher-forced step
+                # (device coin set) the per-step vocab projection is a no-op and select_embed takes the caption word
+                dec_logits(ops, dec, s, t, t + 1, skip_if=dev_coins[t:t + 1])
                 ops.select_embed(s['LOGITS'][t], captions, t, dev_coins, E, ids[t + 1], s['WE'][t + 1], p=pw, seed=seed,
                                  site=SITE_WORD, row0=(t + 1) * B)
+        dec_logits(ops, dec, s, 0, L)          # logits of all steps for the loss, one (L*B)-row product
         return s
     if captions is not None:
         tf_steps = [i for i in range(L) if coins[i]]

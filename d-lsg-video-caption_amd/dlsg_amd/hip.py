@@ -32,7 +32,7 @@ class GemmGroup(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [('mode', i32), ('M', i32), ('N', i32), ('ldc', i32), ('ngroups', i32), ('nbatch', i32), ('flags', i32),
                 ('pad_', i32), ('bsa', i64), ('bsb', i64), ('bsc', i64), ('alpha', f32), ('pad2_', i32),
-                ('bias', c_f32p), ('g', GemmGroup * MAXG)]
+                ('bias', c_f32p), ('skip_if', c_f32p), ('g', GemmGroup * MAXG)]
 
 
 class RowLnArgs(C.Structure):
@@ -300,7 +300,7 @@ class HipOps(object):
             raise RuntimeError('%s failed with code %d' % (what, rc))
 
     # ------------------------------------------------------------------ GEMM
-    def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None):
+    def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None, skip_if=None):
         """groups: list of (A, B, C[, bias]) views (2-d, or 3-d batched with identical batch strides across groups)."""
         a = GemmArgs()
         A0, B0, C0 = groups[0][:3]
@@ -318,6 +318,7 @@ class HipOps(object):
         gbias = any(len(g) > 3 and g[3] is not None for g in groups)
         a.flags = flags | self.extra_flags | (F_BIAS if (bias is not None or gbias) else 0)
         a.bias = _p(bias)
+        a.skip_if = _p(skip_if)          # 1-element int32 device tensor: launch is a no-op when it is non-zero
         assert len(groups) <= MAXG
         for i, grp_ in enumerate(groups):
             A, B, Cc = grp_[:3]

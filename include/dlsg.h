@@ -63,6 +63,8 @@ typedef struct {
     float alpha;
     int32_t pad2_;
     const float* bias;
+    const int32_t* skip_if; /* optional device flag: the launch does nothing when *skip_if != 0 (a hipGraph-replayed step whose
+                               product is needed only on some replays, e.g. per-word logits under scheduled sampling) */
     dlsg_gemm_group g[DLSG_GEMM_MAXG];
 } dlsg_gemm_args;
 int dlsg_gemm(const dlsg_gemm_args* args, void* stream);

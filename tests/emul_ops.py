@@ -58,8 +58,10 @@ class EmulOps(object):
         self.calls[k] = self.calls.get(k, 0) + 1
 
     # ------------------------------------------------------------------ GEMM
-    def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None):
+    def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None, skip_if=None):
         self._count('gemm')
+        if skip_if is not None and int(skip_if.reshape(-1)[0]) != 0:
+            return
         for grp_ in groups:
             A, B, C = grp_[:3]
             gb = grp_[3] if len(grp_) > 3 else None
