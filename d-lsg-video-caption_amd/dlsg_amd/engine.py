@@ -49,6 +49,14 @@ def _ksplit_bounds(K, nsplit, align=32):
     return out
 
 
+def _bwd_bounds(K, M, nsplit):
+    """K-split of an input-gradient product dy (M, K) @ W (K, N).  For the skinny kernel (M <= 64) 1024-deep chunks measured
+    best on the batch-64 step (4 x 1024 for K = 4096: +0.6 % step throughput over 6 x 768 / 8 x 512; 5 x 896 is 2.7 % worse)."""
+    if M <= 64 and K >= 2048:
+        return [(k, min(K, k + 1024)) for k in range(0, K, 1024)]
+    return _ksplit_bounds(K, nsplit, 128 if M <= 64 else 32)
+
+
 def _nsplit_for(M, N, nseg, target=384, cap=16):
     tiles = ((M + 63) // 64) * ((N + 63) // 64)
     n = max(1, target // max(1, tiles * nseg))
@@ -112,7 +120,7 @@ def gemm_nn_multi(ops, dy, Ws, out, ref):
     assert out.shape[1] == tot
     ns = _nsplit_for(M, tot, 1)
     ns = max(1, min(ns, 16 // len(Ws)))
-    bounds = _ksplit_bounds(Nn, ns, 128 if M <= 64 else 32)
+    bounds = _bwd_bounds(Nn, M, ns)
     slabs = _empty(ref, len(bounds), M, tot)
     groups, c0 = [], 0
     for W, wd in zip(Ws, widths):
@@ -132,7 +140,7 @@ def gemm_nn_multi_slabs(ops, dy, Ws, width, ref):
     assert tot <= width
     ns = _nsplit_for(M, tot, 1)
     ns = max(1, min(ns, 16 // len(Ws)))
-    bounds = _ksplit_bounds(Nn, ns, 128 if M <= 64 else 32)
+    bounds = _bwd_bounds(Nn, M, ns)
     slabs = _empty(ref, len(bounds), M, width)
     groups, c0 = [], 0
     for W, wd in zip(Ws, widths):
@@ -510,7 +518,7 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     dG = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
     dcrec = [_empty(ref, B, H), _empty(ref, B, H)]
     ns_r = max(1, min(_nsplit_for(B, 2 * H, 1), 8))
-    rb = _ksplit_bounds(4 * H, ns_r, 128 if B <= 64 else 32)
+    rb = _bwd_bounds(4 * H, B, ns_r)
     slabs = None                       # (S, B, 2H): slabs of [d h_prev of the forward dir | of the reverse dir]
     for step in range(T - 1, -1, -1):
         tt = [step, T - 1 - step]
