@@ -66,7 +66,8 @@ def _nsplit_for(M, N, nseg, target=384, cap=16):
 def seg_gemm_nt(ops, segs, M, N, ref):
     """sum_i  x_i @ W_i^T  as ONE grouped launch writing K-split slabs.  segs: list of (x (M,K_i), W (N,K_i)).
     Returns slabs (S, M, N); the consumer kernel (lstm_pw / slab_reduce) sums them."""
-    ns = _nsplit_for(M, N, len(segs))
+    # M <= 64 (skinny kernel): one group per input segment -- whole 1024-deep segments measured better than 512-deep halves
+    ns = 1 if M <= 64 else _nsplit_for(M, N, len(segs))
     groups = []
     for x, W in segs:
         for k0, k1 in _ksplit_bounds(x.shape[1], ns, 128 if M <= 64 else 32):
