@@ -91,24 +91,31 @@ def gemm_nn_split(ops, dy, W, out, ref, accum=False):
     ops.slab_reduce(slabs, out, flags=F_ACCUM if accum else 0)
 
 
-def gemm_tn_deep(ops, dy, x, gout, ref):
-    """gout (Nout, Kin) += dy^T x for a very deep contraction (rows >= 8192, e.g. the 26624-row obj_embed weight
-    gradient): the output has too few tiles to fill the chip, so the rows are split over groups writing slabs
-    (measured 98 vs 86 TFLOP/s in fp32; in the step, also 0.5 ms faster than un-split on the split-bf16 path) and the
-    slabs are folded into the gradient."""
-    rows = dy.shape[0]
-    if rows < 8192:
-        ops.gemm(GEMM_TN, [(dy, x, gout)], flags=F_ACCUM)
-        return
+def gemm_tn_deep(ops, items, ref):
+    """gout_i (Nout, Kin) += dy_i^T x_i for very deep contractions (rows >= 8192: the 26624-row obj_embed weight gradients):
+    the output has too few tiles to fill the chip, so the rows are split over groups writing slabs (measured 98 vs 86
+    TFLOP/s in fp32; in the step, also 0.5 ms faster than un-split on the split-bf16 path) and the slabs are folded into
+    the gradient.  Several products (the two streams' obj_embed) share ONE launch: 8 row groups x 128 tiles is 1024
+    workgroups on 768 slots -- a second round one third full; two products together are 2048 = 2 2/3 rounds, not 4."""
+    deep = [it for it in items if it[0].shape[0] >= 8192]
+    for dy, x, gout in items:
+        if dy.shape[0] < 8192:
+            ops.gemm(GEMM_TN, [(dy, x, gout)], flags=F_ACCUM)
+    by_shape = {}
+    for it in deep:
+        by_shape.setdefault((it[0].shape, it[1].shape), []).append(it)
     ks = 8
-    step = (rows // ks + 31) // 32 * 32
-    bounds = [(k, min(rows, k + step)) for k in range(0, rows, step)]
-    slabs = _empty(ref, len(bounds), gout.shape[0], gout.shape[1])
-    ops.gemm(GEMM_TN, [(dy[k0:k1], x[k0:k1], slabs[i]) for i, (k0, k1) in enumerate(bounds)])
-    if gout.stride(0) == gout.shape[1]:
-        ops.slab_reduce(slabs, gout, flags=F_ACCUM)
-    else:
-        ops.slab_reduce(slabs, gout, flags=F_ACCUM)
+    for grp in by_shape.values():
+        for i0 in range(0, len(grp), 2):
+            part = grp[i0:i0 + 2]
+            rows = part[0][0].shape[0]
+            step = (rows // ks + 31) // 32 * 32
+            bounds = [(k, min(rows, k + step)) for k in range(0, rows, step)]
+            slabs = [_empty(ref, len(bounds), gout.shape[0], gout.shape[1]) for _, _, gout in part]
+            ops.gemm(GEMM_TN, [(dy[k0:k1], x[k0:k1], sl[i]) for (dy, x, _), sl in zip(part, slabs)
+                               for i, (k0, k1) in enumerate(bounds)])
+            for (_, _, gout), sl in zip(part, slabs):
+                ops.slab_reduce(sl, gout, flags=F_ACCUM)
 
 
 def gemm_nn_multi(ops, dy, Ws, out, ref):
@@ -278,7 +285,7 @@ def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2
     return psl.view(B, P, H)
 
 
-def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed):
+def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed, defer_dw=None):
     """Backward of tun_fwd.  dpsl (B,P,H).  Returns d(visual input) when the stream has no embed, else None."""
     B, T, O, R = regions.shape
     s = sv[pfx]
@@ -353,7 +360,10 @@ def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed):
             dy = o   # reuse the scratch: rowln_bwd reads y/stats, not o
             ops.rowln_bwd(do, y, g_o, b_o, dy, stats=s['ostats'], pre_tanh=2, dgb_part=part)
         ln_grads(ops, part, G, name + '.obj_norm.1', H)
-        gemm_tn_deep(ops, dy, regions.view(B * NO, R), G[name + '.obj_embed.weight'], ref)
+        if defer_dw is not None:
+            defer_dw.append((dy, regions.view(B * NO, R), G[name + '.obj_embed.weight']))
+        else:
+            gemm_tn_deep(ops, [(dy, regions.view(B * NO, R), G[name + '.obj_embed.weight'])], ref)
         ops.colsum(dy, G[name + '.obj_embed.bias'], accum=True)
     else:
         dv = dov

@@ -239,27 +239,19 @@ class CapGnnModel(_HipModel):
         if dmot is not None:
             ops.copy2d(dmot.reshape(-1, H), dmo.view(-1, H), accum=True)
         f2 = frames.view(B * T, F)
-        dmot_in = E.tun_bwd(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, G, dmo, training, seed)
-        if on_bucket:
-            on_bucket('encoder.motion_encoder')
-        # optional second stream: the object-stream encoder backward (large GEMMs) beside the BiLSTM backward
-        side = self._fork(frames)
-        if side is not None:
-            with torch.cuda.stream(side):
-                E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed)
+        # the obj_embed weight gradients of the two streams (the deepest products of the step) are issued together at the
+        # end, so the two small TUN buckets (12 MB each) are reduced last; the 151 MB motion_pre_encoder bucket still
+        # travels under the object stream's backward
+        deep = []
+        dmot_in = E.tun_bwd(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, G, dmo, training, seed,
+                            defer_dw=deep)
         E.encvis_bwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, G, dmot_in, training, seed)
-        if side is None:
-            # the 151 MB motion_pre_encoder bucket travels while the object stream's backward (its largest GEMMs) runs;
-            # only the small obj_encoder bucket is exposed at the end of the step
-            if on_bucket:
-                on_bucket('encoder.motion_pre_encoder')
-            E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed)
-            if on_bucket:
-                on_bucket('encoder.obj_encoder')
-        else:
-            self._join(side)
-            if on_bucket:
-                on_bucket(('encoder.motion_pre_encoder', 'encoder.obj_encoder'))
+        if on_bucket:
+            on_bucket('encoder.motion_pre_encoder')
+        E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed, defer_dw=deep)
+        E.gemm_tn_deep(ops, deep, frames)
+        if on_bucket:
+            on_bucket(('encoder.motion_encoder', 'encoder.obj_encoder'))
 
     # ------------------------------------------------------------------ public forward
     def forward(self, visual_feats, region_feats, caption, max_words=None, teacher_forcing_ratio=1.0):
