@@ -509,9 +509,11 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
             ops.gemm(GEMM_NN, [(dlg, Qp.view(B, T, D2), dK.view(B, T, D2))], alpha=scale)
             ops.gemm(GEMM_TN, [(dlg, Kp.view(B, T, D2), dQ.view(B, T, D2))], alpha=scale)
         dx = _empty(ref, B * T, D2)
-        ops.gemm(GEMM_NN, [(dK, sa.K.weight, dx)])
-        ops.gemm(GEMM_NN, [(dQ, sa.Q.weight, dx)], flags=F_ACCUM)
-        ops.gemm(GEMM_NN, [(dV, sa.V.weight, dx)], flags=F_ACCUM)
+        # dx = dK W_K + dQ W_Q + dV W_V: the three products as groups of one launch into slabs (each alone is 832 tiles on
+        # 768 slots: a second round for 8 % of the work), then one fold
+        sl = _empty(ref, 3, B * T, D2)
+        ops.gemm(GEMM_NN, [(dK, sa.K.weight, sl[0]), (dQ, sa.Q.weight, sl[1]), (dV, sa.V.weight, sl[2])])
+        ops.slab_reduce(sl, dx)
         tn_grouped(ops, [(dK, x, G[name + '.self_attention.K.weight']), (dQ, x, G[name + '.self_attention.Q.weight']),
                          (dV, x, G[name + '.self_attention.V.weight'])])
         nb = ops.rowln_bwd_nblk(B * T)
@@ -818,7 +820,16 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     ops.colsum2(dgl2, G['decoder.lang_lstm.bias_ih'], G['decoder.lang_lstm.bias_hh'], accum=True)
     # ---- word embedding rows
     dWE = _empty(ref, n, W)
-    ops.gemm(GEMM_NN, [(dgq2, ql.weight_ih[:, plan.q_word[0]:plan.q_word[1]], dWE)])
+    Wword = ql.weight_ih[:, plan.q_word[0]:plan.q_word[1]]
+    if n >= 512 and 4 * Q >= 2048:
+        # (L*B x 4Q) @ (4Q x 300): 26 x 5 output tiles for a 4096-deep contraction -- 130 workgroups for 110 us; the
+        # contraction in 1024-deep slabs puts 4x as many on the chip
+        kb = [(k, min(4 * Q, k + 1024)) for k in range(0, 4 * Q, 1024)]
+        sl = _empty(ref, len(kb), n, W)
+        ops.gemm(GEMM_NN, [(dgq2[:, k0:k1], Wword[k0:k1], sl[i]) for i, (k0, k1) in enumerate(kb)])
+        ops.slab_reduce(sl, dWE)
+    else:
+        ops.gemm(GEMM_NN, [(dgq2, Wword, dWE)])
     # one mask stream (site SITE_WORD, row = slot*B + b) covers the bulk embed and the argmax re-embeds
     ops.embed_bwd(dWE, s['IDS'][:L].view(-1), G['decoder.word_embed.weight'], p=s['pw'], seed=seed, site=SITE_WORD)
     # ---- global feature
