@@ -228,8 +228,18 @@ def main():
                     traffic = (json.load(open(tpath)).get(gk) or {}).get('hbm_bytes_per_launch')
                 except Exception:
                     traffic = None
+            # symbol under which rocprofv3 lists this kernel (profiles/*kernel_stats*.csv)
+            parts = gk.split('_')              # gemm_{f32|bf16x3}_mfma_{tile}_{nt|nn|tn}
+            tile, mode = parts[3], parts[-1]
+            tmpl = {'nt': 'false, false', 'nn': 'false, true', 'tn': 'true, true'}.get(mode, '')
+            if tile == '128x128':
+                sym = '%s_w3<128, 128, %s, 32>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
+            elif tile == '64x64':
+                sym = '%s<64, 64, %s, 64>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
+            else:
+                sym = ('skinny_x3_kernel' if is_x3 else 'skinny_kernel') + ('<false>' if mode == 'nt' else '<true>')
             out['roofline'] = {'kernel': gk + (' (3 x v_mfma_f32_32x32x16_bf16 per product; peak = 2500/3)' if is_x3
-                                               else ' (v_mfma_f32_32x32x2_f32)'),
+                                               else ' (v_mfma_f32_32x32x2_f32)') + '; rocprof symbol: ' + sym,
                                'traffic_note': 'HBM bytes/launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes) '
                                                'when that file has this kernel at this launch shape, else null',
                                'bound': 'mfma', 'achieved': round(ach, 2),
