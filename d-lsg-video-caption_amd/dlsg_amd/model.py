@@ -526,6 +526,48 @@ class Trainer(object):
             lo, hi = self._ranges.get(key, (o, end))
             self._ranges[key] = (min(lo, o), max(hi, end))
 
+    # ------------------------------------------------------------------ checkpoint compatibility (run_gun.py:302-310)
+    def optimizer_state_dict(self):
+        """The Adam state in the layout of `torch.optim.Adam(model.parameters(), ...).state_dict()` -- what the reference
+        stores as `optimizer_state_dict` in its checkpoints.  Parameters that never receive a gradient have no entry,
+        as in torch (Adam creates state lazily for parameters with a gradient)."""
+        model = self.model
+        state = {}
+        names = [n for n, _ in model.named_parameters()]
+        for i, (name, p) in enumerate(model.named_parameters()):
+            if name in model.unused_parameters or self.t == 0:
+                continue
+            o = model._offsets[name]
+            state[i] = {'step': torch.tensor(float(self.t)),
+                        'exp_avg': self.m[o:o + p.numel()].view(p.shape).clone(),
+                        'exp_avg_sq': self.v[o:o + p.numel()].view(p.shape).clone()}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'decoupled_weight_decay': False, 'params': list(range(len(names)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        """Resume from a reference checkpoint's `optimizer_state_dict` (torch.optim.Adam layout)."""
+        model = self.model
+        model.flatten_parameters_()
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        for i, (name, p) in enumerate(model.named_parameters()):
+            st = sd['state'].get(i, sd['state'].get(str(i)))
+            if st is None:
+                continue
+            o = model._offsets[name]
+            self.m[o:o + p.numel()].view(p.shape).copy_(st['exp_avg'])
+            self.v[o:o + p.numel()].view(p.shape).copy_(st['exp_avg_sq'])
+            steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError('per-parameter step counts differ (%s): not a state this trainer can resume' % sorted(steps))
+        self.t = steps.pop() if steps else 0
+        g = sd['param_groups'][0]
+        self.lr, self.betas, self.eps = g['lr'], tuple(g['betas']), g['eps']
+        self._graphs = None          # captured graphs bake nothing of this state, but recapture keeps the invariants simple
+
     # ------------------------------------------------------------------ collectives
     def _allreduce(self, key):
         """key: a bucket name or a tuple of bucket names whose gradients are complete."""

@@ -151,3 +151,39 @@ def test_device_coin_path_matches_host_coin_path(tag):
     assert abs(outs[0][0] - outs[1][0]) <= 1e-6
     # Adam normalises: elements whose gradient is rounding noise may move by a fraction of lr (1.6e-4)
     assert (outs[0][1] - outs[1][1]).abs().max().item() <= 3e-5
+
+
+def test_optimizer_state_round_trips_with_torch_adam():
+    """Checkpoint compatibility (run_gun.py:302-310 stores optimizer.state_dict()): the trainer's Adam state equals
+    torch.optim.Adam's after the same steps on the oracle, exports in torch's layout, and a trainer resumed from
+    torch's state continues identically."""
+    from oracle import torch_ref as R
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    args, vocab, _, _ = load_case('small_msvd')
+    orc = R.CapGnnModelRef(args, vocab).eval()
+    orc.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+    opt = R.make_optimizer(orc)
+    tr = dlsg_amd.Trainer(net)
+    for _ in range(2):
+        tr.step(frames, regions, caps, lens, 1.0)
+        R.train_step(orc, opt, frames, regions, caps, lens, 1.0)
+    mine, ref = tr.optimizer_state_dict(), opt.state_dict()
+    assert sorted(mine['state'].keys()) == sorted(ref['state'].keys())
+    for i, st in ref['state'].items():
+        assert float(mine['state'][i]['step']) == float(st['step'])
+        for key in ('exp_avg', 'exp_avg_sq'):
+            scale = st[key].abs().max().item() + 1e-12
+            assert (mine['state'][i][key] - st[key]).abs().max().item() <= 2e-4 * scale + 1e-10, (i, key)
+    # torch accepts the exported layout
+    opt2 = R.make_optimizer(orc)
+    opt2.load_state_dict(mine)
+    # resume a fresh trainer from torch's state: third step equals the oracle's third step
+    net2, *_ = build('small_msvd')
+    net2.load_state_dict({k: v.clone() for k, v in orc.state_dict().items()})
+    tr2 = dlsg_amd.Trainer(net2)
+    tr2.load_optimizer_state_dict(ref)
+    assert tr2.t == 2
+    tr2.step(frames, regions, caps, lens, 1.0)
+    R.train_step(orc, opt, frames, regions, caps, lens, 1.0)
+    for k, v in orc.state_dict().items():
+        assert (net2.state_dict()[k] - v).abs().max().item() <= 2e-6, k
