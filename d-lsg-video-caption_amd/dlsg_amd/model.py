@@ -488,6 +488,12 @@ def ss_epsilon(epoch, ss_factor=20):
     return max(0.6, ss_factor / (ss_factor + math.exp(epoch / ss_factor)))
 
 
+def multistep_lr(epoch, base_lr=1.6e-4, milestones=(4, 7), gamma=0.5):
+    """learning rate of `MultiStepLR(optimizer, milestones=[4, 7], gamma=0.5)` (run_gun.py:94-95) at the start of `epoch`;
+    assign it to `Trainer.lr` (the replayed graphs read the rate from device memory every step)."""
+    return base_lr * gamma ** sum(1 for m in milestones if epoch >= m)
+
+
 class Trainer(object):
     """The reference's per-iteration use of the model (run_gun.py:153-160,181-198,233-234) as one fused schedule:
     forward -> ragged CrossEntropy (mean over sum(cap_lens) rows) -> backward -> [RCCL all-reduce] -> Adam.

@@ -187,3 +187,16 @@ def test_optimizer_state_round_trips_with_torch_adam():
     R.train_step(orc, opt, frames, regions, caps, lens, 1.0)
     for k, v in orc.state_dict().items():
         assert (net2.state_dict()[k] - v).abs().max().item() <= 2e-6, k
+
+
+def test_caller_side_schedules_match_the_reference():
+    """run_gun.py:94-95 (MultiStepLR([4,7], 0.5)) and :136 (scheduled-sampling epsilon)."""
+    import math
+    p = [torch.nn.Parameter(torch.zeros(1))]
+    opt = torch.optim.Adam(p, lr=1.6e-4)
+    sch = torch.optim.lr_scheduler.MultiStepLR(opt, [4, 7], 0.5)
+    for epoch in range(10):
+        assert abs(opt.param_groups[0]['lr'] - dlsg_amd.multistep_lr(epoch)) < 1e-12
+        assert abs(dlsg_amd.ss_epsilon(epoch) - max(0.6, 20 / (20 + math.exp(epoch / 20)))) < 1e-12
+        opt.step()
+        sch.step()
