@@ -203,7 +203,7 @@ class CapGnnModel(_HipModel):
         self._join(side)
         return obj, mot
 
-    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
         ops = self.ops
         ops.extra_flags = self._gemm_flags(False)
         frames = frames.contiguous().float()
@@ -212,6 +212,8 @@ class CapGnnModel(_HipModel):
         sv['frames'], sv['regions'] = frames, regions
         sv['dec_gsrc'] = [obj, mot]
         s = E.dec_fwd(ops, self.decoder, [obj, mot], sv, captions, L, coins, training, seed, dev_coins)
+        if not outputs:            # fused trainer: the loss reads the time-major logits in place
+            return None
         B = frames.shape[0]
         V = self.decoder.vocab_size
         logits = torch.empty(B, L, V, dtype=torch.float32, device=frames.device)
@@ -291,7 +293,7 @@ class CapBaseline1(_HipModel):
     def update_beam_size(self, beam_size):
         self.decoder.update_beam_size(beam_size)
 
-    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
         ops = self.ops
         ops.extra_flags = self._gemm_flags(False)
         frames = frames.contiguous().float()
@@ -382,7 +384,7 @@ class CapBaselineModel(_HipModel):
                         E.SITE_PSL_MOT, self.fused_o2v)
         return mot.view(B, T, -1)
 
-    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None):
+    def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
         ops = self.ops
         ops.extra_flags = self._gemm_flags(False)
         frames = frames.contiguous().float()
@@ -590,7 +592,7 @@ class Trainer(object):
         L = captions.shape[1]
         sv = {}
         training = model.training
-        model._engine_forward(frames, regions, captions, L, coins, training, seed, sv, dev_coins)
+        model._engine_forward(frames, regions, captions, L, coins, training, seed, sv, dev_coins, outputs=False)
         s = sv['dec']
         Bn = captions.shape[0]
         dl = torch.empty_like(s['LOGITS'])
