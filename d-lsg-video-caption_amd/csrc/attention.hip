@@ -35,7 +35,7 @@ struct O2VGeom {
     static constexpr int NCH = EPL / VEC;
     static constexpr int NCB = H / 32;                // 32-column blocks of the aggregation output
     static constexpr int CBW = (NCB + 7) / 8;         // column blocks per wave
-    static constexpr int LDS_FLOATS = O2V_TILE * LDO + 4 * 16 * 64;
+    static constexpr int LDS_FLOATS = O2V_TILE * LDO + 4 * 16 * 64 + 2 * H;   // tile + reduction scratch + obj_norm gamma | beta
 };
 
 __device__ __forceinline__ int crow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
@@ -46,6 +46,11 @@ __global__ __launch_bounds__(O2V_THREADS) void o2v_partial_kernel(const dlsg_o2v
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* o_lds = smem;
     float* red = smem + O2V_TILE * G::LDO;            // [4][16][64]
+    // obj_norm gamma / beta are read by every row of every tile: from LDS, not through 32 global loads per lane and tile
+    float* gam_l = red + 4 * 16 * 64;
+    float* bet_l = gam_l + H;
+    for (int j = threadIdx.x; j < H; j += O2V_THREADS) { gam_l[j] = a.g_obj[j]; bet_l[j] = a.b_obj[j]; }
+    __syncthreads();
 
     const int b = blockIdx.x, sp = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -118,15 +123,15 @@ __global__ __launch_bounds__(O2V_THREADS) void o2v_partial_kernel(const dlsg_o2v
             for (int c = 0; c < G::NCH; ++c) {
                 if (G::VEC == 4) {
                     const int col = c * 256 + 4 * lane;
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.g_obj + col);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_obj + col);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gam_l + col);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bet_l + col);
                     f32x4 o4;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o4[i] = valid ? (x[rr][4 * c + i] - mean) * rstd * g4[i] + b4[i] : 0.f;
                     *reinterpret_cast<f32x4*>(o_lds + row * G::LDO + col) = o4;
                 } else {
                     const int col = c * 64 + lane;
-                    o_lds[row * G::LDO + col] = valid ? (x[rr][c] - mean) * rstd * a.g_obj[col] + a.b_obj[col] : 0.f;
+                    o_lds[row * G::LDO + col] = valid ? (x[rr][c] - mean) * rstd * gam_l[col] + bet_l[col] : 0.f;
                 }
             }
         }
@@ -303,6 +308,10 @@ __global__ __launch_bounds__(O2V_THREADS) void o2v_bwd_scores_kernel(const dlsg_
     __shared__ float fs[5][32];
     float* o_lds = smem;
     float* red = smem + O2V_TILE * G::LDO;            // [4][16][64]
+    float* gam_l = red + 4 * 16 * 64;
+    float* bet_l = gam_l + H;
+    for (int j = threadIdx.x; j < H; j += O2V_THREADS) { gam_l[j] = a.g_obj[j]; bet_l[j] = a.b_obj[j]; }
+    __syncthreads();
 
     const int b = blockIdx.x, sp = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -375,15 +384,15 @@ __global__ __launch_bounds__(O2V_THREADS) void o2v_bwd_scores_kernel(const dlsg_
             for (int c = 0; c < G::NCH; ++c) {
                 if (G::VEC == 4) {
                     const int col = c * 256 + 4 * lane;
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.g_obj + col);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_obj + col);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gam_l + col);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bet_l + col);
                     f32x4 o4;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o4[i] = valid ? (x[rr][4 * c + i] - mean) * rstd * g4[i] + b4[i] : 0.f;
                     *reinterpret_cast<f32x4*>(o_lds + row * G::LDO + col) = o4;
                 } else {
                     const int col = c * 64 + lane;
-                    o_lds[row * G::LDO + col] = valid ? (x[rr][c] - mean) * rstd * a.g_obj[col] + a.b_obj[col] : 0.f;
+                    o_lds[row * G::LDO + col] = valid ? (x[rr][c] - mean) * rstd * gam_l[col] + bet_l[col] : 0.f;
                 }
             }
         }
