@@ -400,3 +400,34 @@ def test_full_size_gradient_is_token_weighted_mean_of_shard_gradients(mode):
     scale = gf.abs().max().item()
     tol = 2e-5 if mode == 'fp32' else 3e-4
     assert (gf - want).abs().max().item() <= tol * scale + 1e-7, ((gf - want).abs().max().item(), scale)
+
+
+def test_graph_trainer_follows_lr_changes_and_resumes_from_torch_adam_state():
+    """The replayed graphs read the learning rate (and Adam's bias corrections) from device memory: changing
+    `trainer.lr` between replays (MultiStepLR, run_gun.py:94-95) must act exactly as on an eager trainer; and a trainer
+    resumed from an exported Adam state continues bit-for-bit like the one that exported it."""
+    res = []
+    for use_graphs in (True, False):
+        net, g, frames, regions, caps, lens, kind = build('small_msvd')
+        tr = dlsg_amd.Trainer(net, use_graphs=use_graphs)
+        random.seed(7)
+        for epoch in (0, 4, 7):
+            tr.lr = dlsg_amd.multistep_lr(epoch)
+            tr.step(frames, regions, caps, lens, 1.0)
+        res.append((net._flat.clone(), tr.optimizer_state_dict()))
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 3e-6
+    # resume: a fresh trainer + exported state == continuing the original
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    tr = dlsg_amd.Trainer(net)
+    net._flat.copy_(res[1][0])
+    tr.load_optimizer_state_dict(res[1][1])
+    assert tr.t == 3 and abs(tr.lr - dlsg_amd.multistep_lr(7)) < 1e-12
+    net2, *_ = build('small_msvd')
+    tr2 = dlsg_amd.Trainer(net2)
+    random.seed(7)
+    for epoch in (0, 4, 7):
+        tr2.lr = dlsg_amd.multistep_lr(epoch)
+        tr2.step(frames, regions, caps, lens, 1.0)
+    tr.step(frames, regions, caps, lens, 1.0)
+    tr2.step(frames, regions, caps, lens, 1.0)
+    assert torch.equal(net._flat, net2._flat)
