@@ -10,9 +10,13 @@ Workload (BASELINE.json configs[1]): batch 64 clips per GPU, 26 frames x (2048 +
 region features, vocab 1000, fp32, dropout active, scheduled-sampling eps = 0.95 (epoch 0).  Weak scaling: the
 per-GPU batch is fixed, gradients are summed over ranks by bucketed RCCL all-reduce overlapping the backward.
 
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the dominant kernel (the fp32-MFMA
-GEMM); `roofline_graph_attention` is the HBM-bound object->frame graph kernel the north_star names;
-`cpu_baseline` times the oracle (CPU port of the reference path) on a bounded sample on the host cores.
+Rank 0 prints ONE JSON line.  `value` is measured with every matrix product in exact fp32 (`--gemm fp32`, the reference's
+arithmetic); the split-bf16 policies are reported beside it under `other_gemm_arithmetic` with their measured gradient
+error.  `roofline` is measured live with HIP events around the dominant kernel (the fp32-MFMA GEMM);
+`roofline_graph_attention` is the HBM-bound object->frame graph kernel the north_star names; `cpu_baseline` times the
+oracle (CPU port of the reference path) on a bounded sample on the host cores; `vs_pytorch_rocm_eager` is BASELINE
+configs[1]'s comparator: the same step run by PyTorch-ROCm eager (the oracle's torch modules moved to the GPU) in the
+same process; `batch_128` is the N = 1 figure at configs[3]'s per-GPU batch.
 """
 import argparse
 import json
@@ -91,6 +95,39 @@ def cpu_baseline(seconds_budget=20.0):
                       'regions, vocab 1000, torch CPU fp32, %d threads' % (n, B, cores)}
 
 
+def gpu_eager_baseline(dev, batch, steps=4, warmup=2):
+    """BASELINE configs[1] comparator, a baseline leg like cpu_baseline(): the oracle's torch restatement of the reference
+    (oracle/torch_ref.py, kind 'port'; same modules, same Adam) on the GPU, stepped by PyTorch-ROCm's own eager kernels
+    (rocBLAS / hipBLASLt / MIOpen, fp32).  Same weights, same batch, train mode, same scheduled-sampling ratio."""
+    import dlsg_amd
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    from oracle import torch_ref as R
+    args = dlsg_amd.msvd_shaped()
+    vocab = dlsg_amd.make_vocab(1000)
+    torch.manual_seed(0)
+    net = R.CapGnnModelRef(args, vocab)
+    net.load_state_dict(synth_state_dict(net.state_dict(), 0))
+    net = net.to(dev).train()
+    opt = R.make_optimizer(net)
+    frames, regions, caps, lens = synth_batch(args, 1000, batch, 1)
+    frames, regions, caps = frames.to(dev), regions.to(dev), caps.to(dev)
+    eps = dlsg_amd.ss_epsilon(0)
+    random.seed(12)
+    for _ in range(warmup):
+        R.train_step(net, opt, frames, regions, caps, lens, eps)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        R.train_step(net, opt, frames, regions, caps, lens, eps)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del net, opt
+    torch.cuda.empty_cache()
+    return {'ms_per_step': round(ms, 2), 'clips_per_s': round(batch / ms * 1e3, 1), 'steps': steps, 'kind': 'port',
+            'what': 'oracle/torch_ref.py modules on cuda:0, torch %s eager (rocBLAS/hipBLASLt), fp32, batch %d, train mode, '
+                    'tf eps %.3f' % (torch.__version__, batch, eps)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -101,8 +138,11 @@ def main():
     ap.add_argument('--no-pass', action='store_true', help='skip the isolated graph-attention pass measurement')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eval-mode', action='store_true', help='dropout off (not the reported configuration)')
-    ap.add_argument('--gemm', default='x3_bwd', choices=['fp32', 'x3_bwd', 'x3_all'],
-                    help='GEMM arithmetic: exact fp32 MFMA, or split-bf16 (3 bf16 MFMAs/product) for backward / all products')
+    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'x3_bwd', 'x3_all'],
+                    help='GEMM arithmetic: exact fp32 MFMA (default, the reference\'s arithmetic), or split-bf16 (3 bf16 '
+                         'MFMAs/product) for backward / all products')
+    ap.add_argument('--no-eager-baseline', action='store_true', help='skip the PyTorch-ROCm eager comparator leg')
+    ap.add_argument('--no-batch128', action='store_true', help='skip the extra N = 1 measurement at 128 clips per GPU')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
     a = ap.parse_args()
 
@@ -141,7 +181,7 @@ def main():
     net.gemm_precision = a.gemm
     frames, regions, caps, lens = synth_batch(args, V, a.batch, 1 + rank)   # each rank its own shard
     frames, regions, caps, lens = frames.to(dev), regions.to(dev), caps.to(dev), lens.to(dev)
-    tr = dlsg_amd.Trainer(net, process_group=pg, world_size=world, use_graphs=not a.no_graphs)
+    tr = dlsg_amd.Trainer(net, process_group=pg, world_size=world, use_graphs=not a.no_graphs, graph_fallback=True)
     random.seed(12)                                                  # same coin sequence on all ranks (train_debug.py:34-36)
     eps = dlsg_amd.ss_epsilon(0)
 
@@ -183,7 +223,7 @@ def main():
             if mode == a.gemm:
                 continue
             net.gemm_precision = mode
-            tr2 = dlsg_amd.Trainer(net, use_graphs=not a.no_graphs)
+            tr2 = dlsg_amd.Trainer(net, use_graphs=not a.no_graphs, graph_fallback=True)
             tr2.m, tr2.v, tr2.t = tr.m, tr.v, tr.t
             for _ in range(2):
                 tr2.step(frames, regions, caps, lens, eps)
@@ -194,7 +234,43 @@ def main():
             torch.cuda.synchronize()
             other[mode] = {'clips_per_s': round(a.batch * a.steps / (time.perf_counter() - t1), 1)}
             del tr2
+        # gradient error of every policy against exact fp32: same weights, batch, dropout seed and coins (lr = 0)
+        probe = dlsg_amd.Trainer(net, lr=0.0)
+        grads = {}
+        for mode in ('fp32', 'x3_bwd', 'x3_all'):
+            net.gemm_precision = mode
+            net.seed_counter = 1000
+            random.seed(99)
+            probe.step(frames, regions, caps, lens, eps)
+            grads[mode] = net._gflat.clone()
+        gs = grads['fp32'].abs().max().item()
+        for mode in ('x3_bwd', 'x3_all'):
+            tgt = other if mode in other else None
+            err = (grads[mode] - grads['fp32']).abs().max().item() / max(gs, 1e-30)
+            if tgt is not None:
+                tgt[mode]['max_grad_err_rel_to_max_grad_vs_fp32'] = float('%.3g' % err)
+        del probe, grads
         net.gemm_precision = a.gemm
+    b128 = None
+    if world == 1 and not a.no_batch128 and a.batch != 128 and a.shape == 'msvd':
+        # BASELINE configs[3] runs 128 clips per GPU: its "8 GPUs vs 1" needs the N = 1 number at that batch
+        torch.cuda.empty_cache()
+        f2, r2, c2, l2 = synth_batch(args, V, 128, 1)
+        f2, r2, c2, l2 = f2.to(dev), r2.to(dev), c2.to(dev), l2.to(dev)
+        tr3 = dlsg_amd.Trainer(net, use_graphs=not a.no_graphs, graph_fallback=True)
+        tr3.m, tr3.v, tr3.t = tr.m, tr.v, tr.t
+        for _ in range(2):
+            tr3.step(f2, r2, c2, l2, eps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            tr3.step(f2, r2, c2, l2, eps)
+        torch.cuda.synchronize()
+        d3 = time.perf_counter() - t1
+        b128 = {'clips_per_s': round(128 * a.steps / d3, 1), 'ms_per_step': round(1e3 * d3 / a.steps, 3), 'batch_per_gpu': 128,
+                'n_gpus': 1, 'gemm_arithmetic': a.gemm, 'steps': a.steps}
+        del tr3, f2, r2, c2, l2
+        torch.cuda.empty_cache()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
@@ -269,16 +345,26 @@ def main():
             pr = run_graph_attention_pass(net.ops, B=1024)
             ptraffic = None
             try:
-                ptraffic = (json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get('graph_attention_pass_1024') or {}).get(
+                ptraffic = (json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get('graph_attention_pass_hbm_part_1024') or {}).get(
                     'hbm_bytes_per_launch')
             except Exception:
                 ptraffic = None
-            out['roofline_graph_attention_pass'] = {'kernel': 'o2v + latent_psl_fwd + sa_core_fwd + decatt_fwd x 26 (forward pass of '
-                                                              'SURVEY.md 8d in isolation, 1024 clips)', 'bound': 'hbm',
-                                                    'achieved': pr['achieved_GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                                    'frac': round(pr['achieved_GBps'] / PEAK_HBM_GBS, 4), 'traffic': ptraffic,
-                                                    'clips_per_s': pr['clips_per_s'], 'ms': pr['ms'], 'parts_ms': pr['parts_ms'],
-                                                    'bytes_per_clip': pr['bytes_per_clip']}
+            hs = pr['hbm_streaming_part']
+            out['roofline_graph_attention_pass'] = {
+                'kernel': 'o2v_fwd x2 + latent_psl_fwd x2 + sa_core_fwd: the HBM-streaming part of the SURVEY.md 8d forward pass '
+                          '(4.96 MB/clip), product kernels, 1024 clips in flight', 'bound': 'hbm',
+                'achieved': hs['achieved_GBps'], 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                'frac': round(hs['achieved_GBps'] / PEAK_HBM_GBS, 4), 'traffic': ptraffic, 'clips_per_s': hs['clips_per_s'],
+                'ms': hs['ms'], 'bytes_per_clip': hs['bytes_per_clip'], 'parts_ms': pr['parts_ms'], 'parts_GBps': pr['parts_GBps'],
+                'decoder_term_cache_resident': pr['decoder_term'],
+                'whole_pass_incl_decoder_term': {'bytes_per_clip': pr['bytes_per_clip'], 'ms': pr['ms'],
+                                                 'GBps': pr['achieved_GBps'], 'clips_per_s': pr['clips_per_s']}}
+        if b128 is not None:
+            out['batch_128'] = b128
+        if world == 1 and not a.no_eager_baseline and a.shape == 'msvd':
+            eb = gpu_eager_baseline(dev, a.batch)
+            eb['speedup'] = round(out['value'] / eb['clips_per_s'], 2)
+            out['vs_pytorch_rocm_eager'] = eb
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         out['dtype_note'] = {'fp32': 'all products on fp32-input MFMA (exact fp32)',

@@ -550,13 +550,16 @@ __global__ __launch_bounds__(256) void ce_ragged_kernel(const float* __restrict_
     for (int j = threadIdx.x; j < V; j += blockDim.x) s += __expf(x[j] - m);
     s = block_sum(s, red);
     const int64_t tgt = targets[(int64_t)b * L + t];
-    const float inv = 1.f / s, invn = 1.f / (float)ntot;
+    // a target outside [0, V) (torch's CrossEntropyLoss raises): no out-of-bounds read; the row's loss -- hence the step's
+    // loss -- and its gradient are NaN, which no caller can miss
+    const bool bad = tgt < 0 || tgt >= V;
+    const float inv = bad ? NAN : 1.f / s, invn = 1.f / (float)ntot;
     for (int j = threadIdx.x; j < V; j += blockDim.x) {
         float p = __expf(x[j] - m) * inv;
         if (j == tgt) p -= 1.f;
         dx[j] = p * invn;
     }
-    if (threadIdx.x == 0) row_loss[row] = (logf(s) + m - x[tgt]) * invn;
+    if (threadIdx.x == 0) row_loss[row] = bad ? NAN : (logf(s) + m - x[tgt]) * invn;
 }
 __global__ __launch_bounds__(256) void sum_to_scalar_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
     __shared__ float red[16];

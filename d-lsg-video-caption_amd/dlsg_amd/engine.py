@@ -109,8 +109,10 @@ def gemm_tn_deep(ops, items, ref):
         for i0 in range(0, len(grp), 2):
             part = grp[i0:i0 + 2]
             rows = part[0][0].shape[0]
-            step = (rows // ks + 31) // 32 * 32
+            # ceil, not floor: rows = 8450 (5 objects x 26 frames x 65 clips) with floor gave 9 chunks -> 18 groups > MAXG
+            step = ((rows + ks - 1) // ks + 31) // 32 * 32
             bounds = [(k, min(rows, k + step)) for k in range(0, rows, step)]
+            assert len(bounds) * len(part) <= 16
             slabs = [_empty(ref, len(bounds), gout.shape[0], gout.shape[1]) for _, _, gout in part]
             ops.gemm(GEMM_TN, [(dy[k0:k1], x[k0:k1], sl[i]) for (dy, x, _), sl in zip(part, slabs)
                                for i, (k0, k1) in enumerate(bounds)])

@@ -42,6 +42,32 @@ class _HipModel(nn.Module):
         self.two_streams = False   # fork/join of the two encoder branches: measured no gain (GEMM grids fill every CU)
         self._side = None
 
+    # ------------------------------------------------------------------ copy / pickle
+    def __getstate__(self):
+        """copy.deepcopy(model) / torch.save(model): the ctypes library handle and the `random` module cannot be pickled and
+        the arenas are rebuilt on first use (flatten_parameters_ notices that the copied parameters are not its views)."""
+        st = dict(self.__dict__)
+        st['_ops_obj'] = None
+        st['rng'] = None
+        for k in ('_flat', '_gflat', '_offsets', '_G', '_side'):
+            st[k] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self.rng = random
+
+    @staticmethod
+    def check_kernel_limits(args, attended_rows, what):
+        """The fused decoder-step kernels (csrc/decstep.hip: MAXW, MAXP) hold one batch row's vectors in LDS: widths up to
+        2048, at most 32 attended rows per attention stream.  Checked at construction, with names, instead of an EINVAL
+        from the first launch."""
+        for k in ('query_hidden_size', 'decode_hidden_size', 'visual_hidden_size'):
+            if getattr(args, k) > 2048:
+                raise ValueError('%s = %d: the fused decoder step supports widths up to 2048' % (k, getattr(args, k)))
+        if attended_rows > 32:
+            raise ValueError('%s = %d: the fused decoder step attends over at most 32 rows per stream' % (what, attended_rows))
+
     # ------------------------------------------------------------------ kernels handle
     @property
     def ops(self):
@@ -150,7 +176,7 @@ class _ModelFn(torch.autograd.Function):
         G = model.grad_views()
         grads = []
         for name, p in model.named_parameters():
-            grads.append(G[name].clone() if name not in model.unused_parameters else None)
+            grads.append(G[name].clone() if (name not in model.unused_parameters and p.requires_grad) else None)
         ctx.sv = None
         return (None,) * 7 + tuple(grads)
 
@@ -173,12 +199,26 @@ class CapGnnModel(_HipModel):
 
     def __init__(self, args, vocab):
         super().__init__()
+        self.check_kernel_limits(args, args.num_proposals, 'num_proposals')
         self.use_visual_gan = args.use_visual_gan
         self.encoder = CapGnnEncoder(args)
         self.decoder = Decoder(args, vocab, multi_modal=True)
 
     def update_beam_size(self, beam_size):
         self.decoder.update_beam_size(beam_size)
+
+    def load_encoder(self, model, model_path):
+        """models/model.py:45-53: load `model_path` into `model`, graft its `.encoder` and `.decoder.word_embed` into this
+        model and freeze the word embedding.  The grafted modules are shared objects, as in the reference; this model's
+        arenas are re-packed around them on the next use (the donor is not meant to be used afterwards, run_gun.py keeps
+        only the grafted model).  `Trainer` leaves parameters with `requires_grad == False` untouched."""
+        if model_path is not None:
+            model.load_state_dict(torch.load(model_path, map_location=next(self.parameters()).device))
+        self.encoder = model.encoder
+        self.decoder.word_embed = model.decoder.word_embed
+        for param in self.decoder.word_embed.parameters():
+            param.requires_grad = False
+        self._flat = None                   # parameters changed identity: re-pack
 
     # ------------------------------------------------------------------ engine schedules
     def _encode(self, frames, regions, training, seed, sv):
@@ -286,6 +326,7 @@ class CapBaseline1(_HipModel):
 
     def __init__(self, args, vocab):
         super().__init__()
+        self.check_kernel_limits(args, args.max_frames, 'max_frames (baseline decoders attend over the frame nodes)')
         self.use_visual_gan = args.use_visual_gan
         self.encoder = EncoderVisual(args, baseline=True)
         self.decoder = Decoder(args, vocab, multi_modal=False, baseline=True)
@@ -367,6 +408,7 @@ class CapBaselineModel(_HipModel):
 
     def __init__(self, args, vocab):
         super().__init__()
+        self.check_kernel_limits(args, args.max_frames, 'max_frames (baseline decoders attend over the frame nodes)')
         self.use_visual_gan = args.use_visual_gan
         self.encoder = CapGnnEncoder(args, baseline=True)
         self.linear_baseline = nn.Linear(args.visual_hidden_size * 2, args.visual_hidden_size)
@@ -510,22 +552,37 @@ class Trainer(object):
     memory: inputs (static buffers), the dropout seed, the scheduled-sampling coins, the Adam bias corrections."""
 
     def __init__(self, model, lr=1.6e-4, betas=(0.5, 0.9), eps=1e-8, process_group=None, world_size=1, use_graphs=False,
-                 device_coins=None):
+                 device_coins=None, graph_fallback=False):
         self.model = model
-        model.flatten_parameters_()
         self.lr, self.betas, self.eps = lr, betas, eps
-        self.m = torch.zeros_like(model._flat)
-        self.v = torch.zeros_like(model._flat)
         self.t = 0
         self.world_size = world_size
         self.pg = process_group
         self.use_graphs = use_graphs
         self.device_coins = use_graphs if device_coins is None else device_coins
+        self.graph_fallback = graph_fallback   # True: a failed capture downgrades to eager launches (with a warning)
         self.force_graph_cuts = False   # test hook: segment the capture at bucket boundaries even on one GPU
+        self.force_collectives = False  # test hook: issue the all-reduces even with one rank (RCCL path on a 1-GPU box)
         self._works = []
+        self._graphs = None
+        self.m = self.v = None
+        self._bind()
+
+    def _bind(self):
+        """(Re)attach to the model's arenas: Adam moments, bucket ranges, trainable ranges.  Runs again whenever the model
+        re-packed its parameters (load_encoder grafts modules) or a parameter's requires_grad changed."""
+        model = self.model
+        model.flatten_parameters_()
+        old_m, old_v = self.m, self.v
+        self.m = torch.zeros_like(model._flat)
+        self.v = torch.zeros_like(model._flat)
+        if old_m is not None and old_m.shape == self.m.shape and old_m.device == self.m.device:
+            self.m.copy_(old_m); self.v.copy_(old_v)      # same layout (only the frozen set changed): keep the moments
+        self._arena = model._flat
         self._graphs = None
         # contiguous arena range of each backward bucket (named_parameters order == arena order)
         self._ranges = {}
+        frozen = []
         for name, p in model.named_parameters():
             key = name.split('.')[0] if not name.startswith('encoder.') or not hasattr(model.encoder, 'obj_encoder') \
                 else '.'.join(name.split('.')[:2])
@@ -533,6 +590,38 @@ class Trainer(object):
             end = o + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
             lo, hi = self._ranges.get(key, (o, end))
             self._ranges[key] = (min(lo, o), max(hi, end))
+            if not p.requires_grad:
+                frozen.append((o, end))
+        self._frozen = tuple(frozen)
+        # maximal runs of trainable parameters: Adam and the all-reduces cover exactly these (torch.optim skips parameters
+        # without a gradient; DDP does not reduce them)
+        self._train_ranges = self._minus_frozen(0, model._flat.numel())
+
+    def _minus_frozen(self, lo, hi):
+        out, cur = [], lo
+        for a, b in self._frozen:
+            if b <= lo or a >= hi:
+                continue
+            if a > cur:
+                out.append((cur, a))
+            cur = max(cur, b)
+        if cur < hi:
+            out.append((cur, hi))
+        return out
+
+    def _check_binding(self):
+        model = self.model
+        model.flatten_parameters_()
+        frozen = tuple((model._offsets[n], model._offsets[n] + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN)
+                       for n, p in model.named_parameters() if not p.requires_grad)
+        if self._arena is not model._flat or frozen != self._frozen:
+            self._bind()
+
+    def _adam(self, step, hyper=None):
+        model, ops = self.model, self.model.ops
+        for lo, hi in self._train_ranges:
+            ops.adam(model._flat[lo:hi], model._gflat[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
+                     self.betas[1], self.eps, step, 1.0 / self.world_size, hyper=hyper)
 
     # ------------------------------------------------------------------ checkpoint compatibility (run_gun.py:302-310)
     def optimizer_state_dict(self):
@@ -543,7 +632,7 @@ class Trainer(object):
         state = {}
         names = [n for n, _ in model.named_parameters()]
         for i, (name, p) in enumerate(model.named_parameters()):
-            if name in model.unused_parameters or self.t == 0:
+            if name in model.unused_parameters or not p.requires_grad or self.t == 0:
                 continue
             o = model._offsets[name]
             state[i] = {'step': torch.tensor(float(self.t)),
@@ -579,12 +668,12 @@ class Trainer(object):
     # ------------------------------------------------------------------ collectives
     def _allreduce(self, key):
         """key: a bucket name or a tuple of bucket names whose gradients are complete."""
-        if self.world_size <= 1:
+        if self.world_size <= 1 and not self.force_collectives:
             return
         import torch.distributed as dist
         for k in (key if isinstance(key, tuple) else (key,)):
-            lo, hi = self._ranges[k]
-            self._works.append(dist.all_reduce(self.model._gflat[lo:hi], group=self.pg, async_op=True))
+            for lo, hi in self._minus_frozen(*self._ranges[k]):
+                self._works.append(dist.all_reduce(self.model._gflat[lo:hi], group=self.pg, async_op=True))
 
     # ------------------------------------------------------------------ one step, as a schedule
     def _schedule(self, frames, regions, captions, cap_lens, coins, seed, dev_coins, on_bucket):
@@ -610,7 +699,7 @@ class Trainer(object):
     def step(self, frames, regions, captions, cap_lens, tf_ratio, max_len=26):
         """One optimisation step.  Returns the (device) scalar loss of this rank's shard."""
         model, ops = self.model, self.model.ops
-        model.flatten_parameters_()
+        self._check_binding()
         captions = captions[:, :max_len].contiguous()
         cap_lens = torch.as_tensor(cap_lens).to(device=captions.device, dtype=torch.int64)
         L = captions.shape[1]
@@ -632,8 +721,7 @@ class Trainer(object):
         loss = self._schedule(frames, regions, captions, cap_lens, coins, seed, dev_coins, self._allreduce)
         for w in self._works:
             w.wait()
-        ops.adam(model._flat, model._gflat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                 1.0 / self.world_size)
+        self._adam(self.t)
         return loss
 
     # ------------------------------------------------------------------ hipGraph path
@@ -647,6 +735,7 @@ class Trainer(object):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         graphs = []
+        cuts = self.world_size > 1 or self.force_graph_cuts
         with torch.cuda.stream(side):
             # eager warm-up on the capture stream (allocator warm, one-time kernel attribute calls)
             self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], None)
@@ -655,36 +744,50 @@ class Trainer(object):
             # thread-local capture mode: calls made by other threads (e.g. the RCCL watchdog) cannot invalidate the capture
             cur = [torch.cuda.CUDAGraph()]
             cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
+            try:
+                def cut(key):
+                    if not cuts:
+                        return
+                    cur[0].capture_end()
+                    graphs.append((cur[0], key))
+                    cur[0] = torch.cuda.CUDAGraph()
+                    cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
 
-            def cut(key):
-                if self.world_size <= 1 and not self.force_graph_cuts:
-                    return
+                loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut)
+                if not cuts or (self.world_size <= 1 and not self.force_collectives):
+                    # no collective between backward and update: Adam is part of the (last) graph; with several ranks it
+                    # follows the all-reduce waits
+                    self._adam(1, hyper=st['hyper'])
                 cur[0].capture_end()
-                graphs.append((cur[0], key))
-                cur[0] = torch.cuda.CUDAGraph()
-                cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
-
-            loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut)
-            if self.world_size <= 1:
-                # single GPU: Adam is part of the (last) graph; with several ranks it follows the all-reduce waits
-                self.model.ops.adam(self.model._flat, self.model._gflat, self.m, self.v, self.lr, self.betas[0],
-                                    self.betas[1], self.eps, 1, 1.0, hyper=st['hyper'])
-            cur[0].capture_end()
-            graphs.append((cur[0], None))
+                graphs.append((cur[0], None))
+            except BaseException:
+                # leave no stream in capture mode behind (a later synchronize would raise on top of the real error) and
+                # drop the partial graphs
+                try:
+                    cur[0].capture_end()
+                except Exception:
+                    pass
+                graphs.clear()
+                self._graphs = None
+                raise
         torch.cuda.current_stream().wait_stream(side)
         self._graphs, self._loss = graphs, loss
+        self._adam_in_graph = not cuts or (self.world_size <= 1 and not self.force_collectives)
 
     def _step_graphs(self, frames, regions, captions, cap_lens, coins, seed):
         model, ops = self.model, self.model.ops
         if self._graphs is None:
-            try:
+            if not self.graph_fallback:
                 self._capture(frames, regions, captions, cap_lens)
-            except Exception as e:      # never lose the run to a capture problem: fall back to kernel-by-kernel launches
-                import warnings
-                warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
-                torch.cuda.synchronize()
-                self.use_graphs, self._graphs = False, None
-                return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
+            else:
+                try:
+                    self._capture(frames, regions, captions, cap_lens)
+                except RuntimeError as e:   # opted in: keep the run alive on kernel-by-kernel launches
+                    import warnings
+                    warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
+                    torch.cuda.synchronize()
+                    self.use_graphs, self._graphs = False, None
+                    return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
         st = self._static
         if (frames.shape, regions.shape, captions.shape) != (st['frames'].shape, st['regions'].shape, st['captions'].shape):
             # a batch of another shape (the short last batch of an epoch): the captured graphs are for one shape only
@@ -700,9 +803,9 @@ class Trainer(object):
             g.replay()
             if key is not None:
                 self._allreduce(key)
-        if self.world_size > 1:
+        if not self._adam_in_graph:
             for w in self._works:
                 w.wait()
-            ops.adam(model._flat, model._gflat, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                     1.0 / self.world_size)
-        return self._loss
+            self._adam(self.t)
+        # the loss lives in the graphs' static memory: hand out a copy, so losses kept across steps do not alias
+        return self._loss.clone()

@@ -415,6 +415,15 @@ class CapGnnModelRef(nn.Module):
     def update_beam_size(self, k):
         self.decoder.beam_size = k
 
+    def load_encoder(self, model, model_path):
+        """models/model.py:45-53: graft the donor's encoder and word embedding, freeze the word embedding."""
+        if model_path is not None:
+            model.load_state_dict(torch.load(model_path, map_location='cpu'))
+        self.encoder = model.encoder
+        self.decoder.word_embed = model.decoder.word_embed
+        for param in self.decoder.word_embed.parameters():
+            param.requires_grad = False
+
 
 class CapBaseline1Ref(nn.Module):
     """models/model.py:94-107 -- frames-only variant (EncoderVisual(baseline) + Decoder(baseline))."""

@@ -51,3 +51,59 @@ def weights_and_inputs(model, g, args):
     if 'frames' in g:
         assert np.array_equal(frames.numpy(), g['frames'])
     return sd, frames, regions, caps, torch.as_tensor(g['cap_lens'])
+
+
+def load_aux(tag, suffix):
+    """Round-2 fixtures (tests/golden/make_goldens_r2.py) share config, weights and inputs with the base case `tag`:
+    -> golden dict of tests/golden/<tag>_<suffix>.npz"""
+    return dict(np.load(os.path.join(GOLD, '%s_%s.npz' % (tag, suffix))))
+
+
+def check_grads(get_grad, named_parameters, g, rel, abs_=2e-5):
+    """every parameter gradient against a fixture holding 'g.<name>' arrays (or 'gnorm.<name>' norms / 'gnone.<name>')"""
+    for k, p in named_parameters:
+        got = get_grad(k, p)
+        if 'gnone.' + k in g:
+            assert got is None or float(got.abs().max()) == 0.0, k
+        elif 'g.' + k in g:
+            ref = g['g.' + k]
+            err = np.abs(got.detach().cpu().numpy() - ref).max()
+            assert err <= abs_ + rel * np.abs(ref).max(), (k, err, np.abs(ref).max())
+        else:
+            ref = float(g['gnorm.' + k])
+            n = float(got.detach().double().norm())
+            assert abs(n - ref) <= 2.5 * rel * max(ref, 1e-6) + 1e-6, (k, n, ref)
+
+
+def graft_and_step(make_model, device, tmp_path, make_trainer):
+    """CapGnnModel.load_encoder (models/model.py:45-53) followed by one optimisation step: returns (model, word-embedding
+    before the step, loss).  make_model(args, vocab) -> model; make_trainer(model) -> object with .step(...)."""
+    args = small_args()
+    vocab = make_vocab(50)
+    torch.manual_seed(0)
+    donor = make_model(args, vocab).eval()
+    sd_donor = synth_state_dict(donor.state_dict(), 31)
+    path = os.path.join(str(tmp_path), 'donor.pt')
+    torch.save(sd_donor, path)
+    net = make_model(args, vocab).eval()
+    net.load_state_dict(synth_state_dict(net.state_dict(), 32))
+    donor, net = donor.to(device), net.to(device)
+    net.load_encoder(donor, path)
+    frames, regions, caps, lens = synth_batch(args, 50, 3, 33)
+    emb0 = net.decoder.word_embed.weight.detach().cpu().clone()
+    assert torch.equal(emb0, sd_donor['decoder.word_embed.weight'])
+    tr = make_trainer(net)
+    loss = tr.step(frames.to(device), regions.to(device), caps.to(device), lens, 1.0)
+    return net, emb0, float(loss)
+
+
+class OracleTrainer(object):
+    """run_gun.py:91,181-198,233-234 around the oracle model: torch.optim.Adam over model.parameters()"""
+
+    def __init__(self, model, lr=1.6e-4):
+        from oracle import torch_ref as R
+        self.R, self.model = R, model
+        self.opt = R.make_optimizer(model, lr)
+
+    def step(self, frames, regions, caps, lens, tf):
+        return self.R.train_step(self.model, self.opt, frames, regions, caps, lens, tf)

@@ -200,3 +200,133 @@ def test_caller_side_schedules_match_the_reference():
         assert abs(dlsg_amd.ss_epsilon(epoch) - max(0.6, 20 / (20 + math.exp(epoch / 20)))) < 1e-12
         opt.step()
         sch.step()
+
+
+@pytest.mark.parametrize('tag', ['small_msvd', 'small_msrvtt', 'small_baseline1'])
+@pytest.mark.parametrize('dev_coins', [False, True])
+def test_gradients_under_scheduled_sampling(tag, dev_coins):
+    """tf = 0.6 with the reference's coin order: host-branching schedule and the device-coin schedule (select_embed /
+    skip_if, what a replayed hipGraph runs) against the reference's loss and gradients (tests/golden/*_ss.npz)."""
+    from helpers import load_aux, check_grads
+    net, _, frames, regions, caps, lens, kind = build(tag)
+    g = load_aux(tag, 'ss')
+    tr = dlsg_amd.Trainer(net, lr=0.0, device_coins=dev_coins)
+    random.seed(12)
+    loss = tr.step(frames, regions, caps, lens, 0.6)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-5
+    G = net.grad_views()
+    check_grads(lambda k, p: G[k], net.named_parameters(), g, rel=2e-4)
+
+
+@pytest.mark.parametrize('tag', ['small_msvd', 'small_msrvtt'])
+@pytest.mark.parametrize('dev_coins', [False, True])
+def test_dropout_placement_matches_reference(tag, dev_coins):
+    """TRAIN mode.  tests/golden/*_drop.npz: the reference's own forward/backward with torch.nn.functional.dropout taking
+    its masks from the build's counter hash, keyed by call order -> site.  A dropout at the wrong place, on the wrong
+    tensor or with the wrong p in engine.py changes logits and gradients."""
+    from helpers import load_aux, check_grads
+    net, _, frames, regions, caps, lens, kind = build(tag)
+    g = load_aux(tag, 'drop')
+    net.train()
+    net.seed_counter = int(g['meta.counter']) - 1
+    tr = dlsg_amd.Trainer(net, lr=0.0, device_coins=dev_coins)
+    random.seed(4)
+    loss = tr.step(frames, regions, caps, lens, float(g['meta.tf']))
+    assert abs(float(loss) - float(g['loss'])) <= 1e-5
+    G = net.grad_views()
+    check_grads(lambda k, p: G[k], net.named_parameters(), g, rel=2e-4)
+    net.seed_counter = int(g['meta.counter']) - 1
+    random.seed(4)
+    with torch.no_grad():
+        logits = net(frames, regions, caps, 26, float(g['meta.tf']))[0]
+    assert np.abs(logits.numpy() - g['logits']).max() <= 2e-5
+
+
+def test_load_encoder_grafts_and_freezes_word_embedding(tmp_path):
+    """models/model.py:45-53 + one step: the grafted encoder / word embedding are the donor's, the frozen embedding stays
+    bit-unchanged (Trainer skips requires_grad == False ranges in Adam and in the buckets), everything else equals the
+    oracle doing the same with torch.optim.Adam."""
+    from helpers import graft_and_step, OracleTrainer
+    from oracle import torch_ref as R
+
+    def mk(args, vocab):
+        m = dlsg_amd.CapGnnModel(args, vocab)
+        m.set_ops(EmulOps())
+        return m
+    net, emb0, loss = graft_and_step(mk, 'cpu', tmp_path, lambda m: dlsg_amd.Trainer(m))
+    orc, emb0_o, loss_o = graft_and_step(R.CapGnnModelRef, 'cpu', tmp_path, OracleTrainer)
+    assert abs(loss - loss_o) <= 1e-5
+    assert torch.equal(net.decoder.word_embed.weight.detach(), emb0)
+    assert not net.decoder.word_embed.weight.requires_grad
+    want = dict(orc.named_parameters())
+    moved = 0
+    for k, p in net.named_parameters():
+        d = (p.detach() - want[k].detach()).abs()
+        # Adam's first step is lr * g / (|g| + eps): elements whose gradient is at rounding level (|g| ~ eps) may differ by up
+        # to lr between two correct implementations; they are rare
+        assert d.max().item() <= 3.3e-4 and (d > 2e-6).float().mean().item() <= 2e-3, (k, d.max().item())
+        moved += int(not torch.equal(p.detach(), emb0) and p.requires_grad)
+    assert moved > 50
+
+
+def test_trainer_rebinds_when_a_parameter_is_frozen_later():
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    tr = dlsg_amd.Trainer(net)
+    tr.step(frames, regions, caps, lens, 1.0)
+    w = net.encoder.obj_encoder.obj_embed.weight
+    w.requires_grad = False
+    before = w.detach().clone()
+    other = net.decoder.word_restore.weight.detach().clone()
+    tr.step(frames, regions, caps, lens, 1.0)
+    assert torch.equal(w.detach(), before)
+    assert not torch.equal(net.decoder.word_restore.weight.detach(), other)
+    sd = tr.optimizer_state_dict()
+    names = [n for n, _ in net.named_parameters()]
+    assert names.index('encoder.obj_encoder.obj_embed.weight') not in sd['state']
+
+
+def test_model_deepcopies_and_pickles(tmp_path):
+    import copy
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    with torch.no_grad():
+        want = net(frames, regions, caps, 26, 1.0)[0]
+    twin = copy.deepcopy(net)
+    twin.set_ops(EmulOps())
+    torch.save(net, str(tmp_path / 'm.pt'))
+    back = torch.load(str(tmp_path / 'm.pt'), weights_only=False)
+    back.set_ops(EmulOps())
+    with torch.no_grad():
+        assert torch.equal(twin(frames, regions, caps, 26, 1.0)[0], want)
+        assert torch.equal(back(frames, regions, caps, 26, 1.0)[0], want)
+
+
+def test_kernel_limits_are_reported_at_construction():
+    from helpers import small_args
+    with pytest.raises(ValueError, match='num_proposals'):
+        dlsg_amd.CapGnnModel(small_args(num_proposals=40), dlsg_amd.make_vocab(50))
+    with pytest.raises(ValueError, match='max_frames'):
+        dlsg_amd.CapBaseline1(small_args(max_frames=40), dlsg_amd.make_vocab(50))
+    with pytest.raises(ValueError, match='decode_hidden_size'):
+        dlsg_amd.CapGnnModel(small_args(decode_hidden_size=4096), dlsg_amd.make_vocab(50))
+
+
+def test_deep_weight_gradient_split_respects_group_limit():
+    """rows = 8450 (5 objects x 26 frames x 65 clips): the row split of gemm_tn_deep must stay within 16 groups per launch."""
+    from dlsg_amd import engine as E
+    ops = EmulOps()
+    launches = []
+    real = ops.gemm
+
+    def spy(mode, groups, **kw):
+        launches.append(len(groups))
+        return real(mode, groups, **kw)
+    ops.gemm = spy
+    g = torch.Generator().manual_seed(0)
+    items = []
+    for _ in range(2):
+        dy, x = torch.randn(8450, 8, generator=g), torch.randn(8450, 6, generator=g)
+        items.append((dy, x, torch.zeros(8, 6)))
+    E.gemm_tn_deep(ops, items, items[0][0])
+    assert max(launches) <= 16
+    for dy, x, gout in items:
+        assert (gout - dy.t() @ x).abs().max().item() <= 1e-3

@@ -150,14 +150,83 @@ def test_full_size_msvd_shape():
             assert abs(got - ref) <= 5e-3 * max(ref, 1e-6) + 1e-6, (k, got, ref)
 
 
-def test_full_size_msrvtt_shape():
+@pytest.mark.parametrize('mode', ['fp32', 'x3_bwd', 'x3_all'])
+def test_full_size_msrvtt_shape(mode):
+    """BASELINE config 3 shape (run_gun.py:31-40: 36 objects -> 936 object nodes, 5 proposals, D = 1536, vocab 10k), every
+    output the fixture holds: top-8 logits, greedy and beam-5 ids, loss, the norm of every parameter gradient (the
+    6144-wide language cell, the 936-object fused graph backward, the 10k-vocab CE / beam_select)."""
     net, g, frames, regions, caps, lens, kind = build('full_msrvtt_b2')
+    net.gemm_precision = mode
     with torch.no_grad():
         logits = net(frames, regions, caps, 26, 1.0)[0].cpu()
-    top = torch.topk(logits, 8, dim=-1)
-    assert np.array_equal(top.indices[..., 0].numpy(), g['logits_top_idx'][..., 0])
-    assert np.abs(top.values.numpy() - g['logits_top_val']).max() <= 1e-3
-    assert np.abs(logits.double().sum(-1).numpy() - g['logits_sum']).max() <= 0.5
+        top = torch.topk(logits, 8, dim=-1)
+        assert np.array_equal(top.indices[..., 0].numpy(), g['logits_top_idx'][..., 0])
+        assert np.abs(top.values.numpy() - g['logits_top_val']).max() <= 1e-3
+        assert np.abs(logits.double().sum(-1).numpy() - g['logits_sum']).max() <= 0.5
+        net.update_beam_size(1)
+        ids = net(frames, regions, None)[0].cpu().numpy()
+        assert np.array_equal(ids, g['greedy_ids']), g['logit_margin'].min()
+        net.update_beam_size(5)
+        bids = net(frames, regions, None)[0].cpu().numpy()
+        assert np.array_equal(bids, g['beam5_ids'])
+    tr = dlsg_amd.Trainer(net)
+    loss = tr.step(frames, regions, caps, lens, 1.0)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-3
+    G = net.grad_views()
+    n = 0
+    for k, p in net.named_parameters():
+        if 'gnorm.' + k in g:
+            ref = float(g['gnorm.' + k])
+            got = float(G[k].double().norm())
+            assert abs(got - ref) <= 5e-3 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+            n += 1
+    assert n >= 80
+
+
+@pytest.mark.parametrize('tag', ['small_msvd', 'small_msrvtt', 'small_baseline1', 'full_msvd_b2'])
+@pytest.mark.parametrize('graphs', [False, True])
+def test_gradients_under_scheduled_sampling_vs_reference(tag, graphs):
+    """tf = 0.6, coin order of random.seed(12): 11 of the 26 steps are fed their own argmax (layer.py:432-439) -- the
+    per-step vocab projection, `select_embed` / `skip_if` under hipGraph replay, the embedding-gradient scatter to sampled
+    ids.  Loss and every gradient against the reference itself (tests/golden/*_ss.npz), eager and replayed."""
+    from helpers import load_aux, check_grads
+    net, _, frames, regions, caps, lens, kind = build(tag)
+    g = load_aux(tag, 'ss')
+    tr = dlsg_amd.Trainer(net, lr=0.0, use_graphs=graphs)
+    for rep in range(2 if graphs else 1):          # second pass = a replay of the captured graphs
+        random.seed(12)
+        loss = tr.step(frames, regions, caps, lens, 0.6)
+        assert abs(float(loss) - float(g['loss'])) <= (1e-4 if 'logits' in g else 1e-3)
+        G = net.grad_views()
+        check_grads(lambda k, p: G[k], net.named_parameters(), g, rel=2e-3)
+    if graphs:
+        assert tr._graphs is not None
+
+
+@pytest.mark.parametrize('tag', ['small_msvd', 'small_msrvtt'])
+@pytest.mark.parametrize('graphs', [False, True])
+def test_dropout_placement_vs_reference(tag, graphs):
+    """TRAIN mode against the reference (tests/golden/*_drop.npz: the reference's forward/backward with
+    torch.nn.functional.dropout drawing its masks from this build's counter hash, keyed by call order -> site): pins the
+    nine dropout sites, their tensors and their p (layer.py:28,53,310,320,328; sublayer.py:21-26,58-61,87,183-187)."""
+    from helpers import load_aux, check_grads
+    net, _, frames, regions, caps, lens, kind = build(tag)
+    g = load_aux(tag, 'drop')
+    net.train()
+    tf = float(g['meta.tf'])
+    tr = dlsg_amd.Trainer(net, lr=0.0, use_graphs=graphs)
+    for rep in range(2 if graphs else 1):
+        net.seed_counter = int(g['meta.counter']) - 1
+        random.seed(4)
+        loss = tr.step(frames, regions, caps, lens, tf)
+        assert abs(float(loss) - float(g['loss'])) <= 1e-4
+        G = net.grad_views()
+        check_grads(lambda k, p: G[k], net.named_parameters(), g, rel=2e-3)
+    net.seed_counter = int(g['meta.counter']) - 1
+    random.seed(4)
+    with torch.no_grad():
+        logits = net(frames, regions, caps, 26, tf)[0]
+    assert np.abs(logits.cpu().numpy() - g['logits']).max() <= LOGIT_TOL
 
 
 def test_train_mode_matches_emulated_masks():
@@ -344,10 +413,12 @@ def test_hipgraph_beam_search_ids_bit_exact(tag):
     assert torch.equal(bg(f2, r2)[0], want)
 
 
-def test_full_size_batch64_clips_are_independent_and_deterministic():
-    """Size-independent properties at the bench configuration (MSVD-shaped, batch 64): the forward is deterministic
+@pytest.mark.parametrize('Bn', [64, 128])
+def test_full_size_batch64_clips_are_independent_and_deterministic(Bn):
+    """Size-independent properties at the bench configuration (MSVD-shaped, batch 64, and 128 = BASELINE
+    config 4's per-GPU batch): the forward is deterministic
     (bit-identical on a second run) and a clip's logits / greedy ids do not depend on which other clips share its batch
-    (same clip alone, in a batch of 3, in the batch of 64): catches any cross-clip indexing at full size."""
+    (same clip alone, in a batch of 3, in the full batch): catches any cross-clip indexing at full size."""
     from dlsg_amd.synth import synth_state_dict, synth_batch
     args = dlsg_amd.msvd_shaped()
     vocab = dlsg_amd.make_vocab(1000)
@@ -355,7 +426,7 @@ def test_full_size_batch64_clips_are_independent_and_deterministic():
     net = dlsg_amd.CapGnnModel(args, vocab).eval()
     net.load_state_dict(synth_state_dict(net.state_dict(), 3))
     net = net.cuda()
-    frames, regions, caps, lens = synth_batch(args, 1000, 64, 5)
+    frames, regions, caps, lens = synth_batch(args, 1000, Bn, 5)
     frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
     with torch.no_grad():
         full = net(frames, regions, caps, 26, 1.0)[0]
@@ -363,7 +434,7 @@ def test_full_size_batch64_clips_are_independent_and_deterministic():
         assert torch.equal(full, again)
         net.update_beam_size(1)
         ids_full = net(frames, regions, None)[0]
-        for sel in ([0], [63], [5, 17, 40]):
+        for sel in ([0], [Bn - 1], [5, 17, 40]):
             idx = torch.tensor(sel, device='cuda')
             part = net(frames[idx].contiguous(), regions[idx].contiguous(), caps[idx].contiguous(), 26, 1.0)[0]
             assert (part - full[idx]).abs().max().item() <= 5e-5, sel
@@ -371,29 +442,32 @@ def test_full_size_batch64_clips_are_independent_and_deterministic():
             assert torch.equal(ids_part, ids_full[idx]), sel
 
 
-@pytest.mark.parametrize('mode', ['fp32', 'x3_bwd'])
-def test_full_size_gradient_is_token_weighted_mean_of_shard_gradients(mode):
-    """Property at the bench configuration (batch 64, MSVD-shaped, dropout off): the ragged CrossEntropy is a mean over
+@pytest.mark.parametrize('mode,Bn,shape', [('fp32', 64, 'msvd'), ('x3_bwd', 64, 'msvd'), ('fp32', 128, 'msvd'),
+                                           ('fp32', 64, 'msrvtt')])
+def test_full_size_gradient_is_token_weighted_mean_of_shard_gradients(mode, Bn, shape):
+    """Property at the bench configurations (batch 64 and 128 MSVD-shaped, batch 64 MSR-VTT-shaped = BASELINE configs 1, 4
+    and 3 per GPU; dropout off): the ragged CrossEntropy is a mean over
     sum(cap_lens) rows, so grad(batch) = (n_A grad(A) + n_B grad(B)) / (n_A + n_B) for any split of the batch.  Exercises
     every backward kernel at full size with no oracle in the loop."""
     from dlsg_amd.synth import synth_state_dict, synth_batch
-    args = dlsg_amd.msvd_shaped()
-    vocab = dlsg_amd.make_vocab(1000)
+    args = dlsg_amd.msvd_shaped() if shape == 'msvd' else dlsg_amd.msrvtt_shaped()
+    V = 1000 if shape == 'msvd' else 10000
+    vocab = dlsg_amd.make_vocab(V)
     torch.manual_seed(0)
     net = dlsg_amd.CapGnnModel(args, vocab).eval()
     net.load_state_dict(synth_state_dict(net.state_dict(), 4))
     net = net.cuda()
     net.gemm_precision = mode
-    frames, regions, caps, lens = synth_batch(args, 1000, 64, 6)
+    frames, regions, caps, lens = synth_batch(args, V, Bn, 6)
     frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
     tr = dlsg_amd.Trainer(net, lr=0.0)
 
     def grad(sl):
         loss = tr.step(frames[sl].contiguous(), regions[sl].contiguous(), caps[sl].contiguous(), lens[sl], 1.0)
         return float(loss), net._gflat.clone(), int(lens[sl].clamp(max=26).sum())
-    lf, gf, nf = grad(slice(0, 64))
+    lf, gf, nf = grad(slice(0, Bn))
     la, ga, na = grad(slice(0, 23))
-    lb, gb, nb = grad(slice(23, 64))
+    lb, gb, nb = grad(slice(23, Bn))
     assert na + nb == nf
     assert abs(lf - (na * la + nb * lb) / nf) <= 2e-5
     want = (na * ga + nb * gb) / nf
@@ -431,3 +505,35 @@ def test_graph_trainer_follows_lr_changes_and_resumes_from_torch_adam_state():
     tr.step(frames, regions, caps, lens, 1.0)
     tr2.step(frames, regions, caps, lens, 1.0)
     assert torch.equal(net._flat, net2._flat)
+
+
+def test_load_encoder_grafts_and_freezes_word_embedding(tmp_path):
+    """models/model.py:45-53 on the GPU: graft + one optimisation step (eager and hipGraph) leaves the frozen word embedding
+    bit-unchanged and equals the oracle doing the same with torch.optim.Adam."""
+    from helpers import graft_and_step, OracleTrainer
+    from oracle import torch_ref as R
+    orc, _, loss_o = graft_and_step(R.CapGnnModelRef, 'cpu', tmp_path, OracleTrainer)
+    want = dict(orc.named_parameters())
+    for graphs in (False, True):
+        net, emb0, loss = graft_and_step(dlsg_amd.CapGnnModel, 'cuda', tmp_path,
+                                         lambda m: dlsg_amd.Trainer(m, use_graphs=graphs))
+        assert abs(loss - loss_o) <= 1e-4
+        assert torch.equal(net.decoder.word_embed.weight.detach().cpu(), emb0)
+        for k, p in net.named_parameters():
+            d = (p.detach().cpu() - want[k].detach()).abs()
+            assert d.max().item() <= 3.3e-4 and (d > 2e-6).float().mean().item() <= 5e-3, (k, d.max().item())
+
+
+def test_out_of_range_caption_id_poisons_the_loss():
+    """torch's CrossEntropyLoss raises on a target >= V; the fused ragged CE cannot raise from the device, it must not read
+    out of bounds and returns a NaN loss."""
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    bad = caps.clone()
+    bad[0, 0] = net.decoder.vocab_size + 7
+    L, Bn, V = 26, caps.shape[0], net.decoder.vocab_size
+    logits = torch.randn(L, Bn, V, device='cuda')
+    dl = torch.empty_like(logits); rl = torch.empty(L * Bn, device='cuda'); loss = torch.empty(1, device='cuda')
+    net.ops.ce_ragged(logits, bad, torch.as_tensor(lens).cuda(), dl, rl, loss, time_major=True)
+    assert torch.isnan(loss).item()
+    net.ops.ce_ragged(logits, caps, torch.as_tensor(lens).cuda(), dl, rl, loss, time_major=True)
+    assert torch.isfinite(loss).item() and torch.isfinite(dl).all().item()

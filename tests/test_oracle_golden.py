@@ -108,3 +108,19 @@ def test_full_size_msvd(tag):
         assert np.array_equal(net(frames, regions, None)[0].numpy(), g['greedy_ids'])
         net.update_beam_size(5)
         assert np.array_equal(net(frames, regions, None)[0].numpy(), g['beam5_ids'])
+
+
+@pytest.mark.parametrize('tag', ['small_msvd', 'small_msrvtt', 'small_baseline1', 'full_msvd_b2'])
+def test_gradients_under_scheduled_sampling(tag):
+    """tf = 0.6, random.seed(12): steps fed their own argmax (layer.py:432-439); loss and every gradient of the reference."""
+    from helpers import load_aux, check_grads
+    net, _, frames, regions, caps, lens, kind = build(tag)
+    g = load_aux(tag, 'ss')
+    random.seed(12)
+    outs = net(frames, regions, caps, 26, 0.6)[0]
+    loss = R.ragged_ce(outs, caps, lens)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5
+    if 'logits' in g:
+        assert np.abs(outs.detach().numpy() - g['logits']).max() <= 1e-5
+    check_grads(lambda k, p: p.grad, net.named_parameters(), g, rel=1e-4, abs_=1e-5)
