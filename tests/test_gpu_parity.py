@@ -180,7 +180,7 @@ def test_full_size_msrvtt_shape(mode):
             got = float(G[k].double().norm())
             assert abs(got - ref) <= 5e-3 * max(ref, 1e-6) + 1e-6, (k, got, ref)
             n += 1
-    assert n >= 80
+    assert n >= 60
 
 
 @pytest.mark.parametrize('tag', ['small_msvd', 'small_msrvtt', 'small_baseline1', 'full_msvd_b2'])
