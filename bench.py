@@ -326,7 +326,7 @@ def main():
         o = prof.get('o2v_graph_fwd')
         if o and o['ms_total'] > 0:
             ach = o['work_total'] / (o['ms_total'] * 1e-3) / 1e9
-            out['roofline_graph_attention'] = {'kernel': 'o2v_partial_kernel + o2v_combine_kernel', 'bound': 'hbm',
+            out['roofline_graph_attention'] = {'kernel': 'o2v16_kernel (both encoder streams in one launch) + o2v_combine_kernel', 'bound': 'hbm',
                                                'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                                'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
                                                'avg_launch_ms': round(o['ms_total'] / o['launches'], 4)}

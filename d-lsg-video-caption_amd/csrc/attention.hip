@@ -5,6 +5,7 @@
 //     over object chunks so that B clips fill 256 CUs.
 //   * decatt fwd / bwd : the per-word attention over the cached, pre-projected proposals
 //     (reference models/sublayer.py:28-43 with K/V (and the Q / output projections) hoisted out of the word loop).
+#include <cstdlib>
 #include <mutex>
 
 #include "common.hpp"
@@ -793,18 +794,41 @@ extern "C" int64_t dlsg_o2v_workspace_bytes(int B, int T, int H, int nsplit) {
     return (int64_t)B * nsplit * ((int64_t)T * H + 64) * 4;
 }
 
-extern "C" int dlsg_o2v_fwd(const dlsg_o2v_args* a, void* stream) {
-    if (!a || a->T < 1 || a->T > 32 || a->NO < 1 || a->nsplit < 1 || a->nsplit > 64) return DLSG_EINVAL;
-    if (a->ws_bytes < dlsg_o2v_workspace_bytes(a->B, a->T, a->H, a->nsplit)) return DLSG_EINVAL;
+int dlsg_o2v16_partial(const dlsg_o2v_args* a, int count, hipStream_t st);   // o2v16.hip
+
+extern "C" int dlsg_o2v_fwd_multi(const dlsg_o2v_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > DLSG_O2V_MAXMULTI) return DLSG_EINVAL;
+    for (int i = 0; i < count; ++i) {
+        if (a[i].T < 1 || a[i].T > 32 || a[i].NO < 1 || a[i].nsplit < 1 || a[i].nsplit > 64) return DLSG_EINVAL;
+        if (a[i].ws_bytes < dlsg_o2v_workspace_bytes(a[i].B, a[i].T, a[i].H, a[i].nsplit)) return DLSG_EINVAL;
+        if (a[i].B != a[0].B || a[i].T != a[0].T || a[i].NO != a[0].NO || a[i].H != a[0].H || a[i].nsplit != a[0].nsplit)
+            return DLSG_EINVAL;          // one launch = one shape
+    }
     if (a->B == 0) return DLSG_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    switch (a->H) {
-        case 1024: return o2v_launch<1024>(a, st);
-        case 512: return o2v_launch<512>(a, st);
-        case 64: return o2v_launch<64>(a, st);
-        default: return DLSG_EINVAL;   // caller falls back to the unfused GEMM + softmax path
+    static const bool gen1 = getenv("DLSG_O2V_GEN1") != nullptr;    // A/B switch of tools/o2v_bench.py: the first-generation kernel
+    if (!gen1 && (a->H == 1024 || a->H == 512 || a->H == 64)) {
+        const int rc = dlsg_o2v16_partial(a, count, st);
+        if (rc != DLSG_OK) return rc;
+        if (a->nsplit > 1) {
+            for (int i = 0; i < count; ++i) hipLaunchKernelGGL(o2v_combine_kernel, dim3(a->B, a->T), dim3(256), 0, st, a[i]);
+            DLSG_CHECK_LAUNCH();
+        }
+        return DLSG_OK;
     }
+    for (int i = 0; i < count; ++i) {
+        int rc;
+        switch (a->H) {
+            case 1024: rc = o2v_launch<1024>(a + i, st); break;
+            case 512: rc = o2v_launch<512>(a + i, st); break;
+            case 64: rc = o2v_launch<64>(a + i, st); break;
+            default: return DLSG_EINVAL;   // caller falls back to the unfused GEMM + softmax path
+        }
+        if (rc != DLSG_OK) return rc;
+    }
+    return DLSG_OK;
 }
+extern "C" int dlsg_o2v_fwd(const dlsg_o2v_args* a, void* stream) { return dlsg_o2v_fwd_multi(a, 1, stream); }
 extern "C" int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream) {
     if (!a || a->T < 1 || a->T > 32 || a->NO < 1 || a->nsplit < 1 || a->nsplit > 64) return DLSG_EINVAL;
     if (a->B == 0) return DLSG_OK;

@@ -24,6 +24,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// The same sum without the LDS crossbar: four DPP adds inside each row of 16 lanes (quad swaps, half-row and row mirror),
+// then the four row sums through scalar registers (v_readlane).  ~10 VALU issue slots instead of six dependent
+// ds_bpermute round trips (~100+ cycles each); every lane gets the result.  Summation order differs from wave_sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum_dpp(float v) {
+    v += dpp_f32<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);      // row_half_mirror
+    v += dpp_f32<0x140>(v);      // row_mirror
+    return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = row16_sum_dpp(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -1,0 +1,449 @@
+// Object->frame conditional graph, forward (reference models/layer.py:184-192), second generation (gfx950).
+//
+//   z[b,t,:] = sum_n softmax_n(scale * o_n . v_t) o_n + v_t,      o_n = obj_norm(y_n)  (LayerNorm, in flight)
+//
+// The first kernel (attention.hip, 32-object tiles, register staging) serialised HBM round trip -> LayerNorm -> two
+// fp32-MFMA phases inside one 148-KB workgroup per CU: ~20 us per tile against a ~7 us matrix-pipe floor.  Here:
+//   * tile = 16 objects x H; TWO tile buffers in LDS (2 x 64.3 KB at H = 1024), filled by LDS-DMA
+//     (`global_load_lds_dwordx4`: 1-KiB pieces, no staging registers): the loads of tile i+1 are issued before tile i is
+//     touched and stay in flight across the tile's three barriers (raw s_barrier + counted vmcnt; a __syncthreads() would
+//     drain them);
+//   * the LayerNorm is never applied to the tile: with o_n = (x_n - mu_n) r_n * gamma + beta,
+//         S[n,t]  = scale ( r_n ( x_n . (gamma*v_t) - mu_n (gamma . v_t) ) + beta . v_t )
+//         agg_t   = gamma * ( sum_n P r_n x_n - sum_n P r_n mu_n ) + beta sum_n P
+//     so both products run on the RAW rows as they landed (gamma folded into the V fragments once per workgroup, the
+//     per-frame scalars gamma.v_t, beta.v_t from the prologue) and a wave only computes mean / rstd of the two rows it
+//     fetched itself (its own vmcnt orders DMA -> ds_read; DPP + v_readlane reductions): no normalised write-back, no
+//     gamma / beta traffic per tile -- with all eight waves in the same phase that pass was LDS-bandwidth bound
+//     (5.0k of 19.4k cycles per tile, tools/o2v_stamps.py);
+//   * both products on v_mfma_f32_16x16x4_f32 (exact fp32, same rate as 32x32x2):
+//       S-product   D[obj][frame] : wave w contracts its H/8 slice of k, V fragments in registers (64 per lane),
+//                   8 partial tiles summed through LDS (one barrier: everyone adds all eight);
+//       aggregation D[frame][col] : the P registers ARE the A operand (k-step j, lane group g <-> object 4g + j, the
+//                   C-layout row order), O from LDS with lanes on consecutive columns;
+//   * nsplit == 1 (>= 256 clips in flight): the kernel finishes z = agg / l + v itself, no partial round trip and no
+//     combine launch; nsplit > 1 writes flash-decoding partials merged by o2v_combine_kernel (attention.hip).
+#include <cstdlib>
+#include <mutex>
+
+#include "common.hpp"
+#include "dlsg.h"
+
+using namespace dlsg;
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int O16_THREADS = 512;
+constexpr int O16_TILE = 16;
+
+template <int H>
+struct O16Geom {
+    static constexpr int LDO = H + 4;                          // LDS row stride (floats); a DMA piece never crosses a row
+    static constexpr int KW = (H / 16 < 8) ? H / 16 : 8;       // waves that split k in the S product
+    static constexpr int HS = H / KW;                          // k slice per wave (multiple of 16)
+    static constexpr int NCHUNK = HS / 16;                     // 16-deep chunks = 4 MFMAs per frame block
+    static constexpr int NCB = H / 16;                         // 16-column blocks of the aggregation output
+    static constexpr int CBW = (NCB + 7) / 8;                  // column blocks per wave
+    static constexpr int VB = (H >= 256) ? 16 : 4;             // bytes per lane of one LDS-DMA piece
+    static constexpr int PPR = H * 4 / (64 * VB);              // pieces per row
+    static constexpr int NP = 2 * PPR;                         // pieces a wave issues per tile (2 rows)
+    static constexpr int EPL = H / 64;                         // elements per lane when a wave holds one row
+    static constexpr int VEC = (EPL % 4 == 0) ? 4 : 1;
+    static constexpr int NCH = EPL / VEC;
+    static constexpr int BUF = O16_TILE * LDO;                 // floats per tile buffer
+    static constexpr int RED = 8 * 2 * 64 * 4;                 // [wave][frame block][lane] float4
+    static constexpr int LDS_FLOATS = 2 * BUF + RED + 2 * H + 32;      // + mean[16] | rstd[16] of the current tile
+};
+
+// LDS writes/reads of this wave retired, then the workgroup barrier.  Deliberately NOT __syncthreads(): its fence waits
+// vmcnt(0) and would drain the LDS-DMA of the next tile.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// one LDS-DMA piece: 64 lanes x VB bytes from per-lane global addresses to a wave-uniform LDS base (+ lane * VB).
+// The 16-byte form is a gfx950 instruction: the host pass of hipcc cannot type-check the builtin (it would silently drop the
+// kernel's host stub), so the body exists in the device pass only.
+template <int VB>
+__device__ __forceinline__ void glds(const char* src, char* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (VB == 16) __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    else __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 4, 0, 0);
+#endif
+}
+
+// STAMP: diagnostic build (tools/o2v_stamps.py, env DLSG_O2V_STAMPS): lane 0 of every wave of workgroup (0,0) records
+// s_memtime at the phase boundaries of each tile into a.ws (unused when nsplit == 1); the product build has no stamp code.
+// Several graphs of one shape per launch (the object and the motion stream of CapGnnEncoder: 2 x 64 clips fill the chip
+// with two object chunks per clip instead of four): blockIdx.z picks the argument block.
+struct O16Pack {
+    dlsg_o2v_args s[DLSG_O2V_MAXMULTI];
+};
+
+template <int H, bool STAMP>
+__global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, int tiles_per_split) {
+    using G = O16Geom<H>;
+    const dlsg_o2v_args& a = pk.s[blockIdx.z];
+    auto stamp = [&](int it_, int k_) {
+        if constexpr (STAMP) {
+            if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0)
+                reinterpret_cast<unsigned long long*>(a.ws)[(it_ * 16 + k_) * 8 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem + 2 * G::BUF;
+    float* gam_l = red + G::RED;                 // obj_norm gamma | beta: epilogue only
+    float* bet_l = gam_l + H;
+    float* stat_l = bet_l + H;                   // mean[16] | rstd[16]
+
+    const int b = blockIdx.x, sp = blockIdx.y;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int f = lane & 15, g = lane >> 4;
+    const int T = a.T, NO = a.NO;
+    const int n_begin = sp * tiles_per_split * O16_TILE;
+    const int n_end = min(NO, n_begin + tiles_per_split * O16_TILE);
+
+    // ---- LDS-DMA of one tile: wave w fetches rows 2w, 2w+1 (rows past the end are clamped here and zeroed by the LayerNorm pass)
+    auto issue_tile = [&](int n0, float* dst) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int row = 2 * w + rr;
+            const int n = min(n0 + row, NO - 1);
+            const char* src = reinterpret_cast<const char*>(a.y + ((int64_t)b * NO + n) * H) + lane * G::VB;
+            char* d = reinterpret_cast<char*>(dst + row * G::LDO);
+#pragma unroll
+            for (int q = 0; q < G::PPR; ++q) glds<G::VB>(src + q * 64 * G::VB, d + q * 64 * G::VB);
+        }
+    };
+    if (n_begin < n_end) issue_tile(n_begin, smem);
+
+    for (int j = threadIdx.x; j < H; j += O16_THREADS) { gam_l[j] = a.g_obj[j]; bet_l[j] = a.b_obj[j]; }
+
+    // ---- V fragments (B operand of the S product), gamma folded in: vreg[fb][4c + s] = gamma[k] V[frame 16 fb + f][k],
+    //      k = w HS + 16 c + 4 g + s; and this lane's share of gv_t = gamma . v_t, bv_t = beta . v_t
+    float vreg[2][G::HS / 4];
+    float gv[2] = {0.f, 0.f}, bv[2] = {0.f, 0.f};
+    {
+        const int k0 = (w % G::KW) * G::HS + 4 * g;
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            const int t = 16 * fb + f;
+            const float* vp = a.v + ((int64_t)b * T + min(t, T - 1)) * H + k0;
+#pragma unroll
+            for (int c = 0; c < G::NCHUNK; ++c) {
+                const f32x4 v4 = *reinterpret_cast<const f32x4*>(vp + 16 * c);
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(a.g_obj + k0 + 16 * c);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.b_obj + k0 + 16 * c);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float vv = (t < T && w < G::KW) ? v4[s] : 0.f;
+                    vreg[fb][4 * c + s] = vv * g4[s];
+                    gv[fb] += vv * g4[s];
+                    bv[fb] += vv * b4[s];
+                }
+            }
+            gv[fb] += __shfl_xor(gv[fb], 16, 64); gv[fb] += __shfl_xor(gv[fb], 32, 64);
+            bv[fb] += __shfl_xor(bv[fb], 16, 64); bv[fb] += __shfl_xor(bv[fb], 32, 64);
+            if (g == 0) { red[(w * 4 + fb * 2) * 16 + f] = gv[fb]; red[(w * 4 + fb * 2 + 1) * 16 + f] = bv[fb]; }
+        }
+    }
+
+    f32x4 acc_o[2][G::CBW];
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int c = 0; c < G::CBW; ++c) acc_o[fb][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f}, c_run[2] = {0.f, 0.f};
+
+    // the V / gamma / beta loads above are done with (the compiler waited for their data), so from here on the only
+    // vector-memory loads in flight are LDS-DMA pieces
+    lds_barrier();
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        gv[fb] = 0.f; bv[fb] = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) { gv[fb] += red[(ww * 4 + fb * 2) * 16 + f]; bv[fb] += red[(ww * 4 + fb * 2 + 1) * 16 + f]; }
+    }
+    lds_barrier();      // `red` is reused by the first tile's partial scores
+
+    int it = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += O16_TILE, ++it) {
+        float* cur = smem + (it & 1) * G::BUF;
+        const bool more = n0 + O16_TILE < n_end;
+        stamp(it, 0);
+        if (more) {
+            issue_tile(n0 + O16_TILE, smem + ((it + 1) & 1) * G::BUF);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NP) : "memory");      // this tile landed, the next stays in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        stamp(it, 1);
+
+        // ---- mean / rstd of the two rows this wave fetched (the rows themselves stay raw).  Both rows' reductions are
+        // independent chains; the sums go through DPP + v_readlane, not the LDS crossbar.
+        {
+            float x[2][G::EPL];
+            float mean[2], rstd[2];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const float* rp = cur + (2 * w + rr) * G::LDO;
+#pragma unroll
+                for (int c = 0; c < G::NCH; ++c) {
+                    if (G::VEC == 4) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(rp + c * 256 + 4 * lane);
+                        x[rr][4 * c] = t4[0]; x[rr][4 * c + 1] = t4[1]; x[rr][4 * c + 2] = t4[2]; x[rr][4 * c + 3] = t4[3];
+                    } else {
+                        x[rr][c] = rp[c * 64 + lane];
+                    }
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < G::EPL; ++i) s += x[rr][i];
+                mean[rr] = wave_sum_dpp(s) / H;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < G::EPL; ++i) { const float d = x[rr][i] - mean[rr]; q += d * d; }
+                rstd[rr] = rsqrtf(wave_sum_dpp(q) / H + a.eps);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int row = 2 * w + rr;
+                    const int n = n0 + row;
+                    stat_l[row] = mean[rr];
+                    stat_l[16 + row] = rstd[rr];
+                    if (n < n_end && a.ostats) {
+                        a.ostats[2 * ((int64_t)b * NO + n)] = mean[rr];
+                        a.ostats[2 * ((int64_t)b * NO + n) + 1] = rstd[rr];
+                    }
+                }
+            }
+        }
+        stamp(it, 2);
+        lds_barrier();
+        stamp(it, 3);
+
+        // ---- partial S over this wave's k slice: D[obj 4g+i][frame 16fb+f]
+        f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (w < G::KW) {
+            const float* ap = cur + f * G::LDO + w * G::HS + 4 * g;        // A[m = f][k = 16c + 4g + s]
+#pragma unroll
+            for (int c = 0; c < G::NCHUNK; ++c) {
+                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 16 * c);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], vreg[0][4 * c + s], sacc[0], 0, 0, 0);
+                    sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], vreg[1][4 * c + s], sacc[1], 0, 0, 0);
+                }
+            }
+            f32x4* r4 = reinterpret_cast<f32x4*>(red);
+            r4[(w * 2 + 0) * 64 + lane] = sacc[0];
+            r4[(w * 2 + 1) * 64 + lane] = sacc[1];
+        }
+        stamp(it, 4);
+        lds_barrier();
+        stamp(it, 5);
+        float p[2][4];
+        float alpha[2];
+        {
+            const f32x4* r4 = reinterpret_cast<const f32x4*>(red);
+            const f32x4 mu4 = *reinterpret_cast<const f32x4*>(stat_l + 4 * g);          // objects 4g .. 4g+3
+            const f32x4 rs4 = *reinterpret_cast<const f32x4*>(stat_l + 16 + 4 * g);
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                f32x4 sv = r4[fb * 64 + lane];
+#pragma unroll
+                for (int ww = 1; ww < G::KW; ++ww) sv += r4[(ww * 2 + fb) * 64 + lane];
+                const int t = 16 * fb + f;
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float s_ = a.scale * (rs4[i] * (sv[i] - mu4[i] * gv[fb]) + bv[fb]);
+                    const int n = n0 + 4 * g + i;
+                    const bool valid = n < n_end;
+                    if (w == 0 && valid && t < T && a.S) a.S[((int64_t)b * NO + n) * T + t] = s_;
+                    s_ = valid ? s_ : -INFINITY;
+                    p[fb][i] = s_;
+                    tmax = fmaxf(tmax, s_);
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[fb], tmax);
+                alpha[fb] = __expf(m_run[fb] - m_new);          // m_run = -inf on the first tile -> 0
+                float psum = 0.f, csum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = __expf(p[fb][i] - m_new);   // invalid rows: exp(-inf) = 0
+                    psum += e;
+                    p[fb][i] = e * rs4[i];                       // the A operand of the aggregation carries rstd_n
+                    csum += p[fb][i] * mu4[i];
+                }
+                // this lane's 4 objects only: the 4 lane groups are added once, after the loop
+                l_run[fb] = l_run[fb] * alpha[fb] + psum;
+                c_run[fb] = c_run[fb] * alpha[fb] + csum;
+                m_run[fb] = m_new;
+            }
+        }
+        stamp(it, 6);
+        // ---- aggregation: acc_o[fb][c] (frame 16fb+4g+i, col 16cb+f) = alpha_frame * acc_o + sum_n P[n][frame] O[n][col]
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            float arow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) arow[i] = __shfl(alpha[fb], 4 * g + i, 64);
+#pragma unroll
+            for (int c = 0; c < G::CBW; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc_o[fb][c][i] *= arow[i];
+        }
+#pragma unroll
+        for (int c = 0; c < G::CBW; ++c) {
+            const int cb = w * G::CBW + c;
+            if (cb < G::NCB) {
+                const float* bp = cur + cb * 16 + f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const float bv = bp[(4 * g + jj) * G::LDO];
+                    acc_o[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][jj], bv, acc_o[0][c], 0, 0, 0);
+                    acc_o[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[1][jj], bv, acc_o[1][c], 0, 0, 0);
+                }
+            }
+        }
+        stamp(it, 7);
+        lds_barrier();      // `cur` is free for the DMA of tile i+2, `red` for the next partials
+        stamp(it, 8);
+    }
+
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        l_run[fb] += __shfl_xor(l_run[fb], 16, 64);
+        l_run[fb] += __shfl_xor(l_run[fb], 32, 64);
+        c_run[fb] += __shfl_xor(c_run[fb], 16, 64);
+        c_run[fb] += __shfl_xor(c_run[fb], 32, 64);
+    }
+    // agg[t][col] = gamma[col] (acc[t][col] - c_t) + beta[col] l_t   (un-normalised: divided by the merged l at the end)
+    float gcol[G::CBW], bcol[G::CBW];
+#pragma unroll
+    for (int c = 0; c < G::CBW; ++c) {
+        const int cb = min(w * G::CBW + c, G::NCB - 1);
+        gcol[c] = gam_l[cb * 16 + f];
+        bcol[c] = bet_l[cb * 16 + f];
+    }
+    if (a.nsplit == 1) {
+        // ---- finish in place: z = agg / l + v.  All residual loads first (clamped rows, no branches), then the stores: a
+        // load -> wait -> store chain per element would be 64 serial memory round trips.
+        float res[2][G::CBW][4];
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int c = 0; c < G::CBW; ++c) {
+                const int cb = min(w * G::CBW + c, G::NCB - 1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = min(16 * fb + 4 * g + i, T - 1);
+                    res[fb][c][i] = a.v[((int64_t)b * T + t) * H + cb * 16 + f];
+                }
+            }
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            float linv[4], crow[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                linv[i] = 1.f / __shfl(l_run[fb], 4 * g + i, 64);
+                crow[i] = __shfl(c_run[fb], 4 * g + i, 64);
+            }
+#pragma unroll
+            for (int c = 0; c < G::CBW; ++c) {
+                const int cb = w * G::CBW + c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = 16 * fb + 4 * g + i;
+                    if (t < T && cb < G::NCB)
+                        a.z[((int64_t)b * T + t) * H + cb * 16 + f] =
+                            gcol[c] * (acc_o[fb][c][i] - crow[i]) * linv[i] + bcol[c] + res[fb][c][i];
+                }
+            }
+            const int t = 16 * fb + f;
+            if (w == 0 && g == 0 && t < T && a.ml) {
+                a.ml[2 * ((int64_t)b * T + t)] = m_run[fb];
+                a.ml[2 * ((int64_t)b * T + t) + 1] = l_run[fb];
+            }
+        }
+        return;
+    }
+    // ---- partial results: ws[(b*nsplit+sp)] = { agg[T][H], m[32], l[32] }
+    float* wsp = a.ws + ((int64_t)b * a.nsplit + sp) * ((int64_t)T * H + 64);
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        float lrow[4], crow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lrow[i] = __shfl(l_run[fb], 4 * g + i, 64);
+            crow[i] = __shfl(c_run[fb], 4 * g + i, 64);
+        }
+#pragma unroll
+        for (int c = 0; c < G::CBW; ++c) {
+            const int cb = w * G::CBW + c;
+            if (cb < G::NCB) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = 16 * fb + 4 * g + i;
+                    if (t < T) wsp[(int64_t)t * H + cb * 16 + f] = gcol[c] * (acc_o[fb][c][i] - crow[i]) + bcol[c] * lrow[i];
+                }
+            }
+        }
+        const int t = 16 * fb + f;
+        if (w == 0 && g == 0 && t < T) {
+            wsp[(int64_t)T * H + t] = m_run[fb];
+            wsp[(int64_t)T * H + 32 + t] = l_run[fb];
+        }
+    }
+}
+
+template <int H>
+int o2v16_launch_t(const dlsg_o2v_args* a, int count, hipStream_t st) {
+    using G = O16Geom<H>;
+    static std::once_flag once;
+    constexpr int lds_bytes = G::LDS_FLOATS * 4;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v16_kernel<H, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v16_kernel<H, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  lds_bytes);
+    });
+    const int tiles = (a->NO + O16_TILE - 1) / O16_TILE;
+    const int tps = (tiles + a->nsplit - 1) / a->nsplit;
+    O16Pack pk;
+    for (int i = 0; i < count; ++i) pk.s[i] = a[i];
+    static const bool stamps = getenv("DLSG_O2V_STAMPS") != nullptr;
+    const dim3 grid(a->B, a->nsplit, count);
+    if (stamps && a->nsplit == 1)
+        hipLaunchKernelGGL((o2v16_kernel<H, true>), grid, dim3(O16_THREADS), lds_bytes, st, pk, tps);
+    else
+        hipLaunchKernelGGL((o2v16_kernel<H, false>), grid, dim3(O16_THREADS), lds_bytes, st, pk, tps);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DLSG_OK : DLSG_ELAUNCH;
+}
+
+}  // namespace
+
+// called by dlsg_o2v_fwd / dlsg_o2v_fwd_multi (attention.hip); the combine launch for nsplit > 1 stays there
+int dlsg_o2v16_partial(const dlsg_o2v_args* a, int count, hipStream_t st) {
+    switch (a->H) {
+        case 1024: return o2v16_launch_t<1024>(a, count, st);
+        case 512: return o2v16_launch_t<512>(a, count, st);
+        case 64: return o2v16_launch_t<64>(a, count, st);
+        default: return DLSG_EINVAL;
+    }
+}

@@ -397,15 +397,50 @@ __global__ void embed_fwd_kernel(const float* __restrict__ E, const int64_t* __r
         out[(int64_t)r * ldo + j] = v;
     }
 }
-__global__ void embed_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const int64_t* __restrict__ ids,
-                                 float* __restrict__ dE, int W, float p, uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr) {
+// dE[ids[r], :] += drop(dout[r, :]) without atomics, so that a step is bit-reproducible (float atomics add in arrival order:
+// the word-embedding gradient differed in the last bit between runs of the same step).  The first row that carries an id
+// owns it: its workgroup adds the rows with that id in row order; workgroups of later duplicates exit.
+__global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const int64_t* __restrict__ ids,
+                                                        float* __restrict__ dE, int rows, int W, float p, uint64_t seed, uint32_t site,
+                                                        int64_t row0, const uint64_t* seed_ptr) {
+    __shared__ int dup;
+    __shared__ unsigned char hit[128];
     if (seed_ptr) seed += *seed_ptr;
     const int r = blockIdx.x;
     const int64_t id = ids[r];
-    for (int j = threadIdx.x; j < W; j += blockDim.x) {
-        float g = dout[(int64_t)r * lddo + j];
-        if (p > 0.f) g *= drop_scale(seed, site, (uint64_t)(row0 + r) * W + j, p);
-        atomicAdd(dE + id * W + j, g);
+    if (threadIdx.x == 0) dup = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < r; i += 128)
+        if (ids[i] == id) dup = 1;
+    __syncthreads();
+    if (dup) return;
+    for (int c0 = 0; c0 < W; c0 += 512) {               // 4 columns per thread and pass
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int base = r; base < rows; base += 128) {
+            const int i = base + threadIdx.x;
+            hit[threadIdx.x] = (i < rows && ids[i] == id) ? 1 : 0;
+            __syncthreads();
+            const int lim = min(128, rows - base);
+            for (int k = 0; k < lim; ++k) {
+                if (!hit[k]) continue;                  // workgroup-uniform
+                const int rr = base + k;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int j = c0 + threadIdx.x + 128 * q;
+                    if (j < W) {
+                        float g = dout[(int64_t)rr * lddo + j];
+                        if (p > 0.f) g *= drop_scale(seed, site, (uint64_t)(row0 + rr) * W + j, p);
+                        acc[q] += g;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = c0 + threadIdx.x + 128 * q;
+            if (j < W) dE[id * W + j] += acc[q];
+        }
     }
 }
 
@@ -832,7 +867,7 @@ extern "C" int dlsg_embed_fwd(const float* E, const int64_t* ids, float* out, in
 extern "C" int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* ids, float* dE, int rows, int W, float p,
                               uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream) {
     if (rows == 0) return DLSG_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, ST(stream), dout, lddo, ids, dE, W, p, seed, site, row0, seed_ptr);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, ST(stream), dout, lddo, ids, dE, rows, W, p, seed, site, row0, seed_ptr);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -222,9 +222,15 @@ def region_projections(ops, mods, regions):
 
 def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2v=True, nsplit=None, y=None):
     """EncoderVisualGraphTUN.forward (models/layer.py:172-201).  visual: (B*T, Hin) view."""
+    tun_frames(ops, m, pfx, visual, regions, sv)
+    tun_graph(ops, [(m, pfx, y)], regions, sv, fused_o2v, nsplit)
+    return tun_latent(ops, m, pfx, regions, sv, training, seed, psl_site)
+
+
+def tun_frames(ops, m, pfx, visual, regions, sv):
+    """frame nodes v = LN(tanh(visual_embed(x))) (layer.py:179-180; the Linear is skipped when use_embed is False)"""
     B, T, O, R = regions.shape
     H = m.visual_norm[1].weight.numel()
-    P = m.v2l_layer.theta.shape[0]
     ref = regions
     s = sv[pfx] = {}
     if m.use_embed:
@@ -235,36 +241,76 @@ def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2
     v = _empty(ref, B * T, H); st_v = _empty(ref, B * T, 2)
     ops.rowln_fwd(v_pre, m.visual_norm[1].weight, m.visual_norm[1].bias, v, st_v, pre_tanh=1)
     s.update(visual=visual, v_pre=v_pre, v=v, st_v=st_v)
-    if O >= 5:
-        NO = T * O
+
+
+def o2v_nsplit(B_eff, NO):
+    """object chunks per clip of the fused graph kernel: one 156-KB-LDS workgroup per CU walks 16-object tiles; split a
+    clip's objects only as far as needed to put ~256 workgroups on the chip (every extra split costs a (T x H) partial
+    written and re-read).  B_eff = clips x streams of the launch."""
+    tiles = (NO + 15) // 16
+    return max(1, min(tiles, 256 // max(B_eff, 1)))
+
+
+def tun_graph(ops, items, regions, sv, fused_o2v=True, nsplit=None):
+    """object -> frame graph (layer.py:184-192) of one or several streams; items: [(module, prefix, y or None)].  Streams of
+    one shape share ONE fused launch (CapGnnEncoder: 2 x 64 clips fill the chip with two object chunks per clip instead
+    of four).  Leaves z = agg + v (pre obj_visual_norm) and the saved statistics in sv[prefix]."""
+    B, T, O, R = regions.shape
+    if O < 5:
+        return
+    NO = T * O
+    ref = regions
+    scale = 1.0 / math.sqrt(R)
+    fused, plain = [], []
+    for m, pfx, y in items:
+        s = sv[pfx]
+        H = m.visual_norm[1].weight.numel()
         if y is None:
             y = _empty(ref, B * NO, H)
             lin(ops, regions.view(B * NO, R), m.obj_embed.weight, y, m.obj_embed.bias, tanh=True)
         z = _empty(ref, B * T, H); ostats = _empty(ref, B * NO, 2); S = _empty(ref, B, NO, T)
-        scale = 1.0 / math.sqrt(R)
-        g_o, b_o = m.obj_norm[1].weight, m.obj_norm[1].bias
-        if fused_o2v and ops.o2v_supported(T, H):
-            if nsplit is None:
-                # one resident workgroup per CU (148 KB of LDS each): split the objects of a clip only as far as needed to
-                # put ~256 workgroups on the chip; every extra split costs a (T x H) partial written and re-read.
-                tiles = (NO + 31) // 32
-                nsplit = max(1, min(tiles, 256 // max(B, 1)))
-            ml = _empty(ref, B * T, 2)
-            ops.o2v_fwd(y.view(B, NO, H), v.view(B, T, H), g_o, b_o, z, ml, ostats, S, scale, nsplit)
-            s.update(ml=ml, o2v_nsplit=nsplit)
-        else:
-            o = _empty(ref, B * NO, H)
-            ops.rowln_fwd(y, g_o, b_o, o, ostats)
-            ops.gemm(GEMM_NT, [(o.view(B, NO, H), v.view(B, T, H), S)], alpha=scale)
-            Pm = _empty(ref, B, NO, T)
-            ops.softmax_fwd(S, Pm, B, NO, T)
-            ops.copy2d(v, z)
-            ops.gemm(GEMM_TN, [(Pm, o.view(B, NO, H), z.view(B, T, H))], flags=F_ACCUM)
+        s.update(y=y, z=z, ostats=ostats, S=S, scale=scale)
+        (fused if fused_o2v and ops.o2v_supported(T, H) else plain).append((m, pfx, H))
+    by_h = {}
+    for it in fused:
+        by_h.setdefault(it[2], []).append(it)
+    for H, grp in by_h.items():
+        for i0 in range(0, len(grp), 2):
+            part = grp[i0:i0 + 2]
+            ns = o2v_nsplit(B * len(part), NO) if nsplit is None else nsplit
+            args = []
+            for m, pfx, _ in part:
+                s = sv[pfx]
+                s['ml'] = _empty(ref, B * T, 2)
+                s['o2v_nsplit'] = max(1, min((NO + 31) // 32, 256 // max(B, 1)))      # chunking of the backward kernels
+                args.append(dict(y=s['y'].view(B, NO, H), v=s['v'].view(B, T, H), g_obj=m.obj_norm[1].weight,
+                                 b_obj=m.obj_norm[1].bias, z=s['z'], ml=s['ml'], ostats=s['ostats'], S=s['S']))
+            ops.o2v_fwd_multi(args, scale, ns)
+    for m, pfx, H in plain:
+        s = sv[pfx]
+        y, v, z, S = s['y'], s['v'], s['z'], s['S']
+        o = _empty(ref, B * NO, H)
+        ops.rowln_fwd(y, m.obj_norm[1].weight, m.obj_norm[1].bias, o, s['ostats'])
+        ops.gemm(GEMM_NT, [(o.view(B, NO, H), v.view(B, T, H), S)], alpha=scale)
+        Pm = _empty(ref, B, NO, T)
+        ops.softmax_fwd(S, Pm, B, NO, T)
+        ops.copy2d(v, z)
+        ops.gemm(GEMM_TN, [(Pm, o.view(B, NO, H), z.view(B, T, H))], flags=F_ACCUM)
+
+
+def tun_latent(ops, m, pfx, regions, sv, training, seed, psl_site):
+    """ov = LN(tanh(agg + v)) (layer.py:192-193) and LatentPSL (layer.py:199, sublayer.py:189-198); baseline streams return ov."""
+    B, T, O, R = regions.shape
+    H = m.visual_norm[1].weight.numel()
+    P = m.v2l_layer.theta.shape[0]
+    ref = regions
+    s = sv[pfx]
+    if O >= 5:
         ov = _empty(ref, B * T, H); st_ov = _empty(ref, B * T, 2)
-        ops.rowln_fwd(z, m.obj_visual_norm[1].weight, m.obj_visual_norm[1].bias, ov, st_ov, pre_tanh=1)
-        s.update(y=y, z=z, ostats=ostats, S=S, ov=ov, st_ov=st_ov, scale=scale)
+        ops.rowln_fwd(s['z'], m.obj_visual_norm[1].weight, m.obj_visual_norm[1].bias, ov, st_ov, pre_tanh=1)
+        s.update(ov=ov, st_ov=st_ov)
     else:
-        ov = v
+        ov = s['v']
         s.update(ov=ov)
     if m.baseline:
         return ov

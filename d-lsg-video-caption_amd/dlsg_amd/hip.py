@@ -152,7 +152,7 @@ class DecattCacheGradsArgs(C.Structure):
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
-           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd',
+           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
@@ -182,6 +182,7 @@ def load_library(path=LIB_PATH):
         'dlsg_colsum2': [vp, i64, i32, i32, vp, vp, i32, i32, i32, vp],
         'dlsg_o2v_workspace_bytes': [i32, i32, i32, i32],
         'dlsg_o2v_fwd': [P(O2VArgs), vp],
+        'dlsg_o2v_fwd_multi': [P(O2VArgs), i32, vp],
         'dlsg_softmax_fwd': [vp, vp, vp, i64, i32, i32, vp],
         'dlsg_softmax_bwd': [vp, vp, vp, i64, i32, i32, vp],
         'dlsg_decatt_fwd': [P(DecAttArgs), vp],
@@ -429,19 +430,29 @@ class HipOps(object):
         return T <= 32 and H in (64, 512, 1024)
 
     def o2v_fwd(self, y, v, g_obj, b_obj, z, ml, ostats, S, scale, nsplit, eps=1e-5):
-        B, NO, H = y.shape
-        T = v.shape[1]
-        a = O2VArgs()
+        self.o2v_fwd_multi([dict(y=y, v=v, g_obj=g_obj, b_obj=b_obj, z=z, ml=ml, ostats=ostats, S=S)], scale, nsplit, eps)
+
+    def o2v_fwd_multi(self, items, scale, nsplit, eps=1e-5):
+        """Several object->frame graphs of one shape in ONE launch (the object and the motion stream of CapGnnEncoder).
+        items: dicts with y (B,NO,H), v (B,T,H), g_obj, b_obj, z, ml, ostats, S."""
+        n = len(items)
+        B, NO, H = items[0]['y'].shape
+        T = items[0]['v'].shape[1]
+        arr = (O2VArgs * n)()
         wsb = self.lib.dlsg_o2v_workspace_bytes(B, T, H, nsplit)
-        ws = torch.empty(wsb // 4, dtype=torch.float32, device=y.device)
-        a.y, a.v, a.g_obj, a.b_obj, a.z, a.ml, a.ostats, a.S = _p(y), _p(v), _p(g_obj), _p(b_obj), _p(z), _p(ml), \
-            _p(ostats), _p(S)
-        a.ws, a.ws_bytes = _p(ws), wsb
-        a.B, a.T, a.NO, a.H, a.nsplit, a.scale, a.eps = B, T, NO, H, nsplit, scale, eps
+        keep = []
+        for a, it in zip(arr, items):
+            assert it['y'].shape == (B, NO, H) and it['v'].shape[1] == T
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=it['y'].device)
+            keep.append(ws)
+            a.y, a.v, a.g_obj, a.b_obj, a.z, a.ml, a.ostats, a.S = _p(it['y']), _p(it['v']), _p(it['g_obj']), _p(it['b_obj']), \
+                _p(it['z']), _p(it['ml']), _p(it['ostats']), _p(it['S'])
+            a.ws, a.ws_bytes = _p(ws), wsb
+            a.B, a.T, a.NO, a.H, a.nsplit, a.scale, a.eps = B, T, NO, H, nsplit, scale, eps
         e0 = self._prof_begin()
-        self._check(self.lib.dlsg_o2v_fwd(C.byref(a), self._stream()), 'dlsg_o2v_fwd')
-        # algorithmic bytes: read y once + read v + write z
-        self._prof_end('o2v_graph_fwd', e0, 4.0 * B * (NO * H + 2 * T * H))
+        self._check(self.lib.dlsg_o2v_fwd_multi(arr, n, self._stream()), 'dlsg_o2v_fwd_multi')
+        # algorithmic bytes (SURVEY.md 8d): read y once + read v + write z, per graph
+        self._prof_end('o2v_graph_fwd', e0, 4.0 * n * B * (NO * H + 2 * T * H))
 
     def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, part, scale, nsplit):
         """backward of o2v_fwd: dz (B,T,H) -> dy (B,NO,H), dv (B,T,H), part (B,2,H) (obj_norm dgamma | dbeta per clip)."""

@@ -39,8 +39,6 @@ class _HipModel(nn.Module):
         # GEMM arithmetic: 'fp32' = exact fp32 MFMA everywhere; 'x3_bwd' = split-bf16 (3 bf16 MFMAs per product,
         # ~1e-5 relative error) for the backward products only; 'x3_all' = split-bf16 for forward and backward.
         self.gemm_precision = 'fp32'
-        self.two_streams = False   # fork/join of the two encoder branches: measured no gain (GEMM grids fill every CU)
-        self._side = None
 
     # ------------------------------------------------------------------ copy / pickle
     def __getstate__(self):
@@ -49,7 +47,7 @@ class _HipModel(nn.Module):
         st = dict(self.__dict__)
         st['_ops_obj'] = None
         st['rng'] = None
-        for k in ('_flat', '_gflat', '_offsets', '_G', '_side'):
+        for k in ('_flat', '_gflat', '_offsets', '_G'):
             st[k] = None
         return st
 
@@ -110,23 +108,6 @@ class _HipModel(nn.Module):
 
     def grad_views(self):
         return self._G
-
-    # ------------------------------------------------------------------ two-stream fork / join
-    def _fork(self, ref):
-        """Returns a side HIP stream ordered after the current one (None off-GPU).  Independent branches of the schedule
-        (object-stream encoder vs. BiLSTM motion pre-encoder) run concurrently: the recurrent part is ~50 small
-        latency-bound launches that hide under the other branch's large GEMMs.  Works inside hipGraph capture."""
-        if not ref.is_cuda or not self.two_streams:
-            return None
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=ref.device)
-        self._side.wait_stream(torch.cuda.current_stream())
-        return self._side
-
-    @staticmethod
-    def _join(side):
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
 
     def _gemm_flags(self, backward):
         from .hip import F_BF16X3
@@ -222,6 +203,8 @@ class CapGnnModel(_HipModel):
 
     # ------------------------------------------------------------------ engine schedules
     def _encode(self, frames, regions, training, seed, sv):
+        """CapGnnEncoder.forward (models/model.py:69-73).  The frame nodes of both streams are computed first (the motion
+        stream's come out of the BiLSTM pre-encoder), then the object->frame graph of BOTH streams runs as one launch."""
         ops, enc = self.ops, self.encoder
         B, T, F = frames.shape
         A = enc.a_feature_size
@@ -229,18 +212,13 @@ class CapGnnModel(_HipModel):
         ys = [None, None]
         if regions.shape[2] >= 5 and enc.obj_encoder.obj_embed.weight.shape == enc.motion_encoder.obj_embed.weight.shape:
             ys = E.region_projections(ops, [enc.obj_encoder, enc.motion_encoder], regions)
-        side = self._fork(frames)
-        if side is not None:
-            with torch.cuda.stream(side):
-                obj = E.tun_fwd(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv, training, seed,
-                                E.SITE_PSL_OBJ, self.fused_o2v, y=ys[0])
-        else:
-            obj = E.tun_fwd(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv, training, seed,
-                            E.SITE_PSL_OBJ, self.fused_o2v, y=ys[0])
+        E.tun_frames(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv)
         mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed)
-        mot = E.tun_fwd(ops, enc.motion_encoder, 'encoder.motion_encoder', mot_in, regions, sv, training, seed,
-                        E.SITE_PSL_MOT, self.fused_o2v, y=ys[1])
-        self._join(side)
+        E.tun_frames(ops, enc.motion_encoder, 'encoder.motion_encoder', mot_in, regions, sv)
+        E.tun_graph(ops, [(enc.obj_encoder, 'encoder.obj_encoder', ys[0]), (enc.motion_encoder, 'encoder.motion_encoder', ys[1])],
+                    regions, sv, self.fused_o2v)
+        obj = E.tun_latent(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, training, seed, E.SITE_PSL_OBJ)
+        mot = E.tun_latent(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, training, seed, E.SITE_PSL_MOT)
         return obj, mot
 
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
@@ -806,6 +784,8 @@ class Trainer(object):
         if not self._adam_in_graph:
             for w in self._works:
                 w.wait()
-            self._adam(self.t)
+            # same arithmetic as the captured Adam launch (bias corrections read from the device word the host just wrote),
+            # so a segmented step is bit-identical to the single-graph step
+            self._adam(self.t, hyper=st['hyper'])
         # the loss lives in the graphs' static memory: hand out a copy, so losses kept across steps do not alias
         return self._loss.clone()

@@ -132,6 +132,11 @@ typedef struct {
 } dlsg_o2v_args;
 int64_t dlsg_o2v_workspace_bytes(int B, int T, int H, int nsplit);
 int dlsg_o2v_fwd(const dlsg_o2v_args* a, void* stream);
+/* `count` (<= DLSG_O2V_MAXMULTI) graphs of one shape (B, T, NO, H, nsplit equal) in one launch: CapGnnEncoder runs the same
+ * graph on the object and the motion stream (models/model.py:69-73); together they fill the chip with half the object
+ * chunks per clip.  a[0..count) are consecutive argument blocks. */
+#define DLSG_O2V_MAXMULTI 2
+int dlsg_o2v_fwd_multi(const dlsg_o2v_args* a, int count, void* stream);
 /* Backward of the fused graph in two passes over y (see attention.hip): given dz (B,T,H) it writes
  *   dy (B,NO,H)  grad wrt the obj_embed pre-activation (through obj_norm's LayerNorm and the tanh of the GEMM epilogue),
  *   dv (B,T,H)   grad wrt the frame nodes v (includes the residual dz),

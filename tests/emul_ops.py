@@ -202,6 +202,10 @@ class EmulOps(object):
         ml.copy_(torch.stack([m.reshape(-1), l.reshape(-1)], 1))
         ostats.copy_(torch.cat([mean.reshape(-1, 1), rstd.reshape(-1, 1)], 1))
 
+    def o2v_fwd_multi(self, items, scale, nsplit, eps=1e-5):
+        for it in items:
+            self.o2v_fwd(it['y'], it['v'], it['g_obj'], it['b_obj'], it['z'], it['ml'], it['ostats'], it['S'], scale, nsplit, eps)
+
     def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, part, scale, nsplit, eps=1e-5):
         self._count('o2v_bwd')
         B, NO, H = y.shape

@@ -327,6 +327,36 @@ def test_o2v_fused(hip, case):
     both(hip, build, run, ['z', 'os', 'S', 'lse'], tol=3e-5, name='o2v %s' % (case,))
 
 
+@pytest.mark.parametrize('case', [(3, 26, 16, 64, 2), (2, 26, 16, 1024, 1), (2, 26, 36, 1024, 3), (2, 7, 5, 512, 2)])
+def test_o2v_two_graphs_in_one_launch(hip, case):
+    """dlsg_o2v_fwd_multi: the object and the motion stream of CapGnnEncoder as one launch (blockIdx.z picks the argument
+    block) must equal the two single launches bit for bit, and the emulation within tolerance."""
+    B, T, O, H, ns = case
+    NO = T * O
+    g = torch.Generator().manual_seed(9)
+    sc = 1.0 / math.sqrt(H / 4.0)
+
+    def mk(dev):
+        g.manual_seed(9)
+        items = []
+        for _ in range(2):
+            items.append(dict(y=torch.tanh(rnd(g, B, NO, H)).to(dev), v=rnd(g, B, T, H).to(dev), g_obj=(1 + 0.2 * rnd(g, H)).to(dev),
+                              b_obj=(0.2 * rnd(g, H)).to(dev), z=torch.zeros(B * T, H, device=dev),
+                              ml=torch.zeros(B * T, 2, device=dev), ostats=torch.zeros(B * NO, 2, device=dev),
+                              S=torch.zeros(B, NO, T, device=dev)))
+        return items
+    multi, single, emu = mk('cuda'), mk('cuda'), mk('cpu')
+    hip.o2v_fwd_multi(multi, sc, ns)
+    for it in single:
+        hip.o2v_fwd(it['y'], it['v'], it['g_obj'], it['b_obj'], it['z'], it['ml'], it['ostats'], it['S'], sc, ns)
+    EmulOps().o2v_fwd_multi(emu, sc, ns)
+    for a, b_, e in zip(multi, single, emu):
+        for k in ('z', 'ml', 'ostats', 'S'):
+            assert torch.equal(a[k], b_[k]), k
+        assert (a['z'].cpu() - e['z']).abs().max().item() <= 3e-5
+        assert (a['S'].cpu() - e['S']).abs().max().item() <= 3e-5
+
+
 @pytest.mark.parametrize('case', O2V_CASES)
 def test_o2v_fused_backward(hip, case):
     """dlsg_o2v_bwd (scores pass + apply pass) against the closed-form backward of the graph; forward state (S, ml,
