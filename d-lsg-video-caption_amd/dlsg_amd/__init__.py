@@ -2,3 +2,4 @@
 encoder/decoder hot path: CapGnnModel forward / train step / inference on hand-written gfx950 kernels."""
 from .config import make_args, make_vocab, msvd_shaped, msrvtt_shaped, apply_dataset_overrides, Vocabulary  # noqa: F401
 from .model import CapGnnModel, CapBaseline1, CapBaselineModel, Trainer, GreedyGraph, BeamGraph, ss_epsilon, multistep_lr  # noqa: F401
+from .gan import DiscV2, GanTrainer, GANLambdaHandler, save_checkpoint, load_checkpoint  # noqa: F401

@@ -17,6 +17,7 @@ def make_args(**kw):
         max_frames=26, max_words=26,
         a_feature_size=1536, m_feature_size=1024, region_feature_size=2048,
         learning_rate=1.6e-4, ss_factor=20,
+        num_topk=3, num_D_visual=5, lambda_D_visual=0.01,          # DiscV2 / WGAN-GP (utils/opt.py:36-37,47)
     )
     a.update(kw)
     return Namespace(**a)
@@ -28,10 +29,12 @@ def apply_dataset_overrides(args):
         args.decode_hidden_size = 1024
         args.num_proposals = 8
         args.num_obj = 16
+        args.num_topk = 3
     else:
         args.decode_hidden_size = 1536
         args.num_proposals = 5
         args.num_obj = 36
+        args.num_topk = 5
     return args
 
 

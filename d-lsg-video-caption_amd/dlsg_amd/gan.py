@@ -1,0 +1,346 @@
+"""the `DiscV2` critic and the WGAN-GP iteration `train_debug.py` really trains
+(models/model.py:110-168, models/layer.py:661-715, run_gun.py:153-234,339-398).
+
+Split of work on the GPU:
+  * generator side -- both forwards of an iteration (the no-grad one of run_gun.py:167 and the trained one of :183), the
+    ragged CrossEntropy, the whole backward and Adam -- run on this repo's HIP kernels through `Trainer`; the critic's
+    gradient w.r.t. the logits enters the hand-scheduled backward as an extra d(logits) term (`Trainer.step(extra_dlogits=)`).
+    The reference detaches the proposals and attention weights before they reach the critic (run_gun.py:214-217), so
+    d(logits) is the only path from the GAN loss into the generator.
+  * critic side -- PyTorch-ROCm eager autograd (it needs a double backward for the gradient penalty, run_gun.py:362-371;
+    SURVEY.md 8f: "keep in PyTorch-ROCm eager first"), restructured so that nothing of size (B, L, V) is materialised:
+      - Conv1d(V -> 512, k = 1) is a linear map over the vocabulary axis: real captions go through an embedding GATHER of
+        its weight columns instead of a one-hot (B, L, V) x (V, 512) product (run_gun.py:447-451 builds the one-hot);
+      - by the same linearity the gradient-penalty sample eps*real + (1-eps)*fake is mixed AFTER the projection, so the
+        three critic forwards of a step (real, fake, mixed) share ONE logit projection and run as one 3B-row batch;
+      - |d mixed_logit / d mixed_captions|^2 = sum_l g_l (W W^T) g_l^T with g = d mixed_logit / d(projection): a 512 x 512
+        Gram matrix replaces the (B, L, V) gradient tensor, and stays differentiable for the second backward;
+      - the LSTM is unrolled over plain matmuls (MIOpen's fused RNN has no double backward; the reference switches cuDNN off
+        for the same reason, train_debug.py:53).
+    All of it is exact up to fp32 reassociation; tests compare against the reference's own numbers (tests/golden/gan_*.npz).
+
+`DiscV2.state_dict()` has the reference's keys and shapes (checkpoint key `model_d_state_dict`, run_gun.py:306).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .modules import LatentPSL, SelfAttention
+
+WIDTH = 512          # DiscV2.dim and every internal width (models/model.py:113, layer.py:665-683)
+PSL_WIDTH = 1024     # proposals enter through Linear(1024, 512) (layer.py:666)
+
+
+class _Residual(nn.Module):
+    """parameter holder with the reference's key `res_block.1.{weight,bias}` (sublayer.py:107-115)"""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.res_block = nn.Sequential(nn.ReLU(True), nn.Conv1d(dim, dim, 3, padding=1))
+
+
+class _PairScorer(nn.Module):
+    """JointEmbedVideoModel2 parameters (sublayer.py:292-303)"""
+
+    def __init__(self, h):
+        super().__init__()
+        self.classify = nn.Linear(h, 1)
+        self.visual_embed = nn.Sequential(nn.Linear(h, h), nn.Tanh())
+        self.sent_embed = nn.Sequential(nn.Linear(h, h), nn.Tanh())
+
+
+class _ProposalScore(nn.Module):
+    """PSLScore2 parameters (layer.py:661-688)"""
+
+    def __init__(self, num_psl, num_top):
+        super().__init__()
+        self.psl_scorer = _PairScorer(WIDTH)
+        self.psl_embed = nn.Sequential(nn.Linear(PSL_WIDTH, WIDTH), nn.Tanh(), nn.LayerNorm(WIDTH))
+        self.psl_norm = nn.Sequential(nn.Tanh(), nn.LayerNorm(WIDTH), nn.Dropout(0.3))
+        self.att_norm = nn.Sequential(nn.Linear(WIDTH, WIDTH), nn.Tanh(), nn.LayerNorm(WIDTH))
+        self.num_top = num_top
+        self.select = num_psl > num_top
+
+
+def _tanh_ln(x, ln):
+    return F.layer_norm(torch.tanh(x), ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+
+
+def _dropout(x, p, on):
+    return F.dropout(x, p, True) if on and p > 0 else x
+
+
+class DiscV2(nn.Module):
+    """Critic of the visual GAN.  forward(inputs (B,L,V), obj (B,P,1024), mot (B,P,1024), att_mask (B,L,L), alpha_all (B,L,2P))
+    -> (B,) scores, the reference's call (models/model.py:143); `score_projected` is the entry the trainer uses."""
+
+    def __init__(self, opt, vocab_size):
+        super().__init__()
+        if opt.visual_hidden_size != PSL_WIDTH:
+            raise ValueError('DiscV2 takes %d-wide proposals (models/layer.py:666); visual_hidden_size = %d'
+                             % (PSL_WIDTH, opt.visual_hidden_size))
+        self.dim = WIDTH
+        self.num_top = opt.num_topk
+        self.seq_len = opt.max_words
+        self.num_psl = opt.num_proposals
+        self.block = nn.Sequential(_Residual(WIDTH))
+        self.conv1d = nn.Conv1d(vocab_size, WIDTH, 1)
+        self.lstm = nn.LSTM(WIDTH, WIDTH, batch_first=True, bidirectional=False)       # parameters only: see _lstm
+        self.layer_norm = nn.LayerNorm(WIDTH)
+        self.att = SelfAttention(WIDTH, WIDTH, WIDTH, 0.3)
+        self.att_norm = nn.Sequential(nn.Tanh(), nn.LayerNorm(WIDTH))
+        self.motion_psl_score = _ProposalScore(opt.num_proposals, self.num_top)
+        self.obj_psl_score = _ProposalScore(opt.num_proposals, self.num_top)
+        self.text_sum = LatentPSL(WIDTH, 1)
+        self.fusion = nn.Parameter(torch.empty(2, WIDTH))
+        nn.init.xavier_uniform_(self.fusion, gain=nn.init.calculate_gain('tanh'))
+
+    # ------------------------------------------------------------------ vocabulary projection (Conv1d, k = 1)
+    def vocab_matrix(self):
+        return self.conv1d.weight.squeeze(-1)                      # (512, V)
+
+    def project(self, x):
+        """(B,L,V) logits or any dense caption representation -> (B,L,512)"""
+        return F.linear(x, self.vocab_matrix(), self.conv1d.bias)
+
+    def project_ids(self, captions):
+        """real captions (B,L) int64: the one-hot product of run_gun.py:447-451 as a gather of weight columns"""
+        return F.embedding(captions, self.vocab_matrix().t()) + self.conv1d.bias
+
+    # ------------------------------------------------------------------ everything behind the projection
+    def _lstm(self, x):
+        """single-layer LSTM, zero initial state, gate order i,f,g,o; unrolled so that autograd can differentiate it twice"""
+        w_ih, w_hh = self.lstm.weight_ih_l0, self.lstm.weight_hh_l0
+        bias = self.lstm.bias_ih_l0 + self.lstm.bias_hh_l0
+        xin = F.linear(x, w_ih, bias)                              # all steps' input gates in one product
+        n, L, _ = x.shape
+        h = x.new_zeros(n, WIDTH)
+        c = x.new_zeros(n, WIDTH)
+        out = []
+        for t in range(L):
+            i, f, g, o = (xin[:, t] + F.linear(h, w_hh)).chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            out.append(h)
+        return torch.stack(out, 1)
+
+    def _proposal_score(self, m, psl, alpha, words, word_mask):
+        """PSLScore2.forward (layer.py:690-715): words (n,L,512) attended by the (top-k) proposals"""
+        n = psl.shape[0]
+        e = _tanh_ln(m.psl_embed[0](psl), m.psl_embed[2])
+        if m.select:
+            top = alpha.sum(dim=1).topk(m.num_top, dim=-1).indices
+            e = e.gather(1, top.unsqueeze(-1).expand(n, m.num_top, WIDTH))
+        a = _tanh_ln(m.att_norm[0](words), m.att_norm[2])
+        adj = torch.softmax(a @ e.transpose(1, 2) / math.sqrt(WIDTH), dim=1) * word_mask       # mask after the softmax (:703-704)
+        weight = adj.sum(dim=1)
+        agg = _dropout(_tanh_ln(adj.transpose(1, 2) @ a, m.psl_norm[1]), 0.3, self.training)
+        sc = m.psl_scorer
+        pair = sc.classify(torch.tanh(sc.visual_embed[0](e)) * torch.tanh(sc.sent_embed[0](agg))).squeeze(-1)
+        return (pair * weight).sum(dim=-1) / weight.sum(dim=-1)                                   # (n,)
+
+    def score_projected(self, h, obj, mot, att_mask, alpha_all, groups=1):
+        """h (n,L,512) = projected captions, n = groups * B rows (`groups` caption sets scored against the same clips in one
+        pass).  PSLScore2 ends with a mean over ITS batch (layer.py:714: `.mean(axis=-1)` on a (B,) tensor), so the two
+        proposal scores are scalars per caption set; the result is (n,)."""
+        n = h.shape[0]
+        B = n // groups
+
+        def rep(t):
+            return t if groups == 1 else t.repeat(groups, *([1] * (t.dim() - 1)))
+        x = torch.relu(h).transpose(1, 2)                          # ResBlock's in-place ReLU also feeds the skip (sublayer.py:111,119)
+        conv = self.block[0].res_block[1]
+        x = (x + 0.3 * F.conv1d(x, conv.weight, conv.bias, padding=1)).transpose(1, 2)
+        y = _dropout(F.layer_norm(self._lstm(x), (WIDTH,), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps),
+                     0.3, self.training)
+        mask = rep(att_mask)
+        sa = self.att
+        logits = sa.K(y) @ sa.Q(y).transpose(1, 2) / math.sqrt(sa.attention_size)
+        w = torch.softmax(torch.where(mask > 0, logits, torch.full_like(logits, -9e15)), dim=-1)
+        words = _tanh_ln(_dropout(sa.output_layer[0](w @ sa.V(y)), sa.dropout, self.training), self.att_norm[1])
+        word_mask = mask[:, 0, :].unsqueeze(2)                     # (n,L,1)
+        alpha = rep(alpha_all) * word_mask
+        P = self.num_psl
+        so = self._proposal_score(self.obj_psl_score, rep(obj), alpha[:, :, :P], words, word_mask)
+        sm = self._proposal_score(self.motion_psl_score, rep(mot), alpha[:, :, -P:], words, word_mask)
+        so = so.view(groups, B).mean(dim=1).repeat_interleave(B)
+        sm = sm.view(groups, B).mean(dim=1).repeat_interleave(B)
+        ts = self.text_sum
+        adj = torch.softmax(words @ ts.theta.t(), dim=1)           # LatentPSL(512, 1): one latent node over the words
+        sent = _dropout(_tanh_ln(adj.transpose(1, 2) @ words, ts.out_norm[1]), 0.3, self.training).squeeze(1)
+        fus = torch.softmax(sent @ self.fusion.t(), dim=-1)
+        return so * fus[:, 0] + sm * fus[:, 1]
+
+    def forward(self, inputs, obj_proposals, motion_proposals, att_mask=None, alpha_all=None):
+        return self.score_projected(self.project(inputs), obj_proposals, motion_proposals, att_mask, alpha_all)
+
+
+def attention_mask(captions):
+    """run_gun.py:164-166: (B,L,L) outer product of the non-<pad> mask"""
+    seq = (captions > 0).to(torch.float32)
+    return seq.unsqueeze(2) * seq.unsqueeze(1)
+
+
+def critic_step_losses(D, captions, f_caption, obj, mot, att_mask, alpha, eps_gp):
+    """run_gun.py:345-375 in one critic pass.  captions (B,L) int64 real ids, f_caption (B,L,V) generator logits (detached),
+    eps_gp (B,1,1).  Returns (loss_D, r_loss, f_loss, gradient_penalty, (r_logit, f_logit, mixed_logit))."""
+    B = captions.shape[0]
+    h_r = D.project_ids(captions)
+    h_f = D.project(f_caption)
+    h_m = eps_gp * h_r + (1 - eps_gp) * h_f                      # == project(eps * onehot + (1 - eps) * f_caption)
+    scores = D.score_projected(torch.cat([h_r, h_f, h_m], 0), obj, mot, att_mask, alpha, groups=3)
+    r_logit, f_logit, m_logit = scores[:B], scores[B:2 * B], scores[2 * B:]
+    g = torch.autograd.grad(m_logit.sum(), h_m, create_graph=True, retain_graph=True)[0]        # (B,L,512)
+    W = D.vocab_matrix()
+    gram = W @ W.t()
+    gn = torch.sqrt(((g @ gram) * g).sum(dim=(1, 2)))            # |d mixed_logit / d mixed_captions|_2 per sample
+    gp = ((gn - 1) * (gn - 1)).mean()
+    r_loss, f_loss = r_logit.mean(), f_logit.mean()
+    return f_loss - r_loss + 10 * gp, r_loss, f_loss, gp, (r_logit, f_logit, m_logit)
+
+
+class GANLambdaHandler(object):
+    """utils/utils.py:196-265: weight of the generator's GAN loss.  Stable at `gan_lambda` while the running caption loss
+    (last 200 steps) does not rise; when its newer half exceeds the older half by 4 % the weight follows one half-cosine dip
+    down to 0.006 and back over 500 steps.  `cap_list` is what the reference stores in its checkpoints."""
+    WIDTH, PERIOD, LOW = 200, 500, 0.006
+
+    def __init__(self, total_step, gan_lambda, cap_list=None):
+        self.cap_list = list(cap_list) if cap_list is not None else []
+        self.total_step = total_step
+        self.current_step = 0
+        self.counter = self.PERIOD
+        self.current_schedule_step = 0
+        self.start_gan_lambda = gan_lambda
+        self.low_gan_lambda = self.LOW
+        amp = (gan_lambda - self.LOW) / 2
+        k = np.arange(self.PERIOD)
+        # sin(pi * x / PERIOD) on x in [PERIOD/2, 3 PERIOD/2) resp. [3 PERIOD/2, 5 PERIOD/2): start high -> low -> high
+        self.decrease_schedule = (np.sin(np.pi * (k + self.PERIOD // 2) / self.PERIOD) * amp + amp + self.LOW).tolist()
+        self.increase_schedule = (np.sin(np.pi * (k + 3 * self.PERIOD // 2) / self.PERIOD) * amp + amp + self.LOW).tolist()
+        self.current_lambda = gan_lambda
+        self.state = 0                      # 0 stable, 1 decrease, 2 increase (never entered by the reference either)
+
+    def update_gan_lambda(self, epoch, i, cap_loss):
+        self.current_step = i - 1 + epoch * self.total_step
+        self.cap_list.append(cap_loss)
+        if len(self.cap_list) <= self.WIDTH:
+            return
+        self.cap_list = self.cap_list[-self.WIDTH:]
+        if self.state == 0:
+            half = self.WIDTH // 2
+            if np.mean(self.cap_list[half:]) > 1.04 * np.mean(self.cap_list[:half]):
+                self.state = 1
+        elif self.current_schedule_step == self.counter - 1:
+            self.current_schedule_step = 0
+            self.state = 0
+
+    def get_current_lambda(self):
+        if self.state != 0:
+            sched = self.decrease_schedule if self.state == 1 else self.increase_schedule
+            self.current_lambda = sched[self.current_schedule_step]
+            self.current_schedule_step += 1
+        return self.current_lambda
+
+
+class GanTrainer(object):
+    """One `RunGAN.train` iteration (run_gun.py:147-234) around the HIP generator.
+
+        it = GanTrainer(model, D); out = it.iteration(frames, regions, captions, cap_lens, tf_ratio, epoch, i)
+
+    `trainer` is the generator's `dlsg_amd.Trainer` (kernel-by-kernel launches: the critic's autograd sits between the
+    generator's forward and backward, so the step is not replayed from a hipGraph)."""
+
+    def __init__(self, model, D, lr=1.6e-4, betas=(0.5, 0.9), num_D=5, gan_lambda=0.01, total_step=1, cap_list=None,
+                 process_group=None, world_size=1):
+        from .model import Trainer
+        self.model, self.D = model, D
+        self.trainer = Trainer(model, lr=lr, betas=betas, process_group=process_group, world_size=world_size, use_graphs=False)
+        self.opt_D = torch.optim.Adam(D.parameters(), lr=lr, betas=betas)                   # run_gun.py:100
+        self.num_D = num_D
+        self.lambda_handler = GANLambdaHandler(total_step, gan_lambda, cap_list)
+        self.world_size, self.pg = world_size, process_group
+        self.eps_source = None              # tests: callable(k) -> (B,1,1) tensor instead of torch.rand
+
+    def _allreduce_D(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            for p in self.D.parameters():
+                if p.grad is not None:
+                    dist.all_reduce(p.grad, group=self.pg)
+                    p.grad.div_(self.world_size)
+
+    def train_disc(self, captions, f_caption, obj, mot, att_mask, alpha):
+        """run_gun.py:339-381: num_D critic updates.  Returns (mean loss_D, mean Wasserstein estimate) as floats."""
+        mean_loss = torch.zeros((), device=f_caption.device)
+        mean_w = torch.zeros((), device=f_caption.device)
+        B = captions.shape[0]
+        for k in range(self.num_D):
+            self.opt_D.zero_grad(set_to_none=True)
+            eps = self.eps_source(k) if self.eps_source is not None else torch.rand(B, 1, 1, device=f_caption.device)
+            loss_D, r_loss, f_loss, gp, _ = critic_step_losses(self.D, captions, f_caption, obj, mot, att_mask, alpha, eps)
+            mean_loss += loss_D.detach() / self.num_D
+            mean_w += (r_loss.detach() - f_loss.detach()) / self.num_D
+            loss_D.backward()
+            self._allreduce_D()
+            self.opt_D.step()
+        return float(mean_loss), float(mean_w)
+
+    def iteration(self, frames, regions, captions, cap_lens, tf_ratio, epoch=0, i=1, max_len=26):
+        model, D = self.model, self.D
+        captions = captions[:, :max_len].contiguous()
+        att_mask = attention_mask(captions)
+        # ---- Train D: the generator's outputs are constants here (run_gun.py:167-174)
+        with torch.no_grad():
+            f_caption, obj, mot, alpha = model(frames, regions, captions, max_len, tf_ratio)
+        loss_D, wass = self.train_disc(captions, f_caption, obj, mot, att_mask, alpha)
+        # ---- Train the captioning model (run_gun.py:180-234)
+        out = {}
+
+        def gan_term(logits_tm, sv):
+            """d(gan_lambda * loss_G) / d logits, time-major (L,B,V); called between the HIP forward and backward"""
+            s = sv['dec']
+            tokens = logits_tm.transpose(0, 1).detach().requires_grad_(True)
+            obj_, mot_ = sv['dec_gsrc'][0].detach(), sv['dec_gsrc'][1].detach()
+            alpha_ = s['ALPHA'].transpose(0, 1).detach()
+            with torch.enable_grad():
+                loss_G = -D(tokens, obj_, mot_, att_mask=att_mask, alpha_all=alpha_).mean()
+                g = torch.autograd.grad(loss_G, tokens)[0]
+            out['loss_G'] = loss_G.detach()
+            out['cap_loss_dev'] = sv['loss_dev']
+            # the reference updates lambda from the caption loss of THIS step before using it (run_gun.py:210,224)
+            self.lambda_handler.update_gan_lambda(epoch, i, float(sv['loss_dev']))
+            out['gan_lambda'] = self.lambda_handler.get_current_lambda()
+            return (g * out['gan_lambda']).transpose(0, 1)
+        cap_loss = self.trainer.step(frames, regions, captions, cap_lens, tf_ratio, max_len=max_len, extra_dlogits=gan_term)
+        out.update(cap_loss=float(cap_loss), loss_G=float(out['loss_G']), loss_D=loss_D, wasserstein=wass)
+        out['total_loss'] = out['cap_loss'] + out['loss_G'] * out['gan_lambda']
+        out.pop('cap_loss_dev')
+        return out
+
+
+# ------------------------------------------------------------------ checkpoints (run_gun.py:302-310, 53-61, 92-109)
+def save_checkpoint(path, epoch, gan):
+    """The dict RunGAN stores: epoch, model_state_dict, optimizer_state_dict (torch.optim.Adam layout), model_d_state_dict,
+    optimizer_d_state_dict, cap_list."""
+    torch.save({'epoch': epoch,
+                'model_state_dict': {k: v.detach().cpu() for k, v in gan.model.state_dict().items()},
+                'optimizer_state_dict': gan.trainer.optimizer_state_dict(),
+                'model_d_state_dict': {k: v.detach().cpu() for k, v in gan.D.state_dict().items()},
+                'optimizer_d_state_dict': gan.opt_D.state_dict(),
+                'cap_list': np.array(gan.lambda_handler.cap_list)}, path)
+
+
+def load_checkpoint(path, gan, map_location=None):
+    """Resume a GanTrainer from a checkpoint written by save_checkpoint or by the reference trainer.  Returns the epoch."""
+    ck = torch.load(path, map_location=map_location or 'cpu', weights_only=False)
+    gan.model.load_state_dict(ck['model_state_dict'])
+    gan.trainer.load_optimizer_state_dict(ck['optimizer_state_dict'])
+    gan.D.load_state_dict(ck['model_d_state_dict'])
+    gan.opt_D.load_state_dict(ck['optimizer_d_state_dict'])
+    h = gan.lambda_handler
+    gan.lambda_handler = GANLambdaHandler(h.total_step, h.start_gan_lambda, cap_list=ck['cap_list'])
+    return ck['epoch']

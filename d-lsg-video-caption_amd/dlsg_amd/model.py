@@ -654,7 +654,7 @@ class Trainer(object):
                 self._works.append(dist.all_reduce(self.model._gflat[lo:hi], group=self.pg, async_op=True))
 
     # ------------------------------------------------------------------ one step, as a schedule
-    def _schedule(self, frames, regions, captions, cap_lens, coins, seed, dev_coins, on_bucket):
+    def _schedule(self, frames, regions, captions, cap_lens, coins, seed, dev_coins, on_bucket, extra_dlogits=None):
         model, ops = self.model, self.model.ops
         L = captions.shape[1]
         sv = {}
@@ -666,6 +666,12 @@ class Trainer(object):
         row_loss = torch.empty(L * Bn, dtype=torch.float32, device=dl.device)
         loss = torch.empty(1, dtype=torch.float32, device=dl.device)
         ops.ce_ragged(s['LOGITS'], captions, cap_lens, dl, row_loss, loss, time_major=True)
+        if extra_dlogits is not None:
+            # another loss on the logits (the GAN term of run_gun.py:218-231): its gradient joins the CrossEntropy's
+            sv['loss_dev'] = loss
+            g = extra_dlogits(s['LOGITS'], sv)
+            V = dl.shape[-1]
+            ops.copy2d(g.contiguous().view(-1, V), dl.view(-1, V), accum=True)
         model._engine_backward(sv, dl, None, None, None, training, seed, on_bucket=on_bucket)
         return loss
 
@@ -674,8 +680,10 @@ class Trainer(object):
         return [self.lr / (1.0 - b1 ** self.t), math.sqrt(1.0 - b2 ** self.t)]
 
     @torch.no_grad()
-    def step(self, frames, regions, captions, cap_lens, tf_ratio, max_len=26):
-        """One optimisation step.  Returns the (device) scalar loss of this rank's shard."""
+    def step(self, frames, regions, captions, cap_lens, tf_ratio, max_len=26, extra_dlogits=None):
+        """One optimisation step.  Returns the (device) scalar loss of this rank's shard.
+        extra_dlogits: optional callable (logits (L,B,V) time-major, saved-state dict) -> (L,B,V) gradient of an additional
+        loss on the logits, added to the CrossEntropy's before the backward (kernel-by-kernel launches only)."""
         model, ops = self.model, self.model.ops
         self._check_binding()
         captions = captions[:, :max_len].contiguous()
@@ -684,11 +692,11 @@ class Trainer(object):
         coins = model._draw_coins(L, False, tf_ratio)
         seed = model.next_seed()
         self.t += 1
-        if self.use_graphs:
+        if self.use_graphs and extra_dlogits is None:
             return self._step_graphs(frames, regions, captions, cap_lens, coins, seed)
-        return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
+        return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True, extra_dlogits=extra_dlogits)
 
-    def _eager_step(self, frames, regions, captions, cap_lens, coins, seed, counted=False):
+    def _eager_step(self, frames, regions, captions, cap_lens, coins, seed, counted=False, extra_dlogits=None):
         model, ops = self.model, self.model.ops
         if not counted:
             self.t += 1
@@ -696,7 +704,7 @@ class Trainer(object):
         if self.device_coins:
             dev_coins = torch.tensor([int(c) for c in coins], dtype=torch.int32).to(captions.device)
         self._works = []
-        loss = self._schedule(frames, regions, captions, cap_lens, coins, seed, dev_coins, self._allreduce)
+        loss = self._schedule(frames, regions, captions, cap_lens, coins, seed, dev_coins, self._allreduce, extra_dlogits)
         for w in self._works:
             w.wait()
         self._adam(self.t)

@@ -27,6 +27,8 @@ def synth_state_dict(template, seed=0):
         if t.dim() >= 2:
             if 'word_embed' in k:
                 w = u
+            elif t.dim() == 3:          # Conv1d weight (out, in, k) of the DiscV2 critic: fan-in = in * k
+                w = u * math.sqrt(3.0 / (t.shape[1] * t.shape[2]))
             else:
                 w = u * math.sqrt(3.0 / t.shape[-1])
         elif k.endswith('weight'):

@@ -148,8 +148,97 @@ def drop_case(tag, args, V, B, seed, tf, counter=7):
     print(tag, 'loss', loss, 'dropout calls', hd.k)
 
 
+def gan_args(**kw):
+    """DiscV2 hard-codes 1024-wide proposals and 512-wide internals (models/layer.py:665-667): H = 1024, the rest small."""
+    base = dict(visual_hidden_size=1024, region_projected_size=1024, num_topk=3)
+    base.update(kw)
+    return small_args(**base)
+
+
+def gan_case(tag, args, V, B, seed, num_D=5, gan_lambda=0.01):
+    """One RunGAN iteration (run_gun.py:153-234, 339-381) around the REFERENCE CapGnnModel and DiscV2, both in eval mode
+    (dropout off), tf = 1.0; `torch.rand` of the gradient penalty replaced by recorded numbers."""
+    from dlsg_amd.synth import checksum
+    vocab = make_vocab(V)
+    torch.manual_seed(0)
+    G = ref_model.CapGnnModel(args, vocab)
+    G.load_state_dict(synth_state_dict(G.state_dict(), seed), strict=True)
+    D = ref_model.DiscV2(args, V)
+    D.load_state_dict(synth_state_dict(D.state_dict(), seed + 1), strict=True)
+    G.eval(); D.eval()
+    frames, regions, caps, lens = synth_batch(args, V, B, seed + 2)
+    for j in range(B):
+        caps[j, int(lens[j]):] = 0                      # <pad> beyond the caption, as the loader delivers it
+    out = {'meta.V': V, 'meta.B': B, 'meta.seed': seed, 'meta.num_D': num_D, 'meta.lambda': gan_lambda, 'cap_lens': lens.numpy(),
+           'captions': caps.numpy()}
+    max_len, bs = 26, B
+    opt_G = torch.optim.Adam(G.parameters(), lr=1.6e-4, betas=(0.5, 0.9))
+    opt_D = torch.optim.Adam(D.parameters(), lr=1.6e-4, betas=(0.5, 0.9))
+    targets = caps
+    # ---- Train D (run_gun.py:163-178)
+    seq_mask = (caps > 0).to(torch.float32)
+    att_mask = torch.matmul(seq_mask.view(bs, max_len, 1), seq_mask.view(bs, 1, max_len))
+    f_caption, object_psl, motion_psl, alpha_all = G(frames, regions, targets, max_len, 1.0)
+    f_caption = f_caption.detach()
+    r_caption = torch.zeros(bs, max_len, V).scatter_(2, targets.unsqueeze(2), 1)          # to_onehot, run_gun.py:447-451
+    object_psl, motion_psl, alpha_all = object_psl.detach(), motion_psl.detach(), alpha_all.detach()
+    gen = torch.Generator().manual_seed(777)
+    eps_all = torch.rand(num_D, bs, 1, 1, generator=gen)
+    out['eps_gp'] = eps_all.numpy()
+    mean_loss, mean_w = 0.0, 0.0
+    for k in range(num_D):                               # run_gun.py:343-381
+        opt_D.zero_grad()
+        r_logit = D(r_caption, object_psl, motion_psl, att_mask, alpha_all)
+        f_logit = D(f_caption, object_psl, motion_psl, att_mask, alpha_all)
+        epsilon_gp = eps_all[k].clone().requires_grad_(True)
+        mixed = r_caption.detach() * epsilon_gp + f_caption.detach() * (1 - epsilon_gp)
+        mixed_logit = D(mixed, object_psl, motion_psl, att_mask, alpha_all)
+        grad_gp = torch.autograd.grad(inputs=mixed, outputs=mixed_logit, grad_outputs=torch.ones_like(mixed_logit),
+                                      create_graph=True, retain_graph=True)[0]
+        gnorm = grad_gp.contiguous().view(len(grad_gp), -1).norm(2, dim=1)
+        gp = ((gnorm - 1) * (gnorm - 1)).mean()
+        r_loss, f_loss = r_logit.mean(), f_logit.mean()
+        loss_D = f_loss - r_loss + 10 * gp
+        mean_loss += loss_D.item() / num_D
+        mean_w += (r_loss.item() - f_loss.item()) / num_D
+        loss_D.backward(retain_graph=True)
+        if k == 0:
+            out.update({'d0.r_logit': r_logit.detach().numpy(), 'd0.f_logit': f_logit.detach().numpy(),
+                        'd0.mixed_logit': mixed_logit.detach().numpy(), 'd0.grad_norm': gnorm.detach().numpy(),
+                        'd0.gp': np.array(gp.item()), 'd0.loss_D': np.array(loss_D.item())})
+            for n, p in D.named_parameters():
+                out['d0.gnorm.' + n] = np.array(float(p.grad.double().norm())) if p.grad is not None else np.array(-1.0)
+        opt_D.step()
+    out['loss_D_mean'] = np.array(mean_loss); out['wasserstein_mean'] = np.array(mean_w)
+    for n, (s_, a_) in checksum(dict(D.named_parameters())).items():
+        out['dpost.' + n] = np.array([s_, a_])
+    # ---- Train the captioning model (run_gun.py:180-234)
+    opt_G.zero_grad()
+    outputs, object_psl, motion_psl, alpha_all = G(frames, regions, targets, max_len, 1.0)
+    tokens = outputs
+    rows = torch.cat([outputs[j][:lens[j]] for j in range(bs)], 0).view(-1, V)
+    tgt = torch.cat([targets[j][:lens[j]] for j in range(bs)], 0).view(-1)
+    cap_loss = torch.nn.CrossEntropyLoss()(rows, tgt)
+    f_logit = D(tokens, object_psl.detach(), motion_psl.detach(), att_mask=att_mask, alpha_all=alpha_all.detach())
+    loss_G = -f_logit.mean()
+    total = cap_loss + loss_G * gan_lambda
+    total.backward()
+    out.update({'cap_loss': np.array(cap_loss.item()), 'loss_G': np.array(loss_G.item()), 'total_loss': np.array(total.item()),
+                'g.f_logit': f_logit.detach().numpy()})
+    for n, p in G.named_parameters():
+        if p.grad is None:
+            out['gnone.' + n] = np.array(1)
+        else:
+            out['gnorm.' + n] = np.array(float(p.grad.double().norm()))
+    opt_G.step()
+    for n, (s_, a_) in checksum(dict(G.named_parameters())).items():
+        out['post.' + n] = np.array([s_, a_])
+    np.savez_compressed(os.path.join(HERE, tag + '.npz'), **out)
+    print(tag, 'loss_D', mean_loss, 'wasserstein', mean_w, 'cap', cap_loss.item(), 'loss_G', loss_G.item(), 'gp0', float(out['d0.gp']))
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ss', 'drop']
+    which = sys.argv[1:] or ['ss', 'drop', 'gan']
     if 'ss' in which:
         ss_case('small_msvd_ss', small_args(), V=50, B=3, seed=11, full=True)
         ss_case('small_msrvtt_ss', small_args(num_obj=6, num_proposals=5, decode_hidden_size=80, dataset='msr-vtt'),
@@ -160,3 +249,8 @@ if __name__ == '__main__':
         drop_case('small_msvd_drop', small_args(), V=50, B=3, seed=11, tf=0.8)
         drop_case('small_msrvtt_drop', small_args(num_obj=6, num_proposals=5, decode_hidden_size=80, dataset='msr-vtt'),
                   V=61, B=4, seed=12, tf=1.0)
+    if 'gan' in which:
+        gan_case('gan_msvd', gan_args(), V=50, B=3, seed=51)
+        # num_proposals <= num_topk: PSLScore2 keeps every proposal (layer.py:686-688), MSR-VTT setting of run_gun.py:36-40
+        gan_case('gan_msrvtt', gan_args(num_obj=6, num_proposals=5, num_topk=5, decode_hidden_size=80, dataset='msr-vtt'),
+                 V=61, B=4, seed=53)

@@ -107,3 +107,42 @@ class OracleTrainer(object):
 
     def step(self, frames, regions, caps, lens, tf):
         return self.R.train_step(self.model, self.opt, frames, regions, caps, lens, tf)
+
+
+def gan_args(**kw):
+    """tests/golden/make_goldens_r2.py gan_args: DiscV2 hard-codes 1024-wide proposals, the rest stays small"""
+    base = dict(visual_hidden_size=1024, region_projected_size=1024, num_topk=3)
+    base.update(kw)
+    return small_args(**base)
+
+
+GAN_CASES = {
+    'gan_msvd': lambda: gan_args(),
+    'gan_msrvtt': lambda: gan_args(num_obj=6, num_proposals=5, num_topk=5, decode_hidden_size=80, dataset='msr-vtt'),
+}
+
+
+def load_gan_case(tag, make_G, make_D):
+    """-> (args, vocab, golden, G, D, frames, regions, padded captions, cap_lens); weights regenerated from the seeds"""
+    g = dict(np.load(os.path.join(GOLD, tag + '.npz')))
+    args = GAN_CASES[tag]()
+    V, B, seed = int(g['meta.V']), int(g['meta.B']), int(g['meta.seed'])
+    vocab = make_vocab(V)
+    torch.manual_seed(0)
+    G = make_G(args, vocab)
+    G.load_state_dict(synth_state_dict(G.state_dict(), seed), strict=True)
+    D = make_D(args, V)
+    D.load_state_dict(synth_state_dict(D.state_dict(), seed + 1), strict=True)
+    frames, regions, caps, lens = synth_batch(args, V, B, seed + 2)
+    for j in range(B):
+        caps[j, int(lens[j]):] = 0
+    assert np.array_equal(caps.numpy(), g['captions'])
+    return args, vocab, g, G.eval(), D.eval(), frames, regions, caps, lens
+
+
+def check_post(named_parameters, g, prefix, tol):
+    """parameters after an Adam step against the fixture's (sum, abs-sum) checksums"""
+    for k, p in named_parameters:
+        s, a = g[prefix + k]
+        got = float(p.detach().double().sum())
+        assert abs(got - s) <= tol * max(1.0, a), (k, got, s)

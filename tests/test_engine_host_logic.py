@@ -330,3 +330,125 @@ def test_deep_weight_gradient_split_respects_group_limit():
     assert max(launches) <= 16
     for dy, x, gout in items:
         assert (gout - dy.t() @ x).abs().max().item() <= 1e-3
+
+
+# ------------------------------------------------------------------ DiscV2 critic + WGAN-GP iteration
+@pytest.mark.parametrize('tag', ['gan_msvd', 'gan_msrvtt'])
+def test_gan_iteration_matches_reference(tag):
+    """dlsg_amd.gan (embedding-gather projection, one 3B-row critic pass, Gram-matrix gradient penalty, unrolled LSTM, GAN
+    term entering the hand-scheduled backward through d(logits)) against the reference's own numbers for one RunGAN
+    iteration: critic scores, gradient penalty, five critic updates, generator loss / gradients / Adam step."""
+    import copy
+    from dlsg_amd import gan
+    from helpers import load_gan_case, check_post
+
+    def mk(args, vocab):
+        m = dlsg_amd.CapGnnModel(args, vocab)
+        m.set_ops(EmulOps())
+        return m
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case(tag, mk, dlsg_amd.DiscV2)
+    assert sorted(D.state_dict().keys()) == sorted([k[len('dpost.'):] for k in g if k.startswith('dpost.')] + ['att.pe.pe'])
+    eps = torch.from_numpy(g['eps_gp'])
+    with torch.no_grad():
+        f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)
+    D0 = copy.deepcopy(D)
+    loss_D, r_loss, f_loss, gp, (rl, fl, ml) = gan.critic_step_losses(D0, caps, f_caption, obj, mot, gan.attention_mask(caps),
+                                                                     alpha, eps[0])
+    assert np.abs(rl.detach().numpy() - g['d0.r_logit']).max() <= 5e-5
+    assert np.abs(fl.detach().numpy() - g['d0.f_logit']).max() <= 5e-5
+    assert np.abs(ml.detach().numpy() - g['d0.mixed_logit']).max() <= 5e-5
+    assert abs(gp.item() - float(g['d0.gp'])) <= 2e-4 * max(1.0, float(g['d0.gp']))
+    assert abs(loss_D.item() - float(g['d0.loss_D'])) <= 5e-4
+    loss_D.backward()
+    for n, p in D0.named_parameters():
+        ref = float(g['d0.gnorm.' + n])
+        got = float(p.grad.double().norm()) if p.grad is not None else -1.0
+        assert abs(got - ref) <= 1e-3 * max(abs(ref), 1e-3), (n, got, ref)
+    # the dense forward (reference call signature) agrees with the gather path
+    with torch.no_grad():
+        dense = D(torch.nn.functional.one_hot(caps, int(g['meta.V'])).float(), obj, mot, gan.attention_mask(caps), alpha)
+    assert np.abs(dense.numpy() - g['d0.r_logit']).max() <= 5e-5
+    it = dlsg_amd.GanTrainer(G, D, num_D=int(g['meta.num_D']), gan_lambda=float(g['meta.lambda']))
+    it.eps_source = lambda k: eps[k]
+    res = it.iteration(frames, regions, caps, lens, 1.0)
+    assert abs(res['loss_D'] - float(g['loss_D_mean'])) <= 1e-3
+    assert abs(res['wasserstein'] - float(g['wasserstein_mean'])) <= 1e-3
+    check_post(D.named_parameters(), g, 'dpost.', 5e-5)
+    assert abs(res['cap_loss'] - float(g['cap_loss'])) <= 2e-5
+    assert abs(res['loss_G'] - float(g['loss_G'])) <= 5e-4
+    assert abs(res['total_loss'] - float(g['total_loss'])) <= 5e-5
+    Gv = G.grad_views()
+    for k, p in G.named_parameters():
+        if 'gnorm.' + k in g:
+            ref = float(g['gnorm.' + k])
+            got = float(Gv[k].double().norm())
+            assert abs(got - ref) <= 1e-3 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+    check_post(G.named_parameters(), g, 'post.', 2e-5)
+
+
+def test_gan_lambda_handler_tracks_the_oracle():
+    from oracle import gan_ref as GR
+    a, b = dlsg_amd.GANLambdaHandler(50, 0.01), GR.GANLambdaHandlerRef(50, 0.01)
+    rng = np.random.RandomState(0)
+    assert np.allclose(a.decrease_schedule, b.decrease_schedule) and np.allclose(a.increase_schedule, b.increase_schedule)
+    for step in range(1, 1500):
+        loss = 3.0 + (0.4 if 300 < step < 420 else 0.0) + 0.01 * rng.randn()
+        for h in (a, b):
+            h.update_gan_lambda(step // 50, step % 50, loss)
+        assert a.get_current_lambda() == b.get_current_lambda() and a.state == b.state, step
+    assert min(a.cap_list) > 2.9 and len(a.cap_list) == 200
+
+
+def test_gan_checkpoint_round_trip(tmp_path):
+    """run_gun.py:302-310 layout: save -> load into a fresh GanTrainer -> both continue identically."""
+    from helpers import load_gan_case
+
+    def mk(args, vocab):
+        m = dlsg_amd.CapGnnModel(args, vocab)
+        m.set_ops(EmulOps())
+        return m
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case('gan_msrvtt', mk, dlsg_amd.DiscV2)
+    eps = torch.from_numpy(g['eps_gp'])
+    it = dlsg_amd.GanTrainer(G, D, num_D=2)
+    it.eps_source = lambda k: eps[k]
+    it.iteration(frames, regions, caps, lens, 1.0, epoch=0, i=1)
+    path = str(tmp_path / '0.pt')
+    dlsg_amd.save_checkpoint(path, 0, it)
+    ck = torch.load(path, weights_only=False)
+    assert sorted(ck.keys()) == ['cap_list', 'epoch', 'model_d_state_dict', 'model_state_dict', 'optimizer_d_state_dict',
+                                 'optimizer_state_dict']
+    args2, vocab2, _, G2, D2, *_ = load_gan_case('gan_msrvtt', mk, dlsg_amd.DiscV2)
+    it2 = dlsg_amd.GanTrainer(G2, D2, num_D=2)
+    it2.eps_source = lambda k: eps[k]
+    assert dlsg_amd.load_checkpoint(path, it2) == 0
+    assert it2.lambda_handler.cap_list == it.lambda_handler.cap_list and it2.trainer.t == it.trainer.t
+    a = it.iteration(frames, regions, caps, lens, 1.0, epoch=0, i=2)
+    b = it2.iteration(frames, regions, caps, lens, 1.0, epoch=0, i=2)
+    assert abs(a['total_loss'] - b['total_loss']) <= 1e-6 and abs(a['loss_D'] - b['loss_D']) <= 1e-6
+    for (k, p), (_, q) in zip(G.named_parameters(), G2.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), k
+    for (k, p), (_, q) in zip(D.named_parameters(), D2.named_parameters()):
+        assert (p.detach() - q.detach()).abs().max().item() <= 1e-7, k
+
+
+def test_proposal_and_attention_gradients_reach_the_encoder():
+    """d(obj_proposals), d(motion_proposals), d(alpha_all) sent into the autograd bridge (models/model.py:36-40 returns them
+    graph-attached) against the oracle's autograd."""
+    from oracle import torch_ref as R
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    args, vocab, _, _ = load_case('small_msvd')
+    orc = R.CapGnnModelRef(args, vocab).eval()
+    orc.load_state_dict(net.state_dict())
+    gen = torch.Generator().manual_seed(3)
+    w_obj, w_mot = torch.randn(3, 8, 64, generator=gen), torch.randn(3, 8, 64, generator=gen)
+    w_al, w_lg = torch.randn(3, 26, 16, generator=gen), torch.randn(3, 26, 50, generator=gen) * 0.1
+    grads = []
+    for m in (orc, net):
+        out, obj, mot, alpha = m(frames, regions, caps, 26, 1.0)
+        ((out * w_lg).sum() + (obj * w_obj).sum() + (mot * w_mot).sum() + (alpha * w_al).sum()).backward()
+        grads.append({k: p.grad for k, p in m.named_parameters()})
+    for k, ref in grads[0].items():
+        if ref is None:
+            continue
+        err = (grads[1][k] - ref).abs().max().item()
+        assert err <= 2e-5 + 2e-4 * ref.abs().max().item(), (k, err)

@@ -1,0 +1,88 @@
+"""GPU (-m gpu): SURVEY.md 8(f) rank 1 -- one RunGAN iteration (run_gun.py:153-234,339-398) with the generator on the HIP
+kernels and the DiscV2 critic on PyTorch-ROCm eager (dlsg_amd/gan.py), against the reference's own numbers
+(tests/golden/gan_*.npz: the imported reference CapGnnModel + DiscV2, five critic updates with recorded gradient-penalty
+epsilons, then the generator step with total_loss = cap_loss + lambda * loss_G)."""
+import numpy as np
+import pytest
+import torch
+
+import dlsg_amd
+from dlsg_amd import gan
+from helpers import load_gan_case, check_post
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('tag', ['gan_msvd', 'gan_msrvtt'])
+def test_gan_iteration_matches_reference(tag):
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case(tag, dlsg_amd.CapGnnModel, dlsg_amd.DiscV2)
+    G, D = G.cuda(), D.cuda()
+    frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
+    eps = torch.from_numpy(g['eps_gp']).cuda()
+    with torch.no_grad():
+        f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)
+    import copy
+    D0 = copy.deepcopy(D)
+    loss_D, r_loss, f_loss, gp, (rl, fl, ml) = gan.critic_step_losses(D0, caps, f_caption, obj, mot, gan.attention_mask(caps),
+                                                                     alpha, eps[0])
+    assert np.abs(rl.detach().cpu().numpy() - g['d0.r_logit']).max() <= 2e-4
+    assert np.abs(fl.detach().cpu().numpy() - g['d0.f_logit']).max() <= 2e-4
+    assert np.abs(ml.detach().cpu().numpy() - g['d0.mixed_logit']).max() <= 2e-4
+    assert abs(gp.item() - float(g['d0.gp'])) <= 1e-3 * max(1.0, float(g['d0.gp']))
+    assert abs(loss_D.item() - float(g['d0.loss_D'])) <= 2e-3
+    loss_D.backward()
+    for n, p in D0.named_parameters():
+        ref = float(g['d0.gnorm.' + n])
+        got = float(p.grad.double().norm()) if p.grad is not None else -1.0
+        assert abs(got - ref) <= 3e-3 * max(abs(ref), 1e-3), (n, got, ref)
+    it = dlsg_amd.GanTrainer(G, D, num_D=int(g['meta.num_D']), gan_lambda=float(g['meta.lambda']))
+    it.eps_source = lambda k: eps[k]
+    res = it.iteration(frames, regions, caps, lens, 1.0)
+    assert abs(res['loss_D'] - float(g['loss_D_mean'])) <= 3e-3
+    assert abs(res['wasserstein'] - float(g['wasserstein_mean'])) <= 3e-3
+    check_post(D.named_parameters(), g, 'dpost.', 2e-4)
+    assert abs(res['cap_loss'] - float(g['cap_loss'])) <= 1e-4
+    assert abs(res['loss_G'] - float(g['loss_G'])) <= 2e-3
+    assert abs(res['total_loss'] - float(g['total_loss'])) <= 2e-4
+    Gv = G.grad_views()
+    for k, p in G.named_parameters():
+        if 'gnorm.' + k in g:
+            ref = float(g['gnorm.' + k])
+            got = float(Gv[k].double().norm())
+            assert abs(got - ref) <= 5e-3 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+    check_post(G.named_parameters(), g, 'post.', 1e-4)
+
+
+def test_proposal_and_attention_gradients_reach_the_encoder():
+    """`obj_proposals`, `motion_proposals` and `alpha_all` are graph-attached outputs of forward() (models/model.py:36-40):
+    a caller that does NOT detach them (unlike run_gun.py:172-174) sends d(obj), d(mot), d(alpha) back through the
+    hand-scheduled backward.  Checked against the oracle's autograd with a loss that touches all four outputs."""
+    from oracle import torch_ref as R
+    from helpers import load_case, weights_and_inputs
+    args, vocab, g, kind = load_case('small_msvd')
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab).eval()
+    sd, frames, regions, caps, lens = weights_and_inputs(net, g, args)
+    net.load_state_dict(sd)
+    orc = R.CapGnnModelRef(args, vocab).eval()
+    orc.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(3)
+    w_obj, w_mot = torch.randn(3, 8, 64, generator=gen), torch.randn(3, 8, 64, generator=gen)
+    w_al, w_lg = torch.randn(3, 26, 16, generator=gen), torch.randn(3, 26, 50, generator=gen) * 0.1
+
+    def loss_of(m, dev):
+        out, obj, mot, alpha = m(frames.to(dev), regions.to(dev), caps.to(dev), 26, 1.0)
+        return (out * w_lg.to(dev)).sum() + (obj * w_obj.to(dev)).sum() + (mot * w_mot.to(dev)).sum() + (alpha * w_al.to(dev)).sum()
+    lo = loss_of(orc, 'cpu')
+    lo.backward()
+    net = net.cuda()
+    lh = loss_of(net, 'cuda')
+    lh.backward()
+    assert abs(lo.item() - lh.item()) <= 1e-3 * max(1.0, abs(lo.item()))
+    want = dict(orc.named_parameters())
+    for k, p in net.named_parameters():
+        if want[k].grad is None:
+            continue
+        ref = want[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item()
+        assert err <= 2e-5 + 2e-3 * ref.abs().max().item(), (k, err, ref.abs().max().item())

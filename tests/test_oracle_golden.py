@@ -124,3 +124,55 @@ def test_gradients_under_scheduled_sampling(tag):
     if 'logits' in g:
         assert np.abs(outs.detach().numpy() - g['logits']).max() <= 1e-5
     check_grads(lambda k, p: p.grad, net.named_parameters(), g, rel=1e-4, abs_=1e-5)
+
+
+@pytest.mark.parametrize('tag', ['gan_msvd', 'gan_msrvtt'])
+def test_gan_critic_and_iteration(tag):
+    """oracle/gan_ref.py against the reference's DiscV2 + one RunGAN iteration (tests/golden/gan_*.npz): critic scores,
+    gradient penalty, the five critic steps, the generator step with cap_loss + lambda * loss_G."""
+    import copy
+    from oracle import gan_ref as GR
+    from helpers import load_gan_case, check_post
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case(tag, R.CapGnnModelRef, GR.DiscV2Ref)
+    eps = torch.from_numpy(g['eps_gp'])
+    V = int(g['meta.V'])
+    with torch.no_grad():
+        f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)
+    D0 = copy.deepcopy(D)
+    loss_D, r_loss, f_loss, gp, (rl, fl, ml) = GR.critic_losses(D0, GR.to_onehot(caps, V), f_caption, obj, mot,
+                                                                 GR.attention_mask(caps), alpha, eps[0])
+    assert np.abs(rl.detach().numpy() - g['d0.r_logit']).max() <= 2e-5
+    assert np.abs(fl.detach().numpy() - g['d0.f_logit']).max() <= 2e-5
+    assert np.abs(ml.detach().numpy() - g['d0.mixed_logit']).max() <= 2e-5
+    assert abs(gp.item() - float(g['d0.gp'])) <= 1e-4 * max(1.0, float(g['d0.gp']))
+    assert abs(loss_D.item() - float(g['d0.loss_D'])) <= 2e-4
+    loss_D.backward()
+    for n, p in D0.named_parameters():
+        ref = float(g['d0.gnorm.' + n])
+        got = float(p.grad.double().norm()) if p.grad is not None else -1.0
+        assert abs(got - ref) <= 2e-4 * max(abs(ref), 1e-3), (n, got, ref)
+    opt_G, opt_D = R.make_optimizer(G), torch.optim.Adam(D.parameters(), lr=1.6e-4, betas=(0.5, 0.9))
+    res = GR.gan_iteration(G, D, opt_G, opt_D, frames, regions, caps, lens, 1.0, float(g['meta.lambda']), int(g['meta.num_D']),
+                           [eps[k] for k in range(eps.shape[0])])
+    assert abs(res['loss_D'] - float(g['loss_D_mean'])) <= 5e-4
+    assert abs(res['wasserstein'] - float(g['wasserstein_mean'])) <= 5e-4
+    check_post(D.named_parameters(), g, 'dpost.', 2e-5)
+    assert abs(res['cap_loss'] - float(g['cap_loss'])) <= 1e-5
+    assert abs(res['loss_G'] - float(g['loss_G'])) <= 2e-4
+    assert abs(res['total_loss'] - float(g['total_loss'])) <= 2e-5
+    check_post(G.named_parameters(), g, 'post.', 1e-5)
+
+
+def test_gan_lambda_handler_state_machine():
+    """utils/utils.py:196-265 restated: stable until the running caption loss rises by 4 %, then one sine-shaped dip."""
+    from oracle import gan_ref as GR
+    h = GR.GANLambdaHandlerRef(total_step=100, gan_lambda=0.01)
+    for i in range(1, 201):
+        h.update_gan_lambda(0, i, 3.0)
+        assert h.get_current_lambda() == 0.01
+    for i in range(201, 330):
+        h.update_gan_lambda(2, i - 200, 3.5)
+    assert h.state == 1
+    lam = [h.get_current_lambda() for _ in range(5)]
+    assert lam[0] <= 0.01 and all(a >= b for a, b in zip(lam, lam[1:]))
+    assert abs(min(h.decrease_schedule) - 0.006) < 1e-4 and abs(max(h.decrease_schedule) - 0.01) < 1e-4
