@@ -10,6 +10,7 @@ authoring container:  python tests/golden/make_goldens_r2.py
                  where a dropout sits, on which tensor, with which p; the fixture pins the nine sites
                  (layer.py:28,53,310,320,328; sublayer.py:21-26,58-61,87,183-187) of the build against it.
   gan_*.npz      DiscV2 / WGAN-GP (models/model.py:110-168, run_gun.py:339-398,210-231), see gan_case().
+  scoring.json   BLEU / ROUGE_L / CIDEr of caption-eval/pycocoevalcap on synthetic tokenized captions, see scoring_case().
 
 Only arrays leave the container; nothing in tests/, smoke() or bench.py reads /root/reference at run time.
 """
@@ -237,8 +238,49 @@ def gan_case(tag, args, V, B, seed, num_D=5, gan_lambda=0.01):
     print(tag, 'loss_D', mean_loss, 'wasserstein', mean_w, 'cap', cap_loss.item(), 'loss_G', loss_G.item(), 'gp0', float(out['d0.gp']))
 
 
+def scoring_case():
+    """BLEU / ROUGE_L / CIDEr of the reference's own scorer classes (caption-eval/pycocoevalcap, pure Python) on synthetic
+    tokenized captions; inputs and outputs go to scoring.json."""
+    import json
+    sys.path.insert(0, os.path.join(REF, 'caption-eval'))
+    from pycocoevalcap.bleu.bleu import Bleu
+    from pycocoevalcap.rouge.rouge import Rouge
+    from pycocoevalcap.cider.cider import Cider
+    rng = np.random.RandomState(5)
+    words = ['a', 'man', 'woman', 'dog', 'cat', 'is', 'are', 'playing', 'running', 'cooking', 'the', 'guitar', 'ball', 'with',
+             'in', 'kitchen', 'park', 'on', 'street', 'two', 'people', 'riding', 'horse', 'bike', 'slicing', 'onion', 'water']
+    cases = []
+    for nvid, nref in ((12, 5), (40, 17), (3, 1)):
+        gts, res = {}, {}
+        for v in range(nvid):
+            base = [words[i] for i in rng.randint(0, len(words), size=rng.randint(3, 12))]
+            refs = []
+            for _ in range(nref):
+                r = list(base)
+                for _ in range(rng.randint(0, 4)):
+                    r[rng.randint(0, len(r))] = words[rng.randint(0, len(words))]
+                if rng.rand() < 0.3:
+                    r = r[:max(2, len(r) - 2)]
+                refs.append(' '.join(r))
+            h = list(base)
+            for _ in range(rng.randint(0, 5)):
+                h[rng.randint(0, len(h))] = words[rng.randint(0, len(words))]
+            if v == 1:
+                h = ['zebra']                                   # no overlap at all
+            gts['vid%d' % v] = refs
+            res['vid%d' % v] = [' '.join(h)]
+        b, bs = Bleu(4).compute_score(gts, res)
+        r, rs = Rouge().compute_score(gts, res)
+        c, cs = Cider().compute_score(gts, res)
+        cases.append({'gts': gts, 'res': res, 'bleu': [float(x) for x in b], 'bleu_per': [[float(y) for y in x] for x in bs],
+                      'rouge': float(r), 'rouge_per': [float(x) for x in rs], 'cider': float(c), 'cider_per': [float(x) for x in cs]})
+        print('scoring case', nvid, nref, 'BLEU4 %.4f ROUGE %.4f CIDEr %.4f' % (b[3], r, c))
+    with open(os.path.join(HERE, 'scoring.json'), 'w') as f:
+        json.dump(cases, f)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ss', 'drop', 'gan']
+    which = sys.argv[1:] or ['ss', 'drop', 'gan', 'scoring']
     if 'ss' in which:
         ss_case('small_msvd_ss', small_args(), V=50, B=3, seed=11, full=True)
         ss_case('small_msrvtt_ss', small_args(num_obj=6, num_proposals=5, decode_hidden_size=80, dataset='msr-vtt'),
@@ -249,6 +291,8 @@ if __name__ == '__main__':
         drop_case('small_msvd_drop', small_args(), V=50, B=3, seed=11, tf=0.8)
         drop_case('small_msrvtt_drop', small_args(num_obj=6, num_proposals=5, decode_hidden_size=80, dataset='msr-vtt'),
                   V=61, B=4, seed=12, tf=1.0)
+    if 'scoring' in which:
+        scoring_case()
     if 'gan' in which:
         gan_case('gan_msvd', gan_args(), V=50, B=3, seed=51)
         # num_proposals <= num_topk: PSLScore2 keeps every proposal (layer.py:686-688), MSR-VTT setting of run_gun.py:36-40

@@ -1,0 +1,137 @@
+"""feature I/O and loaders (dlsg_amd/data.py) against the reference's semantics (utils/data.py:13-147).
+The HDF5 fixtures are written at test time by the HDF5 C library itself (no h5py in the image) in the reference's layout:
+`feats` (N,26,A+M), `vfeats` (N,26,36,R), plus the caption pickle tuple (captions, pos_tags, lengths, video_ids)."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from dlsg_amd import data as D
+
+try:
+    D._libhdf5()
+    HAVE_H5 = True
+except RuntimeError:
+    HAVE_H5 = False
+needs_h5 = pytest.mark.skipif(not HAVE_H5, reason='libhdf5 not available')
+
+
+def make_dataset(tmp_path, N=23, T=26, F=12, O=36, R=8, ncap=57, L=26, seed=0):
+    rng = np.random.RandomState(seed)
+    feats = rng.randn(N, T, F).astype(np.float32)
+    vfeats = rng.randn(N, T, O, R).astype(np.float32)
+    sfeats = rng.rand(N, T, O, 5).astype(np.float32)
+    fp, rp = str(tmp_path / 'msvd_features.h5'), str(tmp_path / 'msvd_region_feature.h5')
+    D.H5File.create(fp).write('feats', feats).close()
+    D.H5File.create(rp).write('vfeats', vfeats).write('sfeats', sfeats).close()
+    vids = rng.randint(0, N, size=ncap).tolist()
+    lens = rng.randint(3, L + 1, size=ncap).tolist()
+    caps = [torch.from_numpy(np.pad(rng.randint(4, 50, size=n), (0, L - n))).long() for n in lens]
+    tags = [torch.from_numpy(np.pad(rng.randint(1, 9, size=n), (0, L - n))).long() for n in lens]
+    cp = str(tmp_path / 'msvd_captions_train.pkl')
+    with open(cp, 'wb') as f:
+        pickle.dump((caps, tags, lens, vids), f)
+    return fp, rp, cp, feats, vfeats, caps, tags, lens, vids
+
+
+@needs_h5
+def test_hdf5_rows_and_conversion(tmp_path):
+    fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
+    with D.H5File(fp) as h:
+        ds = h['feats']
+        assert ds.shape == feats.shape and ds.is_float and ds.itemsize == 4 and len(ds) == feats.shape[0]
+        assert np.array_equal(ds[5], feats[5]) and np.array_equal(ds[-1], feats[-1])
+        assert np.array_equal(ds.read_rows(3, 7), feats[3:10]) and np.array_equal(ds[2:4], feats[2:4])
+        with pytest.raises(IndexError):
+            ds.read_rows(20, 9)
+        with pytest.raises(KeyError):
+            h['nope']
+    p64 = str(tmp_path / 'd.h5')
+    D.H5File.create(p64).write('x', feats.astype(np.float64)).write('i', np.arange(12, dtype=np.int64).reshape(3, 4)).close()
+    with D.H5File(p64) as h:
+        assert h['x'].itemsize == 8 and np.array_equal(h['x'][1], feats[1])           # the library converts to float32
+        assert not h['i'].is_float and np.array_equal(h['i'].read_rows(0, 3, dtype=np.int64), np.arange(12).reshape(3, 4))
+    with pytest.raises(FileNotFoundError):
+        D.H5File(str(tmp_path / 'missing.h5'))
+
+
+@pytest.mark.parametrize('n,world', [(57, 4), (64, 8), (5, 4), (1301, 2)])
+def test_sampler_is_torchs_distributed_sampler(n, world):
+    from torch.utils.data.distributed import DistributedSampler
+    for epoch in (0, 3):
+        for rank in range(world):
+            s = DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=True, seed=0)
+            s.set_epoch(epoch)
+            assert list(iter(s)) == D.distributed_indices(n, world, rank, epoch, True, 0)
+    assert D.distributed_indices(n, 1, 0, 0, shuffle=False) == list(range(n))
+
+
+@needs_h5
+@pytest.mark.parametrize('store', ['resident', 'streamed'])
+def test_train_loader_batches_follow_the_reference_collate(tmp_path, store):
+    fp, rp, cp, feats, vfeats, caps, tags, lens, vids = make_dataset(tmp_path)
+    num_obj = 16
+    fs = D.ResidentFeatures(fp, rp, num_obj, 'cpu', chunk=5) if store == 'resident' else D.StreamedFeatures(fp, rp, num_obj, 'cpu')
+    for world, rank in ((1, 0), (2, 1)):
+        ld = D.TrainLoader(cp, fs, batch_size=8, world_size=world, rank=rank, seed=0)
+        ld.set_epoch(2)
+        want_idx = D.distributed_indices(len(vids), world, rank, 2, True, 0)
+        seen = []
+        nb = 0
+        for frames, regions, spatials, captions, pos_tags, cap_lens, video_ids in ld:
+            nb += 1
+            B = frames.shape[0]
+            assert spatials is None and regions.shape == (B, 26, num_obj, 8) and frames.shape == (B, 26, 12)
+            assert list(video_ids) == sorted(video_ids, reverse=True)                  # utils/data.py:90 sorts by x[-1] = video id
+            for j, v in enumerate(video_ids):
+                assert np.array_equal(frames[j].numpy(), feats[v])
+                assert np.array_equal(regions[j].numpy(), vfeats[v][:, :num_obj])      # run_gun.py:158
+            # caption rows travel with their video: find the sample each row came from
+            chunk = want_idx[len(seen):len(seen) + B]
+            chunk = sorted(chunk, key=lambda i: vids[i], reverse=True)
+            for j, i in enumerate(chunk):
+                assert vids[i] == video_ids[j] and lens[i] == cap_lens[j]
+                assert torch.equal(captions[j], caps[i]) and torch.equal(pos_tags[j], tags[i])
+            seen += chunk
+        assert nb == len(ld) and sorted(seen) == sorted(want_idx)
+    a = [b[-1] for b in D.TrainLoader(cp, fs, 8, seed=0)]
+    ld2 = D.TrainLoader(cp, fs, 8, seed=0)
+    ld2.set_epoch(1)
+    assert a != [b[-1] for b in ld2]                                                    # reshuffled per epoch
+
+
+@needs_h5
+def test_eval_loader_range_and_order(tmp_path):
+    fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
+    fs = D.ResidentFeatures(fp, rp, 36, 'cpu')
+    got = []
+    for frames, regions, spatials, video_ids in D.EvalLoader((13, 23), fs, batch_size=4):
+        assert list(video_ids) == sorted(video_ids) and regions.shape[2] == 36
+        for j, v in enumerate(video_ids):
+            assert np.array_equal(frames[j].numpy(), feats[v])
+        got += list(video_ids)
+    assert got == list(range(13, 23))
+    parts = [sum((list(b[-1]) for b in D.EvalLoader((13, 23), fs, 4, world_size=2, rank=r)), []) for r in range(2)]
+    assert sorted(parts[0] + parts[1]) == list(range(13, 23))
+
+
+@needs_h5
+@pytest.mark.gpu
+def test_resident_features_gather_on_device(tmp_path):
+    """the whole feature set in HBM, a batch = the HIP row gather: bit-identical to the host path and to H2D streaming"""
+    from dlsg_amd.hip import HipOps
+    fp, rp, cp, feats, vfeats, caps, tags, lens, vids = make_dataset(tmp_path, N=40, F=6144, R=2048, O=36, ncap=90)
+    ops = HipOps()
+    res = D.ResidentFeatures(fp, rp, 16, 'cuda', ops=ops, chunk=7)
+    assert res.bytes == 40 * (26 * 6144 + 26 * 16 * 2048) * 4
+    st = D.StreamedFeatures(fp, rp, 16, 'cuda')
+    a = list(D.TrainLoader(cp, res, 16, seed=3))
+    b = list(D.TrainLoader(cp, st, 16, seed=3))
+    assert len(a) == len(b) == 6
+    for x, y in zip(a, b):
+        assert x[-1] == y[-1] and x[-2] == y[-2]
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[3], y[3])
+        for j, v in enumerate(x[-1]):
+            assert np.array_equal(x[0][j].cpu().numpy(), feats[v])
+            assert np.array_equal(x[1][j].cpu().numpy(), vfeats[v][:, :16])
