@@ -19,14 +19,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace dlsg {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-// The same sum without the LDS crossbar: four DPP adds inside each row of 16 lanes (quad swaps, half-row and row mirror),
-// then the four row sums through scalar registers (v_readlane).  ~10 VALU issue slots instead of six dependent
-// ds_bpermute round trips (~100+ cycles each); every lane gets the result.  Summation order differs from wave_sum.
+// Wave-wide reductions without the LDS crossbar: four DPP steps inside each row of 16 lanes (quad swaps, half-row and row
+// mirror), then the four row results through scalar registers (v_readlane).  ~10 VALU issue slots instead of six dependent
+// ds_bpermute round trips (~100+ cycles each, and they queue behind the workgroup's other LDS traffic); every lane gets the
+// result.  (`__shfl_xor` trees measured 5.0k of 19.4k cycles per tile in the object->frame kernel, tools/o2v_stamps.py.)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -46,10 +42,17 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return (r0 + r1) + (r2 + r3);
 }
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // Block-wide sum over blockDim.x threads (multiple of 64, <= 1024).  `red` = >= 16 floats of LDS.
@@ -89,6 +92,32 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, uint32_t site, uint64
     h = mix32(h ^ (uint32_t)(seed >> 32));
     const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
     return u < p ? 0.f : 1.f / (1.f - p);
+}
+
+// XCD-aware workgroup -> (row tile, group, column tile) map of the grouped GEMMs, grid = (tiles_m * tiles_n, groups).
+// Workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest, then y) and each XCD has its own 4-MB L2:
+//   * a multiple of 8 groups (the deep weight gradients: 8 row chunks x streams): a whole GROUP per XCD -- its A and B
+//     panels are fetched into one L2 instead of all eight (the 26624-deep obj_embed gradient read 4.9x its algorithmic
+//     bytes at the L2 -> fabric boundary when every XCD walked every B panel of every group; 2.1x with this map);
+//   * otherwise, per group, the blocks an XCD receives (blockIdx.x % 8) walk consecutive column tiles of one A row panel.
+//     (Tried and dropped: interleaving the groups of a launch so that the two streams' region projections, which read
+//     the same 218 MB of regions, sit next to each other -- with half as many row panels in flight per XCD the weight
+//     panels were re-fetched more often than the shared A saved: 2.1 GB vs 1.3-1.5 GB per launch, FETCH_SIZE.)
+// Bijective for any grid; locality is a speed matter only.
+__device__ __forceinline__ void gemm_tile_map(int tiles_n, int& tm, int& z, int& tn) {
+    const int nblk = gridDim.x, Z = gridDim.y;
+    int t;
+    if ((Z & 7) == 0) {
+        const int lin = blockIdx.x + nblk * blockIdx.y;
+        const int xcd = lin & 7, j = lin >> 3;
+        z = xcd + 8 * (j / nblk);
+        t = j % nblk;
+    } else {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nblk >> 3, rmd = nblk & 7;
+        t = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
+        z = blockIdx.y;
+    }
+    tm = t / tiles_n; tn = t % tiles_n;
 }
 
 }  // namespace dlsg

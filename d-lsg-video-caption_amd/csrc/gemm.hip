@@ -143,19 +143,13 @@ __device__ __forceinline__ void gemm_body(const KArgs& p) {
     float* ldsA = lds;
     float* ldsB = lds + GA::ELEMS;
 
-    // ---- XCD-aware tile order (bijective for any block count)
+    // ---- XCD-aware tile order (common.hpp)
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int xcd = bid & 7, q = nblk >> 3, rmd = nblk & 7;
-        bid = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (bid >> 3);
-    }
-    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    int tm, z, tn;
+    dlsg::gemm_tile_map(tiles_n, tm, z, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
-    const int z = blockIdx.y;
     const int gi = z % p.ngroups, bi = z / p.ngroups;
     const dlsg_gemm_group grp = p.g[gi];
     const float* A = grp.A + (int64_t)bi * p.bsa;
