@@ -6,8 +6,9 @@
 // fp32-MFMA phases inside one 148-KB workgroup per CU: ~20 us per tile against a ~7 us matrix-pipe floor.  Here:
 //   * tile = 16 objects x H; TWO tile buffers in LDS (2 x 64.3 KB at H = 1024), filled by LDS-DMA
 //     (`global_load_lds_dwordx4`: 1-KiB pieces, no staging registers): the loads of tile i+1 are issued before tile i is
-//     touched and stay in flight across the tile's three barriers (raw s_barrier + counted vmcnt; a __syncthreads() would
-//     drain them);
+//     touched and stay in flight across the barrier inside the tile (raw s_barrier; a __syncthreads() would drain them);
+//   * two barriers per tile; the row statistics of tile i+1 (VALU + LDS) are interleaved, slice by slice, with the
+//     aggregation MFMAs of tile i, which would otherwise leave the vector pipes idle (phase timings: tools/o2v_stamps.py);
 //   * the LayerNorm is never applied to the tile: with o_n = (x_n - mu_n) r_n * gamma + beta,
 //         S[n,t]  = scale ( r_n ( x_n . (gamma*v_t) - mu_n (gamma . v_t) ) + beta . v_t )
 //         agg_t   = gamma * ( sum_n P r_n x_n - sum_n P r_n mu_n ) + beta sum_n P
@@ -55,7 +56,7 @@ struct O16Geom {
     static constexpr int NCH = EPL / VEC;
     static constexpr int BUF = O16_TILE * LDO;                 // floats per tile buffer
     static constexpr int RED = 8 * 2 * 64 * 4;                 // [wave][frame block][lane] float4
-    static constexpr int LDS_FLOATS = 2 * BUF + RED + 2 * H + 32;      // + mean[16] | rstd[16] of the current tile
+    static constexpr int LDS_FLOATS = 2 * BUF + RED + 2 * H + 64;      // + 2 x (mean[16] | rstd[16]): this tile's and the next's
 };
 
 // LDS writes/reads of this wave retired, then the workgroup barrier.  Deliberately NOT __syncthreads(): its fence waits
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
     float* red = smem + 2 * G::BUF;
     float* gam_l = red + G::RED;                 // obj_norm gamma | beta: epilogue only
     float* bet_l = gam_l + H;
-    float* stat_l = bet_l + H;                   // mean[16] | rstd[16]
+    float* stat_l = bet_l + H;                   // [tile parity][mean[16] | rstd[16]]
 
     const int b = blockIdx.x, sp = blockIdx.y;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -171,67 +172,73 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
     }
     lds_barrier();      // `red` is reused by the first tile's partial scores
 
-    int it = 0;
-    for (int n0 = n_begin; n0 < n_end; n0 += O16_TILE, ++it) {
-        float* cur = smem + (it & 1) * G::BUF;
-        const bool more = n0 + O16_TILE < n_end;
-        stamp(it, 0);
-        if (more) {
-            issue_tile(n0 + O16_TILE, smem + ((it + 1) & 1) * G::BUF);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NP) : "memory");      // this tile landed, the next stays in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        stamp(it, 1);
-
-        // ---- mean / rstd of the two rows this wave fetched (the rows themselves stay raw).  Both rows' reductions are
-        // independent chains; the sums go through DPP + v_readlane, not the LDS crossbar.
-        {
-            float x[2][G::EPL];
-            float mean[2], rstd[2];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const float* rp = cur + (2 * w + rr) * G::LDO;
+    // ---- row statistics of one tile buffer, for the two rows this wave fetched itself (its own vmcnt ordered DMA -> ds_read),
+    // cut into 8 steps so that they can be interleaved with MFMAs: per row {load, sum + reduce, centred squares + reduce,
+    // publish}.  DPP + v_readlane reductions, not the LDS crossbar.
+    float sx[G::EPL];
+    float smean = 0.f, srstd = 0.f;
+    auto stats_step = [&](int step, const float* buf, float* st, int n0_) {
+        const int rr = step >> 2;
+        const int row = 2 * w + rr;
+        switch (step & 3) {
+            case 0: {
+                const float* rp = buf + row * G::LDO;
 #pragma unroll
                 for (int c = 0; c < G::NCH; ++c) {
                     if (G::VEC == 4) {
                         const f32x4 t4 = *reinterpret_cast<const f32x4*>(rp + c * 256 + 4 * lane);
-                        x[rr][4 * c] = t4[0]; x[rr][4 * c + 1] = t4[1]; x[rr][4 * c + 2] = t4[2]; x[rr][4 * c + 3] = t4[3];
+                        sx[4 * c] = t4[0]; sx[4 * c + 1] = t4[1]; sx[4 * c + 2] = t4[2]; sx[4 * c + 3] = t4[3];
                     } else {
-                        x[rr][c] = rp[c * 64 + lane];
+                        sx[c] = rp[c * 64 + lane];
                     }
                 }
+                break;
             }
+            case 1: {
+                float s_ = 0.f;
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                float s = 0.f;
-#pragma unroll
-                for (int i = 0; i < G::EPL; ++i) s += x[rr][i];
-                mean[rr] = wave_sum_dpp(s) / H;
+                for (int i = 0; i < G::EPL; ++i) s_ += sx[i];
+                smean = wave_sum_dpp(s_) / H;
+                break;
             }
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
+            case 2: {
                 float q = 0.f;
 #pragma unroll
-                for (int i = 0; i < G::EPL; ++i) { const float d = x[rr][i] - mean[rr]; q += d * d; }
-                rstd[rr] = rsqrtf(wave_sum_dpp(q) / H + a.eps);
+                for (int i = 0; i < G::EPL; ++i) { const float d = sx[i] - smean; q += d * d; }
+                srstd = rsqrtf(wave_sum_dpp(q) / H + a.eps);
+                break;
             }
-            if (lane == 0) {
-#pragma unroll
-                for (int rr = 0; rr < 2; ++rr) {
-                    const int row = 2 * w + rr;
-                    const int n = n0 + row;
-                    stat_l[row] = mean[rr];
-                    stat_l[16 + row] = rstd[rr];
+            default: {
+                if (lane == 0) {
+                    const int n = n0_ + row;
+                    st[row] = smean;
+                    st[16 + row] = srstd;
                     if (n < n_end && a.ostats) {
-                        a.ostats[2 * ((int64_t)b * NO + n)] = mean[rr];
-                        a.ostats[2 * ((int64_t)b * NO + n) + 1] = rstd[rr];
+                        a.ostats[2 * ((int64_t)b * NO + n)] = smean;
+                        a.ostats[2 * ((int64_t)b * NO + n) + 1] = srstd;
                     }
                 }
             }
         }
+    };
+    if (n_begin < n_end) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int step = 0; step < 8; ++step) stats_step(step, smem, stat_l, n_begin);
+    }
+    lds_barrier();
+
+    int it = 0;
+    for (int n0 = n_begin; n0 < n_end; n0 += O16_TILE, ++it) {
+        float* cur = smem + (it & 1) * G::BUF;
+        float* nxt = smem + ((it + 1) & 1) * G::BUF;
+        const float* st_cur = stat_l + (it & 1) * 32;
+        float* st_nxt = stat_l + ((it + 1) & 1) * 32;
+        const bool more = n0 + O16_TILE < n_end;
+        stamp(it, 0);
+        if (more) issue_tile(n0 + O16_TILE, nxt);       // `nxt` was released by the barrier that ended the previous tile
+        stamp(it, 1);
         stamp(it, 2);
-        lds_barrier();
         stamp(it, 3);
 
         // ---- partial S over this wave's k slice: D[obj 4g+i][frame 16fb+f]
@@ -242,9 +249,9 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
             for (int c = 0; c < G::NCHUNK; ++c) {
                 const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 16 * c);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], vreg[0][4 * c + s], sacc[0], 0, 0, 0);
-                    sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s], vreg[1][4 * c + s], sacc[1], 0, 0, 0);
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_], vreg[0][4 * c + s_], sacc[0], 0, 0, 0);
+                    sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_], vreg[1][4 * c + s_], sacc[1], 0, 0, 0);
                 }
             }
             f32x4* r4 = reinterpret_cast<f32x4*>(red);
@@ -258,8 +265,8 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
         float alpha[2];
         {
             const f32x4* r4 = reinterpret_cast<const f32x4*>(red);
-            const f32x4 mu4 = *reinterpret_cast<const f32x4*>(stat_l + 4 * g);          // objects 4g .. 4g+3
-            const f32x4 rs4 = *reinterpret_cast<const f32x4*>(stat_l + 16 + 4 * g);
+            const f32x4 mu4 = *reinterpret_cast<const f32x4*>(st_cur + 4 * g);          // objects 4g .. 4g+3
+            const f32x4 rs4 = *reinterpret_cast<const f32x4*>(st_cur + 16 + 4 * g);
 #pragma unroll
             for (int fb = 0; fb < 2; ++fb) {
                 f32x4 sv = r4[fb * 64 + lane];
@@ -296,7 +303,8 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
             }
         }
         stamp(it, 6);
-        // ---- aggregation: acc_o[fb][c] (frame 16fb+4g+i, col 16cb+f) = alpha_frame * acc_o + sum_n P[n][frame] O[n][col]
+        // ---- aggregation: acc_o[fb][c] (frame 16fb+4g+i, col 16cb+f) = alpha_frame * acc_o + sum_n P[n][frame] O[n][col],
+        //      with the statistics of the NEXT tile (whose DMA was issued a whole S-product ago) in the MFMA shadows
 #pragma unroll
         for (int fb = 0; fb < 2; ++fb) {
             float arow[4];
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc_o[fb][c][i] *= arow[i];
         }
+        if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next tile landed (this wave's own rows)
 #pragma unroll
         for (int c = 0; c < G::CBW; ++c) {
             const int cb = w * G::CBW + c;
@@ -314,14 +323,20 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
                 const float* bp = cur + cb * 16 + f;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const float bv = bp[(4 * g + jj) * G::LDO];
-                    acc_o[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][jj], bv, acc_o[0][c], 0, 0, 0);
-                    acc_o[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[1][jj], bv, acc_o[1][c], 0, 0, 0);
+                    const float bvv = bp[(4 * g + jj) * G::LDO];
+                    acc_o[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][jj], bvv, acc_o[0][c], 0, 0, 0);
+                    acc_o[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[1][jj], bvv, acc_o[1][c], 0, 0, 0);
                 }
             }
+            if (more) {
+#pragma unroll
+                for (int step = 0; step < 8; ++step)
+                    if (step * G::CBW / 8 == c) stats_step(step, nxt, st_nxt, n0 + O16_TILE);
+            }
+            // (no sched_barrier here: pinning the slices also pins the B-operand LDS reads behind the previous MFMAs)
         }
         stamp(it, 7);
-        lds_barrier();      // `cur` is free for the DMA of tile i+2, `red` for the next partials
+        lds_barrier();      // `cur` is free for the DMA of tile i+2, `red` for the next partials, tile i+1's statistics are out
         stamp(it, 8);
     }
 

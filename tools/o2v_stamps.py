@@ -32,8 +32,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 tiles = NO // 16
 raw = ws.cpu().numpy().view(np.uint64)[:tiles * 16 * 8].reshape(tiles, 16, 8).astype(np.int64)
-names = ['issue DMA + vmcnt wait', 'LayerNorm in place', 'barrier 1', 'S product + publish', 'barrier 2', 'sum partials + softmax',
-         'rescale + aggregation issue', 'barrier 3']
+names = ['issue DMA of the next tile', '-', '-', 'S product + publish', 'barrier (partials)', 'sum partials + softmax',
+         'rescale + wait DMA + aggregation || next stats', 'barrier (end of tile)']
 d = raw[:, 1:9, :] - raw[:, 0:8, :]
 print('B=%d tiles=%d; cycles per phase (mean over tiles 1..%d), per wave 0..7' % (B, tiles, tiles - 2))
 for k, n in enumerate(names):
