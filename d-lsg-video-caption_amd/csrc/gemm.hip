@@ -11,6 +11,9 @@
 //   * lane (r = lane&31, h = lane>>5) feeds k = 16h + s for MFMA s of a K-tile: A and B use the same k order
 //   * block ids are remapped so that the blocks an XCD receives (id % 8) walk consecutive tiles of one A row
 //     panel: the panel stays in that XCD's L2 instead of being fetched by all eight.
+#include <cstdlib>
+#include <mutex>
+
 #include "common.hpp"
 #include "dlsg.h"
 
@@ -438,14 +441,211 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ skinny GEMM, NT, generation 2
+// Same decomposition as skinny_kernel<false> (64 x 32 output tile per workgroup, the 4 waves split K, K-split groups from the
+// caller), different pipeline: the first kernel staged global -> registers -> LDS with two barriers per 128-deep super-chunk
+// and one chunk of prefetch; at two workgroups per CU that left the matrix pipe ~40 % busy on the recurrent products
+// (23 us per launch against a ~11 us pipe floor).  Here every wave streams ITS OWN k-slices and nobody else's:
+//   * stage = 16 k of one wave: A (64 rows x 64 B) + B (32 rows x 64 B) = 6 LDS-DMA pieces (`global_load_lds_dwordx4`, 16 rows x
+//     4 x 16 B each: 64-B row segments, half a cache line, the other half is the wave's next stage), no staging registers;
+//   * a private 3-stage ring per wave (18 KB; 72 KB per workgroup, two workgroups per CU): two stages in flight under the
+//     16 MFMAs of the current one, ordered by the wave's own counted vmcnt -- NO barrier in the K loop;
+//   * the LDS image is lane-linear per piece (the DMA cannot scatter), so the bank swizzle is applied on the SOURCE address:
+//     slot (row, s) of a piece holds k-segment s ^ ((row >> 2) & 3); fragment reads (b128, lane = row) are conflict-free;
+//   * k order inside a stage: lane half h supplies k-segments 2q + h, the same for A and B.
+// Needs 16-B aligned, 4-float-strided operands and K % 4 == 0 (a partial last stage is masked after the read); anything
+// else goes to skinny_kernel.
+// Measured (tools/recurrent_gemm_bench.py, batch 64): query gates 21.5 us (first kernel 23.5), BiLSTM step 16.8 (18.8), language
+// gates 30.4 (29.8).  What bounds it is NOT the pipeline: with every DMA address pinned to cache-hot lines AND the MFMAs
+// removed, the loop still takes 20 of the 30 us -- the per-CU global -> LDS path (~40 GB/s per CU in this access shape) has to
+// move 6 KB per 16 MFMAs at M = 64, two thirds of it the activations that every 32-column tile re-fetches.  An
+// activation-stationary variant (the wave's 64 x K/4 activation slices in 128 registers, several column tiles per workgroup,
+// weights only through the ring) was built and dropped: 37-46 us -- all workgroups sit in their activation prologue at the
+// same time, then all in their MFMA phase, and the per-tile 4-way partial sums add barriers that one wave per SIMD cannot hide.
+constexpr int S2_STAGE = 16;                 // k per wave and stage
+constexpr int S2_DEPTH = 3;                  // ring slots per wave
+constexpr int S2_A_BYTES = 64 * 64, S2_B_BYTES = 32 * 64, S2_SLOT = S2_A_BYTES + S2_B_BYTES;     // 6144
+constexpr int S2_LDS = 4 * S2_DEPTH * S2_SLOT;                                                    // 73,728 B
+
+template <int VB>
+__device__ __forceinline__ void s2_glds(const char* src, char* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void* lp_t;
+    typedef const __attribute__((address_space(1))) void* gp_t;
+    __builtin_amdgcn_global_load_lds((gp_t)src, (lp_t)dst, 16, 0, 0);
+#endif
+}
+
+__global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char s2_lds[];
+    if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
+    const int z = blockIdx.y;
+    const int gi = z % p.ngroups, bi = z / p.ngroups;
+    const dlsg_gemm_group grp = p.g[gi];
+    const float* A = grp.A + (int64_t)bi * p.bsa;
+    const float* B = grp.B + (int64_t)bi * p.bsb;
+    float* C = grp.C + (int64_t)bi * p.bsc;
+    const int K = grp.K, M = p.M, N = grp.N > 0 ? grp.N : p.N;
+    const int n0 = blockIdx.x * 32;
+    if (n0 >= N) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    char* ring = s2_lds + w * (S2_DEPTH * S2_SLOT);
+
+    // ---- per-lane source rows of the 6 pieces of a stage (row and swizzle never change; only k0 does)
+    const int rho = lane >> 2, sig = lane & 3;
+    const float* srcA[4];
+    const float* srcB[2];
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) {
+        const int R = 16 * pc + rho;
+        srcA[pc] = A + (int64_t)min(R, M - 1) * grp.lda + 4 * (sig ^ ((R >> 2) & 3));
+    }
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+        const int R = 16 * pc + rho;
+        srcB[pc] = B + (int64_t)min(n0 + R, N - 1) * grp.ldb + 4 * (sig ^ ((R >> 2) & 3));
+    }
+    // k-segment this lane fetches must exist: a partial last stage clamps it (the fragment is masked after the read)
+    const int nst = (K + S2_STAGE - 1) / S2_STAGE;            // stages of the whole K range
+    const int mine = (nst - w + 3) / 4;                        // stages s = w, w + 4, ... of this wave
+    auto issue = [&](int i) {                                  // i-th stage of this wave -> ring slot i % DEPTH
+        const int k0 = (4 * i + w) * S2_STAGE;
+        char* slot = ring + (i % S2_DEPTH) * S2_SLOT;
+        // clamp a partial stage's k so that every 16-B read stays inside the row
+        const int kc = min(k0, K - S2_STAGE >= 0 ? K - S2_STAGE : 0);
+        const int koff = (k0 + S2_STAGE <= K) ? k0 : kc;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc)
+            s2_glds<16>(reinterpret_cast<const char*>(srcA[pc] + koff), slot + pc * 1024);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+            s2_glds<16>(reinterpret_cast<const char*>(srcB[pc] + koff), slot + S2_A_BYTES + pc * 1024);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // fragment addresses inside a slot (bytes): row R, k-segment ks -> (R >> 4) * 1024 + (R & 15) * 64 + (ks ^ ((R >> 2) & 3)) * 16
+    int offA[2][2], offB[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int ks = 2 * q + h;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int R = 32 * mi + r;
+            offA[mi][q] = (R >> 4) * 1024 + (R & 15) * 64 + ((ks ^ ((R >> 2) & 3)) * 16);
+        }
+        offB[q] = S2_A_BYTES + (r >> 4) * 1024 + (r & 15) * 64 + ((ks ^ ((r >> 2) & 3)) * 16);
+    }
+
+    if (mine > 0) issue(0);
+    if (mine > 1) issue(1);
+    for (int i = 0; i < mine; ++i) {
+        if (i + 2 < mine) {
+            issue(i + 2);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage i landed, two stages stay in flight
+        } else if (i + 1 < mine) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const char* slot = ring + (i % S2_DEPTH) * S2_SLOT;
+        const int k0 = (4 * i + w) * S2_STAGE;
+        const bool part = k0 + S2_STAGE > K;                     // wave-uniform
+        const int kbase = part ? (K - S2_STAGE >= 0 ? K - S2_STAGE : 0) : k0;     // where the DMA really read
+        f32x4 fa[2][2], fb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            fa[0][q] = *reinterpret_cast<const f32x4*>(slot + offA[0][q]);
+            fa[1][q] = *reinterpret_cast<const f32x4*>(slot + offA[1][q]);
+            fb[q] = *reinterpret_cast<const f32x4*>(slot + offB[q]);
+        }
+        if (part) {
+            // the stage was fetched from kbase (< k0): keep only k in [k0, K), zero the rest (already counted by earlier stages)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = kbase + 4 * (2 * q + h) + j;
+                    const bool keep = k >= k0 && k < K;
+                    fa[0][q][j] = keep ? fa[0][q][j] : 0.f;
+                    fa[1][q][j] = keep ? fa[1][q][j] : 0.f;
+                    fb[q][j] = keep ? fb[q][j] : 0.f;
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][q][j], fb[q][j], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][q][j], fb[q][j], acc[1], 0, 0, 0);
+            }
+    }
+    // ---- sum the 4 waves' partial tiles through LDS (the rings are free now); wave w finalises e in [4w, 4w+4)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(s2_lds);               // [4][2][16][64] floats = 32 KB
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[((w * 2 + mi) * 16 + e) * 64 + lane] = acc[mi][e];
+    __syncthreads();
+    const float* biasp = grp.bias ? grp.bias : p.bias;
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && biasp != nullptr;
+    const bool do_tanh = p.flags & DLSG_GEMM_TANH;
+    const int col = n0 + r;
+    if (col < N) {
+        const float bv = use_bias ? biasp[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const int e = 4 * w + ee;
+                const int row = 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= M) continue;
+                float v = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) v += red[((ww * 2 + mi) * 16 + e) * 64 + lane];
+                v = p.alpha * v + bv;
+                float* cp = C + (int64_t)row * (grp.ldc ? grp.ldc : (int64_t)p.ldc) + col;
+                if (accum) v += *cp;
+                if (do_tanh) v = tanhf(v);
+                *cp = v;
+            }
+    }
+}
+
 int launch_skinny(const dlsg_gemm_args* a, hipStream_t st) {
     KArgs k;
     k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
     k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias; k.skip_if = a->skip_if;
     for (int i = 0; i < a->ngroups; ++i) k.g[i] = a->g[i];
     dim3 grid((a->N + 31) / 32, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
-    if (a->mode == 0) hipLaunchKernelGGL((skinny_kernel<false>), grid, block, 0, st, k);
-    else hipLaunchKernelGGL((skinny_kernel<true>), grid, block, 0, st, k);
+    if (a->mode == 0) {
+        // generation 2 (LDS-DMA rings, no barrier in the K loop) when every operand is 16-B aligned with 4-float strides
+        static const bool gen1 = getenv("DLSG_SKINNY_GEN1") != nullptr;        // A/B switch for tools/skinny_nt_nn_probe.py
+        bool ok = !gen1 && a->nbatch == 1;
+        for (int i = 0; i < a->ngroups && ok; ++i) {
+            const dlsg_gemm_group& g = a->g[i];
+            ok = (g.K % 4 == 0) && g.K >= S2_STAGE && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
+                 ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+        }
+        if (ok) {
+            static std::once_flag once;
+            std::call_once(once, [] {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          S2_LDS);
+            });
+            hipLaunchKernelGGL(skinny2_nt_kernel, grid, block, S2_LDS, st, k);
+        } else {
+            hipLaunchKernelGGL((skinny_kernel<false>), grid, block, 0, st, k);
+        }
+    } else {
+        hipLaunchKernelGGL((skinny_kernel<true>), grid, block, 0, st, k);
+    }
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
