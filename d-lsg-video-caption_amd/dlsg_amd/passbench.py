@@ -56,8 +56,8 @@ def run_graph_attention_pass(ops, B=1024, T=26, O=16, H=1024, P=8, L=26, R=2048,
     ctx = [torch.empty(B, H, device=device) for _ in range(2)]
     st_c = [torch.empty(B, 2, device=device) for _ in range(2)]
     alpha = torch.empty(B, 2 * P, device=device)
-    tiles = (NO + 31) // 32
-    nsplit = max(1, min(tiles, 256 // B))
+    tiles = (NO + 15) // 16
+    nsplit = max(1, min(tiles, 256 // (2 * B)))
     sc = 1.0 / math.sqrt(R)
 
     marks = []
@@ -69,8 +69,8 @@ def run_graph_attention_pass(ops, B=1024, T=26, O=16, H=1024, P=8, L=26, R=2048,
 
     def one_pass():
         mark('start')
-        for i in range(2):
-            ops.o2v_fwd(ys[i], vs[i], gam, bet, z[i], ml, ost, S, sc, nsplit)
+        # both encoder streams in one launch, as CapGnnModel._encode issues it
+        ops.o2v_fwd_multi([dict(y=ys[i], v=vs[i], g_obj=gam, b_obj=bet, z=z[i], ml=ml, ostats=ost, S=S) for i in range(2)], sc, nsplit)
         mark('o2v')
         for i in range(2):
             ops.latent_psl_fwd(z[i].view(B, T, H), theta, gam, bet, adj, u, psl, stp)
