@@ -465,7 +465,8 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
 constexpr int S2_STAGE = 16;                 // k per wave and stage
 constexpr int S2_DEPTH = 3;                  // ring slots per wave
 constexpr int S2_A_BYTES = 64 * 64, S2_B_BYTES = 32 * 64, S2_SLOT = S2_A_BYTES + S2_B_BYTES;     // 6144
-constexpr int S2_LDS = 4 * S2_DEPTH * S2_SLOT;                                                    // 73,728 B
+constexpr int S2_LDS = 4 * S2_DEPTH * S2_SLOT;                                                    // 73,728 B (NJ = 1)
+constexpr int S2_LDS2 = 4 * S2_DEPTH * (S2_A_BYTES + 2 * S2_B_BYTES);                             // 98,304 B (NJ = 2)
 
 template <int VB>
 __device__ __forceinline__ void s2_glds(const char* src, char* dst) {
@@ -476,7 +477,11 @@ __device__ __forceinline__ void s2_glds(const char* src, char* dst) {
 #endif
 }
 
+// NJ = 32-column blocks per workgroup: NJ = 2 halves the activation bytes per flop (the A stage feeds two column blocks);
+// used when the launch still fills the chip with half as many workgroups.
+template <int NJ>
 __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
+    constexpr int SLOT = S2_A_BYTES + NJ * S2_B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char s2_lds[];
     if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
     const int z = blockIdx.y;
@@ -486,51 +491,50 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
     const float* B = grp.B + (int64_t)bi * p.bsb;
     float* C = grp.C + (int64_t)bi * p.bsc;
     const int K = grp.K, M = p.M, N = grp.N > 0 ? grp.N : p.N;
-    const int n0 = blockIdx.x * 32;
+    const int n0 = blockIdx.x * 32 * NJ;
     if (n0 >= N) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    char* ring = s2_lds + w * (S2_DEPTH * S2_SLOT);
+    char* ring = s2_lds + w * (S2_DEPTH * SLOT);
 
-    // ---- per-lane source rows of the 6 pieces of a stage (row and swizzle never change; only k0 does)
+    // ---- per-lane source rows of the pieces of a stage (row and swizzle never change; only k0 does)
     const int rho = lane >> 2, sig = lane & 3;
     const float* srcA[4];
-    const float* srcB[2];
+    const float* srcB[2 * NJ];
 #pragma unroll
     for (int pc = 0; pc < 4; ++pc) {
         const int R = 16 * pc + rho;
         srcA[pc] = A + (int64_t)min(R, M - 1) * grp.lda + 4 * (sig ^ ((R >> 2) & 3));
     }
 #pragma unroll
-    for (int pc = 0; pc < 2; ++pc) {
+    for (int pc = 0; pc < 2 * NJ; ++pc) {
         const int R = 16 * pc + rho;
         srcB[pc] = B + (int64_t)min(n0 + R, N - 1) * grp.ldb + 4 * (sig ^ ((R >> 2) & 3));
     }
-    // k-segment this lane fetches must exist: a partial last stage clamps it (the fragment is masked after the read)
     const int nst = (K + S2_STAGE - 1) / S2_STAGE;            // stages of the whole K range
     const int mine = (nst - w + 3) / 4;                        // stages s = w, w + 4, ... of this wave
     auto issue = [&](int i) {                                  // i-th stage of this wave -> ring slot i % DEPTH
         const int k0 = (4 * i + w) * S2_STAGE;
-        char* slot = ring + (i % S2_DEPTH) * S2_SLOT;
-        // clamp a partial stage's k so that every 16-B read stays inside the row
-        const int kc = min(k0, K - S2_STAGE >= 0 ? K - S2_STAGE : 0);
-        const int koff = (k0 + S2_STAGE <= K) ? k0 : kc;
+        char* slot = ring + (i % S2_DEPTH) * SLOT;
+        // a partial last stage is fetched from K - 16 (every 16-B read stays inside the row) and masked after the read
+        const int koff = (k0 + S2_STAGE <= K) ? k0 : (K - S2_STAGE);
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc)
-            s2_glds<16>(reinterpret_cast<const char*>(srcA[pc] + koff), slot + pc * 1024);
+        for (int pc = 0; pc < 4; ++pc) s2_glds<16>(reinterpret_cast<const char*>(srcA[pc] + koff), slot + pc * 1024);
 #pragma unroll
-        for (int pc = 0; pc < 2; ++pc)
+        for (int pc = 0; pc < 2 * NJ; ++pc)
             s2_glds<16>(reinterpret_cast<const char*>(srcB[pc] + koff), slot + S2_A_BYTES + pc * 1024);
     };
 
-    f32x16 acc[2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][nj][e] = 0.f;
 
     // fragment addresses inside a slot (bytes): row R, k-segment ks -> (R >> 4) * 1024 + (R & 15) * 64 + (ks ^ ((R >> 2) & 3)) * 16
-    int offA[2][2], offB[2];
+    int offA[2][2], offB[NJ][2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int ks = 2 * q + h;
@@ -539,30 +543,36 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
             const int R = 32 * mi + r;
             offA[mi][q] = (R >> 4) * 1024 + (R & 15) * 64 + ((ks ^ ((R >> 2) & 3)) * 16);
         }
-        offB[q] = S2_A_BYTES + (r >> 4) * 1024 + (r & 15) * 64 + ((ks ^ ((r >> 2) & 3)) * 16);
+#pragma unroll
+        for (int nj = 0; nj < NJ; ++nj) {
+            const int R = 32 * nj + r;
+            offB[nj][q] = S2_A_BYTES + (R >> 4) * 1024 + (R & 15) * 64 + ((ks ^ ((R >> 2) & 3)) * 16);
+        }
     }
+    constexpr int PCS = 4 + 2 * NJ;                              // DMA pieces per stage
 
     if (mine > 0) issue(0);
     if (mine > 1) issue(1);
     for (int i = 0; i < mine; ++i) {
         if (i + 2 < mine) {
             issue(i + 2);
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // stage i landed, two stages stay in flight
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PCS) : "memory");      // stage i landed, two stages stay in flight
         } else if (i + 1 < mine) {
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PCS) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const char* slot = ring + (i % S2_DEPTH) * S2_SLOT;
+        const char* slot = ring + (i % S2_DEPTH) * SLOT;
         const int k0 = (4 * i + w) * S2_STAGE;
         const bool part = k0 + S2_STAGE > K;                     // wave-uniform
-        const int kbase = part ? (K - S2_STAGE >= 0 ? K - S2_STAGE : 0) : k0;     // where the DMA really read
-        f32x4 fa[2][2], fb[2];
+        const int kbase = part ? K - S2_STAGE : k0;              // where the DMA really read
+        f32x4 fa[2][2], fb[NJ][2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             fa[0][q] = *reinterpret_cast<const f32x4*>(slot + offA[0][q]);
             fa[1][q] = *reinterpret_cast<const f32x4*>(slot + offA[1][q]);
-            fb[q] = *reinterpret_cast<const f32x4*>(slot + offB[q]);
+#pragma unroll
+            for (int nj = 0; nj < NJ; ++nj) fb[nj][q] = *reinterpret_cast<const f32x4*>(slot + offB[nj][q]);
         }
         if (part) {
             // the stage was fetched from kbase (< k0): keep only k in [k0, K), zero the rest (already counted by earlier stages)
@@ -574,30 +584,37 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
                     const bool keep = k >= k0 && k < K;
                     fa[0][q][j] = keep ? fa[0][q][j] : 0.f;
                     fa[1][q][j] = keep ? fa[1][q][j] : 0.f;
-                    fb[q][j] = keep ? fb[q][j] : 0.f;
+#pragma unroll
+                    for (int nj = 0; nj < NJ; ++nj) fb[nj][q][j] = keep ? fb[nj][q][j] : 0.f;
                 }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][q][j], fb[q][j], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][q][j], fb[q][j], acc[1], 0, 0, 0);
-            }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nj = 0; nj < NJ; ++nj) {
+                    acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][q][j], fb[nj][q][j], acc[0][nj], 0, 0, 0);
+                    acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][q][j], fb[nj][q][j], acc[1][nj], 0, 0, 0);
+                }
     }
     // ---- sum the 4 waves' partial tiles through LDS (the rings are free now); wave w finalises e in [4w, 4w+4)
     __syncthreads();
-    float* red = reinterpret_cast<float*>(s2_lds);               // [4][2][16][64] floats = 32 KB
+    float* red = reinterpret_cast<float*>(s2_lds);               // [4][2][NJ][16][64] floats = NJ x 32 KB
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[((w * 2 + mi) * 16 + e) * 64 + lane] = acc[mi][e];
+        for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(((w * 2 + mi) * NJ + nj) * 16 + e) * 64 + lane] = acc[mi][nj][e];
     __syncthreads();
     const float* biasp = grp.bias ? grp.bias : p.bias;
     const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && biasp != nullptr;
     const bool do_tanh = p.flags & DLSG_GEMM_TANH;
-    const int col = n0 + r;
-    if (col < N) {
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj) {
+        const int col = n0 + 32 * nj + r;
+        if (col >= N) continue;
         const float bv = use_bias ? biasp[col] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
@@ -608,7 +625,7 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
                 if (row >= M) continue;
                 float v = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) v += red[((ww * 2 + mi) * 16 + e) * 64 + lane];
+                for (int ww = 0; ww < 4; ++ww) v += red[(((ww * 2 + mi) * NJ + nj) * 16 + e) * 64 + lane];
                 v = p.alpha * v + bv;
                 float* cp = C + (int64_t)row * (grp.ldc ? grp.ldc : (int64_t)p.ldc) + col;
                 if (accum) v += *cp;
@@ -636,10 +653,21 @@ int launch_skinny(const dlsg_gemm_args* a, hipStream_t st) {
         if (ok) {
             static std::once_flag once;
             std::call_once(once, [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          S2_LDS);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS2);
             });
-            hipLaunchKernelGGL(skinny2_nt_kernel, grid, block, S2_LDS, st, k);
+            // 64-column workgroups (one per CU, 96 KB of LDS) when they still put >= ~one workgroup on every CU
+            static const int force_nj = getenv("DLSG_SKINNY_NJ") ? atoi(getenv("DLSG_SKINNY_NJ")) : 0;
+            const int wg64 = ((a->N + 63) / 64) * a->ngroups * a->nbatch;
+            const bool wide = force_nj ? force_nj == 2 : wg64 >= 224;
+            if (wide) {
+                dim3 grid2((a->N + 63) / 64, a->ngroups * a->nbatch, 1);
+                hipLaunchKernelGGL(skinny2_nt_kernel<2>, grid2, block, S2_LDS2, st, k);
+            } else {
+                hipLaunchKernelGGL(skinny2_nt_kernel<1>, grid, block, S2_LDS, st, k);
+            }
         } else {
             hipLaunchKernelGGL((skinny_kernel<false>), grid, block, 0, st, k);
         }

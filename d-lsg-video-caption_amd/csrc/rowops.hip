@@ -398,47 +398,59 @@ __global__ void embed_fwd_kernel(const float* __restrict__ E, const int64_t* __r
     }
 }
 // dE[ids[r], :] += drop(dout[r, :]) without atomics, so that a step is bit-reproducible (float atomics add in arrival order:
-// the word-embedding gradient differed in the last bit between runs of the same step).  The first row that carries an id
-// owns it: its workgroup adds the rows with that id in row order; workgroups of later duplicates exit.
-__global__ __launch_bounds__(128) void embed_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const int64_t* __restrict__ ids,
-                                                        float* __restrict__ dE, int rows, int W, float p, uint64_t seed, uint32_t site,
-                                                        int64_t row0, const uint64_t* seed_ptr) {
-    __shared__ int dup;
-    __shared__ unsigned char hit[128];
+// the word-embedding gradient differed in the last bit between runs of the same step).  One wave per row.  The first row that
+// carries an id owns it and adds the rows with that id in row order; waves of later duplicates exit.  Matches are found 64 ids
+// at a time with a ballot (eight independent id loads in flight), so only real matches cost a row read.
+__global__ __launch_bounds__(64) void embed_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const int64_t* __restrict__ ids,
+                                                       float* __restrict__ dE, int rows, int W, float p, uint64_t seed, uint32_t site,
+                                                       int64_t row0, const uint64_t* seed_ptr) {
     if (seed_ptr) seed += *seed_ptr;
-    const int r = blockIdx.x;
+    const int r = blockIdx.x, lane = threadIdx.x;
     const int64_t id = ids[r];
-    if (threadIdx.x == 0) dup = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < r; i += 128)
-        if (ids[i] == id) dup = 1;
-    __syncthreads();
-    if (dup) return;
-    for (int c0 = 0; c0 < W; c0 += 512) {               // 4 columns per thread and pass
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int base = r; base < rows; base += 128) {
-            const int i = base + threadIdx.x;
-            hit[threadIdx.x] = (i < rows && ids[i] == id) ? 1 : 0;
-            __syncthreads();
-            const int lim = min(128, rows - base);
-            for (int k = 0; k < lim; ++k) {
-                if (!hit[k]) continue;                  // workgroup-uniform
-                const int rr = base + k;
+    // ---- an earlier row with the same id?  then that row's wave does the work
+    for (int base = 0; base < r; base += 512) {
+        int64_t v[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int j = c0 + threadIdx.x + 128 * q;
-                    if (j < W) {
-                        float g = dout[(int64_t)rr * lddo + j];
-                        if (p > 0.f) g *= drop_scale(seed, site, (uint64_t)(row0 + rr) * W + j, p);
-                        acc[q] += g;
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + 64 * u + lane;
+            v[u] = (i < r) ? ids[i] : -1;
+        }
+        bool hit = false;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) hit = hit || (v[u] == id);
+        if (__ballot(hit)) return;                       // wave-uniform
+    }
+    for (int c0 = 0; c0 < W; c0 += 512) {                 // 8 columns per lane and pass
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int base = r; base < rows; base += 512) {
+            int64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + 64 * u + lane;
+                v[u] = (i < rows) ? ids[i] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                unsigned long long m = __ballot(v[u] == id);
+                while (m) {                               // ascending rows: the sum order is fixed
+                    const int k = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int rr = base + 64 * u + k;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int j = c0 + lane + 64 * q;
+                        if (j < W) {
+                            float g = dout[(int64_t)rr * lddo + j];
+                            if (p > 0.f) g *= drop_scale(seed, site, (uint64_t)(row0 + rr) * W + j, p);
+                            acc[q] += g;
+                        }
                     }
                 }
             }
-            __syncthreads();
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = c0 + threadIdx.x + 128 * q;
+        for (int q = 0; q < 8; ++q) {
+            const int j = c0 + lane + 64 * q;
             if (j < W) dE[id * W + j] += acc[q];
         }
     }
@@ -867,7 +879,7 @@ extern "C" int dlsg_embed_fwd(const float* E, const int64_t* ids, float* out, in
 extern "C" int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* ids, float* dE, int rows, int W, float p,
                               uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream) {
     if (rows == 0) return DLSG_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(128), 0, ST(stream), dout, lddo, ids, dE, rows, W, p, seed, site, row0, seed_ptr);
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(64), 0, ST(stream), dout, lddo, ids, dE, rows, W, p, seed, site, row0, seed_ptr);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -43,6 +43,8 @@ def nt_case(name, N, segs):
             k1 = min(k, k0 + step)
             pieces.append((x[:, k0:k1], W[:, c0 + k0:c0 + k1]))
         c0 += k
+    if os.environ.get('BIGFIRST'):
+        pieces.sort(key=lambda ab: -ab[0].shape[1])
     slabs = torch.empty(len(pieces), B, N, device='cuda')
     groups = [(a_, b_, slabs[i]) for i, (a_, b_) in enumerate(pieces)]
     us = timeit(lambda: ops.gemm(GEMM_NT, groups))
