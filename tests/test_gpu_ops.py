@@ -676,3 +676,22 @@ def test_adam_matches_torch_optim(hip):
         hip.adam(p, gr.cuda(), m, v, 1.6e-4, 0.5, 0.9, 1e-8, i + 1, 0.25)
     torch.cuda.synchronize()
     assert (p.cpu() - ref.detach()).abs().max().item() <= 1e-6
+
+
+def test_masked_self_attention_core_against_reference_fixture(hip):
+    """tests/golden/sa_mask.npz (the reference's SelfAttention with an attention mask, sublayer.py:70-72, as DiscV2 uses it):
+    PE add and the bias-free projections in torch, the masked 26 x 26 core on the HIP kernel."""
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'sa_mask.npz')))
+    x = torch.from_numpy(g['x']).cuda()
+    B, T, D = x.shape
+    x = x + torch.from_numpy(g['w.pe.pe'])[:, :T].cuda()              # the fixture's module was built with get_pe=True
+    Dp = 64                                                            # the kernel takes widths that are multiples of 64:
+    K, Q, V = (torch.nn.functional.pad(x @ torch.from_numpy(g['w.%s.weight' % n]).cuda().t(), (0, Dp - D)).contiguous()
+               for n in 'KQV')                                         # zero columns change neither the logits nor out[:, :, :D]
+    assert hip.sa_core_supported(T, Dp)
+    for mask, key in ((torch.from_numpy(g['mask']).cuda().contiguous(), 'y_masked'), (None, 'y')):
+        w = torch.empty(B, T, T, device='cuda'); out = torch.empty(B, T, Dp, device='cuda')
+        hip.sa_core_fwd(K, Q, V, w, out, 1.0 / math.sqrt(D), mask=mask)
+        y = out[:, :, :D] @ torch.from_numpy(g['w.output_layer.0.weight']).cuda().t()
+        assert np.abs(y.cpu().numpy() - g[key]).max() <= 2e-5, key
