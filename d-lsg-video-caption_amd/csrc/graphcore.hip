@@ -20,39 +20,45 @@ constexpr int PSL_MAXT = 32, PSL_MAXP = 32;
 __device__ __forceinline__ int crow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------------------------------------ LatentPSL forward
-__global__ __launch_bounds__(PSL_THREADS) void latent_psl_fwd_kernel(const dlsg_latent_psl_args a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// NX = float4 per lane of one frame row (H <= 256 NX); NX = 4 (H <= 1024) fits 64 registers: two 1024-thread workgroups per CU
+template <int NX>
+__global__ __launch_bounds__(PSL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void latent_psl_fwd_kernel(const dlsg_latent_psl_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];        // theta: [P][H]
     __shared__ float lgs[PSL_MAXT][PSL_MAXP + 1];       // logits, then adj
     __shared__ float red[16 * 8];
     const int b = blockIdx.x;
     const int T = a.T, P = a.P, H = a.H;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
-    float* ovl = smem;                                   // [T][H]
-    // ---- frame nodes of the clip -> LDS (read once from HBM)
-    {
-        const float* src = a.ov + (int64_t)b * T * H;
-        for (int i = threadIdx.x * 4; i < T * H; i += PSL_THREADS * 4)
-            *reinterpret_cast<f32x4*>(ovl + i) = *reinterpret_cast<const f32x4*>(src + i);
-    }
+    // The clip's frame nodes are NOT staged in LDS (106 KB at T = 26, H = 1024 allowed one workgroup per CU, whose load,
+    // logits, aggregation and LayerNorm phases then ran with nothing to overlap them: 1.0 TB/s).  The logits pass reads every
+    // frame row once from HBM straight into registers; the aggregation pass reads the rows again, from L2 (one clip is 106 KB),
+    // with lanes along the columns.  theta (P x H) is what sits in LDS, so two workgroups share a CU.
+    const float* ovl = a.ov + (int64_t)b * T * H;
+    float* thl = smem;
+    for (int i = threadIdx.x * 4; i < P * H; i += PSL_THREADS * 4)
+        *reinterpret_cast<f32x4*>(thl + i) = *reinterpret_cast<const f32x4*>(a.theta + i);
     __syncthreads();
-    // ---- logits[t][p] = ov[t] . theta[p]: a wave keeps theta[p] in registers and walks a slice of the frames
-    {
-        const int nw = P <= 16 ? 16 / P : 1;             // waves per proposal
-        for (int task = w; task < P * nw; task += PSL_THREADS / 64) {
-            const int p = task / nw, part = task % nw;
-            const int t0 = (T * part) / nw, t1 = (T * (part + 1)) / nw;
-            const float* th = a.theta + (int64_t)p * H;
-            for (int t = t0; t < t1; ++t) {
-                float acc = 0.f;
-                for (int j = lane * 4; j < H; j += 256) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(ovl + t * H + j);
-                    const f32x4 y = *reinterpret_cast<const f32x4*>(th + j);
-                    acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    // ---- logits[t][p] = ov[t] . theta[p]: a wave holds one frame row in registers and walks the proposals
+    for (int t = w; t < T; t += PSL_THREADS / 64) {
+        f32x4 x[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+            const int j = c * 256 + lane * 4;
+            x[c] = (j < H) ? *reinterpret_cast<const f32x4*>(ovl + (int64_t)t * H + j) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int p = 0; p < P; ++p) {
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) {
+                const int j = c * 256 + lane * 4;
+                if (j < H) {
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(thl + p * H + j);
+                    acc += x[c][0] * y[0] + x[c][1] * y[1] + x[c][2] * y[2] + x[c][3] * y[3];
                 }
-                acc = wave_sum(acc);
-                if (lane == 0) lgs[t][p] = acc;
             }
+            acc = wave_sum(acc);
+            if (lane == 0) lgs[t][p] = acc;
         }
     }
     __syncthreads();
@@ -508,14 +514,19 @@ extern "C" int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream) 
         return DLSG_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a->ov) | reinterpret_cast<uintptr_t>(a->theta)) & 15) return DLSG_EINVAL;
     if (a->B == 0) return DLSG_OK;
-    const int lds_bytes = a->T * a->H * 4;
-    if (lds_bytes > 140 * 1024) return DLSG_EINVAL;
+    const int lds_bytes = a->P * a->H * 4;              // theta
+    if (lds_bytes > 64 * 1024) return DLSG_EINVAL;
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&latent_psl_fwd_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&latent_psl_fwd_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&latent_psl_fwd_kernel<8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     });
-    hipLaunchKernelGGL(latent_psl_fwd_kernel, dim3(a->B), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), *a);
+    if (a->H <= 1024)
+        hipLaunchKernelGGL(latent_psl_fwd_kernel<4>, dim3(a->B), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), *a);
+    else
+        hipLaunchKernelGGL(latent_psl_fwd_kernel<8>, dim3(a->B), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
