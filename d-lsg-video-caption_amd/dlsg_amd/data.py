@@ -255,11 +255,17 @@ class ResidentFeatures(_Features):
             self.dev_regions[s:s + c].copy_(sr[:c], non_blocking=False)
         self.bytes = (self.dev_frames.numel() + self.dev_regions.numel()) * 4
 
-    def batch(self, video_ids):
+    def batch(self, video_ids, out=None):
+        """out: optional (frames, regions) device tensors of the batch shape to gather into (e.g. `Trainer.static_inputs()`)"""
         idx = torch.as_tensor(list(video_ids), dtype=torch.int64, device=self.device)
         B = idx.numel()
-        f = torch.empty(B, self.dev_frames.shape[1], dtype=torch.float32, device=self.device)
-        r = torch.empty(B, self.dev_regions.shape[1], dtype=torch.float32, device=self.device)
+        if out is not None:
+            f, r = out[0].view(B, -1), out[1].view(B, -1)
+            assert f.is_contiguous() and r.is_contiguous() and f.shape[1] == self.dev_frames.shape[1] \
+                and r.shape[1] == self.dev_regions.shape[1]
+        else:
+            f = torch.empty(B, self.dev_frames.shape[1], dtype=torch.float32, device=self.device)
+            r = torch.empty(B, self.dev_regions.shape[1], dtype=torch.float32, device=self.device)
         if self.ops is not None:
             self.ops.gather_rows(self.dev_frames, idx, f)
             self.ops.gather_rows(self.dev_regions, idx, r)

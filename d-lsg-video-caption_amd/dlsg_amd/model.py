@@ -760,6 +760,16 @@ class Trainer(object):
         self._graphs, self._loss = graphs, loss
         self._adam_in_graph = not cuts or (self.world_size <= 1 and not self.force_collectives)
 
+    def static_inputs(self):
+        """The captured graphs read their batch from these device buffers: (frames, regions, captions, cap_lens), or None
+        before the first replayed step.  A producer that fills them in place (the HBM-resident feature store gathers a batch
+        straight into them, `ResidentFeatures.batch(ids, out=...)`) and then passes the very same tensors to `step` saves the
+        device-to-device staging copy of the batch (258 MB per step at batch 64, MSVD-shaped)."""
+        if self._graphs is None:
+            return None
+        st = self._static
+        return st['frames'], st['regions'], st['captions'], st['lens']
+
     def _step_graphs(self, frames, regions, captions, cap_lens, coins, seed):
         model, ops = self.model, self.model.ops
         if self._graphs is None:

@@ -102,6 +102,16 @@ def test_train_loader_batches_follow_the_reference_collate(tmp_path, store):
 
 
 @needs_h5
+def test_resident_batch_gathers_into_given_buffers(tmp_path):
+    fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
+    fs = D.ResidentFeatures(fp, rp, 16, 'cpu')
+    f = torch.full((3, 26, 12), -1.0); r = torch.full((3, 26, 16, 8), -1.0)
+    f2, r2 = fs.batch([5, 0, 22], out=(f, r))
+    assert f2.data_ptr() == f.data_ptr() and r2.data_ptr() == r.data_ptr()
+    assert np.array_equal(f.numpy(), feats[[5, 0, 22]]) and np.array_equal(r.numpy(), vfeats[[5, 0, 22]][:, :, :16])
+
+
+@needs_h5
 def test_eval_loader_range_and_order(tmp_path):
     fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
     fs = D.ResidentFeatures(fp, rp, 36, 'cpu')
