@@ -742,6 +742,9 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     // M <= 64, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernel
     if (a->M <= 64 && a->mode != 2 && a->N >= 64) return launch_skinny(a, st);
     // measured on MI355X (tools/gemm_bench.py): the 128x128 tile only wins once it fills the chip several times over
+    // (Wave quantisation is not what these launches lose: giving the 128-tile kernel whole 768-slot rounds only and the remaining
+    // row panels to the 64-tile kernel was measured 1-3 % SLOWER on the region projection (4.33 rounds) and on the deep weight
+    // gradient (2.67 rounds), tools/gemm_split_probe.py -- workgroups of a partly filled last round simply run faster.)
     if (tilesL >= 1000) return launch<128, 128, 32>(a, st);
     return launch<64, 64, 64>(a, st);
 }

@@ -695,3 +695,38 @@ def test_masked_self_attention_core_against_reference_fixture(hip):
         hip.sa_core_fwd(K, Q, V, w, out, 1.0 / math.sqrt(D), mask=mask)
         y = out[:, :, :D] @ torch.from_numpy(g['w.output_layer.0.weight']).cuda().t()
         assert np.abs(y.cpu().numpy() - g[key]).max() <= 2e-5, key
+
+
+@pytest.mark.parametrize('mode', ['nt', 'nn', 'tn'])
+def test_large_gemm_launches_of_the_step(hip, mode):
+    """Launches of several thousand 128 x 128 tiles in the step's own grouping (two groups sharing A with bias + tanh; 16
+    row-chunk groups writing slabs, i.e. the group-per-XCD tile map; accumulate epilogue) against torch on the GPU."""
+    from dlsg_amd.hip import GEMM_NT, GEMM_NN, GEMM_TN, F_TANH, F_ACCUM
+    g = torch.Generator(device='cuda').manual_seed(1)
+
+    def r(*s):
+        return torch.randn(*s, device='cuda', generator=g)
+    if mode == 'nt':        # the step's region projection in miniature: 2 groups share A; 3328 tiles of 128 x 128
+        M, N, K = 26624, 1024, 256
+        A = r(M, K); Ws = [r(N, K) * 0.1, r(N, K) * 0.1]; bs = [r(N), r(N)]
+        Cs = [torch.empty(M, N, device='cuda') for _ in range(2)]
+        hip.gemm(GEMM_NT, [(A, W, C, b) for W, C, b in zip(Ws, Cs, bs)], flags=F_TANH)
+        for W, C, b in zip(Ws, Cs, bs):
+            ref = torch.tanh(A @ W.t() + b)
+            assert (C - ref).abs().max().item() <= 2e-4
+    elif mode == 'nn':
+        M, N, K = 13312, 2048, 192          # 104 x 16 = 1664 tiles = 2.17 rounds
+        A = r(M, K); W = r(K, N) * 0.1
+        C = r(M, N)
+        ref = C + A @ W
+        hip.gemm(GEMM_NN, [(A, W, C)], flags=F_ACCUM)
+        assert (C - ref).abs().max().item() <= 5e-4
+    else:                   # deep weight gradient in miniature: 16 row-chunk groups -> slabs, 8 x 16 tiles each = 2048 tiles
+        Mo, No, rows = 1024, 2048, 16 * 160
+        dY = r(rows, Mo) * 0.1; X = r(rows, No)
+        slabs = torch.empty(16, Mo, No, device='cuda')
+        hip.gemm(GEMM_TN, [(dY[i * 160:(i + 1) * 160], X[i * 160:(i + 1) * 160], slabs[i]) for i in range(16)])
+        ref = dY.t() @ X
+        assert (slabs.sum(0) - ref).abs().max().item() <= 1e-3
+        for i in (0, 7, 15):
+            assert (slabs[i] - dY[i * 160:(i + 1) * 160].t() @ X[i * 160:(i + 1) * 160]).abs().max().item() <= 5e-4
