@@ -562,11 +562,30 @@ __global__ void permute_tb_kernel(const float* __restrict__ src, float* __restri
         dst[i] = src[((int64_t)t * B + b) * n + j];
     }
 }
-__global__ void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ idx,
-                                   float* __restrict__ dst, int64_t ldd, int n) {
-    const int r = blockIdx.x;
+// dst[r, :] = src[idx[r], :].  Rows here are from a 2-KB embedding row to the 3.4-MB feature block of a clip (the HBM-resident
+// feature store's batch gather), so a row is spread over blockIdx.x in 16-KB pieces: 64 rows alone would leave 3/4 of the CUs idle.
+template <bool VEC>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds_, const int64_t* __restrict__ idx,
+                                                          float* __restrict__ dst, int64_t ldd, int n) {
+    const int pieces = (n + 4095) >> 12;
+    const int r = blockIdx.x / pieces, piece = blockIdx.x - r * pieces;
     const float* s = src + idx[r] * lds_;
-    for (int j = threadIdx.x; j < n; j += blockDim.x) dst[(int64_t)r * ldd + j] = s[j];
+    float* d = dst + (int64_t)r * ldd;
+    if constexpr (VEC) {
+        const int n4 = n >> 2;
+        const int base = piece * 1024 + threadIdx.x;
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + u * 256 < n4) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(s) + base + u * 256);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + u * 256 < n4) reinterpret_cast<f4*>(d)[base + u * 256] = v[u];
+    } else {
+        const int hi = min(n, (piece + 1) * 4096);
+        for (int j = piece * 4096 + threadIdx.x; j < hi; j += 256) d[j] = s[j];
+    }
 }
 __global__ void fill_kernel(float* __restrict__ dst, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = v;
@@ -916,7 +935,10 @@ extern "C" int dlsg_dropout(const float* x, int64_t ldx, float* y, int64_t ldy, 
 extern "C" int dlsg_gather_rows(const float* src, int64_t lds_, const int64_t* idx, float* dst, int64_t ldd, int rows, int n,
                                 void* stream) {
     if (rows == 0 || n == 0) return DLSG_OK;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, ST(stream), src, lds_, idx, dst, ldd, n);
+    const bool vec = n % 4 == 0 && lds_ % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0;
+    const dim3 grid((unsigned)((int64_t)((n + 4095) / 4096) * rows));
+    if (vec) hipLaunchKernelGGL(gather_rows_kernel<true>, grid, dim3(256), 0, ST(stream), src, lds_, idx, dst, ldd, n);
+    else hipLaunchKernelGGL(gather_rows_kernel<false>, grid, dim3(256), 0, ST(stream), src, lds_, idx, dst, ldd, n);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -60,7 +60,9 @@ def _libhdf5():
            'H5Sselect_hyperslab': (C.c_int, [hid, C.c_int, hsz, hsz, hsz, hsz]),
            'H5Screate_simple': (hid, [C.c_int, hsz, hsz]), 'H5Dread': (C.c_int, [hid, hid, hid, hid, hid, vp]),
            'H5Dwrite': (C.c_int, [hid, hid, hid, hid, hid, vp]),
-           'H5Dcreate2': (hid, [hid, C.c_char_p, hid, hid, hid, hid, hid]), 'H5Lexists': (C.c_int, [hid, C.c_char_p, hid])}
+           'H5Dcreate2': (hid, [hid, C.c_char_p, hid, hid, hid, hid, hid]), 'H5Lexists': (C.c_int, [hid, C.c_char_p, hid]),
+           'H5Dget_offset': (C.c_uint64, [hid]), 'H5Dget_create_plist': (hid, [hid]), 'H5Pget_layout': (C.c_int, [hid]),
+           'H5Pclose': (C.c_int, [hid]), 'H5Tget_order': (C.c_int, [hid])}
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
@@ -91,7 +93,22 @@ class H5Dataset(object):
         tp = lib.H5Dget_type(did)
         self.is_float = lib.H5Tget_class(tp) == 1
         self.itemsize = int(lib.H5Tget_size(tp))
+        self.little_endian = lib.H5Tget_order(tp) == 0
         lib.H5Tclose(tp)
+        pl = lib.H5Dget_create_plist(did)
+        self.contiguous = lib.H5Pget_layout(pl) == 1            # H5D_CONTIGUOUS (what create_dataset(data=...) writes)
+        lib.H5Pclose(pl)
+        self.path = None
+
+    def memmap(self):
+        """Zero-copy view of a contiguous little-endian float32 dataset: the file region libhdf5 reports (H5Dget_offset)
+        mapped read-only.  None when the layout is chunked / compact or the type needs conversion (then read_rows is used)."""
+        if not (self.contiguous and self.is_float and self.itemsize == 4 and self.little_endian and self.path):
+            return None
+        off = int(self.lib.H5Dget_offset(self.did))
+        if off == 0 or off == 0xFFFFFFFFFFFFFFFF:              # HADDR_UNDEF: no storage allocated
+            return None
+        return np.memmap(self.path, dtype=np.float32, mode='r', offset=off, shape=self.shape)
 
     def __len__(self):
         return self.shape[0]
@@ -157,6 +174,7 @@ class H5File(object):
             if did < 0:
                 raise KeyError(name)
             self._open[name] = H5Dataset(self.lib, did, name)
+            self._open[name].path = self.path
         return self._open[name]
 
     def write(self, name, arr):
@@ -275,42 +293,90 @@ class ResidentFeatures(_Features):
 
 
 class StreamedFeatures(_Features):
-    """Features stay on the host; `prefetch(list of id lists)` yields device batches, read by a thread into pinned buffers
-    `depth` batches ahead and copied on a side HIP stream."""
+    """Features stay on the host; `prefetch(list of id lists)` yields device batches `depth` batches ahead of the consumer.
+    Batches are assembled straight into a ring of PINNED buffers by `workers` threads (numpy's copies release the GIL), from
+    memory-mapped views of the HDF5 datasets when they are stored contiguously (no libhdf5 call, no intermediate array,
+    only the first num_obj objects of a region row are touched), else through hyperslab reads by one thread (libhdf5 is
+    not thread-safe); the H2D copies run on a side HIP stream."""
 
-    def __init__(self, frame_h5, region_h5, num_obj, device, depth=2, **kw):
+    def __init__(self, frame_h5, region_h5, num_obj, device, depth=2, workers=4, **kw):
         super().__init__(frame_h5, region_h5, num_obj, **kw)
-        self.device, self.depth = torch.device(device), depth
+        self.device, self.depth, self.workers = torch.device(device), depth, max(1, workers)
+        self.mm_frames, self.mm_regions = self.frames.memmap(), self.regions.memmap()
+        self.mapped = self.mm_frames is not None and self.mm_regions is not None
+
+    def _fill(self, ids, tf, tr):
+        """tf (B, T, F), tr (B, T, O, R) host tensors <- rows `ids`"""
+        nf, nr = tf.numpy(), tr.numpy()
+        if not self.mapped:
+            for j, v in enumerate(ids):
+                self.frames.read_rows(v, 1, out=nf[j:j + 1])
+                nr[j] = self.regions.read_rows(v, 1)[0][:, :self.num_obj]
+            return
+        O = self.num_obj
+
+        def work(lo, hi):
+            for j in range(lo, hi):
+                nf[j] = self.mm_frames[ids[j]]
+                nr[j] = self.mm_regions[ids[j], :, :O]
+        n = len(ids)
+        k = min(self.workers, n)
+        if k <= 1:
+            work(0, n)
+            return
+        ts = [threading.Thread(target=work, args=(n * i // k, n * (i + 1) // k)) for i in range(k)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
 
     def prefetch(self, id_batches):
+        id_batches = list(id_batches)
+        if not id_batches:
+            return
         cuda = self.device.type == 'cuda'
+        bmax = max(len(b) for b in id_batches)
+        nbuf = self.depth + 2                               # being filled + queued (depth) + being copied
+        ring = [(torch.empty(bmax, *self.frame_shape, dtype=torch.float32, pin_memory=cuda),
+                 torch.empty(bmax, *self.region_shape, dtype=torch.float32, pin_memory=cuda)) for _ in range(nbuf)]
+        free = queue.Queue()
+        for i in range(nbuf):
+            free.put(i)
         q = queue.Queue(maxsize=self.depth)
 
         def reader():
             try:
                 for ids in id_batches:
-                    f, r = self.host_batch(ids)
-                    tf, tr = torch.from_numpy(f), torch.from_numpy(r)
-                    if cuda:
-                        tf, tr = tf.pin_memory(), tr.pin_memory()
-                    q.put((ids, tf, tr))
+                    i = free.get()
+                    tf, tr = ring[i][0][:len(ids)], ring[i][1][:len(ids)]
+                    self._fill(ids, tf, tr)
+                    q.put((ids, i, tf, tr))
             finally:
                 q.put(None)
         threading.Thread(target=reader, daemon=True).start()
         side = torch.cuda.Stream(device=self.device) if cuda else None
+        pending = None                                      # (ring index, event): its H2D copy may still be reading the buffer
         while True:
             item = q.get()
             if item is None:
                 return
-            ids, tf, tr = item
+            ids, i, tf, tr = item
             if cuda:
                 with torch.cuda.stream(side):
                     df, dr = tf.to(self.device, non_blocking=True), tr.to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
                 torch.cuda.current_stream().wait_stream(side)
                 df.record_stream(torch.cuda.current_stream()); dr.record_stream(torch.cuda.current_stream())
+                if pending is not None:                     # the previous batch's copy has certainly been issued before this one
+                    pending[1].synchronize()
+                    free.put(pending[0])
+                pending = (i, ev)
             else:
-                df, dr = tf, tr
+                df, dr = tf.clone(), tr.clone()
+                free.put(i)
             yield ids, df, dr
+        # (the last pending buffer is dropped with the ring)
 
 
 # ================================================================================================ sampler + loaders

@@ -102,6 +102,28 @@ def test_train_loader_batches_follow_the_reference_collate(tmp_path, store):
 
 
 @needs_h5
+@pytest.mark.parametrize('mapped,workers', [(True, 1), (True, 3), (False, 1)])
+def test_streamed_store_paths_agree(tmp_path, mapped, workers):
+    """memory-mapped rows (contiguous datasets) and libhdf5 hyperslab reads fill the pinned ring with the same bytes; ragged
+    last batch, more batches than ring slots"""
+    fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
+    st = D.StreamedFeatures(fp, rp, 16, 'cpu', depth=2, workers=workers)
+    assert st.mapped                                              # H5File.write stores contiguously, as h5py's create_dataset(data=) does
+    off = st.frames.lib.H5Dget_offset(st.frames.did)
+    with open(fp, 'rb') as f:
+        f.seek(off)
+        assert np.array_equal(np.frombuffer(f.read(feats[0].nbytes), np.float32).reshape(feats[0].shape), feats[0])
+    st.mapped = mapped
+    rng = np.random.RandomState(1)
+    batches = [rng.randint(0, feats.shape[0], size=n).tolist() for n in (5, 5, 5, 5, 5, 5, 5, 2)]
+    got = list(st.prefetch(batches))
+    assert [g[0] for g in got] == batches
+    for ids, f, r in got:
+        assert np.array_equal(f.numpy(), feats[ids]) and np.array_equal(r.numpy(), vfeats[ids][:, :, :16])
+    assert list(st.prefetch([])) == []
+
+
+@needs_h5
 def test_resident_batch_gathers_into_given_buffers(tmp_path):
     fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
     fs = D.ResidentFeatures(fp, rp, 16, 'cpu')

@@ -625,6 +625,19 @@ def test_beam_select_and_state_gather(hip, dims, first):
     both(hip, build, run, ['pred', 'nlp', 'back', 'rows', 'cnt', 'd0', 'd1', 'd2', 'd3'], tol=1e-5, name='beam_select %s' % (dims,))
 
 
+@pytest.mark.parametrize('rows,n,pad', [(5, 4096 * 3, 0), (7, 4100, 4), (3, 1001, 0), (64, 26 * 6144, 0), (9, 20, 3), (1, 8191, 1)])
+def test_gather_rows_bit_exact(hip, rows, n, pad):
+    """row pieces of 4096 floats per workgroup: whole pieces, a ragged last piece, unaligned rows (scalar path), strided views"""
+    g = torch.Generator().manual_seed(rows * 1000 + n)
+    src = torch.randn(23, n + pad, generator=g).cuda()
+    idx = torch.randint(0, 23, (rows,), generator=g).cuda()
+    dst = torch.full((rows, n + pad), -7.0).cuda()
+    hip.gather_rows(src[:, :n], idx, dst[:, :n])
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:, :n], src[idx][:, :n])
+    assert (dst[:, n:] == -7.0).all()
+
+
 def test_movers_embed_argmax(hip):
     def build(g):
         lg = rnd(g, 9, 1000)

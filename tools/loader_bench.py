@@ -1,7 +1,8 @@
 """Loader throughput on the GPU box: a synthetic MSVD-shaped feature set written as HDF5
 (`feats` (N,26,6144), `vfeats` (N,26,36,2048)), then
   * ResidentFeatures: one-time upload (host read + H2D) and the per-batch device gather, clips/s
-  * StreamedFeatures: reader thread + pinned buffers + H2D on a side stream, clips/s (the PCIe-inclusive rate)
+  * StreamedFeatures: worker threads filling a ring of pinned buffers from memory-mapped datasets (and the libhdf5
+    hyperslab fallback) + H2D on a side stream, clips/s per worker count (the PCIe-inclusive rate)
 usage: python tools/loader_bench.py [N=192] [batch=64]"""
 import json
 import os
@@ -52,17 +53,33 @@ out['resident_gather_clips_per_s'] = round(n / dt, 1)
 out['resident_gather_GBps'] = round(n * (26 * 6144 + 26 * 16 * 2048) * 4 * 2 / dt / 1e9, 1)     # read + write
 del res, ld
 torch.cuda.empty_cache()
-st = D.StreamedFeatures(fp, rp, 16, 'cuda', depth=3)
-ld = D.TrainLoader(cp, st, B, seed=0, drop_last=True)
-torch.cuda.synchronize()
-t0 = time.time()
-n = 0
-for i, batch in enumerate(ld):
-    n += batch[0].shape[0]
-    if i >= 7:
-        break
-torch.cuda.synchronize()
-dt = time.time() - t0
-out['streamed_clips_per_s'] = round(n / dt, 1)
-out['streamed_GBps_h2d'] = round(n * (26 * 6144 + 26 * 16 * 2048) * 4 / dt / 1e9, 2)
+out['host_cpus'] = os.cpu_count()
+per_clip = (26 * 6144 + 26 * 16 * 2048) * 4
+
+
+def streamed(workers, mapped, max_batches):
+    st = D.StreamedFeatures(fp, rp, 16, 'cuda', depth=3, workers=workers)
+    if not mapped:
+        st.mapped = False
+    ld = D.TrainLoader(cp, st, B, seed=0, drop_last=True)
+    best = 0.0
+    for rep in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        n = 0
+        for i, batch in enumerate(ld):
+            n += batch[0].shape[0]
+            if i + 1 >= max_batches:
+                break
+        torch.cuda.synchronize()
+        best = max(best, n / (time.time() - t0))
+    return best
+
+
+r = streamed(1, False, 6)
+out['streamed_hyperslab_clips_per_s'] = round(r, 1)
+out['streamed_mapped'] = {}
+for w in (1, 2, 4, 8, 16):
+    r = streamed(w, True, 24)
+    out['streamed_mapped'][str(w)] = {'clips_per_s': round(r, 1), 'GBps_h2d': round(r * per_clip / 1e9, 2)}
 print(json.dumps(out))
