@@ -737,6 +737,8 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     const int64_t z = (int64_t)a->ngroups * a->nbatch;
     const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
     if (a->flags & DLSG_GEMM_BF16X3) return dlsg_gemm_bf16x3_dispatch(a, st);
+    if ((a->flags & (DLSG_GEMM_FORCE64 | DLSG_GEMM_FORCE128)) == (DLSG_GEMM_FORCE64 | DLSG_GEMM_FORCE128))
+        return launch<128, 64, 64>(a, st);        // both bits: the 128 x 64 tile
     if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64, 64>(a, st);
     if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128, 32>(a, st);
     // M <= 64, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernel
@@ -746,6 +748,15 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     // row panels to the 64-tile kernel was measured 1-3 % SLOWER on the region projection (4.33 rounds) and on the deep weight
     // gradient (2.67 rounds), tools/gemm_split_probe.py -- workgroups of a partly filled last round simply run faster.)
     if (tilesL >= 1000) return launch<128, 128, 32>(a, st);
+    // Mid-size launches (tools/gemm_tile_probe.py; M = 1664 = 26 frames x 64 clips and the weight gradients over them), when
+    // the 128-row panels waste < 10 % of their rows: from ~700 tiles the 128 x 128 tile is already ahead (2048 x 2048 x 1664 x 3
+    // TN: 402 us against 445), between 200 and 700 a 128 x 64 tile (21 flop per staged byte instead of 16, twice the
+    // workgroups of the square tile) wins 3-8 % over the 64 x 64 one; below that only the small tile fills the chip.
+    const int padM = (a->M + 127) / 128 * 128;
+    if ((padM - a->M) * 10 <= a->M) {
+        if (tilesL >= 700) return launch<128, 128, 32>(a, st);
+        if (tilesL >= 200) return launch<128, 64, 64>(a, st);
+    }
     return launch<64, 64, 64>(a, st);
 }
 

@@ -69,6 +69,57 @@ def test_gemm_plain(hip, mode, shape):
 
 
 @pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
+@pytest.mark.parametrize('shape', [(128, 64, 64), (3, 50, 244), (257, 129, 65), (300, 1000, 96), (1664, 200, 130)])
+def test_gemm_128x64_tile(hip, mode, shape):
+    """the mid-size tile (both FORCE bits): ragged edges, unaligned strides, bias + accumulate, two groups of different width"""
+    M, N, K = shape
+
+    def build(g):
+        if mode == GEMM_NT:
+            A, B = rnd(g, M, K + 3), rnd(g, N, K + 3)
+        elif mode == GEMM_NN:
+            A, B = rnd(g, M, K + 3), rnd(g, K, N + 3)
+        else:
+            A, B = rnd(g, K, M + 3), rnd(g, K, N + 3)
+        return dict(A=A, B=B, C=rnd(g, M, N + 5), C2=rnd(g, M, N + 5), bias=rnd(g, N))
+
+    def run(ops, t):
+        N2 = max(1, N // 2)
+        if mode == GEMM_NT:
+            A, B, B2 = t['A'][:, :K], t['B'][:, :K], t['B'][:N2, :K]
+        elif mode == GEMM_NN:
+            A, B, B2 = t['A'][:, :K], t['B'][:, :N], t['B'][:, :N2]
+        else:
+            A, B, B2 = t['A'][:, :M], t['B'][:, :N], t['B'][:, :N2]
+        ops.gemm(mode, [(A, B, t['C'][:, :N], t['bias']), (A, B2, t['C2'][:, :N2], t['bias'][:N2])], alpha=0.5,
+                 flags=F_ACCUM | F_FORCE64 | F_FORCE128)
+    both(hip, build, run, ['C', 'C2'], tol=1e-5 * max(1.0, math.sqrt(K)), name='gemm 128x64 %d %s' % (mode, shape))
+
+
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
+@pytest.mark.parametrize('shape', [(1664, 2048, 40, 3), (1000, 2048, 64, 2), (1664, 2048, 24, 4)])
+def test_gemm_mid_size_tile_choice(hip, mode, shape):
+    """launches whose tile the dispatcher picks itself: 624 / 256 (128x64) and 832 (128x128) 128-square tiles"""
+    M, N, K, G = shape
+
+    def build(g):
+        d = {}
+        for i in range(G):
+            if mode == GEMM_NT:
+                d['A%d' % i], d['B%d' % i] = rnd(g, M, K), rnd(g, N, K)
+            elif mode == GEMM_NN:
+                d['A%d' % i], d['B%d' % i] = rnd(g, M, K), rnd(g, K, N)
+            else:
+                d['A%d' % i], d['B%d' % i] = rnd(g, K, M), rnd(g, K, N)
+            d['C%d' % i] = torch.zeros(M, N)
+        return d
+
+    def run(ops, t):
+        ops.gemm(mode, [(t['A%d' % i], t['B%d' % i], t['C%d' % i]) for i in range(G)])
+    both(hip, build, run, ['C%d' % i for i in range(G)], tol=1e-5 * max(1.0, math.sqrt(K)), name='mid gemm %d %s' % (mode, shape))
+
+
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
 @pytest.mark.parametrize('force', [F_FORCE64, F_FORCE128])
 @pytest.mark.parametrize('shape', [(128, 128, 64), (3, 50, 244), (70, 33, 100), (257, 129, 65), (416, 26, 64), (300, 1000, 96)])
 def test_gemm_bf16x3(hip, mode, force, shape):

@@ -50,6 +50,22 @@ for it in range(3):
         ops.gemm = traced
     tr.step(frames, regions, caps, lens, dlsg_amd.ss_epsilon(0))
 torch.cuda.synchronize()
+if os.environ.get('CENSUS_SEQUENCE'):             # the launches in issue order (per-word-step skinny launches folded)
+    prev, rep = None, 0
+    for rec in log + [None]:
+        if rec is None:
+            break
+        m, M, Ns, Ks, nb, e0, e1 = rec
+        key = (m, M, Ns, Ks, nb)
+        us = e0.elapsed_time(e1) * 1e3
+        if M <= 64 and key == prev:
+            rep += 1
+            continue
+        if rep:
+            print('      ... x%d more' % rep)
+        rep = 0
+        prev = key
+        print('%-3s M=%-6d N=%-30s K=%-30s nb=%-3d %8.1f us' % (m, M, str(Ns)[:30], str(Ks)[:30], nb, us))
 agg = collections.OrderedDict()
 for m, M, Ns, Ks, nb, e0, e1 in log:
     key = (m, M, Ns if len(set(Ns)) > 1 else (Ns[0],), Ks if len(set(Ks)) > 1 else (Ks[0],), len(Ns), nb)
