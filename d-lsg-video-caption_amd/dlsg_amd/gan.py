@@ -255,15 +255,19 @@ class GanTrainer(object):
     generator's forward and backward, so the step is not replayed from a hipGraph)."""
 
     def __init__(self, model, D, lr=1.6e-4, betas=(0.5, 0.9), num_D=5, gan_lambda=0.01, total_step=1, cap_list=None,
-                 process_group=None, world_size=1):
+                 process_group=None, world_size=1, use_graphs=None):
         from .model import Trainer
         self.model, self.D = model, D
         self.trainer = Trainer(model, lr=lr, betas=betas, process_group=process_group, world_size=world_size, use_graphs=False)
-        self.opt_D = torch.optim.Adam(D.parameters(), lr=lr, betas=betas)                   # run_gun.py:100
+        on_gpu = next(D.parameters()).is_cuda
+        # critic updates replayed from a hipGraph (see _critic_graph): needs Adam's step counter on the device
+        self.use_graphs = on_gpu if use_graphs is None else (use_graphs and on_gpu)
+        self.opt_D = torch.optim.Adam(D.parameters(), lr=lr, betas=betas, capturable=self.use_graphs)   # run_gun.py:100
         self.num_D = num_D
         self.lambda_handler = GANLambdaHandler(total_step, gan_lambda, cap_list)
         self.world_size, self.pg = world_size, process_group
         self.eps_source = None              # tests: callable(k) -> (B,1,1) tensor instead of torch.rand
+        self._cg, self._cg_seen = {}, set()
 
     def _allreduce_D(self):
         if self.world_size > 1:
@@ -273,14 +277,62 @@ class GanTrainer(object):
                     dist.all_reduce(p.grad, group=self.pg)
                     p.grad.div_(self.world_size)
 
+    def _critic_graph(self, inputs):
+        """One critic update -- the three-way critic pass, the gradient penalty's double backward, the backward of loss_D and
+        the Adam step -- is ~3 000 small PyTorch launches (the LSTM is unrolled over 26 steps and differentiated twice):
+        26 ms from Python at batch 64.  It is captured once per batch shape into two hipGraphs (losses + backward | Adam,
+        the gradient all-reduce of a multi-GPU run sits between them) and replayed; inputs, the penalty's epsilon and the
+        parameter gradients live in static buffers.  The first update of a shape runs eagerly (it creates the Adam state and
+        the library handles a capture must not create); a changed learning rate or train/eval mode captures again."""
+        key = (tuple(tuple(t.shape) for t in inputs), tuple(g['lr'] for g in self.opt_D.param_groups), self.D.training)
+        cg = self._cg.get(key)
+        if cg is not None:
+            return cg
+        if key not in self._cg_seen or len(self.opt_D.state) == 0:
+            self._cg_seen.add(key)
+            return None
+        D, opt = self.D, self.opt_D
+        dev = inputs[1].device
+        st = [t.clone() for t in inputs] + [torch.empty(inputs[0].shape[0], 1, 1, device=dev)]
+        params = [p for p in D.parameters() if p.grad is not None]
+        grads = [p.grad for p in params]
+        out = {}
+        torch.cuda.synchronize()
+        gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gA):
+            opt.zero_grad(set_to_none=False)
+            loss_D, r_loss, f_loss, gp, _ = critic_step_losses(D, *st)
+            loss_D.backward()
+            out['loss_D'], out['w'] = loss_D.detach(), (r_loss - f_loss).detach()
+        with torch.cuda.graph(gB, pool=gA.pool()):
+            opt.step()
+        cg = dict(st=st, params=params, grads=grads, out=out, graphs=(gA, gB))
+        self._cg[key] = cg
+        return cg
+
     def train_disc(self, captions, f_caption, obj, mot, att_mask, alpha):
         """run_gun.py:339-381: num_D critic updates.  Returns (mean loss_D, mean Wasserstein estimate) as floats."""
         mean_loss = torch.zeros((), device=f_caption.device)
         mean_w = torch.zeros((), device=f_caption.device)
         B = captions.shape[0]
+        inputs = (captions, f_caption, obj, mot, att_mask, alpha)
+        cg = self._critic_graph(inputs) if self.use_graphs else None
+        if cg is not None:
+            for dst, src in zip(cg['st'], inputs):
+                dst.copy_(src)
+            for p, g in zip(cg['params'], cg['grads']):
+                p.grad = g                    # an eager update in between (another batch shape) re-created the .grad tensors
         for k in range(self.num_D):
-            self.opt_D.zero_grad(set_to_none=True)
             eps = self.eps_source(k) if self.eps_source is not None else torch.rand(B, 1, 1, device=f_caption.device)
+            if cg is not None:
+                cg['st'][-1].copy_(eps)
+                cg['graphs'][0].replay()
+                self._allreduce_D()
+                cg['graphs'][1].replay()
+                mean_loss += cg['out']['loss_D'] / self.num_D
+                mean_w += cg['out']['w'] / self.num_D
+                continue
+            self.opt_D.zero_grad(set_to_none=True)
             loss_D, r_loss, f_loss, gp, _ = critic_step_losses(self.D, captions, f_caption, obj, mot, att_mask, alpha, eps)
             mean_loss += loss_D.detach() / self.num_D
             mean_w += (r_loss.detach() - f_loss.detach()) / self.num_D

@@ -86,3 +86,41 @@ def test_proposal_and_attention_gradients_reach_the_encoder():
         ref = want[k].grad
         err = (p.grad.cpu() - ref).abs().max().item()
         assert err <= 2e-5 + 2e-3 * ref.abs().max().item(), (k, err, ref.abs().max().item())
+
+
+def test_graph_replayed_critic_updates_match_eager_updates():
+    """GanTrainer replays the critic update from hipGraphs from its second call on (first call of a shape: eager); the
+    replayed updates must follow the eager ones -- same losses, same critic weights -- also across a batch of another shape
+    in between (which runs eagerly and re-creates the .grad tensors)."""
+    import copy
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case('gan_msvd', dlsg_amd.CapGnnModel, dlsg_amd.DiscV2)
+    G, D = G.cuda(), D.cuda().eval()                       # dropout off in the critic: both trainers see the same function
+    frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
+    eps = torch.rand(6, caps.shape[0], 1, 1, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)
+    mask = gan.attention_mask(caps)
+    runs = []
+    for graphs in (False, True):
+        Dk = copy.deepcopy(D)
+        it = dlsg_amd.GanTrainer(G, Dk, num_D=2, use_graphs=graphs)
+        if not graphs:                                       # same Adam arithmetic (step count and bias corrections on the device)
+            it.opt_D = torch.optim.Adam(Dk.parameters(), lr=1.6e-4, betas=(0.5, 0.9), capturable=True)
+        log = []
+        for call in range(4):
+            it.eps_source = lambda k, call=call: eps[(2 * call + k) % 6]
+            if call == 2:                                    # another batch shape: eager in both trainers
+                it.eps_source = lambda k: eps[k][:2]
+                log.append(it.train_disc(caps[:2], f_caption[:2], obj[:2], mot[:2], mask[:2], alpha[:2]))
+            else:
+                log.append(it.train_disc(caps, f_caption, obj, mot, mask, alpha))
+        assert bool(it._cg) == graphs
+        runs.append((log, [p.detach().clone() for p in Dk.parameters()]))
+    (la, pa), (lb, pb) = runs
+    for (a0, a1), (b0, b1) in zip(la, lb):
+        assert abs(a0 - b0) <= 1e-4 * max(1.0, abs(a0)) and abs(a1 - b1) <= 1e-4 * max(1.0, abs(a1)), (la, lb)
+    # Adam's first steps move every weight by ~lr whatever its gradient's size, so a weight whose gradient is rounding noise
+    # (embedding rows summed by atomics) may go the other way: bound those by 2 lr per update and ask that they are rare
+    for a, b in zip(pa, pb):
+        d = (a - b).abs()
+        assert d.max().item() <= 8 * 2 * 1.6e-4 and (d > 2e-6).float().mean().item() <= 5e-3, (d.max().item(), (d > 2e-6).float().mean().item())
