@@ -73,6 +73,53 @@ def _dropout(x, p, on):
     return F.dropout(x, p, True) if on and p > 0 else x
 
 
+_HIP = []
+
+
+def _hip_ops():
+    if not _HIP:
+        from .hip import HipOps
+        _HIP.append(HipOps())
+    return _HIP[0]
+
+
+class _LstmCell(torch.autograd.Function):
+    """(h, c) = LSTM cell pointwise on the HIP kernel (`dlsg_lstm_cell_fwd`); its backward is `_LstmCellBwd`, itself a
+    differentiable op, so that the gradient penalty (create_graph=True) and the loss backward through it are one launch each
+    instead of ~20 and ~40 ATen launches per cell step (csrc/critic.hip)."""
+
+    @staticmethod
+    def forward(ctx, ops, a, c_prev):
+        h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+        ops.lstm_cell_fwd(a, c_prev, h, c)
+        ctx.ops = ops
+        ctx.save_for_backward(a, c_prev)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        a, c_prev = ctx.saved_tensors
+        da, dcp = _LstmCellBwd.apply(ctx.ops, a, c_prev, dh.contiguous(), dc.contiguous())
+        return None, da, dcp
+
+
+class _LstmCellBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, a, c_prev, dh, dc):
+        da, dcp = torch.empty_like(a), torch.empty_like(c_prev)
+        ops.lstm_cell_bwd(a, c_prev, dh, dc, da, dcp)
+        ctx.ops = ops
+        ctx.save_for_backward(a, c_prev, dh, dc)
+        return da, dcp
+
+    @staticmethod
+    def backward(ctx, u, uc):
+        a, c_prev, dh, dc = ctx.saved_tensors
+        ga, gcp, gdh, gdc = torch.empty_like(a), torch.empty_like(c_prev), torch.empty_like(c_prev), torch.empty_like(c_prev)
+        ctx.ops.lstm_cell_bwd2(a, c_prev, dh, dc, u.contiguous(), uc.contiguous(), ga, gcp, gdh, gdc)
+        return None, ga, gcp, gdh, gdc
+
+
 class DiscV2(nn.Module):
     """Critic of the visual GAN.  forward(inputs (B,L,V), obj (B,P,1024), mot (B,P,1024), att_mask (B,L,L), alpha_all (B,L,2P))
     -> (B,) scores, the reference's call (models/model.py:143); `score_projected` is the entry the trainer uses."""
@@ -111,15 +158,39 @@ class DiscV2(nn.Module):
         return F.embedding(captions, self.vocab_matrix().t()) + self.conv1d.bias
 
     # ------------------------------------------------------------------ everything behind the projection
+    def set_ops(self, ops):
+        """kernel interface for the fused cell (HipOps; tests: the emulation).  Default: the HIP library for CUDA tensors,
+        the plain ATen recurrence for CPU tensors."""
+        object.__setattr__(self, '_ops', ops)
+        return self
+
+    def _cell_ops(self, x):
+        ops = getattr(self, '_ops', None)
+        if ops is None and x.is_cuda:
+            ops = _hip_ops()                                       # raises if libdlsg_hip.so is missing: no silent fallback on a GPU
+        return ops
+
     def _lstm(self, x):
-        """single-layer LSTM, zero initial state, gate order i,f,g,o; unrolled so that autograd can differentiate it twice"""
+        """single-layer LSTM, zero initial state, gate order i,f,g,o; unrolled so that autograd can differentiate it twice:
+        the recurrent product is an ordinary matmul per step, the cell's pointwise part one fused op per step."""
         w_ih, w_hh = self.lstm.weight_ih_l0, self.lstm.weight_hh_l0
         bias = self.lstm.bias_ih_l0 + self.lstm.bias_hh_l0
-        xin = F.linear(x, w_ih, bias)                              # all steps' input gates in one product
         n, L, _ = x.shape
+        ops = self._cell_ops(x)
         h = x.new_zeros(n, WIDTH)
         c = x.new_zeros(n, WIDTH)
         out = []
+        if ops is not None:
+            # (L, n, 4H) so that a step's rows are dense; unbind, not xin[t]: the backward of 26 selects is 26 zero-filled
+            # (L, n, 4H) tensors summed pairwise, the backward of one unbind is one stack
+            xin = F.linear(x.transpose(0, 1).contiguous(), w_ih, bias).unbind(0)
+            w_hh_t = w_hh.t()
+            for t in range(L):
+                a = xin[t] if t == 0 else torch.addmm(xin[t], h, w_hh_t)
+                h, c = _LstmCell.apply(ops, a, c)
+                out.append(h)
+            return torch.stack(out, 0).transpose(0, 1)             # (L, n, H) storage: a step's gradient slice is dense
+        xin = F.linear(x, w_ih, bias)                              # all steps' input gates in one product
         for t in range(L):
             i, f, g, o = (xin[:, t] + F.linear(h, w_hh)).chunk(4, dim=1)
             c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
@@ -151,9 +222,13 @@ class DiscV2(nn.Module):
 
         def rep(t):
             return t if groups == 1 else t.repeat(groups, *([1] * (t.dim() - 1)))
-        x = torch.relu(h).transpose(1, 2)                          # ResBlock's in-place ReLU also feeds the skip (sublayer.py:111,119)
+        x = torch.relu(h)                                          # ResBlock's in-place ReLU also feeds the skip (sublayer.py:111,119)
         conv = self.block[0].res_block[1]
-        x = (x + 0.3 * F.conv1d(x, conv.weight, conv.bias, padding=1)).transpose(1, 2)
+        # Conv1d(512, 512, 3, padding=1) over the word axis as ONE product on the three shifted copies of the sequence
+        # (MIOpen's choice for this shape is an im2col + GEMM per sample: 2 x 192 launches per call)
+        xp = F.pad(x, (0, 0, 1, 1))
+        taps = torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=2)                          # (n, L, 3 x 512): x[t-1] | x[t] | x[t+1]
+        x = x + 0.3 * F.linear(taps, conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1), conv.bias)
         y = _dropout(F.layer_norm(self._lstm(x), (WIDTH,), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps),
                      0.3, self.training)
         mask = rep(att_mask)
@@ -310,6 +385,38 @@ class GanTrainer(object):
         self._cg[key] = cg
         return cg
 
+    def _generator_term(self, tokens, obj, mot, att_mask, alpha):
+        """loss_G = -D(tokens).mean() (run_gun.py:214-217) and d loss_G / d tokens; replayed from a hipGraph like the critic
+        updates (first call of a shape: eager)."""
+        D = self.D
+
+        def term(tokens, obj, mot, att_mask, alpha):
+            tokens = tokens.detach().requires_grad_(True)
+            with torch.enable_grad():
+                loss_G = -D(tokens, obj, mot, att_mask=att_mask, alpha_all=alpha).mean()
+                g = torch.autograd.grad(loss_G, tokens)[0]
+            return loss_G.detach(), g
+        inputs = (tokens, obj, mot, att_mask, alpha)
+        if not self.use_graphs:
+            return term(*inputs)
+        key = ('G', tuple((tuple(t.shape), tuple(t.stride())) for t in inputs), D.training)
+        gg = self._cg.get(key)
+        if gg is None:
+            if key not in self._cg_seen:
+                self._cg_seen.add(key)
+                return term(*inputs)
+            st = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device).copy_(t) for t in inputs]
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = term(*st)
+            gg = dict(st=st, out=out, graph=graph)
+            self._cg[key] = gg
+        for dst, src in zip(gg['st'], inputs):
+            dst.copy_(src)
+        gg['graph'].replay()
+        return gg['out']
+
     def train_disc(self, captions, f_caption, obj, mot, att_mask, alpha):
         """run_gun.py:339-381: num_D critic updates.  Returns (mean loss_D, mean Wasserstein estimate) as floats."""
         mean_loss = torch.zeros((), device=f_caption.device)
@@ -355,12 +462,10 @@ class GanTrainer(object):
         def gan_term(logits_tm, sv):
             """d(gan_lambda * loss_G) / d logits, time-major (L,B,V); called between the HIP forward and backward"""
             s = sv['dec']
-            tokens = logits_tm.transpose(0, 1).detach().requires_grad_(True)
+            tokens = logits_tm.transpose(0, 1).detach()
             obj_, mot_ = sv['dec_gsrc'][0].detach(), sv['dec_gsrc'][1].detach()
             alpha_ = s['ALPHA'].transpose(0, 1).detach()
-            with torch.enable_grad():
-                loss_G = -D(tokens, obj_, mot_, att_mask=att_mask, alpha_all=alpha_).mean()
-                g = torch.autograd.grad(loss_G, tokens)[0]
+            loss_G, g = self._generator_term(tokens, obj_, mot_, att_mask, alpha_)
             out['loss_G'] = loss_G.detach()
             out['cap_loss_dev'] = sv['loss_dev']
             # the reference updates lambda from the caption loss of THIS step before using it (run_gun.py:210,224)

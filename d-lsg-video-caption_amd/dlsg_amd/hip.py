@@ -159,7 +159,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
-           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd']
+           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2']
 
 
 def load_library(path=LIB_PATH):
@@ -200,6 +200,9 @@ def load_library(path=LIB_PATH):
         'dlsg_copy2d': [vp, i64, vp, i64, i32, i32, i32, vp],
         'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp, vp],
         'dlsg_fill': [vp, i64, f32, vp],
+        'dlsg_lstm_cell_fwd': [vp, i64, vp, vp, vp, i32, i32, vp],
+        'dlsg_lstm_cell_bwd': [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp],
+        'dlsg_lstm_cell_bwd2': [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
         'dlsg_ce_ragged': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         'dlsg_log_softmax': [vp, vp, i32, i32, vp],
         'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
@@ -770,6 +773,30 @@ class HipOps(object):
     def fill(self, t, value):
         assert t.is_contiguous()
         self._check(self.lib.dlsg_fill(_p(t), i64(t.numel()), f32(value), self._stream()), 'fill')
+
+    # ------------------------------------------------------------------ critic LSTM cell (three differentiation levels)
+    def lstm_cell_fwd(self, a, c_prev, h, c):
+        """a (n, 4H) rows strided, c_prev / h / c (n, H) dense: (h, c) = LSTM cell pointwise, gates i,f,g,o"""
+        n, H = c_prev.shape
+        _chk2(a); _chkc(c_prev); _chkc(h); _chkc(c)
+        self._check(self.lib.dlsg_lstm_cell_fwd(_p(a), i64(a.stride(0)), _p(c_prev), _p(h), _p(c), n, H, self._stream()),
+                    'lstm_cell_fwd')
+
+    def lstm_cell_bwd(self, a, c_prev, dh, dc, da, dc_prev):
+        n, H = c_prev.shape
+        _chk2(a)
+        for t in (c_prev, dh, dc, da, dc_prev):
+            _chkc(t)
+        self._check(self.lib.dlsg_lstm_cell_bwd(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh), _p(dc), _p(da), _p(dc_prev), n, H,
+                                                self._stream()), 'lstm_cell_bwd')
+
+    def lstm_cell_bwd2(self, a, c_prev, dh, dc, u, uc, ga, gc_prev, gdh, gdc):
+        n, H = c_prev.shape
+        _chk2(a)
+        for t in (c_prev, dh, dc, u, uc, ga, gc_prev, gdh, gdc):
+            _chkc(t)
+        self._check(self.lib.dlsg_lstm_cell_bwd2(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh), _p(dc), _p(u), _p(uc), _p(ga),
+                                                 _p(gc_prev), _p(gdh), _p(gdc), n, H, self._stream()), 'lstm_cell_bwd2')
 
     def gather_rows(self, src, idx, dst):
         """dst[r] = src[idx[r]] (2-d views; dst must not alias src)."""

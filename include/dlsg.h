@@ -376,6 +376,20 @@ int dlsg_gather_rows(const float* src, int64_t lds, const int64_t* idx, float* d
 /* dst[b,t,:] = src[t,b,:]: time-major decoder buffers -> the (B,L,V) layout Decoder.forward returns (layer.py:447) */
 int dlsg_permute_tb(const float* src, float* dst, int T, int B, int n, void* stream);
 
+/* ---------------------------------------------------------------- DiscV2 critic
+ * Pointwise part of one step of the critic's nn.LSTM(512, 512) (models/model.py:122,147-150), at the three levels the
+ * WGAN-GP critic update differentiates it (run_gun.py:362-371: gradient penalty with create_graph=True, then loss backward):
+ *   a (rows, 4H) row stride lda = x W_ih^T + h_prev W_hh^T + b, gate order i,f,g,o; every other array dense (rows, H) / (rows, 4H).
+ *   fwd : (h, c) = cell(a, c_prev)
+ *   bwd : (da, dc_prev) = cell'(a, c_prev; dh, dc)
+ *   bwd2: vector-Jacobian product of bwd w.r.t. (a, c_prev, dh, dc) for cotangents (u on da, uc on dc_prev)
+ * The recurrent products stay GEMMs of the caller (dlsg_gemm or the framework's matmul). */
+int dlsg_lstm_cell_fwd(const float* a, int64_t lda, const float* c_prev, float* h, float* c, int rows, int H, void* stream);
+int dlsg_lstm_cell_bwd(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, float* da,
+                       float* dc_prev, int rows, int H, void* stream);
+int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, const float* u,
+                        const float* uc, float* ga, float* gc_prev, float* gdh, float* gdc, int rows, int H, void* stream);
+
 /* ---------------------------------------------------------------- loss + optimizer (run_gun.py:189-198, :91)
  * Ragged CrossEntropy: row (b,t) counts iff t < lens[b]; loss = mean over counted rows; dlogits written for all
  * rows (zeros for padded ones).  row_loss (B*L) is scratch; loss[0] receives the mean.  time_major: logits and

@@ -460,6 +460,40 @@ class EmulOps(object):
     def fill(self, t, value):
         t.fill_(value)
 
+    # ---- critic LSTM cell, three levels (csrc/critic.hip)
+    @staticmethod
+    def _cell(a, cp):
+        ai, af, ag, ao = a.chunk(4, 1)
+        i, f, g, o = torch.sigmoid(ai), torch.sigmoid(af), torch.tanh(ag), torch.sigmoid(ao)
+        c = f * cp + i * g
+        tc = torch.tanh(c)
+        return i, f, g, o, c, tc, 1 - tc * tc
+
+    def lstm_cell_fwd(self, a, c_prev, h, c):
+        i, f, g, o, cc, tc, q = self._cell(a, c_prev)
+        c.copy_(cc); h.copy_(o * tc)
+
+    def lstm_cell_bwd(self, a, c_prev, dh, dc, da, dc_prev):
+        i, f, g, o, cc, tc, q = self._cell(a, c_prev)
+        dct = dc + dh * o * q
+        da.copy_(torch.cat([dct * g * i * (1 - i), dct * c_prev * f * (1 - f), dct * i * (1 - g * g), dh * tc * o * (1 - o)], 1))
+        dc_prev.copy_(dct * f)
+
+    def lstm_cell_bwd2(self, a, c_prev, dh, dc, u, uc, ga, gc_prev, gdh, gdc):
+        i, f, g, o, cc, tc, q = self._cell(a, c_prev)
+        ui, uf, ug, uo = u.chunk(4, 1)
+        si, sf, so, sg = i * (1 - i), f * (1 - f), o * (1 - o), 1 - g * g
+        dct = dc + dh * o * q
+        A = ui * g * si + uf * c_prev * sf + ug * i * sg + uc * f
+        Gc = q * (uo * dh * so - 2 * A * dh * o * tc)
+        ga.copy_(torch.cat([dct * si * (ui * g * (1 - 2 * i) + ug * sg) + Gc * g * si,
+                            dct * sf * (uf * c_prev * (1 - 2 * f) + uc) + Gc * c_prev * sf,
+                            dct * sg * (ui * si - 2 * ug * i * g) + Gc * i * sg,
+                            so * dh * (A * q + uo * tc * (1 - 2 * o))], 1))
+        gc_prev.copy_(dct * uf * sf + Gc * f)
+        gdh.copy_(A * o * q + uo * tc * so)
+        gdc.copy_(A)
+
     def gather_rows(self, src, idx, dst):
         dst.copy_(src[idx])
 

@@ -452,3 +452,38 @@ def test_proposal_and_attention_gradients_reach_the_encoder():
             continue
         err = (grads[1][k] - ref).abs().max().item()
         assert err <= 2e-5 + 2e-4 * ref.abs().max().item(), (k, err)
+
+
+def test_critic_fused_cell_and_conv_follow_the_plain_recurrence():
+    """DiscV2 with the fused LSTM-cell op (emulated kernels: level 0 / 1 / 2 formulas of csrc/critic.hip) against the same
+    critic on plain ATen ops: critic scores, gradient penalty (first derivative) and every parameter gradient of loss_D
+    (second derivative through the penalty) must agree."""
+    import copy
+    from helpers import gan_args
+    from dlsg_amd import gan
+    args = gan_args()
+    torch.manual_seed(5)
+    V, B, L, P = 30, 3, 26, args.num_proposals
+    D0 = dlsg_amd.DiscV2(args, V).double().eval()
+    D1 = copy.deepcopy(D0).set_ops(EmulOps())
+    caps = torch.randint(1, V, (B, L))
+    caps[0, 9:] = 0
+    caps[2, 20:] = 0
+    f_caption = torch.randn(B, L, V, dtype=torch.float64)
+    obj, mot = torch.randn(B, P, 1024, dtype=torch.float64), torch.randn(B, P, 1024, dtype=torch.float64)
+    alpha = torch.rand(B, L, 2 * P, dtype=torch.float64)
+    mask = gan.attention_mask(caps).double()
+    eps = torch.rand(B, 1, 1, dtype=torch.float64)
+    res = []
+    for D in (D0, D1):
+        loss_D, r_loss, f_loss, gp, logits = gan.critic_step_losses(D, caps, f_caption, obj, mot, mask, alpha, eps)
+        loss_D.backward()
+        res.append((loss_D.item(), gp.item(), [x.detach() for x in logits], {k: p.grad.clone() for k, p in D.named_parameters()
+                                                                           if p.grad is not None}))
+    (l0, g0, s0, p0), (l1, g1, s1, p1) = res
+    assert abs(l0 - l1) <= 1e-10 * max(1, abs(l0)) and abs(g0 - g1) <= 1e-10 * max(1, abs(g0)), (l0, l1, g0, g1)
+    for a, b in zip(s0, s1):
+        assert (a - b).abs().max().item() <= 1e-10
+    assert p0.keys() == p1.keys() and 'lstm.weight_hh_l0' in p0
+    for k in p0:
+        assert (p0[k] - p1[k]).abs().max().item() <= 1e-9 * max(1.0, p0[k].abs().max().item()), k

@@ -794,3 +794,19 @@ def test_large_gemm_launches_of_the_step(hip, mode):
         assert (slabs.sum(0) - ref).abs().max().item() <= 1e-3
         for i in (0, 7, 15):
             assert (slabs[i] - dY[i * 160:(i + 1) * 160].t() @ X[i * 160:(i + 1) * 160]).abs().max().item() <= 5e-4
+
+
+@pytest.mark.parametrize('n,H,pad', [(192, 512, 0), (5, 7, 3), (64, 96, 0)])
+def test_critic_lstm_cell_three_levels(hip, n, H, pad):
+    """csrc/critic.hip: cell forward, its backward, and the backward of its backward against the ATen formulas"""
+    def build(g):
+        return dict(a=rnd(g, n, 4 * H + pad), cp=rnd(g, n, H), dh=rnd(g, n, H), dc=rnd(g, n, H), u=rnd(g, n, 4 * H), uc=rnd(g, n, H),
+                    h=torch.zeros(n, H), c=torch.zeros(n, H), da=torch.zeros(n, 4 * H), dcp=torch.zeros(n, H),
+                    ga=torch.zeros(n, 4 * H), gcp=torch.zeros(n, H), gdh=torch.zeros(n, H), gdc=torch.zeros(n, H))
+
+    def run(ops, t):
+        a = t['a'][:, :4 * H]
+        ops.lstm_cell_fwd(a, t['cp'], t['h'], t['c'])
+        ops.lstm_cell_bwd(a, t['cp'], t['dh'], t['dc'], t['da'], t['dcp'])
+        ops.lstm_cell_bwd2(a, t['cp'], t['dh'], t['dc'], t['u'], t['uc'], t['ga'], t['gcp'], t['gdh'], t['gdc'])
+    both(hip, build, run, ['h', 'c', 'da', 'dcp', 'ga', 'gcp', 'gdh', 'gdc'], tol=2e-5, name='critic cell %d x %d' % (n, H))
