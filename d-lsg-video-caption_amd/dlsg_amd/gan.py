@@ -326,17 +326,20 @@ class GanTrainer(object):
 
         it = GanTrainer(model, D); out = it.iteration(frames, regions, captions, cap_lens, tf_ratio, epoch, i)
 
-    `trainer` is the generator's `dlsg_amd.Trainer` (kernel-by-kernel launches: the critic's autograd sits between the
-    generator's forward and backward, so the step is not replayed from a hipGraph)."""
+    `trainer` is the generator's `dlsg_amd.Trainer`; on a GPU its step is two hipGraph replays (forward + CrossEntropy |
+    backward + Adam) with the critic's term between them, and the critic updates / the critic's term are replayed graphs of
+    PyTorch-ROCm launches themselves (use_graphs=False: everything kernel by kernel)."""
 
     def __init__(self, model, D, lr=1.6e-4, betas=(0.5, 0.9), num_D=5, gan_lambda=0.01, total_step=1, cap_list=None,
                  process_group=None, world_size=1, use_graphs=None):
         from .model import Trainer
         self.model, self.D = model, D
-        self.trainer = Trainer(model, lr=lr, betas=betas, process_group=process_group, world_size=world_size, use_graphs=False)
         on_gpu = next(D.parameters()).is_cuda
         # critic updates replayed from a hipGraph (see _critic_graph): needs Adam's step counter on the device
         self.use_graphs = on_gpu if use_graphs is None else (use_graphs and on_gpu)
+        # the generator's step replays forward + CrossEntropy and backward + Adam around the GAN term (Trainer.step)
+        self.trainer = Trainer(model, lr=lr, betas=betas, process_group=process_group, world_size=world_size,
+                               use_graphs=self.use_graphs)
         self.opt_D = torch.optim.Adam(D.parameters(), lr=lr, betas=betas, capturable=self.use_graphs)   # run_gun.py:100
         self.num_D = num_D
         self.lambda_handler = GANLambdaHandler(total_step, gan_lambda, cap_list)

@@ -543,6 +543,7 @@ class Trainer(object):
         self.force_collectives = False  # test hook: issue the all-reduces even with one rank (RCCL path on a 1-GPU box)
         self._works = []
         self._graphs = None
+        self._hook_mode, self._hook_sv = False, None
         self.m = self.v = None
         self._bind()
 
@@ -683,7 +684,9 @@ class Trainer(object):
     def step(self, frames, regions, captions, cap_lens, tf_ratio, max_len=26, extra_dlogits=None):
         """One optimisation step.  Returns the (device) scalar loss of this rank's shard.
         extra_dlogits: optional callable (logits (L,B,V) time-major, saved-state dict) -> (L,B,V) gradient of an additional
-        loss on the logits, added to the CrossEntropy's before the backward (kernel-by-kernel launches only)."""
+        loss on the logits, added to the CrossEntropy's before the backward.  With use_graphs the captured step is cut at
+        that point: forward + CrossEntropy replay, the callable runs (on the graphs' static logits / saved state), its result
+        is copied into a static buffer that the replayed backward adds to the CrossEntropy gradient."""
         model, ops = self.model, self.model.ops
         self._check_binding()
         captions = captions[:, :max_len].contiguous()
@@ -692,8 +695,10 @@ class Trainer(object):
         coins = model._draw_coins(L, False, tf_ratio)
         seed = model.next_seed()
         self.t += 1
-        if self.use_graphs and extra_dlogits is None:
-            return self._step_graphs(frames, regions, captions, cap_lens, coins, seed)
+        hook = extra_dlogits is not None
+        if self.use_graphs and (self._graphs is None or self._hook_mode == hook):
+            return self._step_graphs(frames, regions, captions, cap_lens, coins, seed, extra_dlogits)
+        # (a trainer's graphs are captured for one of the two forms of the step; the other form runs kernel by kernel)
         return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True, extra_dlogits=extra_dlogits)
 
     def _eager_step(self, frames, regions, captions, cap_lens, coins, seed, counted=False, extra_dlogits=None):
@@ -711,9 +716,10 @@ class Trainer(object):
         return loss
 
     # ------------------------------------------------------------------ hipGraph path
-    def _capture(self, frames, regions, captions, cap_lens):
+    def _capture(self, frames, regions, captions, cap_lens, hook=False):
         dev = frames.device
         L = captions.shape[1]
+        self._hook_mode, self._hook_sv = hook, None
         st = self._static = dict(frames=frames.clone(), regions=regions.clone(), captions=captions.clone(),
                                  lens=cap_lens.clone(), coins=torch.ones(L, dtype=torch.int32, device=dev),
                                  seed=torch.zeros(1, dtype=torch.int64, device=dev),
@@ -731,15 +737,30 @@ class Trainer(object):
             cur = [torch.cuda.CUDAGraph()]
             cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
             try:
-                def cut(key):
-                    if not cuts:
-                        return
+                def hard_cut(key, between=None):
                     cur[0].capture_end()
                     graphs.append((cur[0], key))
+                    if between is not None:
+                        between()
                     cur[0] = torch.cuda.CUDAGraph()
                     cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
 
-                loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut)
+                def cut(key):
+                    if cuts:
+                        hard_cut(key)
+
+                def placeholder(logits, sv):
+                    # the graphs end here and resume after the caller's term: what it will read (logits, saved state, the
+                    # loss) lives in the graphs' pool, what it returns is copied into st['extra'] before the next replay
+                    # (allocated BETWEEN the two captures: inside one, its zero fill would be replayed over the copy)
+                    def alloc():
+                        st['extra'] = torch.zeros_like(logits)
+                    hard_cut('hook', alloc)
+                    self._hook_sv = (logits, sv)
+                    return st['extra']
+
+                loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut,
+                                      placeholder if hook else None)
                 if not cuts or (self.world_size <= 1 and not self.force_collectives):
                     # no collective between backward and update: Adam is part of the (last) graph; with several ranks it
                     # follows the all-reduce waits
@@ -770,24 +791,25 @@ class Trainer(object):
         st = self._static
         return st['frames'], st['regions'], st['captions'], st['lens']
 
-    def _step_graphs(self, frames, regions, captions, cap_lens, coins, seed):
+    def _step_graphs(self, frames, regions, captions, cap_lens, coins, seed, extra_dlogits=None):
         model, ops = self.model, self.model.ops
+        hook = extra_dlogits is not None
         if self._graphs is None:
             if not self.graph_fallback:
-                self._capture(frames, regions, captions, cap_lens)
+                self._capture(frames, regions, captions, cap_lens, hook)
             else:
                 try:
-                    self._capture(frames, regions, captions, cap_lens)
+                    self._capture(frames, regions, captions, cap_lens, hook)
                 except RuntimeError as e:   # opted in: keep the run alive on kernel-by-kernel launches
                     import warnings
                     warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
                     torch.cuda.synchronize()
                     self.use_graphs, self._graphs = False, None
-                    return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
+                    return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True, extra_dlogits=extra_dlogits)
         st = self._static
         if (frames.shape, regions.shape, captions.shape) != (st['frames'].shape, st['regions'].shape, st['captions'].shape):
             # a batch of another shape (the short last batch of an epoch): the captured graphs are for one shape only
-            return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True)
+            return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True, extra_dlogits=extra_dlogits)
         for k, src in (('frames', frames), ('regions', regions), ('captions', captions), ('lens', cap_lens)):
             if src.data_ptr() != st[k].data_ptr():
                 st[k].copy_(src, non_blocking=True)
@@ -797,7 +819,10 @@ class Trainer(object):
         self._works = []
         for g, key in self._graphs:
             g.replay()
-            if key is not None:
+            if key == 'hook':
+                res = extra_dlogits(*self._hook_sv)
+                st['extra'].copy_(res)
+            elif key is not None:
                 self._allreduce(key)
         if not self._adam_in_graph:
             for w in self._works:

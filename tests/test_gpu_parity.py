@@ -507,6 +507,32 @@ def test_graph_trainer_follows_lr_changes_and_resumes_from_torch_adam_state():
     assert torch.equal(net._flat, net2._flat)
 
 
+def test_graph_trainer_with_an_extra_logit_gradient_matches_eager():
+    """Trainer.step(extra_dlogits=...) in graph mode (forward + CrossEntropy | the caller's term | backward + Adam): the term
+    sees the logits / loss / attention weights of THIS step and its result reaches the backward -- equal to the kernel-by-
+    kernel step over several steps with scheduled sampling and changing terms; a step without the term falls back to eager."""
+    res = []
+    for use_graphs in (True, False):
+        net, g, frames, regions, caps, lens, kind = build('small_msvd')
+        net.train()
+        tr = dlsg_amd.Trainer(net, use_graphs=use_graphs)
+        random.seed(7)
+        seen = []
+        for k in range(4):
+            def term(logits_tm, sv, k=k):
+                seen.append((float(sv['loss_dev']), float(logits_tm.abs().sum()), float(sv['dec']['ALPHA'].sum())))
+                return (0.02 * (k + 1)) * torch.tanh(logits_tm) / logits_tm.shape[1]
+            loss = tr.step(frames, regions, caps, lens, 0.7, extra_dlogits=term)
+            seen.append(float(loss))
+        if use_graphs:
+            assert tr._graphs is not None and [key for _, key in tr._graphs] == ['hook', None]
+        tr.step(frames, regions, caps, lens, 0.7)                      # the other form of the step: eager on this trainer
+        res.append((net._flat.clone(), seen))
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 3e-6
+    for a, b in zip(res[0][1], res[1][1]):
+        assert np.allclose(a, b, rtol=2e-5, atol=1e-6), (a, b)
+
+
 def test_load_encoder_grafts_and_freezes_word_embedding(tmp_path):
     """models/model.py:45-53 on the GPU: graft + one optimisation step (eager and hipGraph) leaves the frozen word embedding
     bit-unchanged and equals the oracle doing the same with torch.optim.Adam."""

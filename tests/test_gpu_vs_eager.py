@@ -72,3 +72,63 @@ def test_train_step_throughput_vs_pytorch_rocm_eager():
     except OSError:
         pass
     assert out['speedup_fp32'] >= 1.5, out
+
+
+def test_gan_iteration_throughput_vs_pytorch_rocm_eager():
+    """One RunGAN iteration (run_gun.py:147-234: no-grad generator forward, 5 critic updates with gradient penalty, generator
+    step with the GAN term) at batch 64, MSVD-shaped: the oracle's restatement of the reference stepped by PyTorch-ROCm eager
+    (cuDNN/MIOpen RNN off, as train_debug.py:53 does for the double backward) against dlsg_amd.GanTrainer."""
+    from oracle import torch_ref as R
+    from oracle import gan_ref
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    B, V, num_D = 64, 1000, 5
+    args = dlsg_amd.msvd_shaped(use_visual_gan=True)
+    vocab = dlsg_amd.make_vocab(V)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab)
+    sd = synth_state_dict(net.state_dict(), 0)
+    frames, regions, caps, lens = synth_batch(args, V, B, 1)
+    frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
+    critic = dlsg_amd.DiscV2(args, V)
+    dsd = {k: v.clone() for k, v in critic.state_dict().items()}
+
+    eager = R.CapGnnModelRef(args, vocab)
+    eager.load_state_dict(sd)
+    eager = eager.cuda().train()
+    Dref = gan_ref.DiscV2Ref(args, V)
+    Dref.load_state_dict(dsd)
+    Dref = Dref.cuda().train()
+    opt_G = R.make_optimizer(eager)
+    opt_D = torch.optim.Adam(Dref.parameters(), lr=1.6e-4, betas=(0.5, 0.9))
+    random.seed(3)
+    eps = [torch.rand(B, 1, 1, device='cuda') for _ in range(num_D)]
+    with torch.backends.cudnn.flags(enabled=False):
+        ms_eager = _time(lambda: gan_ref.gan_iteration(eager, Dref, opt_G, opt_D, frames, regions, caps, lens, 1.0, 0.01, num_D, eps),
+                         1, 3)
+    del eager, Dref, opt_G, opt_D
+    torch.cuda.empty_cache()
+
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    critic = critic.cuda().train()
+    it = dlsg_amd.GanTrainer(net, critic, num_D=num_D, total_step=100)
+    random.seed(3)
+    k = [0]
+
+    def step():
+        k[0] += 1
+        it.iteration(frames, regions, caps, lens, 1.0, 0, k[0])
+    ms = _time(step, 3, 8)
+    out = {'workload': 'RunGAN iteration (generator forward, 5 critic updates with gradient penalty, generator step), '
+                       'MSVD-shaped, batch 64, fp32', 'pytorch_rocm_eager_ms': round(ms_eager, 1), 'hip_ms': round(ms, 1),
+           'pytorch_rocm_eager_clips_per_s': round(B / ms_eager * 1e3, 1), 'hip_clips_per_s': round(B / ms * 1e3, 1),
+           'speedup': round(ms_eager / ms, 2)}
+    print(json.dumps(out))
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'gan_vs_eager.json'), 'w') as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        pass
+    assert out['speedup'] >= 1.5, out
