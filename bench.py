@@ -128,6 +128,70 @@ def gpu_eager_baseline(dev, batch, steps=4, warmup=2):
                     'tf eps %.3f' % (torch.__version__, batch, eps)}
 
 
+def gan_iteration_leg(dev, batch, with_eager=True, iters=6):
+    """SURVEY.md 8(f) rank 1, what train_debug.py really trains: one RunGAN iteration (run_gun.py:147-234 -- no-grad generator
+    forward, 5 critic updates with gradient penalty, generator step with the GAN term) at the bench shape.  The generator runs
+    on the HIP path, the DiscV2 critic on PyTorch-ROCm launches replayed from hipGraphs (dlsg_amd/gan.py); the comparator is
+    the oracle's restatement of the reference (oracle/gan_ref.py, kind 'port') stepped by PyTorch-ROCm eager."""
+    import dlsg_amd
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    V, num_D = 1000, 5
+    args = dlsg_amd.msvd_shaped(use_visual_gan=True)
+    vocab = dlsg_amd.make_vocab(V)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab)
+    sd = synth_state_dict(net.state_dict(), 0)
+    net.load_state_dict(sd)
+    critic = dlsg_amd.DiscV2(args, V)
+    dsd = {k: v.clone() for k, v in critic.state_dict().items()}
+    frames, regions, caps, lens = synth_batch(args, V, batch, 1)
+    frames, regions, caps = frames.to(dev), regions.to(dev), caps.to(dev)
+    eps = dlsg_amd.ss_epsilon(0)
+    net, critic = net.to(dev).train(), critic.to(dev).train()
+    it = dlsg_amd.GanTrainer(net, critic, num_D=num_D, total_step=100)
+    random.seed(12)
+    for i in range(3):
+        it.iteration(frames, regions, caps, lens, eps, 0, i + 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        it.iteration(frames, regions, caps, lens, eps, 0, i + 4)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    out = {'what': 'RunGAN iteration: no-grad generator forward + %d critic updates (WGAN-GP) + generator step with the GAN term; '
+                   'MSVD-shaped, batch %d, fp32' % (num_D, batch), 'ms_per_iteration': round(ms, 2),
+           'clips_per_s': round(batch / ms * 1e3, 1), 'iterations': iters}
+    del it, net, critic
+    torch.cuda.empty_cache()
+    if with_eager:
+        from oracle import torch_ref as R
+        from oracle import gan_ref
+        eager = R.CapGnnModelRef(args, vocab)
+        eager.load_state_dict(sd)
+        eager = eager.to(dev).train()
+        Dref = gan_ref.DiscV2Ref(args, V)
+        Dref.load_state_dict(dsd)
+        Dref = Dref.to(dev).train()
+        opt_G = R.make_optimizer(eager)
+        opt_D = torch.optim.Adam(Dref.parameters(), lr=1.6e-4, betas=(0.5, 0.9))
+        eps_gp = [torch.rand(batch, 1, 1, device=dev) for _ in range(num_D)]
+        random.seed(12)
+        with torch.backends.cudnn.flags(enabled=False):           # train_debug.py:53: the fused RNN has no double backward
+            gan_ref.gan_iteration(eager, Dref, opt_G, opt_D, frames, regions, caps, lens, eps, 0.01, num_D, eps_gp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                gan_ref.gan_iteration(eager, Dref, opt_G, opt_D, frames, regions, caps, lens, eps, 0.01, num_D, eps_gp)
+            torch.cuda.synchronize()
+        ems = (time.perf_counter() - t0) / 3 * 1e3
+        out['vs_pytorch_rocm_eager'] = {'ms_per_iteration': round(ems, 1), 'clips_per_s': round(batch / ems * 1e3, 1),
+                                        'speedup': round(ems / ms, 2), 'kind': 'port',
+                                        'what': 'oracle/torch_ref.py + oracle/gan_ref.py modules on cuda:0, torch %s eager' % torch.__version__}
+        del eager, Dref, opt_G, opt_D
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -144,6 +208,7 @@ def main():
     ap.add_argument('--no-eager-baseline', action='store_true', help='skip the PyTorch-ROCm eager comparator leg')
     ap.add_argument('--no-batch128', action='store_true', help='skip the extra N = 1 measurement at 128 clips per GPU')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
+    ap.add_argument('--no-gan', action='store_true', help='skip the GAN-iteration leg (SURVEY.md 8f rank 1)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -373,6 +438,8 @@ def main():
             eb = gpu_eager_baseline(dev, a.batch)
             eb['speedup'] = round(out['value'] / eb['clips_per_s'], 2)
             out['vs_pytorch_rocm_eager'] = eb
+        if world == 1 and not a.no_gan and a.shape == 'msvd' and a.gemm == 'fp32' and not a.no_graphs:
+            out['gan_iteration'] = gan_iteration_leg(dev, a.batch, with_eager=not a.no_eager_baseline)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         out['dtype_note'] = {'fp32': 'all products on fp32-input MFMA (exact fp32)',
