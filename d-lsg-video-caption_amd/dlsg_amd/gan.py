@@ -349,6 +349,12 @@ class GanTrainer(object):
         self.eps_source = None              # tests: callable(k) -> (B,1,1) tensor instead of torch.rand
         self._cg, self._cg_seen = {}, set()
 
+    def reset_graphs(self):
+        """Drop the captured critic graphs (they hold the Adam state tensors they were captured with: after
+        `opt_D.load_state_dict` those are no longer the optimizer's)."""
+        self._cg.clear()
+        self._cg_seen.clear()
+
     def _allreduce_D(self):
         if self.world_size > 1:
             import torch.distributed as dist
@@ -503,6 +509,7 @@ def load_checkpoint(path, gan, map_location=None):
     gan.trainer.load_optimizer_state_dict(ck['optimizer_state_dict'])
     gan.D.load_state_dict(ck['model_d_state_dict'])
     gan.opt_D.load_state_dict(ck['optimizer_d_state_dict'])
+    gan.reset_graphs()
     h = gan.lambda_handler
     gan.lambda_handler = GANLambdaHandler(h.total_step, h.start_gan_lambda, cap_list=ck['cap_list'])
     return ck['epoch']

@@ -124,3 +124,40 @@ def test_graph_replayed_critic_updates_match_eager_updates():
     for a, b in zip(pa, pb):
         d = (a - b).abs()
         assert d.max().item() <= 8 * 2 * 1.6e-4 and (d > 2e-6).float().mean().item() <= 5e-3, (d.max().item(), (d > 2e-6).float().mean().item())
+
+
+def test_checkpoint_reload_drops_the_captured_critic_graphs(tmp_path):
+    """`opt_D.load_state_dict` installs new state tensors: graphs captured before would keep updating the old ones.  A trainer
+    that reloads its own checkpoint must continue exactly like a fresh trainer that loads it."""
+    import copy
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case('gan_msvd', dlsg_amd.CapGnnModel, dlsg_amd.DiscV2)
+    G, D = G.cuda(), D.cuda().eval()
+    frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
+    eps = torch.rand(2, caps.shape[0], 1, 1, generator=torch.Generator().manual_seed(5)).cuda()
+    a = dlsg_amd.GanTrainer(G, D, num_D=2)
+    a.eps_source = lambda k: eps[k]
+    import random
+    random.seed(1)
+    for i in range(3):
+        a.iteration(frames, regions, caps, lens, 1.0, 0, i + 1)
+    assert a._cg                                                        # critic updates are replayed by now
+    path = str(tmp_path / 'ck.pt')
+    dlsg_amd.save_checkpoint(path, 0, a)
+    G2 = dlsg_amd.CapGnnModel(args, vocab).cuda().train(G.training)
+    D2 = dlsg_amd.DiscV2(args, len(vocab)).cuda().eval()
+    b = dlsg_amd.GanTrainer(G2, D2, num_D=2)
+    b.eps_source = a.eps_source
+    G2.seed_counter = G.seed_counter
+    dlsg_amd.load_checkpoint(path, b)
+    dlsg_amd.load_checkpoint(path, a)
+    assert not a._cg
+    outs = []
+    for t in (a, b):
+        random.seed(2)
+        outs.append([t.iteration(frames, regions, caps, lens, 1.0, 0, 4 + i) for i in range(2)])
+    for x, y in zip(*outs):
+        for k in ('cap_loss', 'loss_G', 'loss_D', 'wasserstein'):
+            assert abs(x[k] - y[k]) <= 2e-5 * max(1.0, abs(x[k])), (k, x, y)
+    for (k, p), (_, q) in zip(D.named_parameters(), D2.named_parameters()):
+        d = (p - q).abs()
+        assert d.max().item() <= 4 * 2 * 1.6e-4 and (d > 2e-6).float().mean().item() <= 5e-3, k
