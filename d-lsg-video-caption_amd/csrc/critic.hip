@@ -97,6 +97,220 @@ __global__ __launch_bounds__(256) void cell_bwd2_kernel(const float* __restrict_
     gdc[idx] = A;
 }
 
+// ------------------------------------------------------------------------------------------------ (tanh +) LayerNorm, three levels
+// y = LN(t) gamma + beta over rows of N, t = tanh(x) or x -- the nine normalisations of the critic (models/model.py:124-131,
+// layer.py:661-689).  On ATen ops one instance costs ~85 launches across forward, backward and the backward of the backward
+// (the double backward of native_layer_norm_backward is a ~40-op composite): ~770 of a critic update's ~2 000.  Here:
+//   level 0  y
+//   level 1  (dx, dgamma, dbeta) from dy:        a = dy gamma, m1 = mean(a), m2 = mean(a n), dt = r (a - m1 - n m2), dx = dt s
+//   level 2  (gx, ggamma, gdy) from cotangents (U on dx, vg on dgamma, vb on dbeta):
+//            W = U s, w1 = mean(W), w2 = mean(W n), core = r (W - w1 - n w2)
+//            gdy = gamma core + vg n + vb;   ggamma = sum_rows dy core
+//            Q = sum(W dt) / r,  Pn = -r (W m2 + a w2) + vg dy,  p1 = mean(Pn), p2 = mean(Pn n)
+//            gx = s [ r (Pn - p1 - n p2) - Q r^2 n / N  - 2 t U dt ]        (last term only with the tanh)
+// with n = (t - mean t) r, r = rsqrt(var t + eps), s = 1 - t^2 (1 without the tanh).  One wave per row (N = 64 E, E <= 16,
+// lane l holds columns l + 64 e: coalesced), statistics recomputed from x at every level; column sums (dgamma, dbeta,
+// ggamma) are per-workgroup partials in a caller workspace, summed in a fixed order by a second launch.
+constexpr int LN_MAXE = 16;
+
+struct RowStats {
+    float mu, r;
+};
+template <bool TANH, int EMAX>
+__device__ __forceinline__ RowStats load_row(const float* __restrict__ xr, int E, int lane, float eps, float (&t)[EMAX]) {
+    float sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e)
+        if (e < E) {
+            const float v = xr[lane + 64 * e];
+            t[e] = TANH ? tanhf(v) : v;
+            sum += t[e];
+        }
+    const float inv = 1.f / (64.f * E);
+    const float mu = dlsg::wave_sum(sum) * inv;
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e)
+        if (e < E) sq += (t[e] - mu) * (t[e] - mu);
+    RowStats st;
+    st.mu = mu;
+    st.r = rsqrtf(dlsg::wave_sum(sq) * inv + eps);
+    return st;
+}
+
+template <bool TANH, int EMAX>
+__global__ __launch_bounds__(256) void tanh_ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y, int rows, int E,
+                                                          float eps) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, N = 64 * E;
+    float t[EMAX];
+    for (int row = gw; row < rows; row += nw) {
+        const RowStats st = load_row<TANH, EMAX>(x + (int64_t)row * N, E, lane, eps, t);
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) {
+                const int j = lane + 64 * e;
+                y[(int64_t)row * N + j] = (t[e] - st.mu) * st.r * gamma[j] + beta[j];
+            }
+    }
+}
+
+template <bool TANH, int EMAX>
+__global__ __launch_bounds__(256) void tanh_ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ part, int rows, int E, float eps) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, N = 64 * E;
+    float t[EMAX], gam[EMAX], pg[EMAX], pb[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        pg[e] = pb[e] = 0.f;
+        gam[e] = e < E ? gamma[lane + 64 * e] : 0.f;
+    }
+    for (int row = gw; row < rows; row += nw) {
+        const RowStats st = load_row<TANH, EMAX>(x + (int64_t)row * N, E, lane, eps, t);
+        float a[EMAX], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) {
+                const float d = dy[(int64_t)row * N + lane + 64 * e];
+                const float n = (t[e] - st.mu) * st.r;
+                a[e] = d * gam[e];
+                s1 += a[e];
+                s2 += a[e] * n;
+                pg[e] += d * n;
+                pb[e] += d;
+            }
+        const float inv = 1.f / (64.f * E);
+        const float m1 = dlsg::wave_sum(s1) * inv, m2 = dlsg::wave_sum(s2) * inv;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) {
+                const float n = (t[e] - st.mu) * st.r;
+                const float dt = st.r * (a[e] - m1 - n * m2);
+                dx[(int64_t)row * N + lane + 64 * e] = TANH ? dt * (1.f - t[e] * t[e]) : dt;
+            }
+    }
+    // per-workgroup column partials: the four waves' sums meet in LDS, one (N)-row per quantity and workgroup leaves
+    __shared__ float red[2][4][64 * EMAX];
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e)
+        if (e < E) {
+            red[0][w][lane + 64 * e] = pg[e];
+            red[1][w][lane + 64 * e] = pb[e];
+        }
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += 256) {
+        part[(int64_t)blockIdx.x * N + j] = (red[0][0][j] + red[0][1][j]) + (red[0][2][j] + red[0][3][j]);
+        part[((int64_t)gridDim.x + blockIdx.x) * N + j] = (red[1][0][j] + red[1][1][j]) + (red[1][2][j] + red[1][3][j]);
+    }
+}
+
+template <bool TANH, int EMAX>
+__global__ __launch_bounds__(256) void tanh_ln_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ dy, const float* __restrict__ U,
+                                                           const float* __restrict__ vg, const float* __restrict__ vb,
+                                                           float* __restrict__ gx, float* __restrict__ gdy,
+                                                           float* __restrict__ part, int rows, int E, float eps) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, N = 64 * E;
+    float t[EMAX], gam[EMAX], vgl[EMAX], vbl[EMAX], pgg[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        pgg[e] = 0.f;
+        gam[e] = e < E ? gamma[lane + 64 * e] : 0.f;
+        vgl[e] = e < E ? vg[lane + 64 * e] : 0.f;
+        vbl[e] = e < E ? vb[lane + 64 * e] : 0.f;
+    }
+    const float inv = 1.f / (64.f * E);
+    for (int row = gw; row < rows; row += nw) {
+        const RowStats st = load_row<TANH, EMAX>(x + (int64_t)row * N, E, lane, eps, t);
+        float d[EMAX], W[EMAX], Uv[EMAX], s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) {
+                const int64_t o = (int64_t)row * N + lane + 64 * e;
+                d[e] = dy[o];
+                const float u = Uv[e] = U[o];
+                const float n = (t[e] - st.mu) * st.r, a = d[e] * gam[e];
+                W[e] = TANH ? u * (1.f - t[e] * t[e]) : u;
+                s1 += a;
+                s2 += a * n;
+                s3 += W[e];
+                s4 += W[e] * n;
+            }
+        const float m1 = dlsg::wave_sum(s1) * inv, m2 = dlsg::wave_sum(s2) * inv;
+        const float w1 = dlsg::wave_sum(s3) * inv, w2 = dlsg::wave_sum(s4) * inv;
+        float Pn[EMAX], q = 0.f, s5 = 0.f, s6 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) {
+                const float n = (t[e] - st.mu) * st.r, a = d[e] * gam[e];
+                const float dt = st.r * (a - m1 - n * m2);
+                q += W[e] * dt;
+                Pn[e] = -st.r * (W[e] * m2 + a * w2) + vgl[e] * d[e];
+                s5 += Pn[e];
+                s6 += Pn[e] * n;
+                const float core = st.r * (W[e] - w1 - n * w2);
+                gdy[(int64_t)row * N + lane + 64 * e] = gam[e] * core + vgl[e] * n + vbl[e];
+                pgg[e] += d[e] * core;
+            }
+        const float Q = dlsg::wave_sum(q) / st.r, p1 = dlsg::wave_sum(s5) * inv, p2 = dlsg::wave_sum(s6) * inv;
+#pragma unroll
+        for (int e = 0; e < EMAX; ++e)
+            if (e < E) {
+                const float n = (t[e] - st.mu) * st.r;
+                float G = st.r * (Pn[e] - p1 - n * p2) - Q * st.r * st.r * n * inv;
+                if (TANH) {
+                    const float s = 1.f - t[e] * t[e];
+                    const float a = d[e] * gam[e];
+                    const float dt = st.r * (a - m1 - n * m2);
+                    G = (G - 2.f * t[e] * Uv[e] * dt) * s;
+                }
+                gx[(int64_t)row * N + lane + 64 * e] = G;
+            }
+    }
+    __shared__ float red[4][64 * EMAX];
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e)
+        if (e < E) red[w][lane + 64 * e] = pgg[e];
+    __syncthreads();
+    for (int j = threadIdx.x; j < N; j += 256)
+        part[(int64_t)blockIdx.x * N + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+}
+
+// out_k[j] = sum_w part[k][w][j], w in order (deterministic); grid (N / 64, K)
+__global__ __launch_bounds__(256) void ln_colsum_kernel(const float* __restrict__ part, int nw, int N, float* __restrict__ o0,
+                                                        float* __restrict__ o1) {
+    __shared__ float red[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
+    const float* p = part + (int64_t)blockIdx.y * nw * N;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int w = q;
+    for (; w + 28 < nw; w += 32) {                       // 8 independent loads in flight per thread
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += p[(int64_t)(w + 4 * u) * N + j];
+    }
+    for (; w < nw; w += 4) acc[0] += p[(int64_t)w * N + j];
+    red[q][c] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (q == 0) (blockIdx.y == 0 ? o0 : o1)[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+inline int ln_blocks(int rows) { return rows < 2048 ? (rows + 3) / 4 : 512; }
+
+// rows of up to 512 columns keep 8 values per lane in registers, wider ones 16
+#define LN_DISPATCH(KERNEL, ...)                                                                                    \
+    do {                                                                                                            \
+        if (N <= 512) {                                                                                             \
+            if (pre_tanh) hipLaunchKernelGGL((KERNEL<true, 8>), grid, block, 0, ST(stream), __VA_ARGS__);           \
+            else hipLaunchKernelGGL((KERNEL<false, 8>), grid, block, 0, ST(stream), __VA_ARGS__);                   \
+        } else {                                                                                                    \
+            if (pre_tanh) hipLaunchKernelGGL((KERNEL<true, 16>), grid, block, 0, ST(stream), __VA_ARGS__);          \
+            else hipLaunchKernelGGL((KERNEL<false, 16>), grid, block, 0, ST(stream), __VA_ARGS__);                  \
+        }                                                                                                           \
+    } while (0)
+
 inline hipStream_t ST(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
@@ -124,6 +338,40 @@ extern "C" int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_p
     if (rows == 0) return DLSG_OK;
     hipLaunchKernelGGL(cell_bwd2_kernel, dim3((rows * H + 255) / 256), dim3(256), 0, ST(stream), a, lda, c_prev, dh, dc, u, uc, ga,
                        gc_prev, gdh, gdc, rows, H);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+extern "C" int64_t dlsg_tanh_ln_ws_floats(int rows, int N) { return (int64_t)2 * ln_blocks(rows) * N; }
+
+extern "C" int dlsg_tanh_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int N, float eps,
+                                int pre_tanh, void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || N < 64 || N % 64 || N > 64 * LN_MAXE) return DLSG_EINVAL;
+    if (rows == 0) return DLSG_OK;
+    const dim3 grid(ln_blocks(rows)), block(256);
+    LN_DISPATCH(tanh_ln_fwd_kernel, x, gamma, beta, y, rows, N / 64, eps);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_tanh_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
+                                float* ws, int rows, int N, float eps, int pre_tanh, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !ws || rows < 1 || N < 64 || N % 64 || N > 64 * LN_MAXE) return DLSG_EINVAL;
+    const int nb = ln_blocks(rows);
+    const dim3 grid(nb), block(256);
+    LN_DISPATCH(tanh_ln_bwd_kernel, x, gamma, dy, dx, ws, rows, N / 64, eps);
+    hipLaunchKernelGGL(ln_colsum_kernel, dim3(N / 64, 2), block, 0, ST(stream), ws, nb, N, dgamma, dbeta);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_tanh_ln_bwd2(const float* x, const float* gamma, const float* dy, const float* U, const float* vg, const float* vb,
+                                 float* gx, float* ggamma, float* gdy, float* ws, int rows, int N, float eps, int pre_tanh,
+                                 void* stream) {
+    if (!x || !gamma || !dy || !U || !vg || !vb || !gx || !ggamma || !gdy || !ws || rows < 1 || N < 64 || N % 64 || N > 64 * LN_MAXE)
+        return DLSG_EINVAL;
+    const int nb = ln_blocks(rows);
+    const dim3 grid(nb), block(256);
+    LN_DISPATCH(tanh_ln_bwd2_kernel, x, gamma, dy, U, vg, vb, gx, gdy, ws, rows, N / 64, eps);
+    hipLaunchKernelGGL(ln_colsum_kernel, dim3(N / 64, 1), block, 0, ST(stream), ws, nb, N, ggamma, ggamma);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

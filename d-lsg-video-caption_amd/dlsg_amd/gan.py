@@ -65,8 +65,12 @@ class _ProposalScore(nn.Module):
         self.select = num_psl > num_top
 
 
-def _tanh_ln(x, ln):
-    return F.layer_norm(torch.tanh(x), ln.normalized_shape, ln.weight, ln.bias, ln.eps)
+def _tanh_ln(x, ln, ops=None, pre_tanh=True):
+    """LayerNorm(tanh(x)) (or LayerNorm(x)); with a kernel interface and a 64..1024-wide row, the fused three-level op"""
+    N = x.shape[-1]
+    if ops is not None and N % 64 == 0 and N <= 1024 and (x.dtype == torch.float32 or getattr(ops, 'name', '') != 'hip'):
+        return _TanhLN.apply(ops, x, ln.weight, ln.bias, ln.eps, pre_tanh)
+    return F.layer_norm(torch.tanh(x) if pre_tanh else x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
 
 
 def _dropout(x, p, on):
@@ -118,6 +122,45 @@ class _LstmCellBwd(torch.autograd.Function):
         ga, gcp, gdh, gdc = torch.empty_like(a), torch.empty_like(c_prev), torch.empty_like(c_prev), torch.empty_like(c_prev)
         ctx.ops.lstm_cell_bwd2(a, c_prev, dh, dc, u.contiguous(), uc.contiguous(), ga, gcp, gdh, gdc)
         return None, ga, gcp, gdh, gdc
+
+
+class _TanhLN(torch.autograd.Function):
+    """y = LayerNorm(tanh(x) or x): one HIP launch per differentiation level (csrc/critic.hip) instead of ~85 ATen launches
+    per instance across forward, backward and the backward of the backward."""
+
+    @staticmethod
+    def forward(ctx, ops, x, gamma, beta, eps, pre_tanh):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y = torch.empty_like(x2)
+        ops.tanh_ln_fwd(x2, gamma.contiguous(), beta.contiguous(), y, eps, pre_tanh)
+        ctx.ops, ctx.eps, ctx.pre_tanh = ops, eps, pre_tanh
+        ctx.save_for_backward(x, gamma)          # the INPUT itself: a reshaped copy made in here has no history, and the
+        return y.view(x.shape)                   # backward of the backward must reach x through it
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        dx, dg, db = _TanhLNBwd.apply(ctx.ops, x2, gamma, dy.reshape(x2.shape).contiguous(), ctx.eps, ctx.pre_tanh)
+        return None, dx.view(x.shape), dg, db, None, None
+
+
+class _TanhLNBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, x2, gamma, dy, eps, pre_tanh):
+        dx, dg, db = torch.empty_like(x2), torch.empty_like(gamma), torch.empty_like(gamma)
+        g = gamma.contiguous()
+        ops.tanh_ln_bwd(x2, g, dy, dx, dg, db, eps, pre_tanh)
+        ctx.ops, ctx.eps, ctx.pre_tanh = ops, eps, pre_tanh
+        ctx.save_for_backward(x2, g, dy)
+        return dx, dg, db
+
+    @staticmethod
+    def backward(ctx, U, vg, vb):
+        x2, g, dy = ctx.saved_tensors
+        gx, gg, gdy = torch.empty_like(x2), torch.empty_like(g), torch.empty_like(dy)
+        ctx.ops.tanh_ln_bwd2(x2, g, dy, U.contiguous(), vg.contiguous(), vb.contiguous(), gx, gg, gdy, ctx.eps, ctx.pre_tanh)
+        return None, gx, gg, gdy, None, None
 
 
 class DiscV2(nn.Module):
@@ -201,14 +244,15 @@ class DiscV2(nn.Module):
     def _proposal_score(self, m, psl, alpha, words, word_mask):
         """PSLScore2.forward (layer.py:690-715): words (n,L,512) attended by the (top-k) proposals"""
         n = psl.shape[0]
-        e = _tanh_ln(m.psl_embed[0](psl), m.psl_embed[2])
+        ops = self._cell_ops(psl)
+        e = _tanh_ln(m.psl_embed[0](psl), m.psl_embed[2], ops)
         if m.select:
             top = alpha.sum(dim=1).topk(m.num_top, dim=-1).indices
             e = e.gather(1, top.unsqueeze(-1).expand(n, m.num_top, WIDTH))
-        a = _tanh_ln(m.att_norm[0](words), m.att_norm[2])
+        a = _tanh_ln(m.att_norm[0](words), m.att_norm[2], ops)
         adj = torch.softmax(a @ e.transpose(1, 2) / math.sqrt(WIDTH), dim=1) * word_mask       # mask after the softmax (:703-704)
         weight = adj.sum(dim=1)
-        agg = _dropout(_tanh_ln(adj.transpose(1, 2) @ a, m.psl_norm[1]), 0.3, self.training)
+        agg = _dropout(_tanh_ln(adj.transpose(1, 2) @ a, m.psl_norm[1], ops), 0.3, self.training)
         sc = m.psl_scorer
         pair = sc.classify(torch.tanh(sc.visual_embed[0](e)) * torch.tanh(sc.sent_embed[0](agg))).squeeze(-1)
         return (pair * weight).sum(dim=-1) / weight.sum(dim=-1)                                   # (n,)
@@ -229,13 +273,14 @@ class DiscV2(nn.Module):
         xp = F.pad(x, (0, 0, 1, 1))
         taps = torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=2)                          # (n, L, 3 x 512): x[t-1] | x[t] | x[t+1]
         x = x + 0.3 * F.linear(taps, conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1), conv.bias)
-        y = _dropout(F.layer_norm(self._lstm(x), (WIDTH,), self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps),
+        ops = self._cell_ops(h)
+        y = _dropout(_tanh_ln(self._lstm(x), self.layer_norm, ops, pre_tanh=False),
                      0.3, self.training)
         mask = rep(att_mask)
         sa = self.att
         logits = sa.K(y) @ sa.Q(y).transpose(1, 2) / math.sqrt(sa.attention_size)
         w = torch.softmax(torch.where(mask > 0, logits, torch.full_like(logits, -9e15)), dim=-1)
-        words = _tanh_ln(_dropout(sa.output_layer[0](w @ sa.V(y)), sa.dropout, self.training), self.att_norm[1])
+        words = _tanh_ln(_dropout(sa.output_layer[0](w @ sa.V(y)), sa.dropout, self.training), self.att_norm[1], ops)
         word_mask = mask[:, 0, :].unsqueeze(2)                     # (n,L,1)
         alpha = rep(alpha_all) * word_mask
         P = self.num_psl
@@ -247,7 +292,7 @@ class DiscV2(nn.Module):
         sm = sm.view(groups, B).mean(dim=1).repeat_interleave(B)
         ts = self.text_sum
         adj = torch.softmax(words @ ts.theta.t(), dim=1)           # LatentPSL(512, 1): one latent node over the words
-        sent = _dropout(_tanh_ln(adj.transpose(1, 2) @ words, ts.out_norm[1]), 0.3, self.training).squeeze(1)
+        sent = _dropout(_tanh_ln(adj.transpose(1, 2) @ words, ts.out_norm[1], ops), 0.3, self.training).squeeze(1)
         fus = torch.softmax(sent @ self.fusion.t(), dim=-1)
         return so * fus[:, 0] + sm * fus[:, 1]
 

@@ -159,7 +159,8 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
-           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2']
+           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2',
+           'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2']
 
 
 def load_library(path=LIB_PATH):
@@ -200,6 +201,10 @@ def load_library(path=LIB_PATH):
         'dlsg_copy2d': [vp, i64, vp, i64, i32, i32, i32, vp],
         'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp, vp],
         'dlsg_fill': [vp, i64, f32, vp],
+        'dlsg_tanh_ln_ws_floats': [i32, i32],
+        'dlsg_tanh_ln_fwd': [vp, vp, vp, vp, i32, i32, f32, i32, vp],
+        'dlsg_tanh_ln_bwd': [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
+        'dlsg_tanh_ln_bwd2': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
         'dlsg_lstm_cell_fwd': [vp, i64, vp, vp, vp, i32, i32, vp],
         'dlsg_lstm_cell_bwd': [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp],
         'dlsg_lstm_cell_bwd2': [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
@@ -224,7 +229,7 @@ def load_library(path=LIB_PATH):
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int64 if name == 'dlsg_o2v_workspace_bytes' else C.c_int
+        fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats') else C.c_int
     return lib
 
 
@@ -797,6 +802,35 @@ class HipOps(object):
             _chkc(t)
         self._check(self.lib.dlsg_lstm_cell_bwd2(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh), _p(dc), _p(u), _p(uc), _p(ga),
                                                  _p(gc_prev), _p(gdh), _p(gdc), n, H, self._stream()), 'lstm_cell_bwd2')
+
+    # ------------------------------------------------------------------ critic (tanh +) LayerNorm, three levels
+    def _ln_ws(self, x):
+        rows, N = x.shape
+        return torch.empty(int(self.lib.dlsg_tanh_ln_ws_floats(rows, N)), dtype=torch.float32, device=x.device)
+
+    def tanh_ln_fwd(self, x, gamma, beta, y, eps, pre_tanh):
+        """x, y (rows, N) dense: y = LayerNorm(tanh(x) if pre_tanh else x) * gamma + beta"""
+        rows, N = x.shape
+        for t in (x, gamma, beta, y):
+            _chkc(t)
+        self._check(self.lib.dlsg_tanh_ln_fwd(_p(x), _p(gamma), _p(beta), _p(y), rows, N, f32(eps), int(pre_tanh), self._stream()),
+                    'tanh_ln_fwd')
+
+    def tanh_ln_bwd(self, x, gamma, dy, dx, dgamma, dbeta, eps, pre_tanh):
+        rows, N = x.shape
+        for t in (x, gamma, dy, dx, dgamma, dbeta):
+            _chkc(t)
+        ws = self._ln_ws(x)
+        self._check(self.lib.dlsg_tanh_ln_bwd(_p(x), _p(gamma), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(ws), rows, N, f32(eps),
+                                              int(pre_tanh), self._stream()), 'tanh_ln_bwd')
+
+    def tanh_ln_bwd2(self, x, gamma, dy, U, vg, vb, gx, ggamma, gdy, eps, pre_tanh):
+        rows, N = x.shape
+        for t in (x, gamma, dy, U, vg, vb, gx, ggamma, gdy):
+            _chkc(t)
+        ws = self._ln_ws(x)
+        self._check(self.lib.dlsg_tanh_ln_bwd2(_p(x), _p(gamma), _p(dy), _p(U), _p(vg), _p(vb), _p(gx), _p(ggamma), _p(gdy), _p(ws),
+                                               rows, N, f32(eps), int(pre_tanh), self._stream()), 'tanh_ln_bwd2')
 
     def gather_rows(self, src, idx, dst):
         """dst[r] = src[idx[r]] (2-d views; dst must not alias src)."""

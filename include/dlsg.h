@@ -390,6 +390,19 @@ int dlsg_lstm_cell_bwd(const float* a, int64_t lda, const float* c_prev, const f
 int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, const float* u,
                         const float* uc, float* ga, float* gc_prev, float* gdh, float* gdc, int rows, int H, void* stream);
 
+/* The critic's normalisations y = LayerNorm(tanh(x)) (pre_tanh = 1) or LayerNorm(x) over dense rows of N = 64..1024 columns
+ * (N % 64 == 0), eps inside the square root, biased variance (models/model.py:124-131, layer.py:661-689), again at the three
+ * levels of the WGAN-GP update: fwd; bwd = (dx, dgamma, dbeta) from dy; bwd2 = vector-Jacobian product of bwd w.r.t.
+ * (x, gamma, dy) for cotangents (U on dx, vg on dgamma, vb on dbeta).  ws: caller scratch of dlsg_tanh_ln_ws_floats(rows, N)
+ * floats (per-workgroup column partials, summed in a fixed order). */
+int64_t dlsg_tanh_ln_ws_floats(int rows, int N);
+int dlsg_tanh_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int N, float eps, int pre_tanh,
+                     void* stream);
+int dlsg_tanh_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* ws,
+                     int rows, int N, float eps, int pre_tanh, void* stream);
+int dlsg_tanh_ln_bwd2(const float* x, const float* gamma, const float* dy, const float* U, const float* vg, const float* vb,
+                      float* gx, float* ggamma, float* gdy, float* ws, int rows, int N, float eps, int pre_tanh, void* stream);
+
 /* ---------------------------------------------------------------- loss + optimizer (run_gun.py:189-198, :91)
  * Ragged CrossEntropy: row (b,t) counts iff t < lens[b]; loss = mean over counted rows; dlogits written for all
  * rows (zeros for padded ones).  row_loss (B*L) is scratch; loss[0] receives the mean.  time_major: logits and

@@ -494,6 +494,42 @@ class EmulOps(object):
         gdh.copy_(A * o * q + uo * tc * so)
         gdc.copy_(A)
 
+    # ---- critic (tanh +) LayerNorm, three levels (csrc/critic.hip)
+    @staticmethod
+    def _ln_stats(x, eps, pre_tanh):
+        t = torch.tanh(x) if pre_tanh else x
+        mu = t.mean(1, keepdim=True)
+        r = (((t - mu) ** 2).mean(1, keepdim=True) + eps).rsqrt()
+        return t, r, (t - mu) * r, ((1 - t * t) if pre_tanh else torch.ones_like(t))
+
+    def tanh_ln_fwd(self, x, gamma, beta, y, eps, pre_tanh):
+        t, r, n, s = self._ln_stats(x, eps, pre_tanh)
+        y.copy_(n * gamma + beta)
+
+    def tanh_ln_bwd(self, x, gamma, dy, dx, dgamma, dbeta, eps, pre_tanh):
+        t, r, n, s = self._ln_stats(x, eps, pre_tanh)
+        a = dy * gamma
+        dt = r * (a - a.mean(1, keepdim=True) - n * (a * n).mean(1, keepdim=True))
+        dx.copy_(dt * s); dgamma.copy_((dy * n).sum(0)); dbeta.copy_(dy.sum(0))
+
+    def tanh_ln_bwd2(self, x, gamma, dy, U, vg, vb, gx, ggamma, gdy, eps, pre_tanh):
+        N = x.shape[1]
+        t, r, n, s = self._ln_stats(x, eps, pre_tanh)
+        a = dy * gamma
+        m1, m2 = a.mean(1, keepdim=True), (a * n).mean(1, keepdim=True)
+        dt = r * (a - m1 - n * m2)
+        W = U * s
+        w1, w2 = W.mean(1, keepdim=True), (W * n).mean(1, keepdim=True)
+        core = r * (W - w1 - n * w2)
+        gdy.copy_(gamma * core + vg * n + vb)
+        ggamma.copy_((dy * core).sum(0))
+        Q = (W * dt).sum(1, keepdim=True) / r
+        Pn = -r * (W * m2 + a * w2) + vg * dy
+        G = r * (Pn - Pn.mean(1, keepdim=True) - n * (Pn * n).mean(1, keepdim=True)) - Q * r * r * n / N
+        if pre_tanh:
+            G = G - 2 * t * U * dt
+        gx.copy_(G * s)
+
     def gather_rows(self, src, idx, dst):
         dst.copy_(src[idx])
 

@@ -455,8 +455,8 @@ def test_proposal_and_attention_gradients_reach_the_encoder():
 
 
 def test_critic_fused_cell_and_conv_follow_the_plain_recurrence():
-    """DiscV2 with the fused LSTM-cell op (emulated kernels: level 0 / 1 / 2 formulas of csrc/critic.hip) against the same
-    critic on plain ATen ops: critic scores, gradient penalty (first derivative) and every parameter gradient of loss_D
+    """DiscV2 with the fused LSTM-cell and (tanh +) LayerNorm ops (emulated kernels: level 0 / 1 / 2 formulas of
+    csrc/critic.hip) against the same critic on plain ATen ops: critic scores, gradient penalty (first derivative) and every parameter gradient of loss_D
     (second derivative through the penalty) must agree."""
     import copy
     from helpers import gan_args

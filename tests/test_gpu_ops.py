@@ -810,3 +810,18 @@ def test_critic_lstm_cell_three_levels(hip, n, H, pad):
         ops.lstm_cell_bwd(a, t['cp'], t['dh'], t['dc'], t['da'], t['dcp'])
         ops.lstm_cell_bwd2(a, t['cp'], t['dh'], t['dc'], t['u'], t['uc'], t['ga'], t['gcp'], t['gdh'], t['gdc'])
     both(hip, build, run, ['h', 'c', 'da', 'dcp', 'ga', 'gcp', 'gdh', 'gdc'], tol=2e-5, name='critic cell %d x %d' % (n, H))
+
+
+@pytest.mark.parametrize('rows,N,pre_tanh', [(4992, 512, True), (4992, 512, False), (7, 64, True), (1536, 1024, True), (513, 192, False)])
+def test_critic_tanh_layernorm_three_levels(hip, rows, N, pre_tanh):
+    """csrc/critic.hip: LayerNorm(tanh(x)) forward, backward, and the backward of the backward against the ATen formulas"""
+    def build(g):
+        return dict(x=rnd(g, rows, N, scale=1.5), gam=rnd(g, N), bet=rnd(g, N), dy=rnd(g, rows, N), U=rnd(g, rows, N), vg=rnd(g, N),
+                    vb=rnd(g, N), y=torch.zeros(rows, N), dx=torch.zeros(rows, N), dg=torch.zeros(N), db=torch.zeros(N),
+                    gx=torch.zeros(rows, N), gg=torch.zeros(N), gdy=torch.zeros(rows, N))
+
+    def run(ops, t):
+        ops.tanh_ln_fwd(t['x'], t['gam'], t['bet'], t['y'], 1e-5, pre_tanh)
+        ops.tanh_ln_bwd(t['x'], t['gam'], t['dy'], t['dx'], t['dg'], t['db'], 1e-5, pre_tanh)
+        ops.tanh_ln_bwd2(t['x'], t['gam'], t['dy'], t['U'], t['vg'], t['vb'], t['gx'], t['gg'], t['gdy'], 1e-5, pre_tanh)
+    both(hip, build, run, ['y', 'dx', 'dg', 'db', 'gx', 'gg', 'gdy'], tol=3e-5, name='critic ln %d x %d' % (rows, N))
