@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(const float* __restrict__
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * H) return;
     const int r = idx / H, j = idx - r * H;
-    const Gates x = gates_of(a, lda, r, j, H, c_prev[idx]);
+    const Gates x = gates_of(a, lda, r, j, H, c_prev ? c_prev[idx] : 0.f);
     c[idx] = x.c;
     h[idx] = x.o * x.tc;
 }
@@ -70,6 +70,35 @@ __global__ __launch_bounds__(256) void cell_bwd_kernel(const float* __restrict__
     dc_prev[idx] = dct * x.f;
 }
 
+// the backward step of the whole-sequence op: dh = dh1 (+ dh2), dc = (dc1) (+ dc2), da = cell'(...) (+ da_inj); the summed
+// dh / dc are kept (dh_tot, dc_tot): they are the cell inputs the backward of this step is differentiated at
+__global__ __launch_bounds__(256) void cell_bwd_seq_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ c_prev,
+                                                           const float* __restrict__ dh1, const float* __restrict__ dh2,
+                                                           const float* __restrict__ dc1, const float* __restrict__ dc2,
+                                                           const float* __restrict__ da_inj, float* __restrict__ da,
+                                                           float* __restrict__ dc_prev, float* __restrict__ dh_tot,
+                                                           float* __restrict__ dc_tot, int rows, int H) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * H) return;
+    const int r = idx / H, j = idx - r * H;
+    const float cp = c_prev ? c_prev[idx] : 0.f;
+    const Gates x = gates_of(a, lda, r, j, H, cp);
+    const float dhv = dh1[idx] + (dh2 ? dh2[idx] : 0.f);
+    const float dcv = (dc1 ? dc1[idx] : 0.f) + (dc2 ? dc2[idx] : 0.f);
+    dh_tot[idx] = dhv;
+    dc_tot[idx] = dcv;
+    const float dct = dcv + dhv * x.o * x.q;
+    float* d = da + (int64_t)r * 4 * H + j;
+    float v0 = dct * x.g * x.i * (1.f - x.i), v1 = dct * cp * x.f * (1.f - x.f), v2 = dct * x.i * (1.f - x.g * x.g),
+          v3 = dhv * x.tc * x.o * (1.f - x.o);
+    if (da_inj) {
+        const float* q = da_inj + (int64_t)r * 4 * H + j;
+        v0 += q[0]; v1 += q[H]; v2 += q[2 * H]; v3 += q[3 * H];
+    }
+    d[0] = v0; d[H] = v1; d[2 * H] = v2; d[3 * H] = v3;
+    dc_prev[idx] = dct * x.f;
+}
+
 __global__ __launch_bounds__(256) void cell_bwd2_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ c_prev,
                                                         const float* __restrict__ dh, const float* __restrict__ dc,
                                                         const float* __restrict__ u, const float* __restrict__ uc,
@@ -78,11 +107,11 @@ __global__ __launch_bounds__(256) void cell_bwd2_kernel(const float* __restrict_
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= rows * H) return;
     const int r = idx / H, j = idx - r * H;
-    const float cp = c_prev[idx];
+    const float cp = c_prev ? c_prev[idx] : 0.f;
     const Gates x = gates_of(a, lda, r, j, H, cp);
     const float dhv = dh[idx];
     const float* ur = u + (int64_t)r * 4 * H + j;
-    const float ui = ur[0], uf = ur[H], ug = ur[2 * H], uo = ur[3 * H], ucv = uc[idx];
+    const float ui = ur[0], uf = ur[H], ug = ur[2 * H], uo = ur[3 * H], ucv = uc ? uc[idx] : 0.f;
     const float si = x.i * (1.f - x.i), sf = x.f * (1.f - x.f), so = x.o * (1.f - x.o), sg = 1.f - x.g * x.g;
     const float dct = dc[idx] + dhv * x.o * x.q;
     const float A = ui * x.g * si + uf * cp * sf + ug * x.i * sg + ucv * x.f;
@@ -92,7 +121,7 @@ __global__ __launch_bounds__(256) void cell_bwd2_kernel(const float* __restrict_
     g[H] = dct * sf * (uf * cp * (1.f - 2.f * x.f) + ucv) + Gc * cp * sf;
     g[2 * H] = dct * sg * (ui * si - 2.f * ug * x.i * x.g) + Gc * x.i * sg;
     g[3 * H] = so * dhv * (A * x.q + uo * x.tc * (1.f - 2.f * x.o));
-    gc_prev[idx] = dct * uf * sf + Gc * x.f;
+    if (gc_prev) gc_prev[idx] = dct * uf * sf + Gc * x.f;
     gdh[idx] = A * x.o * x.q + uo * x.tc * so;
     gdc[idx] = A;
 }
@@ -316,7 +345,7 @@ inline hipStream_t ST(void* s) { return reinterpret_cast<hipStream_t>(s); }
 }  // namespace
 
 extern "C" int dlsg_lstm_cell_fwd(const float* a, int64_t lda, const float* c_prev, float* h, float* c, int rows, int H, void* stream) {
-    if (!a || !c_prev || !h || !c || rows < 0 || H < 1 || lda < 4 * (int64_t)H) return DLSG_EINVAL;
+    if (!a || !h || !c || rows < 0 || H < 1 || lda < 4 * (int64_t)H) return DLSG_EINVAL;     /* c_prev NULL: zero state */
     if (rows == 0) return DLSG_OK;
     hipLaunchKernelGGL(cell_fwd_kernel, dim3((rows * H + 255) / 256), dim3(256), 0, ST(stream), a, lda, c_prev, h, c, rows, H);
     DLSG_CHECK_LAUNCH();
@@ -331,10 +360,20 @@ extern "C" int dlsg_lstm_cell_bwd(const float* a, int64_t lda, const float* c_pr
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
+extern "C" int dlsg_lstm_cell_bwd_seq(const float* a, int64_t lda, const float* c_prev, const float* dh1, const float* dh2, const float* dc1,
+                                      const float* dc2, const float* da_inj, float* da, float* dc_prev, float* dh_tot, float* dc_tot,
+                                      int rows, int H, void* stream) {
+    if (!a || !dh1 || !da || !dc_prev || !dh_tot || !dc_tot || rows < 0 || H < 1 || lda < 4 * (int64_t)H) return DLSG_EINVAL;
+    if (rows == 0) return DLSG_OK;
+    hipLaunchKernelGGL(cell_bwd_seq_kernel, dim3((rows * H + 255) / 256), dim3(256), 0, ST(stream), a, lda, c_prev, dh1, dh2, dc1, dc2,
+                       da_inj, da, dc_prev, dh_tot, dc_tot, rows, H);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
 extern "C" int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, const float* u,
                                    const float* uc, float* ga, float* gc_prev, float* gdh, float* gdc, int rows, int H, void* stream) {
-    if (!a || !c_prev || !dh || !dc || !u || !uc || !ga || !gc_prev || !gdh || !gdc || rows < 0 || H < 1 || lda < 4 * (int64_t)H)
-        return DLSG_EINVAL;
+    if (!a || !dh || !dc || !u || !ga || !gdh || !gdc || rows < 0 || H < 1 || lda < 4 * (int64_t)H)
+        return DLSG_EINVAL;                                  /* c_prev, uc NULL: zeros; gc_prev NULL: not wanted */
     if (rows == 0) return DLSG_OK;
     hipLaunchKernelGGL(cell_bwd2_kernel, dim3((rows * H + 255) / 256), dim3(256), 0, ST(stream), a, lda, c_prev, dh, dc, u, uc, ga,
                        gc_prev, gdh, gdc, rows, H);

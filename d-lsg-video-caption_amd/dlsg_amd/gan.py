@@ -87,41 +87,94 @@ def _hip_ops():
     return _HIP[0]
 
 
-class _LstmCell(torch.autograd.Function):
-    """(h, c) = LSTM cell pointwise on the HIP kernel (`dlsg_lstm_cell_fwd`); its backward is `_LstmCellBwd`, itself a
-    differentiable op, so that the gradient penalty (create_graph=True) and the loss backward through it are one launch each
-    instead of ~20 and ~40 ATen launches per cell step (csrc/critic.hip)."""
+class _LstmSeq(torch.autograd.Function):
+    """The critic's whole LSTM layer as ONE autograd node per differentiation level (zero initial state, gates i,f,g,o):
+        a_t = xin_t + h_{t-1} W^T,  (h_t, c_t) = cell(a_t, c_{t-1})        xin (L, n, 4H) already holds x W_ih^T + b
+    returns (Hs, As, Cs); As and Cs are outputs so that the backward's backward can hand its gradients w.r.t. the saved
+    pre-activations and cell states back to this node.  Per word step every level is one recurrent product plus one cell
+    kernel (csrc/critic.hip); weight gradients are single products over all steps -- no per-step gradient accumulation."""
 
     @staticmethod
-    def forward(ctx, ops, a, c_prev):
-        h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
-        ops.lstm_cell_fwd(a, c_prev, h, c)
+    def forward(ctx, ops, xin, W):
+        L, n, G = xin.shape
+        H = G // 4
+        As = xin.clone()
+        Hs, Cs = xin.new_empty(L, n, H), xin.new_empty(L, n, H)
+        Wt = W.t()
+        for t in range(L):
+            if t:
+                As[t].addmm_(Hs[t - 1], Wt)
+            ops.lstm_cell_fwd(As[t], Cs[t - 1] if t else None, Hs[t], Cs[t])
         ctx.ops = ops
-        ctx.save_for_backward(a, c_prev)
-        return h, c
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(As, Cs, Hs, W)
+        return Hs, As, Cs
 
     @staticmethod
-    def backward(ctx, dh, dc):
-        a, c_prev = ctx.saved_tensors
-        da, dcp = _LstmCellBwd.apply(ctx.ops, a, c_prev, dh.contiguous(), dc.contiguous())
-        return None, da, dcp
+    def backward(ctx, dHs, dAs, dCs):
+        As, Cs, Hs, W = ctx.saved_tensors
+        if dHs is None:
+            dHs = torch.zeros_like(Hs)
+        dxin, dW = _LstmSeqBwd.apply(ctx.ops, As, Cs, Hs, W, dHs.contiguous(), None if dAs is None else dAs.contiguous(),
+                                     None if dCs is None else dCs.contiguous())
+        return None, dxin, dW
 
 
-class _LstmCellBwd(torch.autograd.Function):
+class _LstmSeqBwd(torch.autograd.Function):
+    """Backward through time of `_LstmSeq` with gradients injected on h (dHs), on the pre-activations (dAs) and on the cell
+    states (dCs), itself differentiable:
+        dh_t = dHs_t + DA_{t+1} W,  dc_t = s_t + dCs_t,  (da_t, s_{t-1}) = cell'(a_t, c_{t-1}; dh_t, dc_t),  DA_t = da_t + dAs_t
+        dxin = DA,  dW = sum_{t>=1} DA_t^T h_{t-1}
+    Its backward (cotangents Uxin on DA, UW on dW) runs forward in time:
+        ubar_t = Uxin_t + h_{t-1} UW^T + gdh_{t-1} W^T
+        (ga_t, gc_{t-1}, gdh_t, gdc_t) = cell''(a_t, c_{t-1}, dh_t, dc_t; ubar_t, gdc_{t-1})
+    and returns gAs = ga, gCs_{t-1} = gc_{t-1}, gHs_{t-1} = DA_t UW, gW = sum DA_t^T gdh_{t-1}, g(dHs) = gdh, g(dAs) = ubar,
+    g(dCs) = gdc."""
+
     @staticmethod
-    def forward(ctx, ops, a, c_prev, dh, dc):
-        da, dcp = torch.empty_like(a), torch.empty_like(c_prev)
-        ops.lstm_cell_bwd(a, c_prev, dh, dc, da, dcp)
+    def forward(ctx, ops, As, Cs, Hs, W, dHs, dAs, dCs):
+        L, n, G = As.shape
+        H = G // 4
+        DA = torch.empty_like(As)
+        DH, DC = torch.empty_like(Hs), torch.empty_like(Hs)          # the summed dh_t / dc_t each step was differentiated at
+        s_buf = [torch.empty_like(Hs[0]), torch.empty_like(Hs[0])]
+        r = torch.empty_like(Hs[0])
+        for t in range(L - 1, -1, -1):
+            last = t == L - 1
+            ops.lstm_cell_bwd_seq(As[t], Cs[t - 1] if t else None, dHs[t], None if last else r, None if last else s_buf[(t + 1) & 1],
+                                  None if dCs is None else dCs[t], None if dAs is None else dAs[t], DA[t], s_buf[t & 1], DH[t], DC[t])
+            if t:
+                torch.mm(DA[t], W, out=r)
+        dW = DA[1:].reshape(-1, G).t() @ Hs[:-1].reshape(-1, H) if L > 1 else torch.zeros_like(W)
         ctx.ops = ops
-        ctx.save_for_backward(a, c_prev, dh, dc)
-        return da, dcp
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(As, Cs, Hs, W, DA, DH, DC)
+        ctx.has = (dAs is not None, dCs is not None)
+        return DA, dW
 
     @staticmethod
-    def backward(ctx, u, uc):
-        a, c_prev, dh, dc = ctx.saved_tensors
-        ga, gcp, gdh, gdc = torch.empty_like(a), torch.empty_like(c_prev), torch.empty_like(c_prev), torch.empty_like(c_prev)
-        ctx.ops.lstm_cell_bwd2(a, c_prev, dh, dc, u.contiguous(), uc.contiguous(), ga, gcp, gdh, gdc)
-        return None, ga, gcp, gdh, gdc
+    def backward(ctx, Uxin, UW):
+        As, Cs, Hs, W, DA, DH, DC = ctx.saved_tensors
+        L, n, G = As.shape
+        H = G // 4
+        ops = ctx.ops
+        Ubar = torch.zeros_like(As) if Uxin is None else Uxin.clone()
+        if UW is not None and L > 1:
+            Ubar[1:].view(-1, G).addmm_(Hs[:-1].reshape(-1, H), UW.t())
+        gA, gC, gDH, gDC = torch.empty_like(As), torch.zeros_like(Cs), torch.empty_like(Hs), torch.empty_like(Hs)
+        Wt = W.t()
+        for t in range(L):
+            if t:
+                Ubar[t].addmm_(gDH[t - 1], Wt)
+            ops.lstm_cell_bwd2(As[t], Cs[t - 1] if t else None, DH[t], DC[t], Ubar[t], gDC[t - 1] if t else None, gA[t],
+                               gC[t - 1] if t else None, gDH[t], gDC[t])
+        gW = gHs = None
+        if L > 1:
+            gW = DA[1:].reshape(-1, G).t() @ gDH[:-1].reshape(-1, H)
+            if UW is not None:
+                gHs = torch.zeros_like(Hs)
+                torch.mm(DA[1:].reshape(-1, G), UW, out=gHs[:-1].view(-1, H))
+        return (None, gA, gC, gHs, gW, gDH, Ubar if ctx.has[0] else None, gDC if ctx.has[1] else None)
 
 
 class _TanhLN(torch.autograd.Function):
@@ -224,15 +277,9 @@ class DiscV2(nn.Module):
         c = x.new_zeros(n, WIDTH)
         out = []
         if ops is not None:
-            # (L, n, 4H) so that a step's rows are dense; unbind, not xin[t]: the backward of 26 selects is 26 zero-filled
-            # (L, n, 4H) tensors summed pairwise, the backward of one unbind is one stack
-            xin = F.linear(x.transpose(0, 1).contiguous(), w_ih, bias).unbind(0)
-            w_hh_t = w_hh.t()
-            for t in range(L):
-                a = xin[t] if t == 0 else torch.addmm(xin[t], h, w_hh_t)
-                h, c = _LstmCell.apply(ops, a, c)
-                out.append(h)
-            return torch.stack(out, 0).transpose(0, 1)             # (L, n, H) storage: a step's gradient slice is dense
+            # the whole recurrence as one node per differentiation level (time-major: a step's rows are dense)
+            xin = F.linear(x.transpose(0, 1), w_ih, bias).contiguous()
+            return _LstmSeq.apply(ops, xin, w_hh)[0].transpose(0, 1)
         xin = F.linear(x, w_ih, bias)                              # all steps' input gates in one product
         for t in range(L):
             i, f, g, o = (xin[:, t] + F.linear(h, w_hh)).chunk(4, dim=1)

@@ -159,7 +159,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
-           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2',
+           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2', 'dlsg_lstm_cell_bwd_seq',
            'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2']
 
 
@@ -206,6 +206,7 @@ def load_library(path=LIB_PATH):
         'dlsg_tanh_ln_bwd': [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
         'dlsg_tanh_ln_bwd2': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
         'dlsg_lstm_cell_fwd': [vp, i64, vp, vp, vp, i32, i32, vp],
+        'dlsg_lstm_cell_bwd_seq': [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
         'dlsg_lstm_cell_bwd': [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp],
         'dlsg_lstm_cell_bwd2': [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
         'dlsg_ce_ragged': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
@@ -781,9 +782,11 @@ class HipOps(object):
 
     # ------------------------------------------------------------------ critic LSTM cell (three differentiation levels)
     def lstm_cell_fwd(self, a, c_prev, h, c):
-        """a (n, 4H) rows strided, c_prev / h / c (n, H) dense: (h, c) = LSTM cell pointwise, gates i,f,g,o"""
-        n, H = c_prev.shape
-        _chk2(a); _chkc(c_prev); _chkc(h); _chkc(c)
+        """a (n, 4H) rows strided, c_prev (or None = zero state) / h / c (n, H) dense: (h, c) = LSTM cell pointwise, gates i,f,g,o"""
+        n, H = c.shape
+        _chk2(a); _chkc(h); _chkc(c)
+        if c_prev is not None:
+            _chkc(c_prev)
         self._check(self.lib.dlsg_lstm_cell_fwd(_p(a), i64(a.stride(0)), _p(c_prev), _p(h), _p(c), n, H, self._stream()),
                     'lstm_cell_fwd')
 
@@ -795,11 +798,23 @@ class HipOps(object):
         self._check(self.lib.dlsg_lstm_cell_bwd(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh), _p(dc), _p(da), _p(dc_prev), n, H,
                                                 self._stream()), 'lstm_cell_bwd')
 
+    def lstm_cell_bwd_seq(self, a, c_prev, dh1, dh2, dc1, dc2, da_inj, da, dc_prev, dh_tot, dc_tot):
+        """one backward step of the whole-sequence op: sums of the optional pieces, cell backward, optional injection on da"""
+        n, H = dh1.shape
+        _chk2(a)
+        for t in (c_prev, dh1, dh2, dc1, dc2, da_inj, da, dc_prev, dh_tot, dc_tot):
+            if t is not None:
+                _chkc(t)
+        self._check(self.lib.dlsg_lstm_cell_bwd_seq(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh1), _p(dh2), _p(dc1), _p(dc2), _p(da_inj),
+                                                    _p(da), _p(dc_prev), _p(dh_tot), _p(dc_tot), n, H, self._stream()),
+                    'lstm_cell_bwd_seq')
+
     def lstm_cell_bwd2(self, a, c_prev, dh, dc, u, uc, ga, gc_prev, gdh, gdc):
-        n, H = c_prev.shape
+        n, H = dh.shape
         _chk2(a)
         for t in (c_prev, dh, dc, u, uc, ga, gc_prev, gdh, gdc):
-            _chkc(t)
+            if t is not None:
+                _chkc(t)
         self._check(self.lib.dlsg_lstm_cell_bwd2(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh), _p(dc), _p(u), _p(uc), _p(ga),
                                                  _p(gc_prev), _p(gdh), _p(gdc), n, H, self._stream()), 'lstm_cell_bwd2')
 

@@ -380,13 +380,19 @@ int dlsg_permute_tb(const float* src, float* dst, int T, int B, int n, void* str
  * Pointwise part of one step of the critic's nn.LSTM(512, 512) (models/model.py:122,147-150), at the three levels the
  * WGAN-GP critic update differentiates it (run_gun.py:362-371: gradient penalty with create_graph=True, then loss backward):
  *   a (rows, 4H) row stride lda = x W_ih^T + h_prev W_hh^T + b, gate order i,f,g,o; every other array dense (rows, H) / (rows, 4H).
- *   fwd : (h, c) = cell(a, c_prev)
+ *   fwd : (h, c) = cell(a, c_prev)                 (c_prev NULL: zero state)
  *   bwd : (da, dc_prev) = cell'(a, c_prev; dh, dc)
  *   bwd2: vector-Jacobian product of bwd w.r.t. (a, c_prev, dh, dc) for cotangents (u on da, uc on dc_prev)
  * The recurrent products stay GEMMs of the caller (dlsg_gemm or the framework's matmul). */
 int dlsg_lstm_cell_fwd(const float* a, int64_t lda, const float* c_prev, float* h, float* c, int rows, int H, void* stream);
 int dlsg_lstm_cell_bwd(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, float* da,
                        float* dc_prev, int rows, int H, void* stream);
+/* bwd inside the whole-sequence op (dlsg_amd/gan.py _LstmSeq): dh = dh1 + dh2, dc = dc1 + dc2, da = cell'(a, c_prev; dh, dc) + da_inj;
+ * dh2, dc1, dc2, da_inj and c_prev may be NULL (= 0); the summed dh / dc are written to dh_tot / dc_tot. */
+int dlsg_lstm_cell_bwd_seq(const float* a, int64_t lda, const float* c_prev, const float* dh1, const float* dh2, const float* dc1,
+                           const float* dc2, const float* da_inj, float* da, float* dc_prev, float* dh_tot, float* dc_tot, int rows,
+                           int H, void* stream);
+/* c_prev / uc NULL: zeros (first step); gc_prev NULL: not wanted */
 int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, const float* u,
                         const float* uc, float* ga, float* gc_prev, float* gdh, float* gdc, int rows, int H, void* stream);
 

@@ -470,8 +470,17 @@ class EmulOps(object):
         return i, f, g, o, c, tc, 1 - tc * tc
 
     def lstm_cell_fwd(self, a, c_prev, h, c):
-        i, f, g, o, cc, tc, q = self._cell(a, c_prev)
+        i, f, g, o, cc, tc, q = self._cell(a, c_prev if c_prev is not None else torch.zeros_like(c))
         c.copy_(cc); h.copy_(o * tc)
+
+    def lstm_cell_bwd_seq(self, a, c_prev, dh1, dh2, dc1, dc2, da_inj, da, dc_prev, dh_tot, dc_tot):
+        z = torch.zeros_like(dh1)
+        dh = dh1 + (dh2 if dh2 is not None else z)
+        dc = (dc1 if dc1 is not None else z) + (dc2 if dc2 is not None else z)
+        dh_tot.copy_(dh); dc_tot.copy_(dc)
+        self.lstm_cell_bwd(a, c_prev if c_prev is not None else z, dh, dc, da, dc_prev)
+        if da_inj is not None:
+            da.add_(da_inj)
 
     def lstm_cell_bwd(self, a, c_prev, dh, dc, da, dc_prev):
         i, f, g, o, cc, tc, q = self._cell(a, c_prev)
@@ -480,6 +489,9 @@ class EmulOps(object):
         dc_prev.copy_(dct * f)
 
     def lstm_cell_bwd2(self, a, c_prev, dh, dc, u, uc, ga, gc_prev, gdh, gdc):
+        c_prev = c_prev if c_prev is not None else torch.zeros_like(dh)
+        uc = uc if uc is not None else torch.zeros_like(dh)
+        gc_prev = gc_prev if gc_prev is not None else torch.empty_like(dh)
         i, f, g, o, cc, tc, q = self._cell(a, c_prev)
         ui, uf, ug, uo = u.chunk(4, 1)
         si, sf, so, sg = i * (1 - i), f * (1 - f), o * (1 - o), 1 - g * g

@@ -825,3 +825,22 @@ def test_critic_tanh_layernorm_three_levels(hip, rows, N, pre_tanh):
         ops.tanh_ln_bwd(t['x'], t['gam'], t['dy'], t['dx'], t['dg'], t['db'], 1e-5, pre_tanh)
         ops.tanh_ln_bwd2(t['x'], t['gam'], t['dy'], t['U'], t['vg'], t['vb'], t['gx'], t['gg'], t['gdy'], 1e-5, pre_tanh)
     both(hip, build, run, ['y', 'dx', 'dg', 'db', 'gx', 'gg', 'gdy'], tol=3e-5, name='critic ln %d x %d' % (rows, N))
+
+
+def test_critic_lstm_cell_sequence_step(hip):
+    """the backward step of the whole-sequence op: optional second dh / dc pieces and injection on da, NULL = zero"""
+    n, H = 192, 512
+
+    def build(g):
+        return dict(a=rnd(g, n, 4 * H), cp=rnd(g, n, H), dh1=rnd(g, n, H), dh2=rnd(g, n, H), dc1=rnd(g, n, H), dc2=rnd(g, n, H),
+                    inj=rnd(g, n, 4 * H), da=torch.zeros(n, 4 * H), dcp=torch.zeros(n, H), dht=torch.zeros(n, H), dct=torch.zeros(n, H),
+                    da2=torch.zeros(n, 4 * H), dcp2=torch.zeros(n, H), dht2=torch.zeros(n, H), dct2=torch.zeros(n, H),
+                    h=torch.zeros(n, H), c=torch.zeros(n, H), ga=torch.zeros(n, 4 * H), gdh=torch.zeros(n, H), gdc=torch.zeros(n, H))
+
+    def run(ops, t):
+        ops.lstm_cell_bwd_seq(t['a'], t['cp'], t['dh1'], t['dh2'], t['dc1'], t['dc2'], t['inj'], t['da'], t['dcp'], t['dht'], t['dct'])
+        ops.lstm_cell_bwd_seq(t['a'], None, t['dh1'], None, None, None, None, t['da2'], t['dcp2'], t['dht2'], t['dct2'])
+        ops.lstm_cell_fwd(t['a'], None, t['h'], t['c'])
+        ops.lstm_cell_bwd2(t['a'], None, t['dh1'], t['dc1'], t['inj'], None, t['ga'], None, t['gdh'], t['gdc'])
+    both(hip, build, run, ['da', 'dcp', 'dht', 'dct', 'da2', 'dcp2', 'dht2', 'dct2', 'h', 'c', 'ga', 'gdh', 'gdc'], tol=2e-5,
+         name='critic cell seq step')
