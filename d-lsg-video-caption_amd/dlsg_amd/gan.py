@@ -22,6 +22,7 @@ Split of work on the GPU:
 `DiscV2.state_dict()` has the reference's keys and shapes (checkpoint key `model_d_state_dict`, run_gun.py:306).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -556,8 +557,12 @@ class GanTrainer(object):
         captions = captions[:, :max_len].contiguous()
         att_mask = attention_mask(captions)
         # ---- Train D: the generator's outputs are constants here (run_gun.py:167-174)
-        with torch.no_grad():
-            f_caption, obj, mot, alpha = model(frames, regions, captions, max_len, tf_ratio)
+        fwd = None if os.environ.get('DLSG_GAN_EAGER_FORWARD') else \
+            self.trainer.forward_only(frames, regions, captions, tf_ratio, max_len)       # replayed once the step is captured
+        if fwd is None:
+            with torch.no_grad():
+                fwd = model(frames, regions, captions, max_len, tf_ratio)
+        f_caption, obj, mot, alpha = fwd
         loss_D, wass = self.train_disc(captions, f_caption, obj, mot, att_mask, alpha)
         # ---- Train the captioning model (run_gun.py:180-234)
         out = {}

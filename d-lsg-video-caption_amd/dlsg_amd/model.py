@@ -781,6 +781,32 @@ class Trainer(object):
         self._graphs, self._loss = graphs, loss
         self._adam_in_graph = not cuts or (self.world_size <= 1 and not self.force_collectives)
 
+    @torch.no_grad()
+    def forward_only(self, frames, regions, captions, tf_ratio, max_len=26):
+        """The no-grad generator forward of the GAN iteration (run_gun.py:167) from the captured step's FIRST graph (forward +
+        CrossEntropy): same coin / dropout-seed draws as `model(frames, regions, captions, max_len, tf_ratio)`, returns
+        (logits (B,L,V), obj, mot, alpha (B,L,2P)) as views of the graphs' static buffers -- valid until the next replay --
+        or None when this trainer has no cut graphs for that batch shape (the caller then calls the model)."""
+        if not (self.use_graphs and self._graphs is not None and self._hook_mode and self._hook_sv is not None
+                and self.model.training):
+            return None
+        st = self._static
+        captions = captions[:, :max_len].contiguous()
+        if (frames.shape, regions.shape, captions.shape) != (st['frames'].shape, st['regions'].shape, st['captions'].shape):
+            return None
+        self._check_binding()
+        model = self.model
+        coins = model._draw_coins(captions.shape[1], False, tf_ratio)
+        seed = model.next_seed()
+        for k, src in (('frames', frames), ('regions', regions), ('captions', captions)):
+            if src.data_ptr() != st[k].data_ptr():
+                st[k].copy_(src, non_blocking=True)
+        st['coins'].copy_(torch.tensor([int(c) for c in coins], dtype=torch.int32), non_blocking=True)
+        st['seed'].copy_(torch.tensor([seed], dtype=torch.int64), non_blocking=True)
+        self._graphs[0][0].replay()
+        logits_tm, sv = self._hook_sv
+        return logits_tm.transpose(0, 1), sv['dec_gsrc'][0], sv['dec_gsrc'][1], sv['dec']['ALPHA'].transpose(0, 1)
+
     def static_inputs(self):
         """The captured graphs read their batch from these device buffers: (frames, regions, captions, cap_lens), or None
         before the first replayed step.  A producer that fills them in place (the HBM-resident feature store gathers a batch

@@ -161,3 +161,26 @@ def test_checkpoint_reload_drops_the_captured_critic_graphs(tmp_path):
     for (k, p), (_, q) in zip(D.named_parameters(), D2.named_parameters()):
         d = (p - q).abs()
         assert d.max().item() <= 4 * 2 * 1.6e-4 and (d > 2e-6).float().mean().item() <= 5e-3, k
+
+
+def test_replayed_generator_forward_equals_the_model_call():
+    """GanTrainer takes the no-grad generator forward of run_gun.py:167 from the captured step's first graph once it exists:
+    with the same coin / seed draws it must return what `model(frames, regions, captions, 26, tf)` returns."""
+    import random
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case('gan_msvd', dlsg_amd.CapGnnModel, dlsg_amd.DiscV2)
+    G, D = G.cuda().train(), D.cuda()
+    frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
+    it = dlsg_amd.GanTrainer(G, D, num_D=1)
+    random.seed(4)
+    assert it.trainer.forward_only(frames, regions, caps, 0.7) is None          # nothing captured yet
+    it.iteration(frames, regions, caps, lens, 0.7, 0, 1)
+    state, counter = random.getstate(), G.seed_counter
+    got = [t.clone() for t in it.trainer.forward_only(frames, regions, caps, 0.7)]
+    assert G.seed_counter == counter + 1
+    random.setstate(state)
+    G.seed_counter = counter
+    with torch.no_grad():
+        want = G(frames, regions, caps, 26, 0.7)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert it.trainer.forward_only(frames[:2], regions[:2], caps[:2], 0.7) is None       # another batch shape: the model call
