@@ -478,12 +478,12 @@ class GanTrainer(object):
         out = {}
         torch.cuda.synchronize()
         gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gA):
+        with torch.cuda.graph(gA, capture_error_mode='thread_local'):   # other threads (RCCL watchdog, loaders) keep working
             opt.zero_grad(set_to_none=False)
             loss_D, r_loss, f_loss, gp, _ = critic_step_losses(D, *st)
             loss_D.backward()
             out['loss_D'], out['w'] = loss_D.detach(), (r_loss - f_loss).detach()
-        with torch.cuda.graph(gB, pool=gA.pool()):
+        with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode='thread_local'):
             opt.step()
         cg = dict(st=st, params=params, grads=grads, out=out, graphs=(gA, gB))
         self._cg[key] = cg
@@ -512,7 +512,7 @@ class GanTrainer(object):
             st = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device).copy_(t) for t in inputs]
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode='thread_local'):
                 out = term(*st)
             gg = dict(st=st, out=out, graph=graph)
             self._cg[key] = gg
