@@ -111,3 +111,64 @@ def test_reference_style_loop_with_torch_ddp_wrapper_and_adam(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     t0 = np.load(tmp_path / 'flat0.npy')
     assert np.abs(t0 - f0).max() <= 2e-6
+
+
+def _gan_build():
+    import dlsg_amd
+    from emul_ops import EmulOps
+    from helpers import load_gan_case
+
+    def mk(args, vocab):
+        m = dlsg_amd.CapGnnModel(args, vocab)
+        m.set_ops(EmulOps())
+        return m
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case('gan_msrvtt', mk, dlsg_amd.DiscV2)     # batch 4
+    return G, D.eval(), frames, regions, caps, lens, torch.from_numpy(g['eps_gp'])
+
+
+def _worker_gan(rank, world, port, out_dir):
+    for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'd-lsg-video-caption_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import random
+    import dlsg_amd
+    G, D, frames, regions, caps, lens, eps = _gan_build()
+    sl = slice(rank * 2, rank * 2 + 2)
+    it = dlsg_amd.GanTrainer(G, D, num_D=1, world_size=world)
+    it.eps_source = lambda k: eps[k][sl]
+    random.seed(5)
+    outs = [it.iteration(frames[sl], regions[sl], caps[sl], lens[sl], 1.0, 0, i + 1) for i in range(2)]
+    np.save(os.path.join(out_dir, 'gflat%d.npy' % rank), G._flat.detach().numpy())
+    np.save(os.path.join(out_dir, 'dflat%d.npy' % rank), torch.cat([p.detach().reshape(-1) for p in D.parameters()]).numpy())
+    np.save(os.path.join(out_dir, 'lossd%d.npy' % rank), np.array([o['loss_D'] for o in outs]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gan_iteration_keeps_generator_and_critic_replicas_identical(tmp_path):
+    """GanTrainer with two ranks (run_gun.py wraps both models in DDP, :63-68): critic gradients and generator gradients are
+    averaged over the ranks, so both replicas of both models stay bit-identical after two iterations; each rank's first
+    critic loss is the single-process loss on that shard."""
+    port = _free_port()
+    mp.spawn(_worker_gan, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / 'gflat0.npy'), np.load(tmp_path / 'gflat1.npy'))
+    assert np.array_equal(np.load(tmp_path / 'dflat0.npy'), np.load(tmp_path / 'dflat1.npy'))
+    # single process: the critic loss of each shard
+    import random
+    import dlsg_amd
+    from dlsg_amd import gan
+    G, D, frames, regions, caps, lens, eps = _gan_build()
+    random.seed(5)
+    with torch.no_grad():
+        f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)          # rows are independent: one call, then slices
+    losses = []
+    for r in range(2):
+        sl = slice(r * 2, r * 2 + 2)
+        losses.append(gan.critic_step_losses(D, caps[sl], f_caption[sl], obj[sl], mot[sl], gan.attention_mask(caps[sl]), alpha[sl],
+                                             eps[0][sl])[0].item())
+    for r in range(2):
+        assert abs(np.load(tmp_path / ('lossd%d.npy' % r))[0] - losses[r]) <= 1e-5 * max(1.0, abs(losses[r]))
