@@ -159,7 +159,8 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_
 // One chunk: plain store (deterministic).  Several chunks (tall inputs, e.g. the 26624-row bias gradients): the
 // per-chunk sums are combined with float atomics into `out`, which the caller has initialised (accum semantics).
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ part, int64_t ld, int rows, int n,
-                                                      float* __restrict__ out, int accum, int rows_per_chunk) {
+                                                      float* __restrict__ out, int accum, int rows_per_chunk,
+                                                      float* __restrict__ ws) {
     __shared__ float red[16][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;
@@ -173,7 +174,9 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += red[i][c];
-        if (gridDim.y > 1) {
+        if (gridDim.y > 1 && ws) {
+            ws[(int64_t)blockIdx.y * n + col] = t;            // chunk partial: colsum_finish_kernel adds the chunks in order
+        } else if (gridDim.y > 1) {
             atomicAdd(out + col, t);
         } else {
             if (accum) t += out[col];
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
 // LSTM receive the same gradient).
 __global__ __launch_bounds__(1024) void colsum_v4_kernel(const float* __restrict__ part, int64_t ld, int rows, int n,
                                                          float* __restrict__ out, float* __restrict__ out2, int split, int mode,
-                                                         int accum, int rows_per_chunk) {
+                                                         int accum, int rows_per_chunk, float* __restrict__ ws) {
     __shared__ float red[64][65];
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int col = blockIdx.x * 64 + cg * 4;
@@ -218,7 +221,9 @@ __global__ __launch_bounds__(1024) void colsum_v4_kernel(const float* __restrict
     if (part16 == 0 && oc < n) {
         float* d0 = (mode == 0 && oc >= split) ? out2 + (oc - split) : out + oc;
         float* d1 = mode == 1 ? out2 + oc : nullptr;
-        if (gridDim.y > 1) {
+        if (gridDim.y > 1 && ws) {
+            ws[(int64_t)blockIdx.y * n + oc] = t;
+        } else if (gridDim.y > 1) {
             atomicAdd(d0, t);
             if (d1) atomicAdd(d1, t);
         } else {
@@ -226,6 +231,18 @@ __global__ __launch_bounds__(1024) void colsum_v4_kernel(const float* __restrict
             if (d1) *d1 = accum ? *d1 + t : t;
         }
     }
+}
+
+// chunk partials ws (chunks, n) -> destinations, chunks added in order (bit-reproducible, unlike the atomic combine)
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ ws, int chunks, int n, float* __restrict__ out,
+                                                            float* __restrict__ out2, int split, int mode, int accum) {
+    const int oc = blockIdx.x * 256 + threadIdx.x;
+    if (oc >= n) return;
+    float t = 0.f;
+    for (int c = 0; c < chunks; ++c) t += ws[(int64_t)c * n + oc];
+    float* d0 = (mode == 0 && out2 && oc >= split) ? out2 + (oc - split) : out + oc;
+    *d0 = accum ? *d0 + t : t;
+    if (mode == 1 && out2) out2[oc] = accum ? out2[oc] + t : t;
 }
 
 // ------------------------------------------------------------------------------------------------ softmax (outer, n, inner)
@@ -798,45 +815,62 @@ extern "C" int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream) {
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
+static int colsum_chunks(int rows) {
+    if (rows < 4096) return 1;
+    const int chunks = (rows + 1023) / 1024;
+    return chunks > 32 ? 32 : chunks;
+}
 static int colsum_launch(const float* part, int64_t ld, int rows, int n, float* out, float* out2, int split, int mode, int accum,
-                         void* stream) {
+                         float* ws, void* stream) {
     if (!part || !out || n < 1) return DLSG_EINVAL;
-    int chunks = 1;
-    if (rows >= 4096) {
-        chunks = (rows + 1023) / 1024;
-        if (chunks > 32) chunks = 32;
-    }
+    const int chunks = colsum_chunks(rows);
     const int rpc = (rows + chunks - 1) / chunks;
+    const bool v4 = n % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+    if (chunks > 1 && ws && (v4 || !out2)) {
+        // tall input with a workspace: chunk partials, then a fixed-order combine
+        if (v4) hipLaunchKernelGGL(colsum_v4_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out,
+                                   out2, out2 ? split : n, out2 ? mode : 0, accum, rpc, ws);
+        else hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum,
+                                rpc, ws);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), ws, chunks, n, out, out2,
+                           out2 ? split : n, out2 ? mode : 0, accum);
+        DLSG_CHECK_LAUNCH();
+        return DLSG_OK;
+    }
     if (chunks > 1 && !accum) {
         const int n0 = (out2 && mode == 0) ? split : n;
         hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, ST(stream), out, (int64_t)n0, 0.f);
         if (out2) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, ST(stream), out2, (int64_t)(mode == 0 ? n - split : n), 0.f);
     }
-    const bool v4 = n % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+    float* none = nullptr;
     if (v4) {
         hipLaunchKernelGGL(colsum_v4_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out,
-                           out2, out2 ? split : n, out2 ? mode : 0, accum, rpc);
+                           out2, out2 ? split : n, out2 ? mode : 0, accum, rpc, none);
     } else if (!out2) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum, rpc);
+        hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum, rpc, none);
     } else if (mode == 0) {      // scalar fallback: the two halves / destinations as separate launches
         hipLaunchKernelGGL(colsum_kernel, dim3((split + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, split, out,
-                           accum, rpc);
+                           accum, rpc, none);
         hipLaunchKernelGGL(colsum_kernel, dim3((n - split + 63) / 64, chunks), dim3(1024), 0, ST(stream), part + split, ld, rows,
-                           n - split, out2, accum, rpc);
+                           n - split, out2, accum, rpc, none);
     } else {
-        hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum, rpc);
-        hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out2, accum, rpc);
+        hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum, rpc, none);
+        hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out2, accum, rpc, none);
     }
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
-extern "C" int dlsg_colsum(const float* part, int64_t ld, int rows, int n, float* out, int accum, void* stream) {
-    return colsum_launch(part, ld, rows, n, out, nullptr, n, 0, accum, stream);
+extern "C" int64_t dlsg_colsum_ws_floats(int rows, int n) {
+    const int chunks = colsum_chunks(rows);
+    return chunks > 1 ? (int64_t)chunks * n : 0;
+}
+extern "C" int dlsg_colsum(const float* part, int64_t ld, int rows, int n, float* out, int accum, float* ws, void* stream) {
+    return colsum_launch(part, ld, rows, n, out, nullptr, n, 0, accum, ws, stream);
 }
 extern "C" int dlsg_colsum2(const float* part, int64_t ld, int rows, int n, float* out_a, float* out_b, int split, int dup,
-                            int accum, void* stream) {
+                            int accum, float* ws, void* stream) {
     if (!out_b || (!dup && (split < 0 || split > n))) return DLSG_EINVAL;
-    return colsum_launch(part, ld, rows, n, out_a, out_b, dup ? n : split, dup ? 1 : 0, accum, stream);
+    return colsum_launch(part, ld, rows, n, out_a, out_b, dup ? n : split, dup ? 1 : 0, accum, ws, stream);
 }
 extern "C" int dlsg_softmax_fwd(const float* x, const float* mask, float* y, int64_t outer, int n, int inner, void* stream) {
     const int64_t lines = outer * inner;

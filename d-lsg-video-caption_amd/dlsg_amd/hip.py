@@ -152,7 +152,7 @@ class DecattCacheGradsArgs(C.Structure):
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
-           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
+           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_colsum_ws_floats', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
@@ -179,8 +179,9 @@ def load_library(path=LIB_PATH):
         'dlsg_rowln_fwd': [P(RowLnArgs), vp],
         'dlsg_rowln_bwd': [P(RowLnBwdArgs), vp],
         'dlsg_rowln_bwd_nblk': [i32],
-        'dlsg_colsum': [vp, i64, i32, i32, vp, i32, vp],
-        'dlsg_colsum2': [vp, i64, i32, i32, vp, vp, i32, i32, i32, vp],
+        'dlsg_colsum_ws_floats': [i32, i32],
+        'dlsg_colsum': [vp, i64, i32, i32, vp, i32, vp, vp],
+        'dlsg_colsum2': [vp, i64, i32, i32, vp, vp, i32, i32, i32, vp, vp],
         'dlsg_o2v_workspace_bytes': [i32, i32, i32, i32],
         'dlsg_o2v_fwd': [P(O2VArgs), vp],
         'dlsg_o2v_fwd_multi': [P(O2VArgs), i32, vp],
@@ -230,7 +231,7 @@ def load_library(path=LIB_PATH):
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats') else C.c_int
+        fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats', 'dlsg_colsum_ws_floats') else C.c_int
     return lib
 
 
@@ -416,18 +417,25 @@ class HipOps(object):
         b.nblk = dgb_part.size(0) if dgb_part is not None else 0
         self._check(self.lib.dlsg_rowln_bwd(C.byref(b), self._stream()), 'dlsg_rowln_bwd')
 
+    def _colsum_ws(self, part):
+        """scratch for the fixed-order combine of a tall input's row chunks (None: one chunk, nothing to combine)"""
+        k = int(self.lib.dlsg_colsum_ws_floats(part.size(0), part.size(1)))
+        return torch.empty(k, dtype=torch.float32, device=part.device) if k else None
+
     def colsum(self, part, out, accum=False):
         """out[j] (+)= sum over rows of part (rows, n) view."""
         _chk2(part)
+        ws = self._colsum_ws(part)
         self._check(self.lib.dlsg_colsum(_p(part), i64(part.stride(0)), part.size(0), part.size(1), _p(out), int(accum),
-                                         self._stream()), 'dlsg_colsum')
+                                         _p(ws), self._stream()), 'dlsg_colsum')
 
     def colsum2(self, part, out_a, out_b, split=None, accum=False):
         """one pass, two destinations: split=k -> columns [0,k) to out_a and [k,n) to out_b; split=None -> every column
         to both out_a and out_b."""
         _chk2(part)
+        ws = self._colsum_ws(part)
         self._check(self.lib.dlsg_colsum2(_p(part), i64(part.stride(0)), part.size(0), part.size(1), _p(out_a), _p(out_b),
-                                          0 if split is None else split, int(split is None), int(accum), self._stream()),
+                                          0 if split is None else split, int(split is None), int(accum), _p(ws), self._stream()),
                     'dlsg_colsum2')
 
     def softmax_fwd(self, x, y, outer, n, inner, mask=None):

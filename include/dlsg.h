@@ -105,12 +105,15 @@ typedef struct {
 } dlsg_rowln_bwd_args;
 int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream);
 int dlsg_rowln_bwd_nblk(int rows);
-/* out[j] (+)= sum_r part[r*ld + j], r < rows */
-int dlsg_colsum(const float* part, int64_t ld, int rows, int n, float* out, int accum, void* stream);
+/* out[j] (+)= sum_r part[r*ld + j], r < rows.  Tall inputs (rows >= 4096, e.g. the 26 624-row bias gradient of the region
+ * projection) are summed in row chunks: with ws (>= dlsg_colsum_ws_floats(rows, n) floats of caller scratch) the chunk
+ * partials are combined in a fixed order (bit-reproducible), with ws == NULL by float atomics. */
+int64_t dlsg_colsum_ws_floats(int rows, int n);
+int dlsg_colsum(const float* part, int64_t ld, int rows, int n, float* out, int accum, float* ws, void* stream);
 /* two destinations in one pass: dup == 0 -> columns [0,split) to out_a, [split,n) to out_b (gamma | beta halves of the
  * LayerNorm partials); dup != 0 -> all n columns to both (bias_ih / bias_hh of an LSTM receive the same gradient). */
 int dlsg_colsum2(const float* part, int64_t ld, int rows, int n, float* out_a, float* out_b, int split, int dup, int accum,
-                 void* stream);
+                 float* ws, void* stream);
 
 /* ---------------------------------------------------------------- object->frame conditional graph (layer.py:184-193)
  * y (B, NO, H) = tanh(obj_embed(regions)) (the GEMM epilogue applied tanh); LayerNorm(obj_norm) is applied on the

@@ -844,3 +844,19 @@ def test_critic_lstm_cell_sequence_step(hip):
         ops.lstm_cell_bwd2(t['a'], None, t['dh1'], t['dc1'], t['inj'], None, t['ga'], None, t['gdh'], t['gdc'])
     both(hip, build, run, ['da', 'dcp', 'dht', 'dct', 'da2', 'dcp2', 'dht2', 'dct2', 'h', 'c', 'ga', 'gdh', 'gdc'], tol=2e-5,
          name='critic cell seq step')
+
+
+def test_colsum_tall_is_bit_reproducible(hip):
+    """26 624-row column sums (the region projection's bias gradient): chunk partials are combined in a fixed order"""
+    g = torch.Generator().manual_seed(3)
+    part = (torch.randn(26624, 1024, generator=g) * 3).cuda()
+    outs = []
+    for _ in range(12):
+        a, b = torch.zeros(1024, device='cuda'), torch.full((1024,), 0.5, device='cuda')
+        hip.colsum(part, a)
+        hip.colsum2(part, b, a.clone(), accum=True)
+        outs.append((a.clone(), b.clone()))
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs)
+    ref = part.double().sum(0)
+    assert (outs[0][0].double() - ref).abs().max().item() <= 2e-3

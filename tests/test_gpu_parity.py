@@ -442,6 +442,29 @@ def test_full_size_batch64_clips_are_independent_and_deterministic(Bn):
             assert torch.equal(ids_part, ids_full[idx]), sel
 
 
+def test_full_size_train_step_gradients_are_bit_reproducible():
+    """The whole gradient arena of a batch-64 MSVD-shaped step (eval mode: no dropout seed to vary) is bit-identical across
+    runs, kernel by kernel and replayed: no float atomics are left on the path (word-embedding scatter, tall column sums)."""
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    args = dlsg_amd.msvd_shaped()
+    vocab = dlsg_amd.make_vocab(1000)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab).eval()
+    net.load_state_dict(synth_state_dict(net.state_dict(), 3))
+    net = net.cuda()
+    frames, regions, caps, lens = [t.cuda() for t in synth_batch(args, 1000, 64, 5)]
+    for graphs in (False, True):
+        tr = dlsg_amd.Trainer(net, lr=0.0, use_graphs=graphs)
+        ref = None
+        for _ in range(4):
+            tr.step(frames, regions, caps, lens, 1.0)
+            cur = net._gflat.clone()
+            if ref is None:
+                ref = cur
+                assert float(ref.abs().max()) > 0
+            assert torch.equal(cur, ref), int((cur != ref).sum())
+
+
 @pytest.mark.parametrize('mode,Bn,shape', [('fp32', 64, 'msvd'), ('x3_bwd', 64, 'msvd'), ('fp32', 128, 'msvd'),
                                            ('fp32', 64, 'msrvtt')])
 def test_full_size_gradient_is_token_weighted_mean_of_shard_gradients(mode, Bn, shape):
