@@ -344,18 +344,50 @@ class StreamedFeatures(_Features):
             free.put(i)
         q = queue.Queue(maxsize=self.depth)
 
+        stop = threading.Event()                            # set when the consumer abandons the generator early
+
+        def take(src):
+            while not stop.is_set():
+                try:
+                    return src.get(timeout=0.2)
+                except queue.Empty:
+                    pass
+            return None
+
+        def give(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.2)
+                    return
+                except queue.Full:
+                    pass
+
+        err = []
+
         def reader():
             try:
                 for ids in id_batches:
-                    i = free.get()
+                    i = take(free)
+                    if i is None:
+                        return
                     tf, tr = ring[i][0][:len(ids)], ring[i][1][:len(ids)]
                     self._fill(ids, tf, tr)
-                    q.put((ids, i, tf, tr))
+                    give((ids, i, tf, tr))
+            except BaseException as e:                      # surfaces in the consumer, not in a dead thread
+                err.append(e)
             finally:
-                q.put(None)
+                give(None)
         threading.Thread(target=reader, daemon=True).start()
         side = torch.cuda.Stream(device=self.device) if cuda else None
         pending = None                                      # (ring index, event): its H2D copy may still be reading the buffer
+        try:
+            yield from self._consume(q, free, side, cuda, pending)
+            if err:
+                raise err[0]
+        finally:
+            stop.set()                                      # a `break` in the consumer: the reader thread ends, the ring is freed
+
+    def _consume(self, q, free, side, cuda, pending):
         while True:
             item = q.get()
             if item is None:

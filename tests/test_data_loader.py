@@ -167,3 +167,22 @@ def test_resident_features_gather_on_device(tmp_path):
         for j, v in enumerate(x[-1]):
             assert np.array_equal(x[0][j].cpu().numpy(), feats[v])
             assert np.array_equal(x[1][j].cpu().numpy(), vfeats[v][:, :16])
+
+
+@needs_h5
+def test_streamed_prefetch_can_be_abandoned_and_reports_reader_errors(tmp_path):
+    import threading
+    import time
+    fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
+    st = D.StreamedFeatures(fp, rp, 16, 'cpu', depth=1, workers=2)
+    before = threading.active_count()
+    gen = st.prefetch([[0, 1], [2, 3], [4, 5], [6, 7], [8, 9]])
+    next(gen)
+    gen.close()                                              # the consumer leaves early: the reader thread must end
+    for _ in range(50):
+        if threading.active_count() <= before:
+            break
+        time.sleep(0.1)
+    assert threading.active_count() <= before
+    with pytest.raises(IndexError):                          # a failing read surfaces in the consumer
+        list(st.prefetch([[0, 1], [10 ** 6]]))
