@@ -178,6 +178,51 @@ class _LstmSeqBwd(torch.autograd.Function):
         return (None, gA, gC, gHs, gW, gDH, Ubar if ctx.has[0] else None, gDC if ctx.has[1] else None)
 
 
+class _Softmax(torch.autograd.Function):
+    """softmax over `dim` of a dense tensor, one launch per differentiation level (31 ATen launches per instance otherwise);
+    its backward takes the OUTPUT y as a tracked input, so the second-order term reaches x through this node again."""
+
+    @staticmethod
+    def forward(ctx, ops, x, dim):
+        x = x.contiguous()
+        dim = dim % x.dim()
+        outer = int(math.prod(x.shape[:dim]))
+        inner = int(math.prod(x.shape[dim + 1:]))
+        y = torch.empty_like(x)
+        ops.softmax_fwd(x, y, outer, x.shape[dim], inner)
+        ctx.ops, ctx.geom = ops, (outer, x.shape[dim], inner)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        return None, _SoftmaxBwd.apply(ctx.ops, y, dy.contiguous(), ctx.geom), None
+
+
+class _SoftmaxBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ops, y, dy, geom):
+        dx = torch.empty_like(y)
+        ops.softmax_bwd(y, dy, dx, *geom)
+        ctx.ops, ctx.geom = ops, geom
+        ctx.save_for_backward(y, dy)
+        return dx
+
+    @staticmethod
+    def backward(ctx, u):
+        y, dy = ctx.saved_tensors
+        gy, gdy = torch.empty_like(y), torch.empty_like(y)
+        ctx.ops.softmax_bwd2(y, dy, u.contiguous(), gy, gdy, *ctx.geom)
+        return None, gy, gdy, None
+
+
+def _softmax(x, dim, ops=None):
+    if ops is not None and (x.dtype == torch.float32 or getattr(ops, 'name', '') != 'hip'):
+        return _Softmax.apply(ops, x, dim)
+    return torch.softmax(x, dim=dim)
+
+
 class _TanhLN(torch.autograd.Function):
     """y = LayerNorm(tanh(x) or x): one HIP launch per differentiation level (csrc/critic.hip) instead of ~85 ATen launches
     per instance across forward, backward and the backward of the backward."""
@@ -298,7 +343,7 @@ class DiscV2(nn.Module):
             top = alpha.sum(dim=1).topk(m.num_top, dim=-1).indices
             e = e.gather(1, top.unsqueeze(-1).expand(n, m.num_top, WIDTH))
         a = _tanh_ln(m.att_norm[0](words), m.att_norm[2], ops)
-        adj = torch.softmax(a @ e.transpose(1, 2) / math.sqrt(WIDTH), dim=1) * word_mask       # mask after the softmax (:703-704)
+        adj = _softmax(a @ e.transpose(1, 2) / math.sqrt(WIDTH), 1, ops) * word_mask          # mask after the softmax (:703-704)
         weight = adj.sum(dim=1)
         agg = _dropout(_tanh_ln(adj.transpose(1, 2) @ a, m.psl_norm[1], ops), 0.3, self.training)
         sc = m.psl_scorer
@@ -327,7 +372,7 @@ class DiscV2(nn.Module):
         mask = rep(att_mask)
         sa = self.att
         logits = sa.K(y) @ sa.Q(y).transpose(1, 2) / math.sqrt(sa.attention_size)
-        w = torch.softmax(torch.where(mask > 0, logits, torch.full_like(logits, -9e15)), dim=-1)
+        w = _softmax(torch.where(mask > 0, logits, torch.full_like(logits, -9e15)), -1, ops)
         words = _tanh_ln(_dropout(sa.output_layer[0](w @ sa.V(y)), sa.dropout, self.training), self.att_norm[1], ops)
         word_mask = mask[:, 0, :].unsqueeze(2)                     # (n,L,1)
         alpha = rep(alpha_all) * word_mask
@@ -339,9 +384,9 @@ class DiscV2(nn.Module):
         so = so.view(groups, B).mean(dim=1).repeat_interleave(B)
         sm = sm.view(groups, B).mean(dim=1).repeat_interleave(B)
         ts = self.text_sum
-        adj = torch.softmax(words @ ts.theta.t(), dim=1)           # LatentPSL(512, 1): one latent node over the words
+        adj = _softmax(words @ ts.theta.t(), 1, ops)               # LatentPSL(512, 1): one latent node over the words
         sent = _dropout(_tanh_ln(adj.transpose(1, 2) @ words, ts.out_norm[1], ops), 0.3, self.training).squeeze(1)
-        fus = torch.softmax(sent @ self.fusion.t(), dim=-1)
+        fus = _softmax(sent @ self.fusion.t(), -1, ops)
         return so * fus[:, 0] + sm * fus[:, 1]
 
     def forward(self, inputs, obj_proposals, motion_proposals, att_mask=None, alpha_all=None):

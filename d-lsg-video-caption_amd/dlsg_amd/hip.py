@@ -153,7 +153,7 @@ class DecattCacheGradsArgs(C.Structure):
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
            'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_colsum_ws_floats', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
-           'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
+           'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_softmax_bwd2', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
@@ -187,6 +187,7 @@ def load_library(path=LIB_PATH):
         'dlsg_o2v_fwd_multi': [P(O2VArgs), i32, vp],
         'dlsg_softmax_fwd': [vp, vp, vp, i64, i32, i32, vp],
         'dlsg_softmax_bwd': [vp, vp, vp, i64, i32, i32, vp],
+        'dlsg_softmax_bwd2': [vp, vp, vp, vp, vp, i64, i32, i32, vp],
         'dlsg_decatt_fwd': [P(DecAttArgs), vp],
         'dlsg_decatt_bwd': [P(DecAttBwdArgs), vp],
         'dlsg_lstm_pw_fwd': [P(LstmPwArgs), vp],
@@ -443,6 +444,10 @@ class HipOps(object):
 
     def softmax_bwd(self, y, dy, dx, outer, n, inner):
         self._check(self.lib.dlsg_softmax_bwd(_p(y), _p(dy), _p(dx), i64(outer), n, inner, self._stream()), 'softmax_bwd')
+
+    def softmax_bwd2(self, y, dy, u, gy, gdy, outer, n, inner):
+        self._check(self.lib.dlsg_softmax_bwd2(_p(y), _p(dy), _p(u), _p(gy), _p(gdy), i64(outer), n, inner, self._stream()),
+                    'softmax_bwd2')
 
     # ------------------------------------------------------------------ o2v graph
     def o2v_supported(self, T, H):

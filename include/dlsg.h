@@ -206,6 +206,10 @@ int dlsg_sa_core_bwd(const dlsg_sa_core_bwd_args* a, void* stream);
 int dlsg_softmax_fwd(const float* x, const float* mask, float* y, int64_t outer, int n, int inner, void* stream);
 /* dx = y * (dy - sum_n y*dy) */
 int dlsg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t outer, int n, int inner, void* stream);
+/* backward of dlsg_softmax_bwd w.r.t. (y, dy) for a cotangent u on dx (the DiscV2 critic's softmaxes are differentiated
+ * twice, run_gun.py:362-371): t = sum u y, gdy = y (u - t), gy = u (dy - s) - dy t */
+int dlsg_softmax_bwd2(const float* y, const float* dy, const float* u, float* gy, float* gdy, int64_t outer, int n, int inner,
+                      void* stream);
 
 /* ---------------------------------------------------------------- decoder attention over cached K', V' (sublayer.py:28-43)
  * For stream s in {0,1}: score_p = K'_s[b,p,:].q[b,:] * scale; w = softmax over p; c = sum_p w_p V'_s[b,p,:].

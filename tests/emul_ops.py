@@ -182,6 +182,12 @@ class EmulOps(object):
         s = (yv * dv).sum(1, keepdim=True)
         dx.copy_((yv * (dv - s)).reshape(dx.shape))
 
+    def softmax_bwd2(self, y, dy, u, gy, gdy, outer, n, inner):
+        yv, dv, uv = y.reshape(outer, n, inner), dy.reshape(outer, n, inner), u.reshape(outer, n, inner)
+        s, t = (yv * dv).sum(1, keepdim=True), (yv * uv).sum(1, keepdim=True)
+        gdy.copy_((yv * (uv - t)).reshape(gdy.shape))
+        gy.copy_((uv * (dv - s) - dv * t).reshape(gy.shape))
+
     # ------------------------------------------------------------------ o2v
     def o2v_supported(self, T, H):
         return self.fused_supported and T <= 32

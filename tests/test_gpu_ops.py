@@ -860,3 +860,19 @@ def test_colsum_tall_is_bit_reproducible(hip):
     assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs)
     ref = part.double().sum(0)
     assert (outs[0][0].double() - ref).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize('shape,dim', [((192, 26, 3), 1), ((192, 26, 26), 2), ((192, 26, 1), 1), ((192, 2), 1), ((5, 130, 7), 1)])
+def test_softmax_three_levels(hip, shape, dim):
+    """softmax forward / backward / backward of the backward over an inner or the last axis (the critic's five softmaxes)"""
+    outer = int(np.prod(shape[:dim])); n = shape[dim]; inner = int(np.prod(shape[dim + 1:]))
+
+    def build(g):
+        return dict(x=rnd(g, *shape, scale=2.0), dy=rnd(g, *shape), u=rnd(g, *shape), y=torch.zeros(*shape), dx=torch.zeros(*shape),
+                    gy=torch.zeros(*shape), gdy=torch.zeros(*shape))
+
+    def run(ops, t):
+        ops.softmax_fwd(t['x'], t['y'], outer, n, inner)
+        ops.softmax_bwd(t['y'], t['dy'], t['dx'], outer, n, inner)
+        ops.softmax_bwd2(t['y'], t['dy'], t['u'], t['gy'], t['gdy'], outer, n, inner)
+    both(hip, build, run, ['y', 'dx', 'gy', 'gdy'], tol=2e-5, name='softmax levels %s' % (shape,))
