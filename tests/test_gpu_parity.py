@@ -466,7 +466,7 @@ def test_full_size_train_step_gradients_are_bit_reproducible():
 
 
 @pytest.mark.parametrize('mode,Bn,shape', [('fp32', 64, 'msvd'), ('x3_bwd', 64, 'msvd'), ('fp32', 128, 'msvd'),
-                                           ('fp32', 64, 'msrvtt')])
+                                           ('fp32', 64, 'msrvtt'), ('fp32', 90, 'msvd')])      # 90: 67-row shard, ragged 64-row tiles
 def test_full_size_gradient_is_token_weighted_mean_of_shard_gradients(mode, Bn, shape):
     """Property at the bench configurations (batch 64 and 128 MSVD-shaped, batch 64 MSR-VTT-shaped = BASELINE configs 1, 4
     and 3 per GPU; dropout off): the ragged CrossEntropy is a mean over
