@@ -443,13 +443,16 @@ __global__ void embed_fwd_kernel(const float* __restrict__ E, const int64_t* __r
 // the word-embedding gradient differed in the last bit between runs of the same step).  One wave per row.  The first row that
 // carries an id owns it and adds the rows with that id in row order; waves of later duplicates exit.  Matches are found 64 ids
 // at a time with a ballot (eight independent id loads in flight), so only real matches cost a row read.
-__global__ __launch_bounds__(64) void embed_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const int64_t* __restrict__ ids,
-                                                       float* __restrict__ dE, int rows, int W, float p, uint64_t seed, uint32_t site,
-                                                       int64_t row0, const uint64_t* seed_ptr) {
+__global__ __launch_bounds__(1024) void embed_bwd_kernel(const float* __restrict__ dout, int64_t lddo, const int64_t* __restrict__ ids,
+                                                         float* __restrict__ dE, int rows, int W, float p, uint64_t seed, uint32_t site,
+                                                         int64_t row0, const uint64_t* seed_ptr) {
     if (seed_ptr) seed += *seed_ptr;
-    const int r = blockIdx.x, lane = threadIdx.x;
+    // every wave of the workgroup finds the same matches (ids only) and owns 64 columns per pass: a frequent id (the <pad> word
+    // of the caption tails: 40 % of the rows) is 650 rows added by ONE workgroup, and with the dropout hash per element that
+    // was 87 us in a single wave
+    const int r = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     const int64_t id = ids[r];
-    // ---- an earlier row with the same id?  then that row's wave does the work
+    // ---- an earlier row with the same id?  then that row's workgroup does the work
     for (int base = 0; base < r; base += 512) {
         int64_t v[8];
 #pragma unroll
@@ -460,10 +463,11 @@ __global__ __launch_bounds__(64) void embed_bwd_kernel(const float* __restrict__
         bool hit = false;
 #pragma unroll
         for (int u = 0; u < 8; ++u) hit = hit || (v[u] == id);
-        if (__ballot(hit)) return;                       // wave-uniform
+        if (__ballot(hit)) return;                       // wave-uniform, and the same in every wave
     }
-    for (int c0 = 0; c0 < W; c0 += 512) {                 // 8 columns per lane and pass
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 64 * wv; c0 < W; c0 += 64 * nwv) {       // this wave's column block of the pass
+        const int j = c0 + lane;
+        float acc = 0.f;
         for (int base = r; base < rows; base += 512) {
             int64_t v[8];
 #pragma unroll
@@ -475,26 +479,26 @@ __global__ __launch_bounds__(64) void embed_bwd_kernel(const float* __restrict__
             for (int u = 0; u < 8; ++u) {
                 unsigned long long m = __ballot(v[u] == id);
                 while (m) {                               // ascending rows: the sum order is fixed
-                    const int k = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const int rr = base + 64 * u + k;
+                    int rr[8];                            // up to eight matching rows fetched together, added in order
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int j = c0 + lane + 64 * q;
-                        if (j < W) {
-                            float g = dout[(int64_t)rr * lddo + j];
-                            if (p > 0.f) g *= drop_scale(seed, site, (uint64_t)(row0 + rr) * W + j, p);
-                            acc[q] += g;
-                        }
+                    for (int x = 0; x < 8; ++x) {
+                        rr[x] = m ? base + 64 * u + (__ffsll((long long)m) - 1) : -1;
+                        m &= m - 1;
                     }
+                    float g[8];
+#pragma unroll
+                    for (int x = 0; x < 8; ++x) g[x] = (rr[x] >= 0 && j < W) ? dout[(int64_t)rr[x] * lddo + j] : 0.f;
+#pragma unroll
+                    for (int x = 0; x < 8; ++x)
+                        if (rr[x] >= 0 && j < W) {
+                            float gv = g[x];
+                            if (p > 0.f) gv *= drop_scale(seed, site, (uint64_t)(row0 + rr[x]) * W + j, p);
+                            acc += gv;
+                        }
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int j = c0 + lane + 64 * q;
-            if (j < W) dE[id * W + j] += acc[q];
-        }
+        if (j < W) dE[id * W + j] += acc;
     }
 }
 
@@ -966,7 +970,9 @@ extern "C" int dlsg_embed_fwd(const float* E, const int64_t* ids, float* out, in
 extern "C" int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* ids, float* dE, int rows, int W, float p,
                               uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream) {
     if (rows == 0) return DLSG_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(64), 0, ST(stream), dout, lddo, ids, dE, rows, W, p, seed, site, row0, seed_ptr);
+    const int threads = W >= 1024 ? 1024 : (W + 63) / 64 * 64;           // one wave per 64 columns
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows), dim3(threads), 0, ST(stream), dout, lddo, ids, dE, rows, W, p, seed, site, row0,
+                       seed_ptr);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
