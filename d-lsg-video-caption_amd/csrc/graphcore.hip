@@ -159,6 +159,13 @@ constexpr int SA_THREADS = 512;
 constexpr int SA_CH = 512;
 constexpr int SA_LD = SA_CH + 4;
 constexpr int SA_LDS_FLOATS = 2 * 32 * SA_LD + 4 * 16 * 64;
+// workgroups per clip for the column passes: up to D / 512, as many as keep the launch near one workgroup per CU
+inline int sa_col_split(int B, int D) {
+    int sp = 256 / (B > 0 ? B : 1);
+    const int mx = D / SA_THREADS;
+    if (sp > mx) sp = mx;
+    return sp < 2 ? 1 : sp;
+}
 
 __global__ __launch_bounds__(SA_THREADS) void sa_core_fwd_kernel(const dlsg_sa_core_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -237,10 +244,28 @@ __global__ __launch_bounds__(SA_THREADS) void sa_core_fwd_kernel(const dlsg_sa_c
         for (int o = 16; o > 0; o >>= 1) l += __shfl_xor(l, o, 64);
         const float wv = ex / l;
         wl[i][r] = wv;
-        if (i < T && r < T) a.w[((int64_t)b * T + i) * T + r] = wv;
+        if (i < T && r < T && blockIdx.y == 0) a.w[((int64_t)b * T + i) * T + r] = wv;
     }
     __syncthreads();
     // ---- out[i][cols] = sum_j w[i][j] V[j][cols]
+    if (gridDim.y > 1) {
+        // few clips (B workgroups would leave 3/4 of the CUs idle): the clip's columns are spread over gridDim.y workgroups,
+        // each of which has computed the (cheap) 26 x 26 weights itself; one column per thread
+        for (int c = blockIdx.y * SA_THREADS + threadIdx.x; c < D; c += gridDim.y * SA_THREADS) {
+            float acc[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+            for (int j = 0; j < T; ++j) {
+                const float v = Vb[(int64_t)j * D + c];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) acc[i] += wl[i][j] * v;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (i < T) a.out[((int64_t)b * T + i) * D + c] = acc[i];
+        }
+        return;
+    }
     for (int c = threadIdx.x * 4; c < D; c += SA_THREADS * 4) {
         f32x4 acc[32];
 #pragma unroll
@@ -336,7 +361,44 @@ __global__ __launch_bounds__(SA_THREADS) void sa_core_bwd_kernel(const dlsg_sa_c
         gl[i][r] = wv * (dw - dot) * a.scale;
     }
     __syncthreads();
-    // ---- column-parallel passes: one thread per 4 columns
+    // ---- column-parallel passes
+    if (gridDim.y > 1) {                  // columns of the clip spread over gridDim.y workgroups: one column per thread
+        for (int c = blockIdx.y * SA_THREADS + threadIdx.x; c < D; c += gridDim.y * SA_THREADS) {
+            float acc[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+            for (int i = 0; i < T; ++i) {
+                const float x = Gb[(int64_t)i * D + c];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) acc[j] += wl[i][j] * x;
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j < T) a.dV[base + (int64_t)j * D + c] = acc[j];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+            for (int j = 0; j < T; ++j) {
+                const float x = Qb[(int64_t)j * D + c];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) acc[i] += gl[i][j] * x;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                if (i < T) a.dK[base + (int64_t)i * D + c] = acc[i];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+            for (int i = 0; i < T; ++i) {
+                const float x = Kb[(int64_t)i * D + c];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) acc[j] += gl[i][j] * x;
+            }
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j < T) a.dQ[base + (int64_t)j * D + c] = acc[j];
+        }
+        return;
+    }
+    // one thread per 4 columns
     for (int c = threadIdx.x * 4; c < D; c += SA_THREADS * 4) {
         f32x4 acc[32];
         // dV[j] = sum_i w[i][j] d(out)[i]
@@ -542,7 +604,8 @@ extern "C" int dlsg_sa_core_fwd(const dlsg_sa_core_args* a, void* stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_core_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   SA_LDS_FLOATS * 4);
     });
-    hipLaunchKernelGGL(sa_core_fwd_kernel, dim3(a->B), dim3(SA_THREADS), SA_LDS_FLOATS * 4, reinterpret_cast<hipStream_t>(stream), *a);
+    hipLaunchKernelGGL(sa_core_fwd_kernel, dim3(a->B, sa_col_split(a->B, a->D)), dim3(SA_THREADS), SA_LDS_FLOATS * 4,
+                       reinterpret_cast<hipStream_t>(stream), *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
@@ -559,7 +622,8 @@ extern "C" int dlsg_sa_core_bwd(const dlsg_sa_core_bwd_args* a, void* stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sa_core_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   SA_LDS_FLOATS * 4);
     });
-    hipLaunchKernelGGL(sa_core_bwd_kernel, dim3(a->B), dim3(SA_THREADS), SA_LDS_FLOATS * 4, reinterpret_cast<hipStream_t>(stream), *a);
+    hipLaunchKernelGGL(sa_core_bwd_kernel, dim3(a->B, sa_col_split(a->B, a->D)), dim3(SA_THREADS), SA_LDS_FLOATS * 4,
+                       reinterpret_cast<hipStream_t>(stream), *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

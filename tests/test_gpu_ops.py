@@ -442,7 +442,7 @@ def test_latent_psl_fused_forward(hip, dims):
     both(hip, build, run, ['adj', 'u', 'out', 'st'], tol=3e-5, name='latent_psl %s' % (dims,))
 
 
-@pytest.mark.parametrize('dims', [(3, 26, 128), (64, 26, 2048), (2, 32, 576), (2, 7, 64), (4, 20, 1024)])
+@pytest.mark.parametrize('dims', [(3, 26, 128), (64, 26, 2048), (2, 32, 576), (2, 7, 64), (4, 20, 1024), (100, 26, 2048), (5, 26, 1536)])
 @pytest.mark.parametrize('masked', [False, True])
 def test_self_attention_core_fused_forward(hip, dims, masked):
     B, T, D = dims
@@ -472,7 +472,7 @@ def test_latent_psl_fused_backward(hip, dims):
     both(hip, build, run, ['dov', 'dth', 'part'], tol=3e-5, name='latent_psl bwd %s' % (dims,))
 
 
-@pytest.mark.parametrize('dims', [(3, 26, 128), (64, 26, 2048), (2, 32, 576), (2, 7, 64), (4, 20, 1024)])
+@pytest.mark.parametrize('dims', [(3, 26, 128), (64, 26, 2048), (2, 32, 576), (2, 7, 64), (4, 20, 1024), (100, 26, 2048), (5, 26, 1536)])
 def test_self_attention_core_fused_backward(hip, dims):
     B, T, D = dims
 
