@@ -167,6 +167,16 @@ inline int sa_col_split(int B, int D) {
     return sp < 2 ? 1 : sp;
 }
 
+// rows [0, T) x columns [cbase, cbase + SA_CH) of a (T, D) array -> dst [32][SA_LD] (rows >= T and columns >= D zero)
+__device__ __forceinline__ void sa_stage_rows(float* __restrict__ dst, const float* __restrict__ src, int T, int D, int cbase) {
+    for (int f = threadIdx.x; f < 32 * (SA_CH / 4); f += SA_THREADS) {
+        const int row = f / (SA_CH / 4), c4 = f % (SA_CH / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < T && cbase + 4 * c4 < D) v = *reinterpret_cast<const f32x4*>(src + (int64_t)row * D + cbase + 4 * c4);
+        *reinterpret_cast<f32x4*>(dst + row * SA_LD + 4 * c4) = v;
+    }
+}
+
 __global__ __launch_bounds__(SA_THREADS) void sa_core_fwd_kernel(const dlsg_sa_core_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float wl[32][33];
@@ -251,18 +261,26 @@ __global__ __launch_bounds__(SA_THREADS) void sa_core_fwd_kernel(const dlsg_sa_c
     if (gridDim.y > 1) {
         // few clips (B workgroups would leave 3/4 of the CUs idle): the clip's columns are spread over gridDim.y workgroups,
         // each of which has computed the (cheap) 26 x 26 weights itself; one column per thread
-        for (int c = blockIdx.y * SA_THREADS + threadIdx.x; c < D; c += gridDim.y * SA_THREADS) {
-            float acc[32];
+        // the 512 columns of V are staged through LDS first (16 B x 16 loads per thread in flight): read row by row from
+        // global memory inside the product loop, each of the 26 rows cost its own round trip
+        for (int cbase = blockIdx.y * SA_CH; cbase < D; cbase += gridDim.y * SA_CH) {
+            __syncthreads();
+            sa_stage_rows(kl, Vb, T, D, cbase);
+            __syncthreads();
+            const int c = cbase + threadIdx.x;
+            if (c < D) {
+                float acc[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-            for (int j = 0; j < T; ++j) {
-                const float v = Vb[(int64_t)j * D + c];
+                for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+                for (int j = 0; j < T; ++j) {
+                    const float v = kl[j * SA_LD + threadIdx.x];
 #pragma unroll
-                for (int i = 0; i < 32; ++i) acc[i] += wl[i][j] * v;
+                    for (int i = 0; i < 32; ++i) acc[i] += wl[i][j] * v;
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (i < T) a.out[((int64_t)b * T + i) * D + c] = acc[i];
             }
-#pragma unroll
-            for (int i = 0; i < 32; ++i)
-                if (i < T) a.out[((int64_t)b * T + i) * D + c] = acc[i];
         }
         return;
     }
@@ -363,38 +381,50 @@ __global__ __launch_bounds__(SA_THREADS) void sa_core_bwd_kernel(const dlsg_sa_c
     __syncthreads();
     // ---- column-parallel passes
     if (gridDim.y > 1) {                  // columns of the clip spread over gridDim.y workgroups: one column per thread
-        for (int c = blockIdx.y * SA_THREADS + threadIdx.x; c < D; c += gridDim.y * SA_THREADS) {
+        for (int cbase = blockIdx.y * SA_CH; cbase < D; cbase += gridDim.y * SA_CH) {
+            const int c = cbase + threadIdx.x;
             float acc[32];
+            __syncthreads();
+            sa_stage_rows(al, Gb, T, D, cbase);           // d(out) and Q columns of this block through LDS (see the forward)
+            sa_stage_rows(vl, Qb, T, D, cbase);
+            __syncthreads();
+            if (c < D) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-            for (int i = 0; i < T; ++i) {
-                const float x = Gb[(int64_t)i * D + c];
+                for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+                for (int i = 0; i < T; ++i) {
+                    const float x = al[i * SA_LD + threadIdx.x];
 #pragma unroll
-                for (int j = 0; j < 32; ++j) acc[j] += wl[i][j] * x;
+                    for (int j = 0; j < 32; ++j) acc[j] += wl[i][j] * x;
+                }
+#pragma unroll
+                for (int j = 0; j < 32; ++j)
+                    if (j < T) a.dV[base + (int64_t)j * D + c] = acc[j];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+                for (int j = 0; j < T; ++j) {
+                    const float x = vl[j * SA_LD + threadIdx.x];
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) acc[i] += gl[i][j] * x;
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    if (i < T) a.dK[base + (int64_t)i * D + c] = acc[i];
             }
+            __syncthreads();
+            sa_stage_rows(al, Kb, T, D, cbase);
+            __syncthreads();
+            if (c < D) {
 #pragma unroll
-            for (int j = 0; j < 32; ++j)
-                if (j < T) a.dV[base + (int64_t)j * D + c] = acc[j];
+                for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+                for (int i = 0; i < T; ++i) {
+                    const float x = al[i * SA_LD + threadIdx.x];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) acc[i] = 0.f;
-            for (int j = 0; j < T; ++j) {
-                const float x = Qb[(int64_t)j * D + c];
+                    for (int j = 0; j < 32; ++j) acc[j] += gl[i][j] * x;
+                }
 #pragma unroll
-                for (int i = 0; i < 32; ++i) acc[i] += gl[i][j] * x;
+                for (int j = 0; j < 32; ++j)
+                    if (j < T) a.dQ[base + (int64_t)j * D + c] = acc[j];
             }
-#pragma unroll
-            for (int i = 0; i < 32; ++i)
-                if (i < T) a.dK[base + (int64_t)i * D + c] = acc[i];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) acc[j] = 0.f;
-            for (int i = 0; i < T; ++i) {
-                const float x = Kb[(int64_t)i * D + c];
-#pragma unroll
-                for (int j = 0; j < 32; ++j) acc[j] += gl[i][j] * x;
-            }
-#pragma unroll
-            for (int j = 0; j < 32; ++j)
-                if (j < T) a.dQ[base + (int64_t)j * D + c] = acc[j];
         }
         return;
     }
