@@ -254,13 +254,29 @@ __device__ __forceinline__ void o2v_combine_body(const dlsg_o2v_args& a) {
     const float invL = 1.f / L;
     const float* vp = a.v + ((int64_t)b * T + t) * H;
     float* zp = a.z + ((int64_t)b * T + t) * H;
-    for (int j = threadIdx.x; j < H; j += blockDim.x) {
-        float s_ = 0.f;
-        for (int s = 0; s < ns; ++s) {
-            const float ms = base[s * stride + (int64_t)T * H + t];
-            s_ += __expf(ms - M) * base[s * stride + (int64_t)t * H + j];
+    // chunk weights once per workgroup; rows in 16-byte pieces with every chunk's load issued before the adds
+    __shared__ float wsh[64];
+    if (threadIdx.x < ns) wsh[threadIdx.x] = __expf(base[threadIdx.x * stride + (int64_t)T * H + t] - M) * invL;
+    __syncthreads();
+    if ((H & 3) == 0 && ((reinterpret_cast<uintptr_t>(vp) | reinterpret_cast<uintptr_t>(zp) | reinterpret_cast<uintptr_t>(a.ws)) & 15) == 0) {
+        for (int j = threadIdx.x * 4; j < H; j += blockDim.x * 4) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(vp + j);
+            int s0 = 0;
+            for (; s0 + 2 <= ns; s0 += 2) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(base + s0 * stride + (int64_t)t * H + j);
+                const f32x4 p1 = *reinterpret_cast<const f32x4*>(base + (s0 + 1) * stride + (int64_t)t * H + j);
+                acc += wsh[s0] * p0;
+                acc += wsh[s0 + 1] * p1;
+            }
+            if (s0 < ns) acc += wsh[s0] * *reinterpret_cast<const f32x4*>(base + s0 * stride + (int64_t)t * H + j);
+            *reinterpret_cast<f32x4*>(zp + j) = acc;
         }
-        zp[j] = s_ * invL + vp[j];
+    } else {
+        for (int j = threadIdx.x; j < H; j += blockDim.x) {
+            float s_ = vp[j];
+            for (int s = 0; s < ns; ++s) s_ += wsh[s] * base[s * stride + (int64_t)t * H + j];
+            zp[j] = s_;
+        }
     }
     if (threadIdx.x == 0 && a.ml) {
         a.ml[2 * ((int64_t)b * T + t)] = M;
