@@ -742,6 +742,24 @@ def test_adam_matches_torch_optim(hip):
     assert (p.cpu() - ref.detach()).abs().max().item() <= 1e-6
 
 
+@pytest.mark.parametrize('off,n', [(0, 5000), (1, 4999), (3, 1026), (2, 3), (5, 1), (0, 4), (7, 100003)])
+def test_adam_ranges_at_any_offset(hip, off, n):
+    """trainable ranges of the parameter arena start at arbitrary parameter boundaries: scalar head / 16-byte body / scalar tail"""
+    g = torch.Generator().manual_seed(off * 100 + n)
+    tot = off + n + 9
+    p0, gr = rnd(g, tot), rnd(g, tot)
+    m0, v0 = rnd(g, tot).abs() * 0.1, rnd(g, tot).abs() * 0.1
+    p, gg, m, v = p0.clone().cuda(), gr.cuda(), m0.clone().cuda(), v0.clone().cuda()
+    hip.adam(p[off:off + n], gg[off:off + n], m[off:off + n], v[off:off + n], 1.6e-4, 0.5, 0.9, 1e-8, 3, 0.5)
+    torch.cuda.synchronize()
+    from emul_ops import EmulOps
+    pe, me, ve = p0.clone(), m0.clone(), v0.clone()
+    EmulOps().adam(pe[off:off + n], gr[off:off + n], me[off:off + n], ve[off:off + n], 1.6e-4, 0.5, 0.9, 1e-8, 3, 0.5)
+    for a, b in ((p, pe), (m, me), (v, ve)):
+        assert (a.cpu() - b).abs().max().item() <= 1e-6
+        assert torch.equal(a.cpu()[:off], b[:off]) and torch.equal(a.cpu()[off + n:], b[off + n:])        # nothing outside the range
+
+
 def test_masked_self_attention_core_against_reference_fixture(hip):
     """tests/golden/sa_mask.npz (the reference's SelfAttention with an attention mask, sublayer.py:70-72, as DiscV2 uses it):
     PE add and the bias-free projections in torch, the masked 26 x 26 core on the HIP kernel."""
