@@ -481,7 +481,8 @@ __device__ __forceinline__ void s2_glds(const char* src, char* dst) {
 // used when the launch still fills the chip with half as many workgroups.  (NJ = 4 -- 64 x 128 tiles, 144 KB of rings, the
 // contraction in 8 groups of 512 to keep 256 workgroups -- was measured and dropped: language gates 32.5 us against 28.6, query
 // gates 29.4 against 23.8: eight 16-deep stages per wave no longer amortise the ring's ramp.  A fourth ring slot (three stages
-// in flight, 128 KB) changed nothing either: 21.6 / 28.6 / 16.2 us against 21.6 / 28.0 / 17.3.)
+// in flight, 128 KB) changed nothing either: 21.6 / 28.6 / 16.2 us against 21.6 / 28.0 / 17.3; nor did giving each wave a
+// contiguous k range, so that its consecutive stages are the two halves of the same 128-B lines: 22.3 / 28.9 / 16.4.)
 template <int NJ>
 __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
     constexpr int SLOT = S2_A_BYTES + NJ * S2_B_BYTES;
