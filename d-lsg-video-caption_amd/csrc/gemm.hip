@@ -482,7 +482,9 @@ __device__ __forceinline__ void s2_glds(const char* src, char* dst) {
 // contraction in 8 groups of 512 to keep 256 workgroups -- was measured and dropped: language gates 32.5 us against 28.6, query
 // gates 29.4 against 23.8: eight 16-deep stages per wave no longer amortise the ring's ramp.  A fourth ring slot (three stages
 // in flight, 128 KB) changed nothing either: 21.6 / 28.6 / 16.2 us against 21.6 / 28.0 / 17.3; nor did giving each wave a
-// contiguous k range, so that its consecutive stages are the two halves of the same 128-B lines: 22.3 / 28.9 / 16.4.)
+// contiguous k range, so that its consecutive stages are the two halves of the same 128-B lines: 22.3 / 28.9 / 16.4; nor did
+// issuing the next stage's pieces one by one between the MFMA groups instead of together: 22.0 / 29.6 / 17.4.  The launch is
+// as long as its bytes take through the CUs' load paths, whatever the schedule around them.)
 template <int NJ>
 __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
     constexpr int SLOT = S2_A_BYTES + NJ * S2_B_BYTES;
