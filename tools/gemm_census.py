@@ -2,7 +2,6 @@
 bracketed by events, grouped by (mode, M, N, K per group, groups, batch count); count, total time and TFLOP/s per shape.
 usage: python tools/gemm_census.py [fp32|x3_bwd|x3_all] [batch] [msvd|msrvtt]"""
 import collections
-import json
 import os
 import random
 import sys
