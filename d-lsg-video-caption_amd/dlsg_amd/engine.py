@@ -161,16 +161,33 @@ def gemm_nn_multi_slabs(ops, dy, Ws, width, ref):
     return slabs
 
 
-def tn_grouped(ops, items):
+def tn_grouped(ops, items, defer=None):
     """Weight gradients gout_i += dy_i^T x_i for several (dy, x, gout) triples: one grouped launch per distinct output
     height (dy width) instead of one launch each.  A 4096 x 1024 gradient block is 256 tiles of 128 x 128 -- one per CU,
-    nothing to hide latency behind; seven of them in one launch fill every CU three deep and run on the large tile."""
+    nothing to hide latency behind; seven of them in one launch fill every CU three deep and run on the large tile.
+    defer: a list collecting the triples instead (one process, no bucket cuts: the backward launches ALL its mid-size weight
+    gradients at its end, grouped by height across modules -- the decoder's and the BiLSTM's 4096-row blocks are 2.3 + 1.3
+    rounds of workgroups apart and 3.7 together; worth 0.04 ms of the 15.05-ms step: a partly filled round's workgroups run
+    faster, so little was lost to begin with)."""
+    if defer is not None:
+        defer.extend(items)
+        return
     by_m = {}
     for dy, x, gout in items:
         by_m.setdefault(dy.shape[1], []).append((dy, x, gout))
     for grp in by_m.values():
-        for i in range(0, len(grp), 16):
-            ops.gemm(GEMM_TN, grp[i:i + 16], flags=F_ACCUM)
+        # two triples writing the same gradient block must not share a launch (accumulating groups would race)
+        waves, seen = [[]], [set()]
+        for it in grp:
+            key = (it[2].data_ptr(), tuple(it[2].shape))
+            for w_, sn in zip(waves, seen):
+                if key not in sn and len(w_) < 16:
+                    w_.append(it); sn.add(key)
+                    break
+            else:
+                waves.append([it]); seen.append({key})
+        for w_ in waves:
+            ops.gemm(GEMM_TN, w_, flags=F_ACCUM)
 
 
 def gemm_bucketed(ops, mode, groups, flags=0):
@@ -563,7 +580,7 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
         ops.gemm(GEMM_NN, [(dK, sa.K.weight, sl[0]), (dQ, sa.Q.weight, sl[1]), (dV, sa.V.weight, sl[2])])
         ops.slab_reduce(sl, dx)
         tn_grouped(ops, [(dK, x, G[name + '.self_attention.K.weight']), (dQ, x, G[name + '.self_attention.Q.weight']),
-                         (dV, x, G[name + '.self_attention.V.weight'])])
+                         (dV, x, G[name + '.self_attention.V.weight'])], sv.get('tn_defer'))
         nb = ops.rowln_bwd_nblk(B * T)
         part = _empty(ref, nb, 2, D2)
         ops.rowln_bwd(dx, out2, ln.weight, ln.bias, dout, stats=s['st_l'], pe=s['pe'], p1=s['pd'], site1=SITE_LSTM,
@@ -603,7 +620,8 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     de = _empty(ref, B * T, H)
     e = s['e']
     tn_grouped(ops, [(dG[d].view(B * T, 4 * H), src, G[name + '.lstm.' + wn + sfx[d]])
-                     for d in range(2) for src, wn in ((e, 'weight_ih_l0'), (hprev[d].view(B * T, H), 'weight_hh_l0'))])
+                     for d in range(2) for src, wn in ((e, 'weight_ih_l0'), (hprev[d].view(B * T, H), 'weight_hh_l0'))],
+               sv.get('tn_defer'))
     for d in range(2):
         dg2 = dG[d].view(B * T, 4 * H)
         ops.gemm(GEMM_NN, [(dg2, Wih[d], de)], flags=F_ACCUM if d else 0)
@@ -862,7 +880,7 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
                      (dgq2, qh, G['decoder.query_lstm.weight_hh'])] +
                [(dgl2, s['CTX'][i].view(n, H), Gl_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]]) for i in range(ns)] +
                [(dgl2, s['QCUR'].view(n, Q), Gl_ih[:, plan.l_q[0]:plan.l_q[1]]),
-                (dgl2, lhp, G['decoder.lang_lstm.weight_hh'])])
+                (dgl2, lhp, G['decoder.lang_lstm.weight_hh'])], sv.get('tn_defer'))
     ops.gemm(GEMM_TN, [(dgq_sum, s['gfeat'], Gq_ih[:, plan.q_glob[0]:plan.q_glob[1]])], flags=F_ACCUM)
     ops.colsum2(dgq2, G['decoder.query_lstm.bias_ih'], G['decoder.query_lstm.bias_hh'], accum=True)
     ops.colsum2(dgl2, G['decoder.lang_lstm.bias_ih'], G['decoder.lang_lstm.bias_hh'], accum=True)
@@ -894,11 +912,11 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     # every product once for all streams: dW_Q = K^T dK', dW_O = dV'^T V | dK = dK' W_Q^T | dV = dV' W_O |
     # dW_K = dK^T m, dW_V = dV^T m | dm = dK W_K (+ dV W_V)
     tn_grouped(ops, [g for i in R for g in ((s['K'][i], dkps[i], G[att_names[i] + '.Q.weight']),
-                                            (dvps[i], s['V'][i], G[att_names[i] + '.output_layer.0.weight']))])
+                                            (dvps[i], s['V'][i], G[att_names[i] + '.output_layer.0.weight']))], sv.get('tn_defer'))
     gemm_bucketed(ops, GEMM_NT, [(dkps[i], atts[i].Q.weight, dKs[i]) for i in R])
     gemm_bucketed(ops, GEMM_NN, [(dvps[i], atts[i].output_layer[0].weight, dVs[i]) for i in R])
     tn_grouped(ops, [g for i in R for g in ((dKs[i], m2s[i], G[att_names[i] + '.K.weight']),
-                                            (dVs[i], m2s[i], G[att_names[i] + '.V.weight']))])
+                                            (dVs[i], m2s[i], G[att_names[i] + '.V.weight']))], sv.get('tn_defer'))
     gemm_bucketed(ops, GEMM_NN, [(dKs[i], atts[i].K.weight, dms[i]) for i in R])
     gemm_bucketed(ops, GEMM_NN, [(dVs[i], atts[i].V.weight, dms[i]) for i in R], flags=F_ACCUM)
     dmems = [dms[i].view(s['mems'][i].shape) for i in R]

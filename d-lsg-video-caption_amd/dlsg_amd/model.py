@@ -115,6 +115,9 @@ class _HipModel(nn.Module):
         assert mode in ('fp32', 'x3_bwd', 'x3_all'), mode
         return F_BF16X3 if (mode == 'x3_all' or (mode == 'x3_bwd' and backward)) else 0
 
+    merge_weight_grads = True          # see engine.tn_grouped
+    _defer_ok = True                   # cleared by a Trainer whose backward is cut at gradient buckets (several ranks)
+
     def next_seed(self):
         self.seed_counter += 1
         return (0x5DEECE66D * self.seed_counter + 0xB) & 0xFFFFFFFFFFFF
@@ -245,6 +248,8 @@ class CapGnnModel(_HipModel):
         ops.extra_flags = self._gemm_flags(True)
         G = self._G
         ops.fill(self._gflat, 0.0)
+        if self.merge_weight_grads and self._defer_ok:
+            sv['tn_defer'] = []             # mid-size weight gradients of every module: launched together at the end
         frames, regions = sv['frames'], sv['regions']
         B, T, F = frames.shape
         H = self.decoder.visual_hidden_size
@@ -270,6 +275,8 @@ class CapGnnModel(_HipModel):
             on_bucket('encoder.motion_pre_encoder')
         E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed, defer_dw=deep)
         E.gemm_tn_deep(ops, deep, frames)
+        if 'tn_defer' in sv:
+            E.tn_grouped(ops, sv.pop('tn_defer'))
         if on_bucket:
             on_bucket(('encoder.motion_encoder', 'encoder.obj_encoder'))
 
@@ -657,6 +664,8 @@ class Trainer(object):
     # ------------------------------------------------------------------ one step, as a schedule
     def _schedule(self, frames, regions, captions, cap_lens, coins, seed, dev_coins, on_bucket, extra_dlogits=None):
         model, ops = self.model, self.model.ops
+        # weight gradients may wait for the end of the backward only where no bucket is reduced before it
+        model._defer_ok = self.world_size <= 1 and not self.force_graph_cuts and not self.force_collectives
         L = captions.shape[1]
         sv = {}
         training = model.training
