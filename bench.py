@@ -10,6 +10,10 @@ Workload (BASELINE.json configs[1]): batch 64 clips per GPU, 26 frames x (2048 +
 region features, vocab 1000, fp32, dropout active, scheduled-sampling eps = 0.95 (epoch 0).  Weak scaling: the
 per-GPU batch is fixed, gradients are summed over ranks by bucketed RCCL all-reduce overlapping the backward.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh child processes,
+one per GPU, before anything in the parent touches the GPU) and relays rank 0's line; a world size that does not equal
+--gpus, or fewer visible devices than ranks, is an error (non-zero exit), never a silently smaller run.
+
 Rank 0 prints ONE JSON line.  `value` is measured with every matrix product in exact fp32 (`--gemm fp32`, the reference's
 arithmetic); the split-bf16 policies are reported beside it under `other_gemm_arithmetic` with their measured gradient
 error.  `roofline` is measured live with HIP events around the dominant kernel (the fp32-MFMA GEMM);
@@ -60,39 +64,64 @@ def usable_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """Oracle (oracle/torch_ref.py, kind 'port') train step at BASELINE configs[0]: B=8, MSVD-shaped, CPU fp32.
-    Bounded: one warm-up step, then steps until the budget is spent; if the warm-up alone exceeds the budget it IS
-    the sample."""
+def cpu_baseline(seconds_budget=24.0):
+    """Oracle (oracle/torch_ref.py, kind 'port') at BASELINE configs[0]: B=8, MSVD-shaped, CPU fp32 -- the train step
+    (`value`, all usable cores) and, as BASELINE.md section 3.2 asks, the eval forward and both again on 8 threads.
+    Bounded: every column gets a share of the budget; a column's warm-up run is its sample if the host is that slow."""
     import dlsg_amd
     from dlsg_amd.synth import synth_state_dict, synth_batch
     from oracle import torch_ref as R
     cores = usable_cores()
-    torch.set_num_threads(cores)
     args = dlsg_amd.msvd_shaped()
     vocab = dlsg_amd.make_vocab(1000)
     torch.manual_seed(0)
     net = R.CapGnnModelRef(args, vocab)
     net.load_state_dict(synth_state_dict(net.state_dict(), 0))
-    net.train()
     opt = R.make_optimizer(net)
     B = 8
     frames, regions, caps, lens = synth_batch(args, 1000, B, 1)
-    random.seed(12)
-    t0 = time.time()
-    R.train_step(net, opt, frames, regions, caps, lens, 0.95)     # warm-up (also the sample if the host is slow)
-    warm = time.time() - t0
-    n, dt = 1, warm
-    if warm < seconds_budget / 3:
+
+    def timed(fn, budget, cap=40):
         t0 = time.time()
-        n = 0
-        while time.time() - t0 < seconds_budget - warm and n < 40:
-            R.train_step(net, opt, frames, regions, caps, lens, 0.95)
+        fn()                                       # warm-up (also the sample if the host is slow)
+        warm = time.time() - t0
+        if warm >= budget / 3:
+            return 1, warm
+        t0, n = time.time(), 0
+        while time.time() - t0 < budget - warm and n < cap:
+            fn()
             n += 1
-        dt = time.time() - t0
-    return {'value': round(B * n / dt, 3), 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+        return n, time.time() - t0
+
+    def train():
+        R.train_step(net, opt, frames, regions, caps, lens, 0.95)
+
+    def forward():
+        with torch.no_grad():
+            net(frames, regions, caps, 26, 1.0)
+
+    cols = {}
+    plan = [('train', cores, train, 0.42)]
+    plan.append(('forward', cores, forward, 0.12))
+    if cores != 8:
+        plan += [('train_8_threads', 8, train, 0.34), ('forward_8_threads', 8, forward, 0.12)]
+    for name, nthr, fn, share in plan:
+        torch.set_num_threads(nthr)
+        net.train(fn is train)
+        random.seed(12)
+        n, dt = timed(fn, seconds_budget * share)
+        cols[name] = {'clips_per_s': round(B * n / dt, 3), 'threads': nthr, 'runs': n}
+    torch.set_num_threads(cores)
+    if cores == 8:
+        cols['train_8_threads'], cols['forward_8_threads'] = cols['train'], cols['forward']
+    return {'value': cols['train']['clips_per_s'], 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
             'sample': '%d train steps (fwd+CE+bwd+Adam) of oracle/torch_ref.py, batch %d, MSVD-shaped 26x(2048+4096)+16x2048 '
-                      'regions, vocab 1000, torch CPU fp32, %d threads' % (n, B, cores)}
+                      'regions, vocab 1000, torch CPU fp32, %d threads' % (cols['train']['runs'], B, cores),
+            'eval_forward': {'value': cols['forward']['clips_per_s'], 'unit': 'clips/s', 'threads': cores,
+                             'sample': '%d eval forwards (teacher-forced, dropout off), same batch' % cols['forward']['runs']},
+            'threads_8': {'train_clips_per_s': cols['train_8_threads']['clips_per_s'],
+                          'eval_forward_clips_per_s': cols['forward_8_threads']['clips_per_s'],
+                          'note': 'torch.set_num_threads(8): comparable with the 8-core authoring container (BASELINE.md 3.2)'}}
 
 
 def gpu_eager_baseline(dev, batch, steps=4, warmup=2):
@@ -192,6 +221,195 @@ def gan_iteration_leg(dev, batch, with_eager=True, iters=6):
     return out
 
 
+def gemm_roofline(prof, nsteps, root=ROOT):
+    """`roofline` object of the GEMM kernel symbol with the largest share of the timed step.  prof: HipOps.prof_summary().
+    `traffic` = PMC-measured HBM-side bytes per launch (profiles/traffic.json, keyed by kernel symbol + launch shape), averaged
+    over the launches that were timed -- only when the file has EVERY launch shape this kernel ran in the step, else null."""
+    gk = max((k for k in prof if k.startswith('gemm_')), key=lambda k: prof[k]['ms_total'], default=None)
+    g = prof.get(gk) if gk else None
+    if not g or g['ms_total'] <= 0:
+        return None
+    ach = g['work_total'] / (g['ms_total'] * 1e-3) / 1e12
+    is_x3 = 'bf16x3' in gk
+    peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if is_x3 else PEAK_FP32_MFMA_TFLOPS
+    tj = {}
+    try:
+        tj = json.load(open(os.path.join(root, 'profiles', 'traffic.json'))).get('per_launch_shape', {})
+    except Exception:
+        tj = {}
+    shapes, tsum, tn, all_known = [], 0.0, 0, True
+    for shp, d in sorted(g['shapes'].items(), key=lambda kv: -kv[1]['ms_total']):
+        ent = tj.get(gk + ' | ' + shp)
+        tb = ent.get('hbm_bytes_per_launch') if ent else None
+        if tb is None:
+            all_known = False
+        else:
+            tsum += tb * d['launches']; tn += d['launches']
+        a_s = d['work_total'] / (d['ms_total'] * 1e-3) / 1e12
+        shapes.append({'shape': shp, 'launches_timed': d['launches'], 'avg_launch_ms': round(d['ms_total'] / d['launches'], 4),
+                       'achieved': round(a_s, 2), 'frac': round(a_s / peak, 4), 'traffic': tb,
+                       'algorithmic_bytes': ent.get('algorithmic_bytes') if ent else None})
+    # symbol under which rocprofv3 lists this kernel (profiles/*kernel_stats*.csv)
+    parts = gk.split('_')              # gemm_{f32|bf16x3}_mfma_{tile}_{nt|nn|tn}
+    tile, mode = parts[3], parts[-1]
+    tmpl = {'nt': 'false, false', 'nn': 'false, true', 'tn': 'true, true'}.get(mode, '')
+    if tile == '128x128':
+        sym = '%s_w3<128, 128, %s, 32>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
+    elif tile == '64x64':
+        sym = '%s<64, 64, %s, 64>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
+    else:
+        sym = ('skinny_x3_kernel' if is_x3 else 'skinny_kernel') + ('<false>' if mode == 'nt' else '<true>')
+    return {'kernel': gk + (' (3 x v_mfma_f32_32x32x16_bf16 per product; peak = 2500/3)' if is_x3
+                            else ' (v_mfma_f32_32x32x2_f32)') + '; rocprof symbol: ' + sym,
+            'traffic_note': 'HBM-side bytes/launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, keyed by '
+                            'kernel + launch shape), mean over the timed launches; null unless every launch shape of this kernel is in the file',
+            'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'traffic': round(tsum / tn) if (all_known and tn) else None, 'launches_timed': g['launches'],
+            'avg_launch_ms': round(g['ms_total'] / g['launches'], 4),
+            'ms_per_step_in_this_kernel': round(g['ms_total'] / max(1, nsteps), 3), 'launch_shapes': shapes}
+
+
+def profile_eager_steps(net, tr, batch, eps, nsteps):
+    """HIP events around every heavy launch.  Events cannot be read back from inside a replayed graph, so the same step is
+    launched kernel by kernel for a few extra steps (not part of `value`) on the same stream."""
+    frames, regions, caps, lens = batch
+    use_graphs, tr.use_graphs = tr.use_graphs, False
+    tr.step(frames, regions, caps, lens, eps)
+    torch.cuda.synchronize()
+    net.ops.prof = {}
+    for _ in range(nsteps):
+        tr.step(frames, regions, caps, lens, eps)
+    torch.cuda.synchronize()
+    prof = net.ops.prof_summary()
+    net.ops.prof = None
+    tr.use_graphs = use_graphs
+    return prof
+
+
+def launch_mode(tr, requested_graphs):
+    """what actually ran: a Trainer built with graph_fallback=True downgrades to eager launches when a capture fails"""
+    if not requested_graphs:
+        return 'eager (--no-graphs)'
+    if tr.use_graphs and tr._graphs is not None:
+        return 'hipGraph replay'
+    return 'eager (hipGraph capture failed)'
+
+
+def msrvtt_leg(dev, a):
+    """BASELINE configs[2]'s per-GPU step: MSR-VTT-shaped (36 regions, 5 proposals, D = 1536, vocab 10 000), batch 64, the same
+    fused train step; with the roofline of ITS dominant kernel."""
+    import dlsg_amd
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    args, V, B = dlsg_amd.msrvtt_shaped(), 10000, 64
+    vocab = dlsg_amd.make_vocab(V)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab)
+    net.load_state_dict(synth_state_dict(net.state_dict(), 0))
+    net = net.to(dev).train()
+    net.gemm_precision = a.gemm
+    batch = [t.to(dev) for t in synth_batch(args, V, B, 1)]
+    tr = dlsg_amd.Trainer(net, use_graphs=not a.no_graphs, graph_fallback=True)
+    eps = dlsg_amd.ss_epsilon(0)
+    random.seed(12)
+    for _ in range(2):
+        tr.step(*batch, eps)
+    fb = tr.static_inputs() or batch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tr.step(*fb, eps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {'what': 'CapGnnModel train step, MSR-VTT-shaped: 26 frames x (2048+4096), 36 x 2048 regions, 5 proposals, D 1536, vocab '
+                   '10000, dropout on; BASELINE configs[2] per-GPU shard', 'batch_per_gpu': B, 'n_gpus': 1,
+           'ms_per_step': round(1e3 * dt / a.steps, 3), 'clips_per_s': round(B * a.steps / dt, 1), 'steps': a.steps,
+           'gemm_arithmetic': a.gemm, 'launch': launch_mode(tr, not a.no_graphs), 'final_loss': round(float(loss), 5)}
+    nprof = min(2, a.steps)
+    prof = profile_eager_steps(net, tr, fb, eps, nprof)
+    out['roofline'] = gemm_roofline(prof, nprof)
+    for key, name, label in (('o2v_graph_fwd', 'roofline_graph_attention', 'o2v16_kernel'), ('o2v_graph_bwd', 'roofline_graph_attention_bwd', 'o2v backward')):
+        o = prof.get(key)
+        if o and o['ms_total'] > 0:
+            ach = o['work_total'] / (o['ms_total'] * 1e-3) / 1e9
+            out[name] = {'kernel': label, 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                         'frac': round(ach / PEAK_HBM_GBS, 4), 'avg_launch_ms': round(o['ms_total'] / o['launches'], 4)}
+    del tr, net, batch, fb
+    torch.cuda.empty_cache()
+    return out
+
+
+def inference_leg(dev, a):
+    """BASELINE configs[4]: inference at batch 128 on one GPU -- greedy and allennlp-style beam search with beam 5 -- each as
+    one replayed hipGraph (GreedyGraph / BeamGraph: encoder + all 26 word steps, no host synchronisation inside)."""
+    import dlsg_amd
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    args, V, B = dlsg_amd.msvd_shaped(), 1000, 128
+    vocab = dlsg_amd.make_vocab(V)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab)
+    net.load_state_dict(synth_state_dict(net.state_dict(), 0))
+    net = net.to(dev).eval()
+    net.gemm_precision = a.gemm
+    frames, regions, _, _ = synth_batch(args, V, B, 1)
+    frames, regions = frames.to(dev), regions.to(dev)
+    out = {'what': 'CapGnnModel inference, MSVD-shaped, batch %d, one hipGraph replay per batch (encoder + 26 word steps); ids of the '
+                   'replayed graphs are asserted equal to the kernel-by-kernel path in tests/test_gpu_parity.py' % B,
+           'batch': B, 'gemm_arithmetic': a.gemm}
+    reps = max(3, min(10, a.steps))
+    for name, k, cls in (('greedy', 1, dlsg_amd.GreedyGraph), ('beam5', 5, dlsg_amd.BeamGraph)):
+        net.update_beam_size(k)
+        n0 = net.ops.launches
+        g = cls(net, frames, regions)
+        launches = (net.ops.launches - n0) // 2        # the constructor runs the schedule twice: warm-up + capture
+        g(g.frames, g.regions)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res = g(g.frames, g.regions)
+        ids = res[0] if isinstance(res, tuple) else res
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        L = net.decoder.max_words
+        out[name] = {'beam_size': k, 'ms_per_batch': round(ms, 3), 'clips_per_s': round(B / ms * 1e3, 1), 'replays_timed': reps,
+                     'launches_per_batch': launches, 'launches_per_word_step': round(launches / L, 1), 'ids_shape': list(ids.shape),
+                     'launch': 'hipGraph replay (%s)' % cls.__name__}
+        del g
+    del net, frames, regions
+    torch.cuda.empty_cache()
+    return out
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (the parent makes no GPU call,
+    before or after -- counting devices does not initialise the runtime on this image), one per device, RCCL rendezvous on
+    127.0.0.1; rank 0's stdout (the JSON line) is relayed, the exit code is the first failing rank's."""
+    import socket
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < n:
+        sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible: refusing to run a smaller job under that label\n' % (n, ndev))
+        return 3
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', DLSG_BENCH_SPAWNED='1')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write('bench.py: rank(s) failed: %s\n' % bad)
+        return bad[0][1] if bad[0][1] > 0 else 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -209,21 +427,39 @@ def main():
     ap.add_argument('--no-batch128', action='store_true', help='skip the extra N = 1 measurement at 128 clips per GPU')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
     ap.add_argument('--no-gan', action='store_true', help='skip the GAN-iteration leg (SURVEY.md 8f rank 1)')
+    ap.add_argument('--no-inference', action='store_true', help='skip the inference leg (BASELINE configs[4])')
+    ap.add_argument('--no-msrvtt', action='store_true', help='skip the MSR-VTT-shaped batch-64 leg (BASELINE configs[2] per GPU)')
+    ap.add_argument('--comm', default='auto', choices=['auto', 'rccl', 'torch'],
+                    help='gradient all-reduce: "rccl" = librccl called through the C ABI and captured inside the step\'s hipGraph; '
+                         '"torch" = torch.distributed between graph segments; "auto" = rccl on the nccl backend')
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error('--gpus must be >= 1')
 
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        sys.stderr.write('bench.py: WORLD_SIZE = %d but --gpus %d: launch with --nproc-per-node == --gpus (or without a launcher: '
+                         'bench.py starts its own ranks)\n' % (world, a.gpus))
+        sys.exit(2)
     import dlsg_amd
     from dlsg_amd.synth import synth_state_dict, synth_batch
     # test hooks (tests/test_gpu_bench_two_ranks.py): a 1-GPU box can rehearse the N>1 code path with both ranks on device 0
     # over gloo; the driver's runs use neither variable (one rank per GPU, backend nccl = RCCL)
-    if os.environ.get('DLSG_BENCH_ALL_RANKS_ON_DEVICE0') == '1':
+    rehearsal = os.environ.get('DLSG_BENCH_ALL_RANKS_ON_DEVICE0') == '1'
+    if rehearsal:
         local = 0
     backend = os.environ.get('DLSG_BENCH_BACKEND', 'nccl')
+    if not rehearsal and torch.cuda.device_count() <= local:
+        sys.stderr.write('bench.py: rank %d has no device %d (%d visible)\n' % (rank, local, torch.cuda.device_count()))
+        sys.exit(3)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     pg = None
+    comm_info = {'rccl_ranks': 1, 'backend': None}
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -231,7 +467,20 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == a.gpus or world == 1, 'launch with torch.distributed.run --nproc-per-node == --gpus'
+        if dist.get_world_size() != a.gpus:
+            sys.stderr.write('bench.py: process group has %d ranks, --gpus %d\n' % (dist.get_world_size(), a.gpus))
+            sys.exit(2)
+        devs = [None] * world
+        dist.all_gather_object(devs, '%s:%d' % (socket_hostname(), torch.cuda.current_device()))
+        if not rehearsal and len(set(devs)) != world:
+            sys.stderr.write('bench.py: ranks share devices %s: one rank per GPU is required\n' % devs)
+            sys.exit(2)
+        comm_info = {'rccl_ranks': dist.get_world_size(), 'backend': backend, 'devices': devs}
+        if backend == 'nccl':
+            try:
+                comm_info['rccl_version'] = '.'.join(map(str, torch.cuda.nccl.version()))
+            except Exception:
+                comm_info['rccl_version'] = None
 
     if a.shape == 'msvd':
         args, V = dlsg_amd.msvd_shaped(), 1000
@@ -246,7 +495,10 @@ def main():
     net.gemm_precision = a.gemm
     frames, regions, caps, lens = synth_batch(args, V, a.batch, 1 + rank)   # each rank its own shard
     frames, regions, caps, lens = frames.to(dev), regions.to(dev), caps.to(dev), lens.to(dev)
-    tr = dlsg_amd.Trainer(net, process_group=pg, world_size=world, use_graphs=not a.no_graphs, graph_fallback=True)
+    comm = a.comm
+    if comm == 'auto':
+        comm = 'rccl' if (world > 1 and backend == 'nccl') else 'torch'
+    tr = dlsg_amd.Trainer(net, process_group=pg, world_size=world, use_graphs=not a.no_graphs, graph_fallback=True, comm=comm)
     random.seed(12)                                                  # same coin sequence on all ranks (train_debug.py:34-36)
     eps = dlsg_amd.ss_epsilon(0)
 
@@ -271,21 +523,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     loss_v = float(loss)
-    # per-kernel HIP-event timing for the roofline objects.  Events cannot be read back from inside a replayed graph, so
-    # the same step is launched kernel by kernel for a few extra (untimed-for-`value`) steps on the same stream.
-    prof = {}
-    if rank == 0 or world > 1:
-        use_graphs, tr.use_graphs = tr.use_graphs, False
-        tr.step(frames, regions, caps, lens, eps)
-        torch.cuda.synchronize()
-        net.ops.prof = {}
-        for _ in range(min(3, a.steps)):
-            tr.step(frames, regions, caps, lens, eps)
-        torch.cuda.synchronize()
-        prof = net.ops.prof_summary()
-        net.ops.prof = None
-        tr.use_graphs = use_graphs
-        barrier()
+    launch = launch_mode(tr, not a.no_graphs)
+    comm_info.update(tr.collectives_info())
+    # per-kernel HIP-event timing for the roofline objects (every rank runs it: the step has collectives)
+    nprof = max(1, min(3, a.steps))
+    prof = profile_eager_steps(net, tr, (frames, regions, caps, lens), eps, nprof)
+    barrier()
     # the same step under the other GEMM arithmetic policies (informational; `value` is the --gemm policy)
     other = {}
     if world == 1:
@@ -342,7 +585,7 @@ def main():
         torch.cuda.synchronize()
         d3 = time.perf_counter() - t1
         b128 = {'clips_per_s': round(128 * a.steps / d3, 1), 'ms_per_step': round(1e3 * d3 / a.steps, 3), 'batch_per_gpu': 128,
-                'n_gpus': 1, 'gemm_arithmetic': a.gemm, 'steps': a.steps}
+                'n_gpus': 1, 'gemm_arithmetic': a.gemm, 'steps': a.steps, 'launch': launch_mode(tr3, not a.no_graphs)}
         del tr3, f2, r2, c2, l2
         torch.cuda.empty_cache()
       except Exception as e:                 # noqa: BLE001
@@ -365,54 +608,38 @@ def main():
                                    % (' + RCCL grad all-reduce' if world > 1 else '', a.shape.upper(), args.num_obj, V,
                                       'off' if a.eval_mode else 'on', eps),
                        'batch_per_gpu': a.batch, 'global_batch': a.batch * world, 'parallelism': 'dp%d' % world,
-                       'launch': 'eager' if a.no_graphs else 'hipGraph replay', 'gemm_arithmetic': a.gemm, 'final_loss': round(loss_v, 5)},
+                       'launch': launch, 'inputs': 'resident in the replayed graphs\' static device buffers (where the HBM-resident '
+                                                   'feature store gathers a batch); no per-step staging copy in the timed region',
+                       'gemm_arithmetic': a.gemm, 'final_loss': round(loss_v, 5)},
+            'rccl_ranks': comm_info.get('rccl_ranks', 1), 'collectives': comm_info,
         }
-        gk = max((k for k in prof if k.startswith('gemm_')), key=lambda k: prof[k]['ms_total'], default=None)
-        g = prof.get(gk) if gk else None
-        out['kernel_time_ms_per_step'] = {k: round(v['ms_total'] / max(1, min(3, a.steps)), 3) for k, v in prof.items()}
-        if g and g['ms_total'] > 0:
-            ach = g['work_total'] / (g['ms_total'] * 1e-3) / 1e12
-            is_x3 = 'bf16x3' in gk
-            peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if is_x3 else PEAK_FP32_MFMA_TFLOPS
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-            if os.path.exists(tpath):
-                try:
-                    traffic = (json.load(open(tpath)).get(gk) or {}).get('hbm_bytes_per_launch')
-                except Exception:
-                    traffic = None
-            # symbol under which rocprofv3 lists this kernel (profiles/*kernel_stats*.csv)
-            parts = gk.split('_')              # gemm_{f32|bf16x3}_mfma_{tile}_{nt|nn|tn}
-            tile, mode = parts[3], parts[-1]
-            tmpl = {'nt': 'false, false', 'nn': 'false, true', 'tn': 'true, true'}.get(mode, '')
-            if tile == '128x128':
-                sym = '%s_w3<128, 128, %s, 32>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
-            elif tile == '64x64':
-                sym = '%s<64, 64, %s, 64>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
-            else:
-                sym = ('skinny_x3_kernel' if is_x3 else 'skinny_kernel') + ('<false>' if mode == 'nt' else '<true>')
-            out['roofline'] = {'kernel': gk + (' (3 x v_mfma_f32_32x32x16_bf16 per product; peak = 2500/3)' if is_x3
-                                               else ' (v_mfma_f32_32x32x2_f32)') + '; rocprof symbol: ' + sym,
-                               'traffic_note': 'HBM bytes/launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes) '
-                                               'when that file has this kernel at this launch shape, else null',
-                               'bound': 'mfma', 'achieved': round(ach, 2),
-                               'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                               'traffic': traffic, 'launches_timed': g['launches'],
-                               'avg_launch_ms': round(g['ms_total'] / g['launches'], 4),
-                               'ms_per_step_in_this_kernel': round(g['ms_total'] / max(1, min(3, a.steps)), 3)}
+        out['kernel_time_ms_per_step'] = {k: round(v['ms_total'] / nprof, 3) for k, v in prof.items()}
+        rl = gemm_roofline(prof, nprof)
+        if rl:
+            out['roofline'] = rl
+        tj = {}
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get('per_launch_shape', {})
+        except Exception:
+            tj = {}
+
+        def o2v_traffic(key):
+            shp = list(prof[key]['shapes'])
+            ent = tj.get(key + ' | ' + shp[0]) if len(shp) == 1 else None
+            return ent.get('hbm_bytes_per_launch') if ent else None
         o = prof.get('o2v_graph_fwd')
         if o and o['ms_total'] > 0:
             ach = o['work_total'] / (o['ms_total'] * 1e-3) / 1e9
             out['roofline_graph_attention'] = {'kernel': 'o2v16_kernel (both encoder streams in one launch) + o2v_combine_kernel', 'bound': 'hbm',
                                                'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                               'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+                                               'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': o2v_traffic('o2v_graph_fwd'),
                                                'avg_launch_ms': round(o['ms_total'] / o['launches'], 4)}
         ob = prof.get('o2v_graph_bwd')
         if ob and ob['ms_total'] > 0:
             ach = ob['work_total'] / (ob['ms_total'] * 1e-3) / 1e9
-            out['roofline_graph_attention_bwd'] = {'kernel': 'o2v_bwd_scores_kernel + o2v_bwd_apply_kernel', 'bound': 'hbm',
+            out['roofline_graph_attention_bwd'] = {'kernel': O2V_BWD_KERNELS, 'bound': 'hbm',
                                                    'achieved': round(ach, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                                   'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': None,
+                                                   'frac': round(ach / PEAK_HBM_GBS, 4), 'traffic': o2v_traffic('o2v_graph_bwd'),
                                                    'avg_launch_ms': round(ob['ms_total'] / ob['launches'], 4)}
         if world == 1 and not a.no_pass:
             # the graph-attention pass (object->frame graph x2, LatentPSL x2, self-attention core, decoder
@@ -450,6 +677,11 @@ def main():
             eb = gpu_eager_baseline(dev, a.batch)
             eb['speedup'] = round(out['value'] / eb['clips_per_s'], 2)
             return eb
+        side = world == 1 and a.shape == 'msvd' and a.batch == 64
+        if side and not a.no_inference:
+            leg('inference', lambda: inference_leg(dev, a))
+        if side and not a.no_msrvtt:
+            leg('msrvtt_b64', lambda: msrvtt_leg(dev, a))
         if world == 1 and not a.no_eager_baseline and a.shape == 'msvd':
             leg('vs_pytorch_rocm_eager', eager_leg)
         if world == 1 and not a.no_gan and a.shape == 'msvd' and a.gemm == 'fp32' and not a.no_graphs:
@@ -462,9 +694,20 @@ def main():
                              'x3_all': 'all products: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate'}[a.gemm]
         out['other_gemm_arithmetic'] = other
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         import torch.distributed as dist
+        dist.barrier()
+        tr.close()
         dist.destroy_process_group()
+
+
+def socket_hostname():
+    import socket
+    return socket.gethostname()
+
+
+O2V_BWD_KERNELS = 'o2v_bwd_scores_kernel + o2v_bwd_apply_kernel'
 
 
 if __name__ == '__main__':

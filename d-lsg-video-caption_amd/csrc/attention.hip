@@ -640,7 +640,7 @@ int o2v_bwd_launch(const dlsg_o2v_bwd_args* a, hipStream_t st) {
 // 2*P*(Q+H)*4 B per clip, stream and step); dots are wave reductions, softmax over P <= 32 in LDS.
 constexpr int DA_HALF = 256;
 constexpr int DA_THREADS = 2 * DA_HALF;
-constexpr int DA_MAXP = 32;
+constexpr int DA_MAXP = 72;
 constexpr int DA_MAXQ = 2048;
 
 template <bool VEC>

@@ -3,10 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define DLSG_OK 0
-#define DLSG_EINVAL (-1)
-#define DLSG_ELAUNCH (-2)
-#define DLSG_EALIGN (-3)
+#include "dlsg.h"   // DLSG_OK / DLSG_E* return codes are part of the public ABI
 
 #define DLSG_CHECK_LAUNCH()                                  \
     do {                                                     \

@@ -17,7 +17,7 @@ namespace {
 
 constexpr int DT = 1024;         // threads per row: one workgroup has to hide the whole chain's memory latency itself
 constexpr int MAXW = 2048;       // max Q / H / D
-constexpr int MAXP = 32;
+constexpr int MAXP = 72;        // attended rows per stream: proposals, or the frame nodes of the baseline decoders (PositionalEncoding max_len, sublayer.py:87)
 
 template <int V> struct Vec;
 template <> struct Vec<4> { using T = float4; };

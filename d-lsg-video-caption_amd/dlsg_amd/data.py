@@ -430,6 +430,9 @@ def distributed_indices(n, world, rank, epoch, shuffle=True, seed=0):
     return idx[rank:total:world]
 
 
+STREAMED_MAX_RANKS_PER_HOST = 2     # beyond this the streamed store cannot feed the ranks (see TrainLoader)
+
+
 class TrainLoader(object):
     """get_train_loader (utils/data.py:115-131): yields (frames, regions, None, captions, pos_tags, cap_lens, video_ids), the
     tuple run_gun.py:147 unpacks (`spatials` is read by the reference and never used; it is not loaded here).
@@ -441,6 +444,14 @@ class TrainLoader(object):
         self.features, self.batch_size = features, batch_size
         self.world, self.rank, self.shuffle, self.seed, self.drop_last = world_size, rank, shuffle, seed, drop_last
         self.epoch = 0
+        if isinstance(features, StreamedFeatures) and world_size > STREAMED_MAX_RANKS_PER_HOST:
+            # measured (tools/loader_bench.py): one process streams 3.9-6.6 k clips/s (16-27 GB/s of host reads + H2D), at or
+            # below what ONE GPU's train step consumes; N ranks on one host would need N times that out of the same DRAM / PCIe
+            # root -- 8 ranks ~ 35 k clips/s ~ 145 GB/s.  Only the HBM-resident store scales with the GPUs.
+            import warnings
+            warnings.warn('StreamedFeatures with %d ranks per host: the host-side stream (about 4-6 k clips/s per process, '
+                          'shared DRAM / PCIe) will bound the step rate; use ResidentFeatures (the whole MSVD / MSR-VTT feature '
+                          'set fits in one GPU\'s HBM) for multi-GPU training' % world_size, RuntimeWarning, stacklevel=2)
 
     def set_epoch(self, epoch):
         self.epoch = epoch

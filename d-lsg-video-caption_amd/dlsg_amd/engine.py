@@ -260,12 +260,15 @@ def tun_frames(ops, m, pfx, visual, regions, sv):
     s.update(visual=visual, v_pre=v_pre, v=v, st_v=st_v)
 
 
+O2V_MAX_NSPLIT = 64      # csrc/attention.hip: dlsg_o2v_fwd_multi / dlsg_o2v_bwd refuse more chunks per clip
+
+
 def o2v_nsplit(B_eff, NO):
     """object chunks per clip of the fused graph kernel: one 156-KB-LDS workgroup per CU walks 16-object tiles; split a
     clip's objects only as far as needed to put ~256 workgroups on the chip (every extra split costs a (T x H) partial
     written and re-read).  B_eff = clips x streams of the launch."""
     tiles = (NO + 15) // 16
-    return max(1, min(tiles, 256 // max(B_eff, 1)))
+    return max(1, min(tiles, 256 // max(B_eff, 1), O2V_MAX_NSPLIT))
 
 
 def tun_graph(ops, items, regions, sv, fused_o2v=True, nsplit=None):
@@ -299,7 +302,7 @@ def tun_graph(ops, items, regions, sv, fused_o2v=True, nsplit=None):
             for m, pfx, _ in part:
                 s = sv[pfx]
                 s['ml'] = _empty(ref, B * T, 2)
-                s['o2v_nsplit'] = max(1, min((NO + 31) // 32, 256 // max(B, 1)))      # chunking of the backward kernels
+                s['o2v_nsplit'] = max(1, min((NO + 31) // 32, 256 // max(B, 1), O2V_MAX_NSPLIT))      # chunking of the backward kernels
                 args.append(dict(y=s['y'].view(B, NO, H), v=s['v'].view(B, T, H), g_obj=m.obj_norm[1].weight,
                                  b_obj=m.obj_norm[1].bias, z=s['z'], ml=s['ml'], ostats=s['ostats'], S=s['S']))
             ops.o2v_fwd_multi(args, scale, ns)

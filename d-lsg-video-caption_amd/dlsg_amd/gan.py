@@ -411,7 +411,10 @@ def critic_step_losses(D, captions, f_caption, obj, mot, att_mask, alpha, eps_gp
     g = torch.autograd.grad(m_logit.sum(), h_m, create_graph=True, retain_graph=True)[0]        # (B,L,512)
     W = D.vocab_matrix()
     gram = W @ W.t()
-    gn = torch.sqrt(((g @ gram) * g).sum(dim=(1, 2)))            # |d mixed_logit / d mixed_captions|_2 per sample
+    # |d mixed_logit / d mixed_captions|_2 per sample.  The floor keeps sqrt's derivative finite where a sample's critic
+    # gradient is exactly zero / underflows (torch's .norm(2) of the reference, run_gun.py:366-371, has subgradient 0 there;
+    # an unclamped sqrt would put NaN into every critic parameter through the double backward)
+    gn = torch.sqrt(((g @ gram) * g).sum(dim=(1, 2)).clamp_min(1e-24))
     gp = ((gn - 1) * (gn - 1)).mean()
     r_loss, f_loss = r_logit.mean(), f_logit.mean()
     return f_loss - r_loss + 10 * gp, r_loss, f_loss, gp, (r_logit, f_logit, m_logit)
@@ -492,6 +495,17 @@ class GanTrainer(object):
         `opt_D.load_state_dict` those are no longer the optimizer's)."""
         self._cg.clear()
         self._cg_seen.clear()
+
+    def _rank_mean(self, value):
+        """run_gun.py:433-437 `reduce_tensor`: the mean over ranks of a logged scalar.  Every rank then sees the same caption
+        loss, so GANLambdaHandler switches its schedule at the same step everywhere (run_gun.py:202-203,212)."""
+        if self.world_size <= 1:
+            return float(value)
+        import torch.distributed as dist
+        t = value.detach().reshape(1).to(torch.float32).clone() if torch.is_tensor(value) else \
+            torch.tensor([float(value)], dtype=torch.float32, device=next(self.D.parameters()).device)
+        dist.all_reduce(t, group=self.pg)
+        return float(t) / self.world_size
 
     def _allreduce_D(self):
         if self.world_size > 1:
@@ -595,7 +609,7 @@ class GanTrainer(object):
             loss_D.backward()
             self._allreduce_D()
             self.opt_D.step()
-        return float(mean_loss), float(mean_w)
+        return self._rank_mean(mean_loss), self._rank_mean(mean_w)
 
     def iteration(self, frames, regions, captions, cap_lens, tf_ratio, epoch=0, i=1, max_len=26):
         model, D = self.model, self.D
@@ -622,11 +636,15 @@ class GanTrainer(object):
             out['loss_G'] = loss_G.detach()
             out['cap_loss_dev'] = sv['loss_dev']
             # the reference updates lambda from the caption loss of THIS step before using it (run_gun.py:210,224)
-            self.lambda_handler.update_gan_lambda(epoch, i, float(sv['loss_dev']))
+            # -- with several ranks the all-reduced mean, as the reference feeds it (run_gun.py:202-203,212)
+            out['cap_loss_record'] = self._rank_mean(sv['loss_dev'])
+            self.lambda_handler.update_gan_lambda(epoch, i, out['cap_loss_record'])
             out['gan_lambda'] = self.lambda_handler.get_current_lambda()
             return (g * out['gan_lambda']).transpose(0, 1)
         cap_loss = self.trainer.step(frames, regions, captions, cap_lens, tf_ratio, max_len=max_len, extra_dlogits=gan_term)
-        out.update(cap_loss=float(cap_loss), loss_G=float(out['loss_G']), loss_D=loss_D, wasserstein=wass)
+        # cap_loss / loss_G: this rank's values (what its backward used); *_record: the means over ranks the reference logs
+        out.update(cap_loss=float(cap_loss), loss_G_record=self._rank_mean(out['loss_G']), loss_G=float(out['loss_G']),
+                   loss_D=loss_D, wasserstein=wass)
         out['total_loss'] = out['cap_loss'] + out['loss_G'] * out['gan_lambda']
         out.pop('cap_loss_dev')
         return out

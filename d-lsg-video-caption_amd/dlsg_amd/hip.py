@@ -15,6 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 
+ABI_VERSION = 2            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3 = 256, 512, 1024
@@ -160,7 +161,9 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
            'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2', 'dlsg_lstm_cell_bwd_seq',
-           'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2']
+           'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2',
+           'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
+           'dlsg_allreduce_buckets']
 
 
 def load_library(path=LIB_PATH):
@@ -227,6 +230,12 @@ def load_library(path=LIB_PATH):
         'dlsg_gather_rows_multi': [P(GatherMultiArgs), vp],
         'dlsg_sa_core_bwd': [P(SaCoreBwdArgs), vp],
         'dlsg_latent_psl_bwd': [P(LatentPslBwdArgs), vp],
+        'dlsg_comm_unique_id': [vp],
+        'dlsg_comm_init': [P(vp), vp, i32, i32],
+        'dlsg_comm_destroy': [vp],
+        'dlsg_comm_info': [vp, P(i32), P(i32), P(i32)],
+        'dlsg_allreduce_bucket': [vp, vp, i64, vp],
+        'dlsg_allreduce_buckets': [vp, P(vp), P(i64), i32, vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -273,8 +282,9 @@ class HipOps(object):
         if not torch.cuda.is_available():
             raise RuntimeError('dlsg_amd needs an MI355X (gfx950) device: torch.cuda.is_available() is False and '
                                'there is no CPU fallback')
-        if self.lib.dlsg_abi_version() != 1:
-            raise RuntimeError('libdlsg_hip.so ABI mismatch')
+        if self.lib.dlsg_abi_version() != ABI_VERSION:
+            raise RuntimeError('libdlsg_hip.so ABI mismatch: library %d, binding %d (rebuild: make -C d-lsg-video-caption_amd/csrc)'
+                               % (self.lib.dlsg_abi_version(), ABI_VERSION))
         self.prof = None          # set to {} by bench.py: key -> list of (start event, end event, algorithmic work)
         self.extra_flags = 0      # OR-ed into every dlsg_gemm call (precision policy: F_BF16X3), set by the model
 
@@ -286,19 +296,26 @@ class HipOps(object):
         e0.record()
         return e0
 
-    def _prof_end(self, key, e0, work):
+    def _prof_end(self, key, e0, work, shape=''):
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.prof.setdefault(key, []).append((e0, e1, work))
+        self.prof.setdefault(key, []).append((e0, e1, work, shape))
 
     def prof_summary(self):
-        """key -> dict(launches, ms_total, work_total); call after torch.cuda.synchronize()."""
+        """key -> dict(launches, ms_total, work_total, shapes: launch shape -> the same three); call after
+        torch.cuda.synchronize().  A kernel symbol runs several launch shapes in a step; traffic counters are per shape."""
         out = {}
         for key, rec in (self.prof or {}).items():
-            ms = sum(a.elapsed_time(b) for a, b, _ in rec)
-            out[key] = dict(launches=len(rec), ms_total=ms, work_total=float(sum(w for _, _, w in rec)))
+            shapes = {}
+            tot = 0.0
+            for a, b, w, shp in rec:
+                ms = a.elapsed_time(b)
+                tot += ms
+                d = shapes.setdefault(shp, dict(launches=0, ms_total=0.0, work_total=0.0))
+                d['launches'] += 1; d['ms_total'] += ms; d['work_total'] += float(w)
+            out[key] = dict(launches=len(rec), ms_total=tot, work_total=float(sum(r[2] for r in rec)), shapes=shapes)
         return out
 
     # ------------------------------------------------------------------ plumbing
@@ -306,8 +323,10 @@ class HipOps(object):
     def _stream():
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    @staticmethod
-    def _check(rc, what):
+    launches = 0              # entry-point calls made through this binding (bench.py: launches per decode step)
+
+    def _check(self, rc, what):
+        self.launches += 1
         if rc != 0:
             raise RuntimeError('%s failed with code %d' % (what, rc))
 
@@ -373,7 +392,9 @@ class HipOps(object):
             else:
                 variant = '64x64'
             # one key per kernel symbol (arithmetic, tile, operand layout), as rocprofv3 --stats lists them
-            self._prof_end('gemm_%s_mfma_%s_%s' % ('bf16x3' if x3 else 'f32', variant, ('nt', 'nn', 'tn')[mode]), e0, flops)
+            ks = sorted(set(a.g[i].K for i in range(len(groups))))
+            shape = '%s M=%d N=%d K=%s groups=%d batch=%d' % (('NT', 'NN', 'TN')[mode], M, N, '/'.join(map(str, ks)), len(groups), nb)
+            self._prof_end('gemm_%s_mfma_%s_%s' % ('bf16x3' if x3 else 'f32', variant, ('nt', 'nn', 'tn')[mode]), e0, flops, shape)
 
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""
@@ -476,7 +497,7 @@ class HipOps(object):
         e0 = self._prof_begin()
         self._check(self.lib.dlsg_o2v_fwd_multi(arr, n, self._stream()), 'dlsg_o2v_fwd_multi')
         # algorithmic bytes: read y once + read v + write z, per graph
-        self._prof_end('o2v_graph_fwd', e0, 4.0 * n * B * (NO * H + 2 * T * H))
+        self._prof_end('o2v_graph_fwd', e0, 4.0 * n * B * (NO * H + 2 * T * H), 'B=%d T=%d NO=%d H=%d streams=%d nsplit=%d' % (B, T, NO, H, n, nsplit))
 
     def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, part, scale, nsplit):
         """backward of o2v_fwd: dz (B,T,H) -> dy (B,NO,H), dv (B,T,H), part (B,2,H) (obj_norm dgamma | dbeta per clip)."""
@@ -494,7 +515,7 @@ class HipOps(object):
         e0 = self._prof_begin()
         self._check(self.lib.dlsg_o2v_bwd(C.byref(a), self._stream()), 'dlsg_o2v_bwd')
         # algorithmic bytes: y read by both passes is counted once (SURVEY.md 8d convention) + dy written + dz, v, dv
-        self._prof_end('o2v_graph_bwd', e0, 4.0 * B * (2 * NO * H + 3 * T * H))
+        self._prof_end('o2v_graph_bwd', e0, 4.0 * B * (2 * NO * H + 3 * T * H), 'B=%d T=%d NO=%d H=%d' % (B, T, NO, H))
 
     # ------------------------------------------------------------------ beam search
     def beam_select(self, logits, last, last_lp, pred, new_lp, back, rows, k, end, first=False, ended_count=None):

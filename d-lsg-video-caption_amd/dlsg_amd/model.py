@@ -58,13 +58,14 @@ class _HipModel(nn.Module):
     @staticmethod
     def check_kernel_limits(args, attended_rows, what):
         """The fused decoder-step kernels (csrc/decstep.hip: MAXW, MAXP) hold one batch row's vectors in LDS: widths up to
-        2048, at most 32 attended rows per attention stream.  Checked at construction, with names, instead of an EINVAL
+        2048, at most 72 attended rows per attention stream (72 = the longest clip the reference's positional
+        encoding admits, sublayer.py:87; the baseline decoders attend over the frame nodes).  Checked at construction, with names, instead of an EINVAL
         from the first launch."""
         for k in ('query_hidden_size', 'decode_hidden_size', 'visual_hidden_size'):
             if getattr(args, k) > 2048:
                 raise ValueError('%s = %d: the fused decoder step supports widths up to 2048' % (k, getattr(args, k)))
-        if attended_rows > 32:
-            raise ValueError('%s = %d: the fused decoder step attends over at most 32 rows per stream' % (what, attended_rows))
+        if attended_rows > 72:
+            raise ValueError('%s = %d: the fused decoder step attends over at most 72 rows per stream' % (what, attended_rows))
 
     # ------------------------------------------------------------------ kernels handle
     @property
@@ -116,7 +117,7 @@ class _HipModel(nn.Module):
         return F_BF16X3 if (mode == 'x3_all' or (mode == 'x3_bwd' and backward)) else 0
 
     merge_weight_grads = True          # see engine.tn_grouped
-    _defer_ok = True                   # cleared by a Trainer whose backward is cut at gradient buckets (several ranks)
+    _defer_ok = True                   # weight gradients may be collected and launched grouped (flushed at every gradient bucket)
 
     def next_seed(self):
         self.seed_counter += 1
@@ -254,8 +255,16 @@ class CapGnnModel(_HipModel):
         B, T, F = frames.shape
         H = self.decoder.visual_hidden_size
         dmems, dgfeat = E.dec_bwd(ops, self.decoder, sv, G, dlogits_tm, seed, training, dalpha_tm)
-        if on_bucket:
-            on_bucket('decoder')
+
+        def bucket(key):
+            # a bucket's gradients must be complete when it is handed to the all-reduce: the weight gradients deferred so far
+            # go out now, as one grouped launch per height (with one process nothing is reduced and they wait for the end)
+            if on_bucket:
+                if sv.get('tn_defer'):
+                    E.tn_grouped(ops, sv['tn_defer'])
+                    sv['tn_defer'] = []
+                on_bucket(key)
+        bucket('decoder')
         dob, dmo = dmems
         ops.mean_rows_bwd(dgfeat[:, :H], dob, accum=True)
         ops.mean_rows_bwd(dgfeat[:, H:], dmo, accum=True)
@@ -271,8 +280,7 @@ class CapGnnModel(_HipModel):
         dmot_in = E.tun_bwd(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, G, dmo, training, seed,
                             defer_dw=deep)
         E.encvis_bwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, G, dmot_in, training, seed)
-        if on_bucket:
-            on_bucket('encoder.motion_pre_encoder')
+        bucket('encoder.motion_pre_encoder')
         E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed, defer_dw=deep)
         E.gemm_tn_deep(ops, deep, frames)
         if 'tn_defer' in sv:
@@ -537,7 +545,19 @@ class Trainer(object):
     memory: inputs (static buffers), the dropout seed, the scheduled-sampling coins, the Adam bias corrections."""
 
     def __init__(self, model, lr=1.6e-4, betas=(0.5, 0.9), eps=1e-8, process_group=None, world_size=1, use_graphs=False,
-                 device_coins=None, graph_fallback=False):
+                 device_coins=None, graph_fallback=False, comm='auto'):
+        """comm: how the gradient buckets are summed over ranks.
+          'rccl'  -- librccl through the C ABI (dlsg_allreduce_bucket) on a side stream forked by an event: the collectives
+                     are part of the captured step, so one iteration is ONE hipGraph replay and a bucket's all-reduce runs
+                     under the backward that follows it;
+          'torch' -- torch.distributed.all_reduce(async_op=True) issued by the host between hipGraph segments (any backend:
+                     this is what the CPU / gloo tests run);
+          'auto'  -- 'rccl' when the model lives on a GPU, else 'torch'."""
+        assert comm in ('auto', 'rccl', 'torch'), comm
+        self.comm = comm
+        self._rccl = None
+        self._comm_stream = None
+        self._comm_pending = False
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.t = 0
@@ -652,20 +672,81 @@ class Trainer(object):
         self._graphs = None          # captured graphs bake nothing of this state, but recapture keeps the invariants simple
 
     # ------------------------------------------------------------------ collectives
+    def _comm_mode(self):
+        """'none' | 'rccl' | 'torch' for this trainer's next step"""
+        if self.world_size <= 1 and not self.force_collectives:
+            return 'none'
+        if self.comm == 'torch':
+            return 'torch'
+        on_gpu = self.model._flat is not None and self.model._flat.is_cuda
+        if self.comm == 'rccl' and not on_gpu:
+            raise RuntimeError("comm='rccl' needs the model on a GPU")
+        return 'rccl' if on_gpu else 'torch'
+
+    def _rccl_comm(self):
+        if self._rccl is None:
+            from .comm import RcclComm
+            rank = 0
+            if self.world_size > 1:
+                import torch.distributed as dist
+                rank = dist.get_rank(self.pg)
+            self._rccl = RcclComm(self.world_size, rank, self.pg, lib=getattr(self.model.ops, 'lib', None))
+            self._comm_stream = torch.cuda.Stream(device=self.model._flat.device)
+        return self._rccl
+
     def _allreduce(self, key):
         """key: a bucket name or a tuple of bucket names whose gradients are complete."""
-        if self.world_size <= 1 and not self.force_collectives:
+        mode = self._comm_mode()
+        if mode == 'none':
+            return
+        views = [self.model._gflat[lo:hi] for k in (key if isinstance(key, tuple) else (key,))
+                 for lo, hi in self._minus_frozen(*self._ranges[k])]
+        if mode == 'rccl':
+            comm = self._rccl_comm()
+            # fork: the side stream waits for everything enqueued so far (the bucket's gradients), the main stream goes on
+            # with the rest of the backward; under stream capture both become edges of the step's graph
+            ev = torch.cuda.Event()
+            ev.record()
+            self._comm_stream.wait_event(ev)
+            comm.allreduce(views, self._comm_stream)
+            self._comm_pending = True
             return
         import torch.distributed as dist
-        for k in (key if isinstance(key, tuple) else (key,)):
-            for lo, hi in self._minus_frozen(*self._ranges[k]):
-                self._works.append(dist.all_reduce(self.model._gflat[lo:hi], group=self.pg, async_op=True))
+        for v in views:
+            self._works.append(dist.all_reduce(v, group=self.pg, async_op=True))
+
+    def _join_comm(self):
+        """the main stream waits for the side stream's collectives (before Adam; before a capture segment ends)"""
+        if self._comm_pending:
+            ev = torch.cuda.Event()
+            ev.record(self._comm_stream)
+            torch.cuda.current_stream().wait_event(ev)
+            self._comm_pending = False
+
+    def collectives_info(self):
+        mode = self._comm_mode()
+        info = {'mode': {'none': 'none (one rank)', 'rccl': 'RCCL through the C ABI (dlsg_allreduce_bucket), side stream',
+                         'torch': 'torch.distributed all_reduce(async_op=True) issued by the host'}[mode],
+                'where': None if mode == 'none' else ('inside the step\'s hipGraph' if (mode == 'rccl' and self.use_graphs and
+                                                      self._graphs is not None and len(self._graphs) == 1)
+                                                     else ('between hipGraph segments' if self.use_graphs and self._graphs is not None
+                                                           else 'between eager launches')),
+                'graph_replays_per_step': len(self._graphs) if (self.use_graphs and self._graphs is not None) else 0,
+                'buckets_MB': {k: round(4e-6 * sum(hi - lo for lo, hi in self._minus_frozen(*r)), 1) for k, r in self._ranges.items()}}
+        if self._rccl is not None:
+            info['rccl_version'] = self._rccl.rccl_version
+        return info
+
+    def close(self):
+        """destroy the RCCL communicator (collective: every rank calls it)"""
+        if self._rccl is not None:
+            torch.cuda.synchronize()
+            self._rccl.close()
+            self._rccl = None
 
     # ------------------------------------------------------------------ one step, as a schedule
     def _schedule(self, frames, regions, captions, cap_lens, coins, seed, dev_coins, on_bucket, extra_dlogits=None):
         model, ops = self.model, self.model.ops
-        # weight gradients may wait for the end of the backward only where no bucket is reduced before it
-        model._defer_ok = self.world_size <= 1 and not self.force_graph_cuts and not self.force_collectives
         L = captions.shape[1]
         sv = {}
         training = model.training
@@ -721,6 +802,7 @@ class Trainer(object):
         loss = self._schedule(frames, regions, captions, cap_lens, coins, seed, dev_coins, self._allreduce, extra_dlogits)
         for w in self._works:
             w.wait()
+        self._join_comm()
         self._adam(self.t)
         return loss
 
@@ -736,11 +818,20 @@ class Trainer(object):
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         graphs = []
-        cuts = self.world_size > 1 or self.force_graph_cuts
+        mode = self._comm_mode()
+        # host-issued collectives need the capture cut at every bucket; RCCL's own launches are captured with the step
+        cuts = mode == 'torch' or self.force_graph_cuts
+        if mode == 'rccl':
+            self._rccl_comm()              # communicator setup (a collective itself) outside any capture
         with torch.cuda.stream(side):
             # eager warm-up on the capture stream (allocator warm, one-time kernel attribute calls)
-            self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], None)
+            # (with RCCL the warm-up also runs the collectives once: channel buffers are set up before the capture)
+            self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'],
+                           self._allreduce if mode == 'rccl' else None)
+            self._join_comm()
             side.synchronize()
+            if self._comm_stream is not None:
+                self._comm_stream.synchronize()
             pool = torch.cuda.graph_pool_handle()
             # thread-local capture mode: calls made by other threads (e.g. the RCCL watchdog) cannot invalidate the capture
             cur = [torch.cuda.CUDAGraph()]
@@ -755,8 +846,12 @@ class Trainer(object):
                     cur[0].capture_begin(pool=pool, capture_error_mode='thread_local')
 
                 def cut(key):
+                    if mode == 'rccl':
+                        self._allreduce(key)               # captured: fork to the side stream
+                        if cuts:
+                            self._join_comm()              # a capture segment must end with its forks joined
                     if cuts:
-                        hard_cut(key)
+                        hard_cut(key if mode == 'torch' else None)
 
                 def placeholder(logits, sv):
                     # the graphs end here and resume after the caller's term: what it will read (logits, saved state, the
@@ -770,9 +865,10 @@ class Trainer(object):
 
                 loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut,
                                       placeholder if hook else None)
-                if not cuts or (self.world_size <= 1 and not self.force_collectives):
-                    # no collective between backward and update: Adam is part of the (last) graph; with several ranks it
-                    # follows the all-reduce waits
+                if mode != 'torch':
+                    # no host-issued collective between backward and update: Adam is part of the (last) graph, behind the
+                    # join of the side stream's RCCL launches; with host-issued collectives it follows their waits
+                    self._join_comm()
                     self._adam(1, hyper=st['hyper'])
                 cur[0].capture_end()
                 graphs.append((cur[0], None))
@@ -785,10 +881,11 @@ class Trainer(object):
                     pass
                 graphs.clear()
                 self._graphs = None
+                self._comm_pending = False
                 raise
         torch.cuda.current_stream().wait_stream(side)
         self._graphs, self._loss = graphs, loss
-        self._adam_in_graph = not cuts or (self.world_size <= 1 and not self.force_collectives)
+        self._adam_in_graph = mode != 'torch'
 
     @torch.no_grad()
     def forward_only(self, frames, regions, captions, tf_ratio, max_len=26):

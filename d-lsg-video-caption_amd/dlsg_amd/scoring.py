@@ -187,9 +187,30 @@ def gather_results(net, eval_loader):
     return result
 
 
-def evaluate(net, eval_loader, reference):
-    """evaluate.py:56-98 -> (scores, result).  `reference`: dict from convert_data_to_coco_scorer_format."""
+def merge_rank_results(result, process_group=None):
+    """run_gun.py:270-276: every rank decodes its partition of the test clips (`EvalLoader(world_size, rank)`), the per-rank
+    caption dicts are exchanged with `all_gather_object` and merged in rank order.  The reference hard-codes four ranks
+    (`[None for _ in range(4)]`, `{**r[0], **r[1], **r[2], **r[3]}`); here it is the group's size.  Every rank gets the
+    merged dict (the reference scores it on rank 0 only)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return result
+    parts = [None] * dist.get_world_size(process_group)
+    dist.all_gather_object(parts, result, group=process_group)
+    merged = collections.OrderedDict()
+    for part in parts:
+        merged.update(part)
+    return merged
+
+
+def evaluate(net, eval_loader, reference, process_group=None, gather=True):
+    """evaluate.py:56-98 -> (scores, result).  `reference`: dict from convert_data_to_coco_scorer_format.  Inside an
+    initialised process group (several GPUs, each with its own partition of the clips in `eval_loader`) the ranks' results are
+    merged first (`evaluate_multi_gpu` of evaluate.py:120-134 on the gathered dict, run_gun.py:268-281), so the scores cover
+    the whole test set on every rank; gather=False scores this rank's partition only."""
     result = gather_results(net, eval_loader)
+    if gather:
+        result = merge_rank_results(result, process_group)
     pred = convert_prediction(result)
     scores, _ = CaptionScorer().score(reference, pred, list(pred.keys()))
     return scores, result

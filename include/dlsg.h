@@ -15,8 +15,18 @@
 extern "C" {
 #endif
 
-#define DLSG_ABI_VERSION 1
+/* Bumped whenever the signature or the meaning of an existing entry point changes (2: dlsg_colsum / dlsg_colsum2 take a
+ * workspace pointer before the stream; the RCCL communicator entry points and the persistent BiLSTM were added).  A binding
+ * must refuse a library whose version differs from the header it was written against. */
+#define DLSG_ABI_VERSION 2
 int dlsg_abi_version(void);
+
+/* Return codes of every entry point that returns int: 0 or one of these. */
+#define DLSG_OK 0
+#define DLSG_EINVAL (-1)  /* an argument is out of the supported range (shape, count, NULL where data is required) */
+#define DLSG_ELAUNCH (-2) /* the HIP runtime refused the launch / an RCCL call failed */
+#define DLSG_EALIGN (-3)  /* a pointer or leading dimension misses the alignment the vector loads need */
+#define DLSG_ENOCOMM (-4) /* librccl could not be loaded or the communicator handle is invalid */
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
  * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args, 15 beam_select_args,
@@ -448,6 +458,30 @@ int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
               float grad_scale, const float* hyper, void* stream);
 /* hyper (optional, device): {lr / (1 - b1^step), sqrt(1 - b2^step)} -- overrides lr/step so a captured graph can be
  * replayed with a new step count. */
+
+
+/* ---------------------------------------------------------------- gradient all-reduce over RCCL / xGMI
+ * Replaces the gradient exchange of `DistributedDataParallel(model, find_unused_parameters=True)` over NCCL
+ * (run_gun.py:63-64, train_debug.py:20): one process per GPU, sum of ranges of the flat gradient arena over all ranks,
+ * in place; the mean (1/world) is folded into dlsg_adam's grad_scale.  librccl is resolved at run time (the instance a
+ * PyTorch process has already mapped is reused), so the library loads without it; these calls then return DLSG_ENOCOMM.
+ *
+ * The communicator handle is the ONLY state the library keeps and the caller owns it:
+ *   rank 0: dlsg_comm_unique_id(id)  ->  the caller ships the 128 bytes to every rank (any side channel: torch.distributed
+ *   store, MPI, a file)  ->  every rank, with its device current: dlsg_comm_init(&c, id, world, rank) (collective)
+ *   ...  dlsg_allreduce_bucket(c, grads + lo, hi - lo, stream) per gradient bucket, same order on every rank  ...
+ *   dlsg_comm_destroy(c).
+ * The collectives are asynchronous on `stream` and may be stream-captured: dlsg_amd.Trainer forks a side stream inside the
+ * capture of the train step, so the bucket all-reduces overlap the remaining backward within ONE replayed hipGraph. */
+#define DLSG_COMM_ID_BYTES 128
+typedef struct dlsg_comm dlsg_comm;
+int dlsg_comm_unique_id(void* id128);
+int dlsg_comm_init(dlsg_comm** out, const void* id128, int world, int rank);
+int dlsg_comm_destroy(dlsg_comm* c);
+int dlsg_comm_info(const dlsg_comm* c, int32_t* world, int32_t* rank, int32_t* rccl_version);
+int dlsg_allreduce_bucket(dlsg_comm* c, float* grads, int64_t count, void* stream);
+/* n ranges of one bucket as one RCCL group (one fused launch) */
+int dlsg_allreduce_buckets(dlsg_comm* c, float* const* grads, const int64_t* counts, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -4,7 +4,7 @@ import os
 import numpy as np
 import torch
 
-from dlsg_amd.config import make_args, make_vocab, msvd_shaped, msrvtt_shaped
+from dlsg_amd.config import make_args, make_vocab, msvd_shaped, msrvtt_shaped, apply_dataset_overrides
 from dlsg_amd.synth import synth_state_dict, synth_batch, checksum
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -26,6 +26,8 @@ CASES = {
     'small_baselinemodel': (lambda: small_args(), 'baselinemodel'),
     'full_msvd_b2': (lambda: msvd_shaped(), 'capgnn'),
     'full_msrvtt_b2': (lambda: msrvtt_shaped(), 'capgnn'),
+    # the reference's own default feature widths (utils/opt.py:69-70: A = 1536, M = 1024), tests/golden/make_goldens_r3.py
+    'full_default_b2': (lambda: apply_dataset_overrides(make_args(dataset='msvd')), 'capgnn'),
 }
 
 

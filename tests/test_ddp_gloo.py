@@ -145,14 +145,19 @@ def _worker_gan(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, 'gflat%d.npy' % rank), G._flat.detach().numpy())
     np.save(os.path.join(out_dir, 'dflat%d.npy' % rank), torch.cat([p.detach().reshape(-1) for p in D.parameters()]).numpy())
     np.save(os.path.join(out_dir, 'lossd%d.npy' % rank), np.array([o['loss_D'] for o in outs]))
+    h = it.lambda_handler
+    np.save(os.path.join(out_dir, 'lambda%d.npy' % rank), np.array(list(h.cap_list) + [h.state, h.current_lambda, h.current_schedule_step]
+                                                                   + [o['cap_loss_record'] for o in outs] + [o['loss_G_record'] for o in outs]))
+    np.save(os.path.join(out_dir, 'caploss%d.npy' % rank), np.array([o['cap_loss'] for o in outs]))
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
 def test_two_rank_gan_iteration_keeps_generator_and_critic_replicas_identical(tmp_path):
     """GanTrainer with two ranks (run_gun.py wraps both models in DDP, :63-68): critic gradients and generator gradients are
-    averaged over the ranks, so both replicas of both models stay bit-identical after two iterations; each rank's first
-    critic loss is the single-process loss on that shard."""
+    averaged over the ranks, so both replicas of both models stay bit-identical after two iterations; the recorded critic
+    loss is the mean over ranks of the single-process losses of the shards, and GANLambdaHandler is fed the all-reduced
+    caption loss (run_gun.py:202-203,212), so its state (`cap_list`, schedule position) is identical on both ranks."""
     port = _free_port()
     mp.spawn(_worker_gan, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert np.array_equal(np.load(tmp_path / 'gflat0.npy'), np.load(tmp_path / 'gflat1.npy'))
@@ -170,5 +175,46 @@ def test_two_rank_gan_iteration_keeps_generator_and_critic_replicas_identical(tm
         sl = slice(r * 2, r * 2 + 2)
         losses.append(gan.critic_step_losses(D, caps[sl], f_caption[sl], obj[sl], mot[sl], gan.attention_mask(caps[sl]), alpha[sl],
                                              eps[0][sl])[0].item())
+    want = 0.5 * (losses[0] + losses[1])
     for r in range(2):
-        assert abs(np.load(tmp_path / ('lossd%d.npy' % r))[0] - losses[r]) <= 1e-5 * max(1.0, abs(losses[r]))
+        assert abs(np.load(tmp_path / ('lossd%d.npy' % r))[0] - want) <= 1e-5 * max(1.0, abs(want))
+    # the lambda handler saw the same (rank-mean) caption losses on both ranks: same cap_list, same schedule state
+    l0, l1 = np.load(tmp_path / 'lambda0.npy'), np.load(tmp_path / 'lambda1.npy')
+    assert np.array_equal(l0, l1)
+    c0, c1 = np.load(tmp_path / 'caploss0.npy'), np.load(tmp_path / 'caploss1.npy')
+    assert not np.array_equal(c0, c1)                       # the shards' own losses do differ ...
+    assert np.abs(l0[:2] - 0.5 * (c0 + c1)).max() <= 1e-6   # ... and cap_list holds their mean
+
+
+def _worker_eval(rank, world, port, out_dir):
+    for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'd-lsg-video-caption_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import json
+    import collections
+    from dlsg_amd import scoring
+    from dlsg_amd.data import distributed_indices
+    ids = list(range(100, 111))                                  # 11 test clips: the sampler pads to 12 (one duplicate)
+    mine = [ids[i] for i in distributed_indices(len(ids), world, rank, 0, True, 0)]
+    part = collections.OrderedDict((vid, 'caption of clip %d' % vid) for vid in mine)
+    merged = scoring.merge_rank_results(part)
+    json.dump({'mine': mine, 'merged': list(merged.items())}, open(os.path.join(out_dir, 'eval%d.json' % rank), 'w'))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_evaluation_merges_the_ranks_caption_dicts(tmp_path):
+    """run_gun.py:268-276: each rank decodes its partition of the test clips, `all_gather_object` + dict merge in rank order
+    gives every clip exactly once on every rank (the reference hard-codes world size 4 there; here any size)."""
+    import json
+    port = _free_port()
+    mp.spawn(_worker_eval, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (json.load(open(tmp_path / ('eval%d.json' % r))) for r in range(2))
+    assert r0['merged'] == r1['merged']
+    assert sorted(k for k, _ in r0['merged']) == list(range(100, 111))
+    assert set(r0['mine']) != set(r1['mine']) and set(r0['mine']) | set(r1['mine']) == set(range(100, 111))
+    assert all(v == 'caption of clip %d' % k for k, v in r0['merged'])

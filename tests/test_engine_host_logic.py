@@ -303,9 +303,10 @@ def test_model_deepcopies_and_pickles(tmp_path):
 def test_kernel_limits_are_reported_at_construction():
     from helpers import small_args
     with pytest.raises(ValueError, match='num_proposals'):
-        dlsg_amd.CapGnnModel(small_args(num_proposals=40), dlsg_amd.make_vocab(50))
+        dlsg_amd.CapGnnModel(small_args(num_proposals=80), dlsg_amd.make_vocab(50))
     with pytest.raises(ValueError, match='max_frames'):
-        dlsg_amd.CapBaseline1(small_args(max_frames=40), dlsg_amd.make_vocab(50))
+        dlsg_amd.CapBaseline1(small_args(max_frames=73), dlsg_amd.make_vocab(50))
+    dlsg_amd.CapBaseline1(small_args(max_frames=72), dlsg_amd.make_vocab(50))      # the reference's longest legal clip (sublayer.py:87)
     with pytest.raises(ValueError, match='decode_hidden_size'):
         dlsg_amd.CapGnnModel(small_args(decode_hidden_size=4096), dlsg_amd.make_vocab(50))
 

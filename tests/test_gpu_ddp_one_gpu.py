@@ -47,7 +47,7 @@ def _worker(rank, world, port, out_dir, use_graphs):
     import dlsg_amd
     net, frames, regions, caps, lens = _build()
     sl = slice(rank * 2, rank * 2 + 2)
-    tr = dlsg_amd.Trainer(net, world_size=world, use_graphs=use_graphs)
+    tr = dlsg_amd.Trainer(net, world_size=world, use_graphs=use_graphs, comm='torch')      # gloo: host-issued collectives
     for _ in range(2):                                      # second step replays the captured segments
         loss = tr.step(frames[sl].contiguous(), regions[sl].contiguous(), caps[sl].contiguous(), lens[sl], 1.0)
     torch.cuda.synchronize()

@@ -33,7 +33,7 @@ def build(tag, fused=True):
 def test_native_library_is_what_runs():
     from dlsg_amd.hip import HipOps, LIB_PATH
     ops = HipOps()
-    assert ops.lib.dlsg_abi_version() == 1
+    assert ops.lib.dlsg_abi_version() == 2
     with open('/proc/self/maps') as f:
         assert 'libdlsg_hip.so' in f.read(), LIB_PATH
 
@@ -148,6 +148,44 @@ def test_full_size_msvd_shape():
             ref = float(g['gnorm.' + k])
             got = float(G[k].double().norm())
             assert abs(got - ref) <= 5e-3 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+
+
+def test_full_size_reference_default_feature_dims():
+    """The reference's DEFAULT feature widths, `--a_feature_size 1536 --m_feature_size 1024` (utils/opt.py:69-70; SURVEY.md
+    section 0 row 3), full hidden sizes: the 2-D stream is the strided 1536-column slice of the 2560-wide frame block
+    (models/model.py:70).  Top-8 logits, greedy and beam-5 ids, proposals, attention weights, loss, every gradient norm,
+    post-Adam checksums of the reference (tests/golden/make_goldens_r3.py)."""
+    net, g, frames, regions, caps, lens, kind = build('full_default_b2')
+    assert frames.shape[-1] == 1536 + 1024 and net.encoder.a_feature_size == 1536
+    with torch.no_grad():
+        out = net(frames, regions, caps, 26, 1.0)
+        logits = out[0].cpu()
+        top = torch.topk(logits, 8, dim=-1)
+        assert np.array_equal(top.indices[..., 0].numpy(), g['logits_top_idx'][..., 0])
+        assert np.abs(top.values.numpy() - g['logits_top_val']).max() <= 1e-3
+        assert np.abs(logits.double().sum(-1).numpy() - g['logits_sum']).max() <= 0.05
+        assert np.abs(out[1].cpu().numpy() - g['obj_psl']).max() <= LOGIT_TOL
+        assert np.abs(out[2].cpu().numpy() - g['mot_psl']).max() <= LOGIT_TOL
+        assert np.abs(out[3].cpu().numpy() - g['alpha']).max() <= LOGIT_TOL
+        net.update_beam_size(1)
+        assert np.array_equal(net(frames, regions, None)[0].cpu().numpy(), g['greedy_ids']), g['logit_margin'].min()
+        net.update_beam_size(5)
+        assert np.array_equal(net(frames, regions, None)[0].cpu().numpy(), g['beam5_ids'])
+    tr = dlsg_amd.Trainer(net)
+    loss = tr.step(frames, regions, caps, lens, 1.0)
+    assert abs(float(loss) - float(g['loss'])) <= 1e-3
+    G = net.grad_views()
+    n = 0
+    for k, p in net.named_parameters():
+        if 'gnorm.' + k in g:
+            ref = float(g['gnorm.' + k])
+            got = float(G[k].double().norm())
+            assert abs(got - ref) <= 5e-3 * max(ref, 1e-6) + 1e-6, (k, got, ref)
+            n += 1
+    assert n >= 60
+    for k, p in net.named_parameters():
+        s_, a_ = g['post.' + k]
+        assert abs(float(p.detach().double().sum()) - s_) <= 1e-4 * max(1.0, a_), k
 
 
 @pytest.mark.parametrize('mode', ['fp32', 'x3_bwd', 'x3_all'])
@@ -586,3 +624,133 @@ def test_out_of_range_caption_id_poisons_the_loss():
     assert torch.isnan(loss).item()
     net.ops.ce_ragged(logits, caps, torch.as_tensor(lens).cuda(), dl, rl, loss, time_major=True)
     assert torch.isfinite(loss).item() and torch.isfinite(dl).all().item()
+
+
+@pytest.mark.parametrize('end_bias', [0.0, 9.0])
+def test_beam5_at_batch128_config4_as_stated(end_bias):
+    """BASELINE configs[4] as it is stated: allennlp-style beam search with beam 5 at batch 128, MSVD-shaped, one GPU
+    (layer.py:449-460,489-567; allennlp_beamsearch.py:51-294).  640 beam rows go through `dec_mid` / `dec_tail`, the state
+    gathers and `beam_select`.  Asserted: (1) the hipGraph-captured search (no host sync inside) returns exactly the ids
+    of the eager search with its host-side early exit -- also when every beam ends early (`end_bias` lifts <end>'s logit so
+    the whole batch stops after a few words and the cut of `beam_finish` is exercised); (2) a clip's beam ids do not depend on
+    which other clips share its batch (alone, among 3, among 128) beyond the common length of the two results; (3) three clips
+    agree with the oracle's beam search (CPU restatement of the reference) token for token."""
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    from oracle import torch_ref as R
+    args = dlsg_amd.msvd_shaped()
+    vocab = dlsg_amd.make_vocab(1000)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab).eval()
+    sd = synth_state_dict(net.state_dict(), 3)
+    if end_bias:
+        sd['decoder.word_restore.bias'] = sd['decoder.word_restore.bias'].clone()
+        sd['decoder.word_restore.bias'][vocab('<end>')] += end_bias
+    net.load_state_dict(sd)
+    net = net.cuda()
+    Bn = 128
+    frames, regions, caps, lens = synth_batch(args, 1000, Bn, 5)
+    fc, rc = frames.cuda(), regions.cuda()
+    net.update_beam_size(5)
+    with torch.no_grad():
+        ids_eager = net(fc, rc, None)[0]
+    assert ids_eager.shape[0] == Bn and 1 <= ids_eager.shape[1] <= 26
+    if end_bias:
+        assert ids_eager.shape[1] < 26, 'the biased <end> was meant to stop the whole batch early'
+    bg = dlsg_amd.BeamGraph(net, fc, rc)
+    ids_graph = bg(fc, rc)[0]
+    assert torch.equal(ids_graph, ids_eager)
+    ids_again = bg(fc, rc)[0]
+    assert torch.equal(ids_again, ids_eager)
+    end = vocab('<end>')
+    with torch.no_grad():
+        for sel in ([0], [Bn - 1], [5, 77, 100]):
+            idx = torch.tensor(sel, device='cuda')
+            part = net(fc[idx].contiguous(), rc[idx].contiguous(), None)[0]
+            n = min(part.shape[1], ids_eager.shape[1])
+            assert torch.equal(part[:, :n], ids_eager[idx][:, :n]), sel
+            # past the shorter result the longer one only appends <end> (all beams of those clips had ended)
+            assert bool((part[:, n:] == end).all()) and bool((ids_eager[idx][:, part.shape[1]:] == end).all()), sel
+    orc = R.CapGnnModelRef(args, vocab).eval()
+    orc.load_state_dict(sd)
+    orc.update_beam_size(5)
+    sel = [3, 64, 127]
+    with torch.no_grad():
+        want = orc(frames[sel], regions[sel], None)[0]
+    n = min(want.shape[1], ids_eager.shape[1])
+    got = ids_eager[torch.tensor(sel, device='cuda')].cpu()
+    assert torch.equal(got[:, :n], want[:, :n])
+    assert bool((got[:, n:] == end).all()) and bool((want[:, n:] == end).all())
+
+
+def test_single_long_clip_with_many_objects_stays_inside_the_graph_kernel_limits():
+    """B = 1, T = 32 frames, 36 objects: 72 object tiles for one clip-stream used to ask the fused graph kernel for more
+    chunks per clip (72) than it accepts (64) -> EINVAL (round-2 advisor).  Forward and a train step against the oracle."""
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    from dlsg_amd.engine import o2v_nsplit, O2V_MAX_NSPLIT
+    from oracle import torch_ref as R
+    assert o2v_nsplit(1, 32 * 36) == O2V_MAX_NSPLIT and o2v_nsplit(2, 29 * 36) <= O2V_MAX_NSPLIT
+    args = dlsg_amd.make_args(visual_hidden_size=64, region_projected_size=64, query_hidden_size=48, decode_hidden_size=96,
+                              a_feature_size=40, m_feature_size=72, region_feature_size=32, word_size=20, num_proposals=8,
+                              num_obj=36, max_frames=32, train_batch_size=1)
+    vocab = dlsg_amd.make_vocab(50)
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, vocab).eval()
+    sd = synth_state_dict(net.state_dict(), 11)
+    net.load_state_dict(sd)
+    orc = R.CapGnnModelRef(args, vocab).eval()
+    orc.load_state_dict(sd)
+    frames, regions, caps, lens = synth_batch(args, 50, 1, 12)
+    assert frames.shape[1] == 32 and regions.shape[2] == 36
+    with torch.no_grad():
+        want = orc(frames, regions, caps, 26, 1.0)[0]
+    net = net.cuda()
+    with torch.no_grad():
+        got = net(frames.cuda(), regions.cuda(), caps.cuda(), 26, 1.0)[0].cpu()
+    assert (got - want).abs().max().item() <= LOGIT_TOL
+    tr = dlsg_amd.Trainer(net)
+    loss = float(tr.step(frames.cuda(), regions.cuda(), caps.cuda(), lens, 1.0))
+    assert abs(loss - R.ragged_ce(want, caps, lens).item()) <= 1e-3
+
+
+@pytest.mark.parametrize('kind', ['baseline1', 'baselinemodel'])
+def test_baseline_decoders_attend_over_clips_longer_than_32_frames(kind):
+    """The baseline decoders attend over the frame nodes (models/model.py:76-107): clips of 33..72 frames are legal in the
+    reference (positional-encoding table of 72 rows, sublayer.py:87) and used to be refused at construction because the fused
+    word-step kernel held 32 attention rows.  40 frames: logits, greedy ids and a train step against the oracle."""
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    from oracle import torch_ref as R
+    args = dlsg_amd.make_args(visual_hidden_size=64, region_projected_size=64, query_hidden_size=48, decode_hidden_size=96,
+                              a_feature_size=40, m_feature_size=72, region_feature_size=32, word_size=20, num_proposals=8,
+                              num_obj=16, max_frames=40, train_batch_size=3)
+    vocab = dlsg_amd.make_vocab(50)
+    torch.manual_seed(0)
+    net = MODELS[kind](args, vocab).eval()
+    sd = synth_state_dict(net.state_dict(), 21)
+    net.load_state_dict(sd)
+    orc = {'baseline1': R.CapBaseline1Ref, 'baselinemodel': R.CapBaselineModelRef}[kind](args, vocab).eval()
+    orc.load_state_dict(sd)
+    frames, regions, caps, lens = synth_batch(args, 50, 3, 22)
+    assert frames.shape[1] == 40
+    with torch.no_grad():
+        want = orc(frames, regions, caps, 26, 1.0)[0]
+        orc.update_beam_size(1)
+        want_ids = orc(frames, regions, None)[0]
+    net = net.cuda()
+    with torch.no_grad():
+        got = net(frames.cuda(), regions.cuda(), caps.cuda(), 26, 1.0)[0].cpu()
+        net.update_beam_size(1)
+        ids = net(frames.cuda(), regions.cuda(), None)[0].cpu()
+    assert (got - want).abs().max().item() <= LOGIT_TOL
+    assert torch.equal(ids, want_ids)
+    ref_tr = R.make_optimizer(orc)
+    want_loss = R.train_step(orc.train(False), ref_tr, frames, regions, caps, lens, 1.0)
+    tr = dlsg_amd.Trainer(net)
+    loss = float(tr.step(frames.cuda(), regions.cuda(), caps.cuda(), lens, 1.0))
+    assert abs(loss - float(want_loss)) <= 1e-3
+    G = net.grad_views()
+    for k, p in orc.named_parameters():
+        if p.grad is None:
+            continue
+        ref = p.grad
+        err = (G[k].cpu() - ref).abs().max().item()
+        assert err <= 2e-5 + 2e-3 * ref.abs().max().item(), (k, err)

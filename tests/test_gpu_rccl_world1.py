@@ -1,6 +1,9 @@
-"""GPU (-m gpu): the RCCL code path of dlsg_amd.Trainer executed for real on the one GPU of the test box.
+"""GPU (-m gpu): the RCCL code paths of dlsg_amd.Trainer executed for real on the one GPU of the test box.
 
-RCCL refuses two ranks on one device, so the collective itself runs with world_size 1 (backend 'nccl' == RCCL on ROCm):
+RCCL refuses two ranks on one device, so the collectives run with world_size 1.  Two forms are under test:
+(a) comm='rccl' (the default on a GPU): librccl through the C ABI (dlsg_comm_init / dlsg_allreduce_bucket), enqueued on a side
+stream forked by an event INSIDE the capture of the step -- the step stays ONE hipGraph with Adam in it;
+(b) comm='torch' (backend 'nccl' == RCCL on ROCm):
 what is under test is everything the N > 1 bench does around it -- `dist.all_reduce(async_op=True)` on slices of the
 gradient arena issued BETWEEN hipGraph segments captured in thread_local mode, the RCCL stream / event ordering against
 the next segment replay and against the `fill(gflat, 0)` of the next step, the NCCL watchdog thread alive during
@@ -52,18 +55,46 @@ def _worker(rank, port, out_dir):
         return net, frames.cuda(), regions.cuda(), caps.cuda(), lens
 
     res = {}
-    for name, graphs, coll in (('graph_uncut', True, False), ('graph_rccl', True, True), ('eager', False, False),
-                               ('eager_rccl', False, True)):
+    for name, graphs, coll, comm in (('graph_uncut', True, False, 'auto'), ('graph_rccl', True, True, 'torch'),
+                                     ('graph_rccl_ingraph', True, True, 'rccl'), ('eager', False, False, 'auto'),
+                                     ('eager_rccl', False, True, 'torch'), ('eager_rccl_abi', False, True, 'rccl')):
         net, frames, regions, caps, lens = build()
-        tr = dlsg_amd.Trainer(net, use_graphs=graphs, device_coins=True)
-        tr.force_graph_cuts = coll
+        tr = dlsg_amd.Trainer(net, use_graphs=graphs, device_coins=True, comm=comm)
+        tr.force_graph_cuts = coll and comm == 'torch'
         tr.force_collectives = coll
         random.seed(5)
         losses = [float(tr.step(frames, regions, caps, lens, 0.8)) for _ in range(3)]
         torch.cuda.synchronize()
-        if graphs and coll:
+        if graphs and coll and comm == 'torch':
             assert len(tr._graphs) == 4 and not tr._adam_in_graph
+        if graphs and coll and comm == 'rccl':
+            assert len(tr._graphs) == 1 and tr._adam_in_graph          # collectives captured with the step: one replay
+            info = tr.collectives_info()
+            assert info['where'] == "inside the step's hipGraph" and info['rccl_version'], info
+        if coll and comm == 'rccl':
+            assert tr._rccl is not None and tr._rccl.world == 1
+            tr.close()
         res[name] = (losses, net._flat.cpu().numpy().copy())
+    # the C-ABI communicator on a buffer of the bench's real bucket size, on a side stream, captured into a graph and replayed
+    from dlsg_amd.comm import RcclComm
+    c = RcclComm(1, 0)
+    buf = torch.full((45 * 1024 * 1024,), 3.0, device='cuda')
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    c.allreduce([buf], st)
+    c.allreduce([buf[:1024], buf[4096:8192]], st)            # grouped form
+    st.synchronize()
+    assert float(buf[0]) == 3.0 and float(buf[-1]) == 3.0
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        g.capture_begin(capture_error_mode='thread_local')
+        buf.mul_(2.0)
+        c.allreduce([buf], st)
+        g.capture_end()
+    g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert float(buf[0]) == 12.0 and float(buf[-1]) == 12.0
+    c.close()
     # a collective of the bench's real bucket size, to be sure RCCL moved data through its own kernels
     big = torch.ones(45 * 1024 * 1024, device='cuda')
     w = dist.all_reduce(big, async_op=True)
@@ -81,6 +112,9 @@ def test_rccl_all_reduce_between_graph_segments_world1(tmp_path):
     r = dict(np.load(tmp_path / 'res.npz'))
     assert np.array_equal(r['graph_rccl_loss'], r['graph_uncut_loss'])
     assert np.array_equal(r['graph_rccl_flat'], r['graph_uncut_flat'])
+    assert np.array_equal(r['graph_rccl_ingraph_loss'], r['graph_uncut_loss'])
+    assert np.array_equal(r['graph_rccl_ingraph_flat'], r['graph_uncut_flat'])
     assert np.array_equal(r['eager_rccl_loss'], r['eager_loss'])
     assert np.array_equal(r['eager_rccl_flat'], r['eager_flat'])
+    assert np.array_equal(r['eager_rccl_abi_flat'], r['eager_flat'])
     assert np.abs(r['graph_rccl_flat'] - r['eager_flat']).max() <= 1e-4

@@ -110,6 +110,32 @@ def test_full_size_msvd(tag):
         assert np.array_equal(net(frames, regions, None)[0].numpy(), g['beam5_ids'])
 
 
+def test_full_size_reference_default_feature_dims():
+    """A = 1536, M = 1024 (utils/opt.py:69-70), tests/golden/make_goldens_r3.py: the oracle against the reference's top-8
+    logits, ids, loss and gradient norms."""
+    net, g, frames, regions, caps, lens, kind = build('full_default_b2')
+    assert frames.shape[-1] == 2560
+    with torch.no_grad():
+        logits = net(frames, regions, caps, 26, 1.0)[0]
+        top = torch.topk(logits, 8, dim=-1)
+        assert np.array_equal(top.indices.numpy(), g['logits_top_idx'])
+        assert np.abs(top.values.numpy() - g['logits_top_val']).max() <= 2e-5
+        net.update_beam_size(1)
+        assert np.array_equal(net(frames, regions, None)[0].numpy(), g['greedy_ids'])
+        net.update_beam_size(5)
+        assert np.array_equal(net(frames, regions, None)[0].numpy(), g['beam5_ids'])
+    outs = net(frames, regions, caps, 26, 1.0)[0]
+    loss = R.ragged_ce(outs, caps, lens)
+    loss.backward()
+    assert abs(loss.item() - float(g['loss'])) <= 1e-5
+    for k, p in net.named_parameters():
+        if 'gnorm.' + k in g:
+            ref = float(g['gnorm.' + k])
+            assert abs(float(p.grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-6) + 1e-7, k
+        else:
+            assert p.grad is None, k
+
+
 @pytest.mark.parametrize('tag', ['small_msvd', 'small_msrvtt', 'small_baseline1', 'full_msvd_b2'])
 def test_gradients_under_scheduled_sampling(tag):
     """tf = 0.6, random.seed(12): steps fed their own argmax (layer.py:432-439); loss and every gradient of the reference."""
