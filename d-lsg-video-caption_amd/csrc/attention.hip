@@ -811,6 +811,7 @@ extern "C" int dlsg_struct_size(int which) {
         case 16: return (int)sizeof(dlsg_gather_multi_args);
         case 17: return (int)sizeof(dlsg_sa_core_bwd_args);
         case 18: return (int)sizeof(dlsg_latent_psl_bwd_args);
+        case 19: return (int)sizeof(dlsg_bilstm_args);
         default: return -1;
     }
 }

@@ -449,24 +449,8 @@ def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed, defer_dw=None):
 
 
 # ================================================================================================ EncoderVisual
-def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
-    """EncoderVisual.forward (models/layer.py:46-61).  frames2d (B*T, A+M).  Returns (B*T, H)."""
-    H = m.hidden_size
-    ref = frames2d
-    s = sv[pfx] = {}
-    e = _empty(ref, B * T, H)
-    lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
-    lstm = m.lstm
-    Wih = [lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]
-    Whh = [lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]
-    bih = [lstm.bias_ih_l0, lstm.bias_ih_l0_reverse]
-    bhh = [lstm.bias_hh_l0, lstm.bias_hh_l0_reverse]
-    xg = [_empty(ref, B * T, 4 * H), _empty(ref, B * T, 4 * H)]
-    ops.gemm(GEMM_NT, [(e, Wih[0], xg[0]), (e, Wih[1], xg[1])])
-    out = _empty(ref, B, T, 2 * H)
-    hprev = [_zeros(ref, B, T, H), _zeros(ref, B, T, H)]       # h of the previous step of each direction
-    cst = [_empty(ref, B, T, H), _empty(ref, B, T, H)]
-    gates = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
+def _bilstm_steps_fwd(ops, xg, Whh, bih, bhh, out, hprev, cst, gates, B, T, H, ref):
+    """the BiLSTM recurrence step by step: per step one grouped K-split skinny GEMM (both directions) + one pointwise launch"""
     ns = _nsplit_for(B, 4 * H, 2)
     bounds = _ksplit_bounds(H, ns, 128 if B <= 64 else 32)
     for step in range(T):
@@ -491,6 +475,32 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
                               c_prev=cst[d][:, tp[d]] if step > 0 else None, h=out[:, t, d * H:(d + 1) * H], h2=h2,
                               gates=gates[d][:, t]))
         ops.lstm_pw_fwd_multi(calls)            # both directions: one launch
+
+
+def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
+    """EncoderVisual.forward (models/layer.py:46-61).  frames2d (B*T, A+M).  Returns (B*T, H)."""
+    H = m.hidden_size
+    ref = frames2d
+    s = sv[pfx] = {}
+    e = _empty(ref, B * T, H)
+    lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
+    lstm = m.lstm
+    Wih = [lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]
+    Whh = [lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]
+    bih = [lstm.bias_ih_l0, lstm.bias_ih_l0_reverse]
+    bhh = [lstm.bias_hh_l0, lstm.bias_hh_l0_reverse]
+    xg = [_empty(ref, B * T, 4 * H), _empty(ref, B * T, 4 * H)]
+    ops.gemm(GEMM_NT, [(e, Wih[0], xg[0]), (e, Wih[1], xg[1])])
+    out = _empty(ref, B, T, 2 * H)
+    hprev = [_zeros(ref, B, T, H), _zeros(ref, B, T, H)]       # h of the previous step of each direction
+    cst = [_empty(ref, B, T, H), _empty(ref, B, T, H)]
+    gates = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
+    if getattr(ops, 'bilstm_supported', None) is not None and ops.bilstm_supported(B, T, H):
+        # the whole recurrence of both directions as ONE persistent launch: W_hh slices resident in LDS, h_t exchanged through
+        # L2 (csrc/bilstm.hip) -- instead of 25 x (grouped skinny GEMM + pointwise launch)
+        ops.bilstm_fwd(xg, Whh, bih, bhh, out, hprev, cst, gates)
+    else:
+        _bilstm_steps_fwd(ops, xg, Whh, bih, bhh, out, hprev, cst, gates, B, T, H, ref)
     out2 = out.view(B * T, 2 * H)
     pd = m.p_drop if training else 0.0
     s.update(e=e, out=out2, hprev=hprev, cst=cst, gates=gates, pd=pd)

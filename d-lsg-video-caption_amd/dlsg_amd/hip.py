@@ -91,6 +91,12 @@ class LatentPslBwdArgs(C.Structure):
                [('B', i32), ('T', i32), ('P', i32), ('H', i32), ('p', f32), ('site', u32), ('seed', u64), ('seed_ptr', c_f32p)]
 
 
+class BilstmArgs(C.Structure):
+    _fields_ = [('xg', C.c_void_p * 2), ('ldxg', i64), ('w_hh', C.c_void_p * 2), ('b_ih', C.c_void_p * 2), ('b_hh', C.c_void_p * 2),
+                ('out', c_f32p), ('hprev', C.c_void_p * 2), ('c', C.c_void_p * 2), ('gates', C.c_void_p * 2), ('hx', c_f32p),
+                ('flags', c_f32p), ('err', c_f32p), ('B', i32), ('T', i32), ('H', i32), ('pad_', i32)]
+
+
 class DecAttArgs(C.Structure):
     _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
                 ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
@@ -162,6 +168,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
            'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2', 'dlsg_lstm_cell_bwd_seq',
            'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2',
+           'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd',
            'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
            'dlsg_allreduce_buckets']
 
@@ -230,6 +237,10 @@ def load_library(path=LIB_PATH):
         'dlsg_gather_rows_multi': [P(GatherMultiArgs), vp],
         'dlsg_sa_core_bwd': [P(SaCoreBwdArgs), vp],
         'dlsg_latent_psl_bwd': [P(LatentPslBwdArgs), vp],
+        'dlsg_bilstm_supported': [i32, i32, i32],
+        'dlsg_bilstm_hx_floats': [i32, i32],
+        'dlsg_bilstm_flag_words': [i32, i32],
+        'dlsg_bilstm_fwd': [P(BilstmArgs), vp],
         'dlsg_comm_unique_id': [vp],
         'dlsg_comm_init': [P(vp), vp, i32, i32],
         'dlsg_comm_destroy': [vp],
@@ -241,14 +252,15 @@ def load_library(path=LIB_PATH):
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats', 'dlsg_colsum_ws_floats') else C.c_int
+        fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats', 'dlsg_colsum_ws_floats',
+                                            'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words') else C.c_int
     return lib
 
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
            SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs,
-           LatentPslBwdArgs]
+           LatentPslBwdArgs, BilstmArgs]
 
 
 def _p(t):
@@ -705,6 +717,36 @@ class HipOps(object):
             a.dcpre[i], a.dKp[i], a.dVp[i] = dcpre[i].data_ptr(), dKp[i].data_ptr(), dVp[i].data_ptr()
         a.L, a.B, a.Q, a.H, a.P, a.nstream = L, B, Q, dVp[0].size(2), dKp[0].size(1), ns
         self._check(self.lib.dlsg_decatt_cache_grads(C.byref(a), self._stream()), 'dlsg_decatt_cache_grads')
+
+    # ------------------------------------------------------------------ persistent BiLSTM recurrence
+    persistent_bilstm = True      # False: the per-step schedule (grouped skinny GEMM + pointwise launch per step)
+
+    def bilstm_supported(self, B, T, H):
+        return self.persistent_bilstm and bool(self.lib.dlsg_bilstm_supported(B, T, H))
+
+    def bilstm_fwd(self, xg, w_hh, b_ih, b_hh, out, hprev, c, gates):
+        """all T steps of both directions in one launch (csrc/bilstm.hip).  xg[d] (B*T, 4H) rows b*T+t; out (B,T,2H);
+        hprev[d] (B,T,H) zero-filled by the caller; c[d] (B,T,H); gates[d] (B,T,4H).  Returns the int32 error word (device)."""
+        B, T, H2 = out.shape
+        H = H2 // 2
+        a = BilstmArgs()
+        dev = out.device
+        hx = torch.empty(int(self.lib.dlsg_bilstm_hx_floats(T, H)), dtype=torch.float32, device=dev)
+        flags = torch.empty(int(self.lib.dlsg_bilstm_flag_words(T, H)), dtype=torch.int32, device=dev)
+        if getattr(self, '_bilstm_err', None) is None or self._bilstm_err.device != dev:
+            self._bilstm_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        for d in range(2):
+            for t in (xg[d], w_hh[d], hprev[d], c[d], gates[d]):
+                _chkc(t) if t is not xg[d] else _chk2(t)
+            a.xg[d], a.w_hh[d], a.b_ih[d], a.b_hh[d] = xg[d].data_ptr(), w_hh[d].data_ptr(), b_ih[d].data_ptr(), b_hh[d].data_ptr()
+            a.hprev[d], a.c[d], a.gates[d] = hprev[d].data_ptr(), c[d].data_ptr(), gates[d].data_ptr()
+        _chkc(out)
+        a.ldxg = xg[0].stride(0)
+        assert xg[1].stride(0) == a.ldxg
+        a.out, a.hx, a.flags, a.err = _p(out), _p(hx), _p(flags), _p(self._bilstm_err)
+        a.B, a.T, a.H = B, T, H
+        self._check(self.lib.dlsg_bilstm_fwd(C.byref(a), self._stream()), 'dlsg_bilstm_fwd')
+        return self._bilstm_err
 
     # ------------------------------------------------------------------ LSTM pointwise
     @staticmethod

@@ -30,7 +30,7 @@ int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
  * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args, 15 beam_select_args,
- * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args): lets a binding verify its
+ * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args, 19 bilstm_args): lets a binding verify its
  * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
@@ -459,6 +459,37 @@ int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
 /* hyper (optional, device): {lr / (1 - b1^step), sqrt(1 - b2^step)} -- overrides lr/step so a captured graph can be
  * replayed with a new step count. */
 
+
+/* ---------------------------------------------------------------- persistent BiLSTM recurrence (csrc/bilstm.hip)
+ * Replaces the time loop of `nn.LSTM(H, H, bidirectional=True, batch_first=True)` in EncoderVisual (models/layer.py:26,52)
+ * once the input half of the gates xg = e W_ih^T is known for all steps: ONE launch runs all T steps of both directions,
+ * 2 * H/8 workgroups (one per CU, all resident), each keeping its 32 x H slice of W_hh in LDS and its cell states in
+ * registers; h_t travels between workgroups through `hx` with write-through stores and per-step flags.
+ * Layouts: xg[d] (B*T, >= 4H) rows b*T + t, gate order i,f,g,o (PyTorch); out (B, T, 2H) with direction d in columns
+ * [dH, (d+1)H); hprev[d] (B, T, H) = h of the PREVIOUS step of direction d at each time index (the caller zero-fills it: the
+ * first step of a direction is never written); c[d] (B, T, H); gates[d] (B, T, 4H) activated gates (what the backward reads).
+ * Scratch owned by the caller: hx = dlsg_bilstm_hx_floats(T, H) floats, flags = dlsg_bilstm_flag_words(T, H) 32-bit words
+ * (zeroed by the call itself), err = optional int32 that is set to 1 if a workgroup timed out waiting for another (the result
+ * is then invalid; the device is never left spinning).  dlsg_bilstm_supported: B <= 64, H in {64, 512, 1024}. */
+typedef struct {
+    const float* xg[2];
+    int64_t ldxg;
+    const float* w_hh[2];
+    const float* b_ih[2];
+    const float* b_hh[2];
+    float* out;
+    float* hprev[2];
+    float* c[2];
+    float* gates[2];
+    float* hx;
+    uint32_t* flags;
+    int32_t* err;
+    int32_t B, T, H, pad_;
+} dlsg_bilstm_args;
+int dlsg_bilstm_supported(int B, int T, int H);
+int64_t dlsg_bilstm_hx_floats(int T, int H);
+int64_t dlsg_bilstm_flag_words(int T, int H);
+int dlsg_bilstm_fwd(const dlsg_bilstm_args* a, void* stream);
 
 /* ---------------------------------------------------------------- gradient all-reduce over RCCL / xGMI
  * Replaces the gradient exchange of `DistributedDataParallel(model, find_unused_parameters=True)` over NCCL

@@ -917,3 +917,58 @@ def test_embed_bwd_with_a_dominant_id(hip):
         hip.embed_bwd(dwe, ids, dE, p=0.0, seed=0, site=0, row0=0)
         outs.append(dE)
     assert all(torch.equal(outs[0], o) for o in outs)
+
+
+# ------------------------------------------------------------------------------------------------ persistent BiLSTM recurrence
+def _bilstm_reference(xg, Whh, bih, bhh, B, T, H):
+    """plain torch fp32 restatement of nn.LSTM's recurrence (gate order i, f, g, o; models/layer.py:26,52) given the x-gates"""
+    out = torch.zeros(B, T, 2 * H)
+    hprev = [torch.zeros(B, T, H), torch.zeros(B, T, H)]
+    cst = [torch.zeros(B, T, H), torch.zeros(B, T, H)]
+    gates = [torch.zeros(B, T, 4 * H), torch.zeros(B, T, 4 * H)]
+    for d in range(2):
+        h = torch.zeros(B, H); c = torch.zeros(B, H)
+        order = range(T) if d == 0 else range(T - 1, -1, -1)
+        for t in order:
+            hprev[d][:, t] = h
+            pre = xg[d].view(B, T, 4 * H)[:, t] + bih[d] + bhh[d] + h @ Whh[d].t()
+            i, f, g, o = pre.split(H, dim=1)
+            i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+            c = f * c + i * g
+            h = o * torch.tanh(c)
+            out[:, t, d * H:(d + 1) * H] = h
+            cst[d][:, t] = c
+            gates[d][:, t] = torch.cat([i, f, g, o], 1)
+    return out, hprev, cst, gates
+
+
+@pytest.mark.parametrize('B,T,H', [(3, 26, 64), (64, 26, 64), (1, 1, 64), (2, 7, 512), (64, 26, 1024), (17, 26, 1024), (64, 40, 512)])
+def test_persistent_bilstm_forward(hip, B, T, H):
+    """csrc/bilstm.hip: all T steps of both directions in ONE launch (W_hh slices resident in LDS, h_t exchanged between the
+    workgroups through L2 with write-through stores and flags) against the plain recurrence; twice, so that stale exchange
+    data or flags of the first launch would show; the time-out word must stay 0."""
+    assert hip.lib.dlsg_bilstm_supported(B, T, H) == 1
+    assert hip.lib.dlsg_bilstm_supported(65, T, H) == 0 and hip.lib.dlsg_bilstm_supported(B, T, 96) == 0
+    g = torch.Generator().manual_seed(7)
+    sc = 1.0 / math.sqrt(H)
+    xg = [rnd(g, B * T, 4 * H), rnd(g, B * T, 4 * H)]
+    Whh = [rnd(g, 4 * H, H, scale=2 * sc), rnd(g, 4 * H, H, scale=2 * sc)]
+    bih = [rnd(g, 4 * H, scale=0.3), rnd(g, 4 * H, scale=0.3)]
+    bhh = [rnd(g, 4 * H, scale=0.3), rnd(g, 4 * H, scale=0.3)]
+    want = _bilstm_reference(xg, Whh, bih, bhh, B, T, H)
+    cu = lambda ts: [t.cuda() for t in ts]
+    xg_, W_, bi_, bh_ = cu(xg), cu(Whh), cu(bih), cu(bhh)
+    for rep in range(2):
+        out = torch.full((B, T, 2 * H), float('nan'), device='cuda')
+        hprev = [torch.zeros(B, T, H, device='cuda') for _ in range(2)]
+        cst = [torch.full((B, T, H), float('nan'), device='cuda') for _ in range(2)]
+        gates = [torch.full((B, T, 4 * H), float('nan'), device='cuda') for _ in range(2)]
+        err = hip.bilstm_fwd(xg_, W_, bi_, bh_, out, hprev, cst, gates)
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0, 'a workgroup timed out waiting for its producers'
+        got = (out, hprev, cst, gates)
+        for name, a, b in (('out', want[0], got[0]), ('hprev0', want[1][0], got[1][0]), ('hprev1', want[1][1], got[1][1]),
+                           ('c0', want[2][0], got[2][0]), ('c1', want[2][1], got[2][1]), ('gates0', want[3][0], got[3][0]),
+                           ('gates1', want[3][1], got[3][1])):
+            e = (a - b.cpu()).abs().max().item()
+            assert e <= 3e-5, (rep, name, e)
