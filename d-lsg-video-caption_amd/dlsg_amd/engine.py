@@ -541,6 +541,33 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
     return res
 
 
+def _bilstm_steps_bwd(ops, gates, cst, dout3, Whh, dG, B, T, H, ref):
+    """BiLSTM backward through time step by step: per step one pointwise launch + one grouped skinny NN GEMM (both directions)"""
+    dcrec = [_empty(ref, B, H), _empty(ref, B, H)]
+    ns_r = max(1, min(_nsplit_for(B, 2 * H, 1), 8))
+    rb = _bwd_bounds(4 * H, B, ns_r)
+    slabs = None                       # (S, B, 2H): slabs of [d h_prev of the forward dir | of the reverse dir]
+    for step in range(T - 1, -1, -1):
+        tt = [step, T - 1 - step]
+        tp = [step - 1, T - step]
+        last = step == T - 1
+        # both directions in one launch; the recurrent gradient is read straight from the GEMM's slabs
+        ops.lstm_pw_bwd_multi([dict(gates=gates[d][:, tt[d]], c=cst[d][:, tt[d]], dgates=dG[d][:, tt[d]], B=B, H=H,
+                                    c_prev=cst[d][:, tp[d]] if step > 0 else None,
+                                    dh=dout3[:, tt[d], d * H:(d + 1) * H],
+                                    dh4=None if last else slabs[:, :, d * H:(d + 1) * H],
+                                    dc_next=None if last else dcrec[d], dc_prev=dcrec[d]) for d in range(2)])
+        if step > 0:
+            # recurrent gradient of both directions: one grouped launch
+            slabs = _empty(ref, len(rb), B, 2 * H)
+            groups = []
+            for d in range(2):
+                dg = dG[d][:, tt[d]]
+                for i, (k0, k1) in enumerate(rb):
+                    groups.append((dg[:, k0:k1], Whh[d][k0:k1, :], slabs[i][:, d * H:(d + 1) * H]))
+            ops.gemm(GEMM_NN, groups)
+
+
 def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     H = m.hidden_size
     ref = frames2d
@@ -607,29 +634,10 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     dout3 = dout.view(B, T, D2)
     gates, cst, hprev = s['gates'], s['cst'], s['hprev']
     dG = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
-    dcrec = [_empty(ref, B, H), _empty(ref, B, H)]
-    ns_r = max(1, min(_nsplit_for(B, 2 * H, 1), 8))
-    rb = _bwd_bounds(4 * H, B, ns_r)
-    slabs = None                       # (S, B, 2H): slabs of [d h_prev of the forward dir | of the reverse dir]
-    for step in range(T - 1, -1, -1):
-        tt = [step, T - 1 - step]
-        tp = [step - 1, T - step]
-        last = step == T - 1
-        # both directions in one launch; the recurrent gradient is read straight from the GEMM's slabs
-        ops.lstm_pw_bwd_multi([dict(gates=gates[d][:, tt[d]], c=cst[d][:, tt[d]], dgates=dG[d][:, tt[d]], B=B, H=H,
-                                    c_prev=cst[d][:, tp[d]] if step > 0 else None,
-                                    dh=dout3[:, tt[d], d * H:(d + 1) * H],
-                                    dh4=None if last else slabs[:, :, d * H:(d + 1) * H],
-                                    dc_next=None if last else dcrec[d], dc_prev=dcrec[d]) for d in range(2)])
-        if step > 0:
-            # recurrent gradient of both directions: one grouped launch
-            slabs = _empty(ref, len(rb), B, 2 * H)
-            groups = []
-            for d in range(2):
-                dg = dG[d][:, tt[d]]
-                for i, (k0, k1) in enumerate(rb):
-                    groups.append((dg[:, k0:k1], Whh[d][k0:k1, :], slabs[i][:, d * H:(d + 1) * H]))
-            ops.gemm(GEMM_NN, groups)
+    if getattr(ops, 'bilstm_supported', None) is not None and ops.bilstm_supported(B, T, H):
+        ops.bilstm_bwd(gates, cst, dout3, Whh, dG)          # all steps of both directions: one persistent launch
+    else:
+        _bilstm_steps_bwd(ops, gates, cst, dout3, Whh, dG, B, T, H, ref)
     de = _empty(ref, B * T, H)
     e = s['e']
     tn_grouped(ops, [(dG[d].view(B * T, 4 * H), src, G[name + '.lstm.' + wn + sfx[d]])

@@ -97,6 +97,12 @@ class BilstmArgs(C.Structure):
                 ('flags', c_f32p), ('err', c_f32p), ('B', i32), ('T', i32), ('H', i32), ('pad_', i32)]
 
 
+class BilstmBwdArgs(C.Structure):
+    _fields_ = [('gates', C.c_void_p * 2), ('c', C.c_void_p * 2), ('dout', c_f32p), ('w_hh', C.c_void_p * 2),
+                ('dgates', C.c_void_p * 2), ('gx', c_f32p), ('px', c_f32p), ('flags', c_f32p), ('err', c_f32p),
+                ('B', i32), ('T', i32), ('H', i32), ('pad_', i32)]
+
+
 class DecAttArgs(C.Structure):
     _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
                 ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
@@ -168,7 +174,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
            'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2', 'dlsg_lstm_cell_bwd_seq',
            'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2',
-           'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd',
+           'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd', 'dlsg_bilstm_bwd_x_floats', 'dlsg_bilstm_bwd',
            'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
            'dlsg_allreduce_buckets']
 
@@ -241,6 +247,8 @@ def load_library(path=LIB_PATH):
         'dlsg_bilstm_hx_floats': [i32, i32],
         'dlsg_bilstm_flag_words': [i32, i32],
         'dlsg_bilstm_fwd': [P(BilstmArgs), vp],
+        'dlsg_bilstm_bwd_x_floats': [i32, i32],
+        'dlsg_bilstm_bwd': [P(BilstmBwdArgs), vp],
         'dlsg_comm_unique_id': [vp],
         'dlsg_comm_init': [P(vp), vp, i32, i32],
         'dlsg_comm_destroy': [vp],
@@ -253,14 +261,14 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats', 'dlsg_colsum_ws_floats',
-                                            'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words') else C.c_int
+                                            'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_bwd_x_floats') else C.c_int
     return lib
 
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
            SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs,
-           LatentPslBwdArgs, BilstmArgs]
+           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs]
 
 
 def _p(t):
@@ -746,6 +754,28 @@ class HipOps(object):
         a.out, a.hx, a.flags, a.err = _p(out), _p(hx), _p(flags), _p(self._bilstm_err)
         a.B, a.T, a.H = B, T, H
         self._check(self.lib.dlsg_bilstm_fwd(C.byref(a), self._stream()), 'dlsg_bilstm_fwd')
+        return self._bilstm_err
+
+    def bilstm_bwd(self, gates, c, dout, w_hh, dgates):
+        """backward through time of bilstm_fwd in one launch: dout (B,T,2H) -> dgates[d] (B,T,4H).  Returns the error word."""
+        B, T, H2 = dout.shape
+        H = H2 // 2
+        a = BilstmBwdArgs()
+        dev = dout.device
+        nx = int(self.lib.dlsg_bilstm_bwd_x_floats(T, H))
+        gx = torch.empty(nx, dtype=torch.float32, device=dev)
+        px = torch.empty(nx, dtype=torch.float32, device=dev)
+        flags = torch.empty(2 * int(self.lib.dlsg_bilstm_flag_words(T, H)), dtype=torch.int32, device=dev)
+        if getattr(self, '_bilstm_err', None) is None or self._bilstm_err.device != dev:
+            self._bilstm_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        _chkc(dout)
+        for d in range(2):
+            for t in (gates[d], c[d], w_hh[d], dgates[d]):
+                _chkc(t)
+            a.gates[d], a.c[d], a.w_hh[d], a.dgates[d] = gates[d].data_ptr(), c[d].data_ptr(), w_hh[d].data_ptr(), dgates[d].data_ptr()
+        a.dout, a.gx, a.px, a.flags, a.err = _p(dout), _p(gx), _p(px), _p(flags), _p(self._bilstm_err)
+        a.B, a.T, a.H = B, T, H
+        self._check(self.lib.dlsg_bilstm_bwd(C.byref(a), self._stream()), 'dlsg_bilstm_bwd')
         return self._bilstm_err
 
     # ------------------------------------------------------------------ LSTM pointwise

@@ -30,7 +30,7 @@ int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
  * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args, 15 beam_select_args,
- * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args, 19 bilstm_args): lets a binding verify its
+ * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args, 19 bilstm_args, 20 bilstm_bwd_args): lets a binding verify its
  * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
@@ -490,6 +490,24 @@ int dlsg_bilstm_supported(int B, int T, int H);
 int64_t dlsg_bilstm_hx_floats(int T, int H);
 int64_t dlsg_bilstm_flag_words(int T, int H);
 int dlsg_bilstm_fwd(const dlsg_bilstm_args* a, void* stream);
+/* Backward through time of the same recurrence, again ONE launch: from the saved activated gates / cell states and
+ * dout (B, T, 2H) = d loss / d out, writes dgates[d] (B, T, 4H) = d loss / d (gate pre-activations) for every step (what the
+ * weight / input gradient products after the loop contract).  Scratch: gx, px = dlsg_bilstm_bwd_x_floats(T, H) floats each
+ * (per-step exchange of dG and of the K-quarter partials of dh), flags = 2 * dlsg_bilstm_flag_words(T, H) words. */
+typedef struct {
+    const float* gates[2];
+    const float* c[2];
+    const float* dout;
+    const float* w_hh[2];
+    float* dgates[2];
+    float* gx;
+    float* px;
+    uint32_t* flags;
+    int32_t* err;
+    int32_t B, T, H, pad_;
+} dlsg_bilstm_bwd_args;
+int64_t dlsg_bilstm_bwd_x_floats(int T, int H);
+int dlsg_bilstm_bwd(const dlsg_bilstm_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------- gradient all-reduce over RCCL / xGMI
  * Replaces the gradient exchange of `DistributedDataParallel(model, find_unused_parameters=True)` over NCCL

@@ -972,3 +972,45 @@ def test_persistent_bilstm_forward(hip, B, T, H):
                            ('gates1', want[3][1], got[3][1])):
             e = (a - b.cpu()).abs().max().item()
             assert e <= 3e-5, (rep, name, e)
+
+
+@pytest.mark.parametrize('B,T,H', [(3, 26, 64), (64, 26, 64), (1, 1, 64), (2, 7, 512), (64, 26, 1024), (17, 26, 1024)])
+def test_persistent_bilstm_backward(hip, B, T, H):
+    """backward through time in one launch against torch autograd of the plain recurrence: d loss / d (gate pre-activations)
+    of every step and direction for a random d loss / d out; run twice (reused exchange buffers / flags)."""
+    g = torch.Generator().manual_seed(11)
+    sc = 1.0 / math.sqrt(H)
+    xg = [rnd(g, B * T, 4 * H).requires_grad_(True) for _ in range(2)]
+    Whh = [rnd(g, 4 * H, H, scale=2 * sc), rnd(g, 4 * H, H, scale=2 * sc)]
+    bih = [rnd(g, 4 * H, scale=0.3), rnd(g, 4 * H, scale=0.3)]
+    bhh = [rnd(g, 4 * H, scale=0.3), rnd(g, 4 * H, scale=0.3)]
+    dout = rnd(g, B, T, 2 * H)
+    # autograd through the recurrence: the gradient w.r.t. xg IS the gradient w.r.t. the gate pre-activations
+    outs = []
+    for d in range(2):
+        h = torch.zeros(B, H); c = torch.zeros(B, H)
+        hs = [None] * T
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            pre = xg[d].view(B, T, 4 * H)[:, t] + bih[d] + bhh[d] + h @ Whh[d].t()
+            i, f, gg, o = pre.split(H, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            hs[t] = h
+        outs.append(torch.stack(hs, 1))
+    out = torch.cat(outs, 2)
+    (out * dout).sum().backward()
+    want = [xg[d].grad.view(B, T, 4 * H) for d in range(2)]
+    with torch.no_grad():
+        _, _, cst, gates = _bilstm_reference([x.detach() for x in xg], Whh, bih, bhh, B, T, H)
+    cu = lambda ts: [t.contiguous().cuda() for t in ts]
+    gates_, c_, W_ = cu(gates), cu(cst), cu(Whh)
+    dout_ = dout.cuda()
+    for rep in range(2):
+        dG = [torch.full((B, T, 4 * H), float('nan'), device='cuda') for _ in range(2)]
+        err = hip.bilstm_bwd(gates_, c_, dout_, W_, dG)
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0, 'a workgroup timed out waiting for its producers (code %d)' % int(err.item())
+        for d in range(2):
+            ref = want[d]
+            e = (ref - dG[d].cpu()).abs().max().item()
+            assert e <= 2e-5 * max(1.0, ref.abs().max().item()), (rep, d, e, ref.abs().max().item())

@@ -59,13 +59,32 @@ def timeit(fn, n=20, graph=False):
     return (time.perf_counter() - t0) / n * 1e3
 
 
+dout = torch.randn(B, T, 2 * H, generator=g).to(dev)
+dG = [torch.empty(B, T, 4 * H, device=dev) for _ in range(2)]
+
+
+def persistent_bwd():
+    ops.bilstm_bwd(gates, cst, dout, Whh, dG)
+
+
+def steps_bwd():
+    E._bilstm_steps_bwd(ops, gates, cst, dout, Whh, dG, B, T, H, out)
+
+
 persistent()
 torch.cuda.synchronize()
 ref = out.clone()
 steps()
 torch.cuda.synchronize()
 print('max |persistent - per-step| on h: %.3g   time-out word: %d' % ((ref - out).abs().max().item(), int(ops._bilstm_err.item())))
-for name, fn in (('persistent', persistent), ('per-step', steps)):
+persistent_bwd()
+torch.cuda.synchronize()
+refg = dG[0].clone()
+steps_bwd()
+torch.cuda.synchronize()
+print('max |persistent - per-step| on dG: %.3g (scale %.3g)  time-out word: %d' % ((refg - dG[0]).abs().max().item(), refg.abs().max().item(),
+                                                                               int(ops._bilstm_err.item())))
+for name, fn in (('persistent', persistent), ('per-step', steps), ('persist-bwd', persistent_bwd), ('perstep-bwd', steps_bwd)):
     for graph in (False, True):
         ms = timeit(fn, graph=graph)
         print('%-11s %-6s B=%d T=%d H=%d: %.3f ms per sequence = %.2f us per step' % (name, 'graph' if graph else 'eager', B, T, H, ms,
