@@ -117,7 +117,8 @@ class _HipModel(nn.Module):
         return F_BF16X3 if (mode == 'x3_all' or (mode == 'x3_bwd' and backward)) else 0
 
     merge_weight_grads = True          # see engine.tn_grouped
-    _defer_ok = True                   # weight gradients may be collected and launched grouped (flushed at every gradient bucket)
+    _defer_ok = True                   # weight gradients may be collected and launched grouped ...
+    _flush_at_buckets = False          # ... at the end of the backward (one rank) or at every gradient bucket (set by a Trainer that reduces buckets)
 
     def next_seed(self):
         self.seed_counter += 1
@@ -260,7 +261,7 @@ class CapGnnModel(_HipModel):
             # a bucket's gradients must be complete when it is handed to the all-reduce: the weight gradients deferred so far
             # go out now, as one grouped launch per height (with one process nothing is reduced and they wait for the end)
             if on_bucket:
-                if sv.get('tn_defer'):
+                if sv.get('tn_defer') and self._flush_at_buckets:
                     E.tn_grouped(ops, sv['tn_defer'])
                     sv['tn_defer'] = []
                 on_bucket(key)
@@ -750,6 +751,8 @@ class Trainer(object):
         L = captions.shape[1]
         sv = {}
         training = model.training
+        # a bucket handed to a reduction (or closing a graph segment) must be complete: deferred weight gradients go out there
+        model._flush_at_buckets = self._comm_mode() != 'none' or self.force_graph_cuts
         model._engine_forward(frames, regions, captions, L, coins, training, seed, sv, dev_coins, outputs=False)
         s = sv['dec']
         Bn = captions.shape[0]
