@@ -861,17 +861,53 @@ extern "C" int dlsg_o2v_fwd_multi(const dlsg_o2v_args* a, int count, void* strea
     return DLSG_OK;
 }
 extern "C" int dlsg_o2v_fwd(const dlsg_o2v_args* a, void* stream) { return dlsg_o2v_fwd_multi(a, 1, stream); }
-extern "C" int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream) {
-    if (!a || a->T < 1 || a->T > 32 || a->NO < 1 || a->nsplit < 1 || a->nsplit > 64) return DLSG_EINVAL;
+int dlsg_o2v16_bwd(const dlsg_o2v_bwd_args* a, int count, hipStream_t st);   // o2v16_bwd.hip
+
+extern "C" int dlsg_o2v_bwd_multi(const dlsg_o2v_bwd_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > DLSG_O2V_MAXMULTI) return DLSG_EINVAL;
+    for (int i = 0; i < count; ++i) {
+        if (a[i].T < 1 || a[i].T > 32 || a[i].NO < 1 || a[i].nsplit < 1 || a[i].nsplit > 64) return DLSG_EINVAL;
+        if (a[i].B != a[0].B || a[i].T != a[0].T || a[i].NO != a[0].NO || a[i].H != a[0].H || a[i].nsplit != a[0].nsplit)
+            return DLSG_EINVAL;          // one launch = one shape
+        if (a[i].nsplit > 1 && (!a[i].ws || a[i].ws_bytes < dlsg_o2v_workspace_bytes(a[i].B, a[i].T, a[i].H, a[i].nsplit)))
+            return DLSG_EINVAL;
+    }
     if (a->B == 0) return DLSG_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    switch (a->H) {
-        case 1024: return o2v_bwd_launch<1024>(a, st);
-        case 512: return o2v_bwd_launch<512>(a, st);
-        case 64: return o2v_bwd_launch<64>(a, st);
-        default: return DLSG_EINVAL;
+    static const bool gen1 = getenv("DLSG_O2V_BWD_GEN1") != nullptr;    // A/B switch: the first-generation two-pass kernels
+    if (gen1) {
+        // the first generation writes one dgamma | dbeta partial per clip: rows [0, B) of `part`; the caller zero-fills the rest
+        for (int i = 0; i < count; ++i) {
+            int rc;
+            switch (a->H) {
+                case 1024: rc = o2v_bwd_launch<1024>(a + i, st); break;
+                case 512: rc = o2v_bwd_launch<512>(a + i, st); break;
+                case 64: rc = o2v_bwd_launch<64>(a + i, st); break;
+                default: return DLSG_EINVAL;
+            }
+            if (rc != DLSG_OK) return rc;
+        }
+        return DLSG_OK;
     }
+    if (a->H != 1024 && a->H != 512 && a->H != 64) return DLSG_EINVAL;
+    const int rc = dlsg_o2v16_bwd(a, count, st);
+    if (rc != DLSG_OK) return rc;
+    if (a->nsplit > 1) {
+        // dv = dz + sum over the object chunks of the partial aggregations: the forward's combine launch with m = 0, l = 1/nsplit
+        O2VCombinePack pk;
+        for (int i = 0; i < count; ++i) {
+            dlsg_o2v_args c = {};
+            c.v = a[i].dz; c.z = a[i].dv; c.ml = nullptr; c.ws = a[i].ws; c.ws_bytes = a[i].ws_bytes;
+            c.B = a[i].B; c.T = a[i].T; c.NO = a[i].NO; c.H = a[i].H; c.nsplit = a[i].nsplit;
+            pk.s[i] = c;
+        }
+        hipLaunchKernelGGL(o2v_combine_multi_kernel, dim3(a->B, a->T, count), dim3(256), 0, st, pk);
+        DLSG_CHECK_LAUNCH();
+    }
+    return DLSG_OK;
 }
+extern "C" int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream) { return dlsg_o2v_bwd_multi(a, 1, stream); }
+extern "C" int dlsg_o2v_bwd_gen1(void) { return getenv("DLSG_O2V_BWD_GEN1") != nullptr; }
 
 extern "C" int dlsg_decatt_fwd(const dlsg_decatt_args* a, void* stream) {
     if (!a || a->P < 1 || a->P > DA_MAXP || a->nstream < 1 || a->nstream > 2) return DLSG_EINVAL;

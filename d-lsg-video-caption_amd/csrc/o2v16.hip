@@ -27,56 +27,12 @@
 #include <cstdlib>
 #include <mutex>
 
-#include "common.hpp"
-#include "dlsg.h"
+#include "o2v16.hpp"
 
 using namespace dlsg;
+using namespace o16;
 
 namespace {
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-
-constexpr int O16_THREADS = 512;
-constexpr int O16_TILE = 16;
-
-template <int H>
-struct O16Geom {
-    static constexpr int LDO = H + 4;                          // LDS row stride (floats); a DMA piece never crosses a row
-    static constexpr int KW = (H / 16 < 8) ? H / 16 : 8;       // waves that split k in the S product
-    static constexpr int HS = H / KW;                          // k slice per wave (multiple of 16)
-    static constexpr int NCHUNK = HS / 16;                     // 16-deep chunks = 4 MFMAs per frame block
-    static constexpr int NCB = H / 16;                         // 16-column blocks of the aggregation output
-    static constexpr int CBW = (NCB + 7) / 8;                  // column blocks per wave
-    static constexpr int VB = (H >= 256) ? 16 : 4;             // bytes per lane of one LDS-DMA piece
-    static constexpr int PPR = H * 4 / (64 * VB);              // pieces per row
-    static constexpr int NP = 2 * PPR;                         // pieces a wave issues per tile (2 rows)
-    static constexpr int EPL = H / 64;                         // elements per lane when a wave holds one row
-    static constexpr int VEC = (EPL % 4 == 0) ? 4 : 1;
-    static constexpr int NCH = EPL / VEC;
-    static constexpr int BUF = O16_TILE * LDO;                 // floats per tile buffer
-    static constexpr int RED = 8 * 2 * 64 * 4;                 // [wave][frame block][lane] float4
-    static constexpr int LDS_FLOATS = 2 * BUF + RED + 2 * H + 64;      // + 2 x (mean[16] | rstd[16]): this tile's and the next's
-};
-
-// LDS writes/reads of this wave retired, then the workgroup barrier.  Deliberately NOT __syncthreads(): its fence waits
-// vmcnt(0) and would drain the LDS-DMA of the next tile.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-// one LDS-DMA piece: 64 lanes x VB bytes from per-lane global addresses to a wave-uniform LDS base (+ lane * VB).
-// The 16-byte form is a gfx950 instruction: the host pass of hipcc cannot type-check the builtin (it would silently drop the
-// kernel's host stub), so the body exists in the device pass only.
-template <int VB>
-__device__ __forceinline__ void glds(const char* src, char* dst) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (VB == 16) __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
-    else __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 4, 0, 0);
-#endif
-}
 
 // STAMP: diagnostic build (tools/o2v_stamps.py, env DLSG_O2V_STAMPS): lane 0 of every wave of workgroup (0,0) records
 // s_memtime at the phase boundaries of each tile into a.ws (unused when nsplit == 1); the product build has no stamp code.

@@ -346,7 +346,6 @@ def tun_graph(ops, items, regions, sv, fused_o2v=True, nsplit=None):
             for m, pfx, _ in part:
                 s = sv[pfx]
                 s['ml'] = _empty(ref, B * T, 2)
-                s['o2v_nsplit'] = max(1, min((NO + 31) // 32, 256 // max(B, 1), O2V_MAX_NSPLIT))      # chunking of the backward kernels
                 args.append(dict(y=s['y'].view(B, NO, H), v=s['v'].view(B, T, H), g_obj=m.obj_norm[1].weight,
                                  b_obj=m.obj_norm[1].bias, z=s['z'], ml=s['ml'], ostats=s['ostats'], S=s['S']))
             ops.o2v_fwd_multi(args, scale, ns)
@@ -399,6 +398,13 @@ def tun_latent(ops, m, pfx, regions, sv, training, seed, psl_site):
 
 def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed, defer_dw=None):
     """Backward of tun_fwd.  dpsl (B,P,H).  Returns d(visual input) when the stream has no embed, else None."""
+    tun_bwd_head(ops, m, pfx, regions, sv, G, dpsl, training, seed)
+    tun_graph_bwd(ops, [(m, pfx)], regions, sv, G)
+    return tun_bwd_tail(ops, m, pfx, regions, sv, G, defer_dw)
+
+
+def tun_bwd_head(ops, m, pfx, regions, sv, G, dpsl, training, seed):
+    """LatentPSL and obj_visual_norm backward: leaves dz = d(agg + v) in sv[pfx] (or d(v) directly when the graph is skipped)."""
     B, T, O, R = regions.shape
     s = sv[pfx]
     H = m.visual_norm[1].weight.numel()
@@ -435,50 +441,91 @@ def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed, defer_dw=None):
             ops.gemm(GEMM_NN, [(dlg, theta.unsqueeze(0).expand(B, P, H), dov.view(B, T, H))], flags=F_ACCUM)
             ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[name + '.v2l_layer.theta'])], flags=F_ACCUM)
     if O >= 5:
-        NO = T * O
         lnv = m.obj_visual_norm[1]
         nb = ops.rowln_bwd_nblk(B * T)
         part = _empty(ref, nb, 2, H)
         dz = _empty(ref, B * T, H)
         ops.rowln_bwd(dov, s['z'], lnv.weight, lnv.bias, dz, stats=s['st_ov'], pre_tanh=1, dgb_part=part)
         ln_grads(ops, part, G, name + '.obj_visual_norm.1', H)
-        g_o, b_o = m.obj_norm[1].weight, m.obj_norm[1].bias
-        y, v, S, scale = s['y'], s['v'], s['S'], s['scale']
+        s['dz'] = dz
+    else:
+        s['dv'] = dov
+
+
+def tun_graph_bwd(ops, items, regions, sv, G):
+    """Backward of the object -> frame graph (layer.py:184-192) of one or several streams; items: [(module, prefix)].  Streams
+    whose forward ran the fused kernel share ONE launch per pass (csrc/o2v16_bwd.hip).  Leaves dy (gradient w.r.t. the
+    obj_embed pre-activation) and dv in sv[prefix]; folds obj_norm's dgamma / dbeta."""
+    B, T, O, R = regions.shape
+    if O < 5:
+        return
+    NO = T * O
+    ref = regions
+    by_h = {}
+    for m, pfx in items:
+        if 'ml' in sv[pfx]:
+            by_h.setdefault(m.visual_norm[1].weight.numel(), []).append((m, pfx))
+    for H, grp in by_h.items():
+        for i0 in range(0, len(grp), 2):
+            part_items = grp[i0:i0 + 2]
+            args = []
+            for m, pfx in part_items:
+                s = sv[pfx]
+                s['dy'] = _empty(ref, B * NO, H)
+                s['dv'] = _empty(ref, B * T, H)
+                args.append(dict(y=s['y'].view(B, NO, H), ostats=s['ostats'], g_obj=m.obj_norm[1].weight, b_obj=m.obj_norm[1].bias,
+                                 v=s['v'].view(B, T, H), z=s['z'].view(B, T, H), dz=s['dz'].view(B, T, H), S=s['S'], ml=s['ml'],
+                                 dy=s['dy'].view(B, NO, H), dv=s['dv'].view(B, T, H)))
+            ns = o2v_nsplit(B * len(part_items), NO)
+            parts = ops.o2v_bwd_multi(args, sv[part_items[0][1]]['scale'], ns)
+            for (m, pfx), part in zip(part_items, parts):
+                ln_grads(ops, part, G, pfx + '.obj_norm.1', H)
+    for m, pfx in items:
+        s = sv[pfx]
         if 'ml' in s:
-            # fused backward of the graph: two passes over y (scores, apply) instead of ten launches
-            dy = _empty(ref, B * NO, H)
-            dv = _empty(ref, B * T, H)
-            part = _empty(ref, B, 2, H)
-            ops.o2v_bwd(y.view(B, NO, H), s['ostats'], g_o, b_o, v.view(B, T, H), s['z'].view(B, T, H), dz.view(B, T, H), S,
-                        s['ml'], dy.view(B, NO, H), dv.view(B, T, H), part, scale, s['o2v_nsplit'])
-        else:
-            o = _empty(ref, B * NO, H)
-            ops.rowln_fwd(y, g_o, b_o, o, None)
-            o3, dz3, v3 = o.view(B, NO, H), dz.view(B, T, H), v.view(B, T, H)
-            Pm = _empty(ref, B, NO, T)
-            ops.softmax_fwd(S, Pm, B, NO, T)
-            dP = _empty(ref, B, NO, T)
-            ops.gemm(GEMM_NT, [(o3, dz3, dP)])
-            dS = _empty(ref, B, NO, T)
-            ops.softmax_bwd(Pm, dP, dS, B, NO, T)
-            do = _empty(ref, B * NO, H)
-            ops.gemm(GEMM_NN, [(Pm, dz3, do.view(B, NO, H))])
-            ops.gemm(GEMM_NN, [(dS, v3, do.view(B, NO, H))], alpha=scale, flags=F_ACCUM)
-            dv = _empty(ref, B * T, H)
-            ops.copy2d(dz, dv)
-            ops.gemm(GEMM_TN, [(dS, o3, dv.view(B, T, H))], alpha=scale, flags=F_ACCUM)
-            nb = ops.rowln_bwd_nblk(B * NO)
-            part = _empty(ref, nb, 2, H)
-            dy = o   # reuse the scratch: rowln_bwd reads y/stats, not o
-            ops.rowln_bwd(do, y, g_o, b_o, dy, stats=s['ostats'], pre_tanh=2, dgb_part=part)
-        ln_grads(ops, part, G, name + '.obj_norm.1', H)
+            continue
+        H = m.visual_norm[1].weight.numel()
+        g_o, b_o = m.obj_norm[1].weight, m.obj_norm[1].bias
+        y, v, S, scale, dz = s['y'], s['v'], s['S'], s['scale'], s['dz']
+        o = _empty(ref, B * NO, H)
+        ops.rowln_fwd(y, g_o, b_o, o, None)
+        o3, dz3, v3 = o.view(B, NO, H), dz.view(B, T, H), v.view(B, T, H)
+        Pm = _empty(ref, B, NO, T)
+        ops.softmax_fwd(S, Pm, B, NO, T)
+        dP = _empty(ref, B, NO, T)
+        ops.gemm(GEMM_NT, [(o3, dz3, dP)])
+        dS = _empty(ref, B, NO, T)
+        ops.softmax_bwd(Pm, dP, dS, B, NO, T)
+        do = _empty(ref, B * NO, H)
+        ops.gemm(GEMM_NN, [(Pm, dz3, do.view(B, NO, H))])
+        ops.gemm(GEMM_NN, [(dS, v3, do.view(B, NO, H))], alpha=scale, flags=F_ACCUM)
+        dv = _empty(ref, B * T, H)
+        ops.copy2d(dz, dv)
+        ops.gemm(GEMM_TN, [(dS, o3, dv.view(B, T, H))], alpha=scale, flags=F_ACCUM)
+        nb = ops.rowln_bwd_nblk(B * NO)
+        part = _empty(ref, nb, 2, H)
+        dy = o   # reuse the scratch: rowln_bwd reads y/stats, not o
+        ops.rowln_bwd(do, y, g_o, b_o, dy, stats=s['ostats'], pre_tanh=2, dgb_part=part)
+        ln_grads(ops, part, G, pfx + '.obj_norm.1', H)
+        s['dy'], s['dv'] = dy, dv
+
+
+def tun_bwd_tail(ops, m, pfx, regions, sv, G, defer_dw=None):
+    """obj_embed and frame-node gradients.  Returns d(visual input) when the stream has no embed, else None."""
+    B, T, O, R = regions.shape
+    s = sv[pfx]
+    H = m.visual_norm[1].weight.numel()
+    ref = regions
+    name = pfx
+    if O >= 5:
+        NO = T * O
+        dy = s['dy']
         if defer_dw is not None:
             defer_dw.append((dy, regions.view(B * NO, R), G[name + '.obj_embed.weight']))
         else:
             gemm_tn_deep(ops, [(dy, regions.view(B * NO, R), G[name + '.obj_embed.weight'])], ref)
         ops.colsum(dy, G[name + '.obj_embed.bias'], accum=True)
-    else:
-        dv = dov
+    dv = s['dv']
     lnv = m.visual_norm[1]
     nb = ops.rowln_bwd_nblk(B * T)
     part = _empty(ref, nb, 2, H)

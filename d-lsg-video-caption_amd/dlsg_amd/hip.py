@@ -56,8 +56,8 @@ class O2VArgs(C.Structure):
 
 class O2VBwdArgs(C.Structure):
     _fields_ = [(n, c_f32p) for n in ('y', 'ostats', 'g_obj', 'b_obj', 'v', 'z', 'dz', 'S', 'ml', 'pd', 'm12', 'dy', 'dv',
-                                      'part')] + [('B', i32), ('T', i32), ('NO', i32), ('H', i32), ('nsplit', i32),
-                                                  ('scale', f32)]
+                                      'part', 'ws')] + [('ws_bytes', i64), ('B', i32), ('T', i32), ('NO', i32), ('H', i32),
+                                                        ('nsplit', i32), ('scale', f32)]
 
 
 class LatentPslArgs(C.Structure):
@@ -170,7 +170,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
-           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd',
+           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd', 'dlsg_o2v_bwd_multi', 'dlsg_o2v_bwd_gen1',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
            'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2', 'dlsg_lstm_cell_bwd_seq',
            'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2',
@@ -237,6 +237,8 @@ def load_library(path=LIB_PATH):
         'dlsg_dec_mid_bwd': [P(DecMidBwdArgs), vp],
         'dlsg_decatt_cache_grads': [P(DecattCacheGradsArgs), vp],
         'dlsg_o2v_bwd': [P(O2VBwdArgs), vp],
+        'dlsg_o2v_bwd_multi': [P(O2VBwdArgs), i32, vp],
+        'dlsg_o2v_bwd_gen1': [],
         'dlsg_latent_psl_fwd': [P(LatentPslArgs), vp],
         'dlsg_sa_core_fwd': [P(SaCoreArgs), vp],
         'dlsg_beam_select': [P(BeamSelectArgs), vp],
@@ -519,23 +521,42 @@ class HipOps(object):
         # algorithmic bytes: read y once + read v + write z, per graph
         self._prof_end('o2v_graph_fwd', e0, 4.0 * n * B * (NO * H + 2 * T * H), 'B=%d T=%d NO=%d H=%d streams=%d nsplit=%d' % (B, T, NO, H, n, nsplit))
 
-    def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, part, scale, nsplit):
-        """backward of o2v_fwd: dz (B,T,H) -> dy (B,NO,H), dv (B,T,H), part (B,2,H) (obj_norm dgamma | dbeta per clip)."""
-        B, NO, H = y.shape
-        T = v.shape[1]
-        for t in (y, ostats, v, z, dz, S, ml, dy, dv, part):
-            _chkc(t)
-        pd = torch.empty(B, NO, 64, dtype=torch.float32, device=y.device)
-        m12 = torch.empty(B, NO, 2, dtype=torch.float32, device=y.device)
-        a = O2VBwdArgs()
-        a.y, a.ostats, a.g_obj, a.b_obj, a.v, a.z, a.dz, a.S, a.ml = _p(y), _p(ostats), _p(g_obj), _p(b_obj), _p(v), _p(z), \
-            _p(dz), _p(S), _p(ml)
-        a.pd, a.m12, a.dy, a.dv, a.part = _p(pd), _p(m12), _p(dy), _p(dv), _p(part)
-        a.B, a.T, a.NO, a.H, a.nsplit, a.scale = B, T, NO, H, nsplit, scale
+    def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, scale, nsplit):
+        """backward of o2v_fwd: dz (B,T,H) -> dy (B,NO,H), dv (B,T,H); returns part (B*nsplit,2,H) (obj_norm dgamma | dbeta per
+        (clip, object chunk))."""
+        return self.o2v_bwd_multi([dict(y=y, ostats=ostats, g_obj=g_obj, b_obj=b_obj, v=v, z=z, dz=dz, S=S, ml=ml, dy=dy, dv=dv)],
+                                  scale, nsplit)[0]
+
+    def o2v_bwd_multi(self, items, scale, nsplit):
+        """the backward of several object->frame graphs of one shape, one launch per pass (both encoder streams).
+        items: dicts with y (B,NO,H), ostats, g_obj, b_obj, v, z, dz (B,T,H), S, ml, dy, dv.  Returns the list of `part` arrays."""
+        n = len(items)
+        B, NO, H = items[0]['y'].shape
+        T = items[0]['v'].shape[1]
+        dev = items[0]['y'].device
+        arr = (O2VBwdArgs * n)()
+        wsb = int(self.lib.dlsg_o2v_workspace_bytes(B, T, H, nsplit))
+        gen1 = bool(self.lib.dlsg_o2v_bwd_gen1())
+        keep, parts = [], []
+        for a, it in zip(arr, items):
+            for k in ('y', 'ostats', 'v', 'z', 'dz', 'S', 'ml', 'dy', 'dv'):
+                _chkc(it[k])
+            assert it['y'].shape == (B, NO, H) and it['v'].shape[1] == T
+            pd = torch.empty(B, NO, 64, dtype=torch.float32, device=dev)
+            m12 = torch.empty(B, NO, 2, dtype=torch.float32, device=dev)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+            part = (torch.zeros if gen1 else torch.empty)(B * nsplit, 2, H, dtype=torch.float32, device=dev)
+            keep += [pd, m12, ws]
+            parts.append(part)
+            for k in ('y', 'ostats', 'g_obj', 'b_obj', 'v', 'z', 'dz', 'S', 'ml', 'dy', 'dv'):
+                setattr(a, k, _p(it[k]))
+            a.pd, a.m12, a.part, a.ws, a.ws_bytes = _p(pd), _p(m12), _p(part), _p(ws), wsb
+            a.B, a.T, a.NO, a.H, a.nsplit, a.scale = B, T, NO, H, nsplit, scale
         e0 = self._prof_begin()
-        self._check(self.lib.dlsg_o2v_bwd(C.byref(a), self._stream()), 'dlsg_o2v_bwd')
+        self._check(self.lib.dlsg_o2v_bwd_multi(arr, n, self._stream()), 'dlsg_o2v_bwd_multi')
         # algorithmic bytes: y read by both passes is counted once (SURVEY.md 8d convention) + dy written + dz, v, dv
-        self._prof_end('o2v_graph_bwd', e0, 4.0 * B * (2 * NO * H + 3 * T * H), 'B=%d T=%d NO=%d H=%d' % (B, T, NO, H))
+        self._prof_end('o2v_graph_bwd', e0, 4.0 * n * B * (2 * NO * H + 3 * T * H), 'B=%d T=%d NO=%d H=%d streams=%d nsplit=%d' % (B, T, NO, H, n, nsplit))
+        return parts
 
     # ------------------------------------------------------------------ beam search
     def beam_select(self, logits, last, last_lp, pred, new_lp, back, rows, k, end, first=False, ended_count=None):

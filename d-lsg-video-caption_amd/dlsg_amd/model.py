@@ -278,11 +278,16 @@ class CapGnnModel(_HipModel):
         # end, so the two small TUN buckets (12 MB each) are reduced last; the 151 MB motion_pre_encoder bucket still
         # travels under the object stream's backward
         deep = []
-        dmot_in = E.tun_bwd(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, G, dmo, training, seed,
-                            defer_dw=deep)
+        mot, obj = (enc.motion_encoder, 'encoder.motion_encoder'), (enc.obj_encoder, 'encoder.obj_encoder')
+        # both streams' LatentPSL / obj_visual_norm backward first, so that the object->frame graph of BOTH streams runs its
+        # backward as one launch per pass (2 x 64 clips: two object chunks per clip instead of four)
+        E.tun_bwd_head(ops, mot[0], mot[1], regions, sv, G, dmo, training, seed)
+        E.tun_bwd_head(ops, obj[0], obj[1], regions, sv, G, dob, training, seed)
+        E.tun_graph_bwd(ops, [mot, obj], regions, sv, G)
+        dmot_in = E.tun_bwd_tail(ops, mot[0], mot[1], regions, sv, G, defer_dw=deep)
         E.encvis_bwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, G, dmot_in, training, seed)
         bucket('encoder.motion_pre_encoder')
-        E.tun_bwd(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, G, dob, training, seed, defer_dw=deep)
+        E.tun_bwd_tail(ops, obj[0], obj[1], regions, sv, G, defer_dw=deep)
         E.gemm_tn_deep(ops, deep, frames)
         if 'tn_defer' in sv:
             E.tn_grouped(ops, sv.pop('tn_defer'))

@@ -150,21 +150,29 @@ int dlsg_o2v_fwd(const dlsg_o2v_args* a, void* stream);
  * chunks per clip.  a[0..count) are consecutive argument blocks. */
 #define DLSG_O2V_MAXMULTI 2
 int dlsg_o2v_fwd_multi(const dlsg_o2v_args* a, int count, void* stream);
-/* Backward of the fused graph in two passes over y (see attention.hip): given dz (B,T,H) it writes
+/* Backward of the fused graph in two passes over y (csrc/o2v16_bwd.hip; one workgroup per (clip, object chunk, stream) on
+ * the forward's LDS-DMA tile pipeline): given dz (B,T,H) it writes
  *   dy (B,NO,H)  grad wrt the obj_embed pre-activation (through obj_norm's LayerNorm and the tanh of the GEMM epilogue),
  *   dv (B,T,H)   grad wrt the frame nodes v (includes the residual dz),
- *   part (B,2,H) per-clip dgamma | dbeta of obj_norm (fold with dlsg_colsum2).
- * y, ostats, S, ml, z are the forward's inputs / outputs; pd (B,NO,64) and m12 (B,NO,2) are workspaces.
+ *   part (B*nsplit,2,H) dgamma | dbeta of obj_norm per (clip, object chunk) (fold with dlsg_colsum2).
+ * y, ostats, S, ml, z are the forward's inputs / outputs; pd (B,NO,64) and m12 (B,NO,2) are workspaces, ws = dlsg_o2v_workspace_bytes
+ * (B, T, H, nsplit) bytes of chunk partials of dv (needed when nsplit > 1).  dlsg_o2v_bwd_multi: `count` (<= DLSG_O2V_MAXMULTI)
+ * graphs of one shape in one launch per pass (the object and the motion stream of CapGnnEncoder).
  * Same support as the forward (T <= 32, H in {64,512,1024}); otherwise the caller runs the unfused chain
- * (dlsg_softmax_fwd/bwd on S + batched dlsg_gemm + dlsg_rowln_bwd; engine.py tun_bwd). */
+ * (dlsg_softmax_fwd/bwd on S + batched dlsg_gemm + dlsg_rowln_bwd; engine.py tun_bwd).
+ * dlsg_o2v_bwd_gen1() != 0: the environment selects the first-generation kernels (A/B measurements), which write only rows
+ * [0, B) of `part` -- the caller zero-fills it. */
 typedef struct {
     const float* y; const float* ostats; const float* g_obj; const float* b_obj;
     const float* v; const float* z; const float* dz; const float* S; const float* ml;
     float* pd; float* m12;
     float* dy; float* dv; float* part;
+    float* ws; int64_t ws_bytes;
     int32_t B, T, NO, H, nsplit;
     float scale;
 } dlsg_o2v_bwd_args;
+int dlsg_o2v_bwd_multi(const dlsg_o2v_bwd_args* a, int count, void* stream);
+int dlsg_o2v_bwd_gen1(void);
 int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------- LatentPSL forward (sublayer.py:189-198), one launch

@@ -212,9 +212,15 @@ class EmulOps(object):
         for it in items:
             self.o2v_fwd(it['y'], it['v'], it['g_obj'], it['b_obj'], it['z'], it['ml'], it['ostats'], it['S'], scale, nsplit, eps)
 
-    def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, part, scale, nsplit, eps=1e-5):
+    def o2v_bwd_multi(self, items, scale, nsplit, eps=1e-5):
+        return [self.o2v_bwd(it['y'], it['ostats'], it['g_obj'], it['b_obj'], it['v'], it['z'], it['dz'], it['S'], it['ml'], it['dy'],
+                             it['dv'], scale, nsplit, eps) for it in items]
+
+    def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, scale, nsplit, eps=1e-5):
+        """returns part (B*nsplit, 2, H): the per-clip dgamma | dbeta in the first chunk's rows, zeros in the others"""
         self._count('o2v_bwd')
         B, NO, H = y.shape
+        part = torch.zeros(B, nsplit, 2, H, dtype=y.dtype)
         mean = y.mean(2, keepdim=True)
         rstd = 1.0 / torch.sqrt(((y - mean) ** 2).mean(2, keepdim=True) + eps)
         xh = (y - mean) * rstd
@@ -224,11 +230,12 @@ class EmulOps(object):
         dS = P * (dP - (P * dP).sum(1, keepdim=True))
         do = P @ dz + scale * (dS @ v)
         dv.copy_(dz + scale * (dS.transpose(1, 2) @ o))
-        part[:, 0] = (do * xh).sum(1)
-        part[:, 1] = do.sum(1)
+        part[:, 0, 0] = (do * xh).sum(1)
+        part[:, 0, 1] = do.sum(1)
         gx = do * g_obj
         d = rstd * (gx - gx.mean(2, keepdim=True) - xh * (gx * xh).mean(2, keepdim=True))
         dy.copy_(d * (1 - y * y))
+        return part.view(B * nsplit, 2, H)
 
     def beam_select(self, logits, last, last_lp, pred, new_lp, back, rows, k, end, first=False, ended_count=None):
         # allennlp_beamsearch.py:114-129 (first step) and :140-260 (later steps) on one step's logits

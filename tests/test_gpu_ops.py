@@ -410,8 +410,9 @@ def test_o2v_two_graphs_in_one_launch(hip, case):
 
 @pytest.mark.parametrize('case', O2V_CASES)
 def test_o2v_fused_backward(hip, case):
-    """dlsg_o2v_bwd (scores pass + apply pass) against the closed-form backward of the graph; forward state (S, ml,
-    ostats, z) comes from each side's own forward."""
+    """dlsg_o2v_bwd (scores + dv pass, apply pass, chunk combine: csrc/o2v16_bwd.hip) against the closed-form backward of the
+    graph; forward state (S, ml, ostats, z) comes from each side's own forward.  dgamma | dbeta are compared after the fold
+    over the (clip, chunk) partial rows."""
     B, T, O, H, ns = case
     NO = T * O
 
@@ -423,9 +424,34 @@ def test_o2v_fused_backward(hip, case):
     def run(ops, t):
         sc = 1.0 / math.sqrt(H / 4.0)
         ops.o2v_fwd(t['y'], t['v'], t['go'], t['bo'], t['z'], t['ml'], t['os'], t['S'], sc, ns)
-        ops.o2v_bwd(t['y'], t['os'], t['go'], t['bo'], t['v'], t['z'].view(B, T, H), t['dz'], t['S'], t['ml'], t['dy'], t['dv'],
-                    t['part'], sc, ns)
+        part = ops.o2v_bwd(t['y'], t['os'], t['go'], t['bo'], t['v'], t['z'].view(B, T, H), t['dz'], t['S'], t['ml'], t['dy'], t['dv'],
+                           sc, ns)
+        assert part.shape == (B * ns, 2, H)
+        t['part'] = part.view(B, ns, 2, H).sum(1)
     both(hip, build, run, ['dy', 'dv', 'part'], tol=5e-5, name='o2v bwd %s' % (case,))
+
+
+def test_o2v_fused_backward_two_streams_one_launch(hip):
+    """dlsg_o2v_bwd_multi: the object and the motion stream's graphs in one launch per pass == each stream alone."""
+    B, T, O, H, ns = 5, 26, 16, 1024, 3
+    NO = T * O
+    g = torch.Generator().manual_seed(3)
+    sc = 1.0 / math.sqrt(2048.0)
+    items, single = [], []
+    for i in range(2):
+        t = dict(y=torch.tanh(rnd(g, B, NO, H)).cuda(), v=rnd(g, B, T, H).cuda(), g_obj=(1 + 0.2 * rnd(g, H)).cuda(),
+                 b_obj=(0.2 * rnd(g, H)).cuda(), z=torch.zeros(B * T, H).cuda(), ml=torch.zeros(B * T, 2).cuda(),
+                 ostats=torch.zeros(B * NO, 2).cuda(), S=torch.zeros(B, NO, T).cuda(), dz=rnd(g, B, T, H).cuda())
+        hip.o2v_fwd(t['y'], t['v'], t['g_obj'], t['b_obj'], t['z'], t['ml'], t['ostats'], t['S'], sc, ns)
+        t['z'] = t['z'].view(B, T, H)
+        items.append(dict(t, dy=torch.zeros(B, NO, H).cuda(), dv=torch.zeros(B, T, H).cuda()))
+        one = dict(t, dy=torch.zeros(B, NO, H).cuda(), dv=torch.zeros(B, T, H).cuda())
+        one['part'] = hip.o2v_bwd_multi([one], sc, ns)[0]
+        single.append(one)
+    parts = hip.o2v_bwd_multi(items, sc, ns)
+    torch.cuda.synchronize()
+    for it, one, part in zip(items, single, parts):
+        assert torch.equal(it['dy'], one['dy']) and torch.equal(it['dv'], one['dv']) and torch.equal(part, one['part'])
 
 
 @pytest.mark.parametrize('dims', [(3, 26, 8, 64), (64, 26, 8, 1024), (2, 26, 5, 1024), (2, 32, 32, 96), (1, 7, 3, 2048),
