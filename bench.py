@@ -327,7 +327,7 @@ def msrvtt_leg(dev, a):
     nprof = min(2, a.steps)
     prof = profile_eager_steps(net, tr, fb, eps, nprof)
     out['roofline'] = gemm_roofline(prof, nprof)
-    for key, name, label in (('o2v_graph_fwd', 'roofline_graph_attention', 'o2v16_kernel'), ('o2v_graph_bwd', 'roofline_graph_attention_bwd', 'o2v backward')):
+    for key, name, label in (('o2v_graph_fwd', 'roofline_graph_attention', 'o2v16_kernel'), ('o2v_graph_bwd', 'roofline_graph_attention_bwd', O2V_BWD_KERNELS)):
         o = prof.get(key)
         if o and o['ms_total'] > 0:
             ach = o['work_total'] / (o['ms_total'] * 1e-3) / 1e9
@@ -707,7 +707,7 @@ def socket_hostname():
     return socket.gethostname()
 
 
-O2V_BWD_KERNELS = 'o2v_bwd_scores_kernel + o2v_bwd_apply_kernel'
+O2V_BWD_KERNELS = 'o2v16_bwd_scores_kernel + o2v16_bwd_apply_kernel + o2v_combine_multi_kernel (both encoder streams per launch)'
 
 
 if __name__ == '__main__':

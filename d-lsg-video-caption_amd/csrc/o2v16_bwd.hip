@@ -319,10 +319,30 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_bwd_scores_kernel(const B16
 }
 
 // ================================================================================================ pass 2: do, dy, dgamma / dbeta
-template <int H>
-__global__ __launch_bounds__(O16_THREADS) void o2v16_bwd_apply_kernel(const B16Pack pk, int tiles_per_split) {
-    using G = O16Geom<H>;
-    const dlsg_o2v_bwd_args& a = pk.s[blockIdx.z];
+// Column-parallel (nothing here contracts over H): at H = 1024 a workgroup takes HALF the columns of its (clip, chunk) -- four
+// waves, 16 x 512 tiles, 2 x 33 KB of LDS -- so that TWO workgroups share a CU and run out of phase: with one 8-wave workgroup
+// per CU every wave reached its MFMA block, its LayerNorm epilogue and its write-out at the same time as its SIMD partner.
+template <int H, int NSL>
+struct ApGeom {
+    static constexpr int W = H / NSL;                          // columns of a workgroup
+    static constexpr int NW = 8 / NSL;                         // waves
+    static constexpr int RPW = O16_TILE / NW;                  // tile rows a wave fetches / writes out
+    static constexpr int LDO = W + 4;
+    static constexpr int VB = (W >= 256) ? 16 : 4;
+    static constexpr int PPR = W * 4 / (64 * VB);              // LDS-DMA pieces per row slice
+    static constexpr int EPL = W / 64;
+    static constexpr int VEC = (EPL % 4 == 0) ? 4 : 1;
+    static constexpr int NCH = EPL / VEC;
+    static constexpr int NCB = W / 16;
+    static constexpr int CBW = (NCB + NW - 1) / NW;
+    static constexpr int BUF = O16_TILE * LDO;
+};
+
+template <int H, int NSL>
+__global__ __launch_bounds__(512 / NSL) void o2v16_bwd_apply_kernel(const B16Pack pk, int tiles_per_split) {
+    using G = ApGeom<H, NSL>;
+    const dlsg_o2v_bwd_args& a = pk.s[blockIdx.z / NSL];
+    const int col0 = (blockIdx.z % NSL) * G::W;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int b = blockIdx.x, sp = blockIdx.y;
@@ -334,10 +354,10 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_bwd_apply_kernel(const B16P
 
     auto issue_tile = [&](int n0, float* dst) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row = 2 * w + rr;
+        for (int rr = 0; rr < G::RPW; ++rr) {
+            const int row = G::RPW * w + rr;
             const int n = min(n0 + row, NO - 1);
-            const char* src = reinterpret_cast<const char*>(a.y + ((int64_t)b * NO + n) * H) + lane * G::VB;
+            const char* src = reinterpret_cast<const char*>(a.y + ((int64_t)b * NO + n) * H + col0) + lane * G::VB;
             char* d = reinterpret_cast<char*>(dst + row * G::LDO);
 #pragma unroll
             for (int q = 0; q < G::PPR; ++q) glds<G::VB>(src + q * 64 * G::VB, d + q * 64 * G::VB);
@@ -351,13 +371,13 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_bwd_apply_kernel(const B16P
 #pragma unroll
     for (int c = 0; c < G::CBW; ++c) {
         const int cb = min(w * G::CBW + c, G::NCB - 1);
-        gcol[c] = a.g_obj[cb * 16 + f];
+        gcol[c] = a.g_obj[col0 + cb * 16 + f];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int k = 16 * j + 4 * g + s, t = k & 31;
-                const float* src = (k < 32 ? a.dz : a.v) + ((int64_t)b * T + min(t, T - 1)) * H + cb * 16 + f;
+                const float* src = (k < 32 ? a.dz : a.v) + ((int64_t)b * T + min(t, T - 1)) * H + col0 + cb * 16 + f;
                 dzv[c][4 * j + s] = t < T ? *src : 0.f;
             }
     }
@@ -417,14 +437,14 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_bwd_apply_kernel(const B16P
         }
         if (more) fetch_small(n0 + O16_TILE);         // next tile's pd rows / statistics: in flight over the write-out
         lds_barrier();                                // the whole tile now holds dy
-        // ---- write out the two rows this wave fetched: 16 bytes per lane, whole rows
+        // ---- write out the rows this wave fetched: 16 bytes per lane, whole row slices
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row = 2 * w + rr;
+        for (int rr = 0; rr < G::RPW; ++rr) {
+            const int row = G::RPW * w + rr;
             const int n = n0 + row;
             if (n < n_end) {
                 const float* rp = cur + row * G::LDO;
-                float* dp = a.dy + ((int64_t)b * NO + n) * H;
+                float* dp = a.dy + ((int64_t)b * NO + n) * H + col0;
 #pragma unroll
                 for (int c = 0; c < G::NCH; ++c) {
                     if (G::VEC == 4) {
@@ -435,12 +455,9 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_bwd_apply_kernel(const B16P
                 }
             }
         }
-        // everything this wave has in flight is older than the stores just issued except nothing: the DMA of the next tile and
-        // the small loads precede them in the queue, so waiting for all but the stores means both have landed
-        if (more) {
-            if (G::VEC == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::NCH) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // the DMA of the next tile and its small loads were issued BEFORE these stores and the queue retires in order: once no
+        // more than the stores are outstanding, both have landed (a non-final tile has all 16 rows, so the count is exact)
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::RPW * G::NCH) : "memory");
         lds_barrier();                                // `cur` is free for the DMA of tile i+2; tile i+1 is complete in `nxt`
     }
     // ---- obj_norm dgamma | dbeta partials of this (clip, chunk): sum the four object groups
@@ -450,7 +467,7 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_bwd_apply_kernel(const B16P
         bsum[c] += __shfl_xor(bsum[c], 16, 64); bsum[c] += __shfl_xor(bsum[c], 32, 64);
         const int cb = w * G::CBW + c;
         if (g == 0 && cb < G::NCB) {
-            float* pp = a.part + ((int64_t)b * a.nsplit + sp) * 2 * H + cb * 16 + f;
+            float* pp = a.part + ((int64_t)b * a.nsplit + sp) * 2 * H + col0 + cb * 16 + f;
             pp[0] = gsum[c];
             pp[H] = bsum[c];
         }
@@ -461,10 +478,12 @@ template <int H>
 int launch_t(const dlsg_o2v_bwd_args* a, int count, hipStream_t st) {
     using G = O16Geom<H>;
     static std::once_flag once;
-    constexpr int lds1 = G::LDS_FLOATS * 4, lds2 = 2 * G::BUF * 4;
+    constexpr int NSL = H >= 1024 ? 2 : 1;
+    using GA = ApGeom<H, NSL>;
+    constexpr int lds1 = G::LDS_FLOATS * 4, lds2 = 2 * GA::BUF * 4;
     std::call_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v16_bwd_scores_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds1);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v16_bwd_apply_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v16_bwd_apply_kernel<H, NSL>), hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
     });
     const int tiles = (a->NO + O16_TILE - 1) / O16_TILE;
     const int tps = (tiles + a->nsplit - 1) / a->nsplit;
@@ -472,7 +491,7 @@ int launch_t(const dlsg_o2v_bwd_args* a, int count, hipStream_t st) {
     for (int i = 0; i < count; ++i) pk.s[i] = a[i];
     const dim3 grid(a->B, a->nsplit, count);
     hipLaunchKernelGGL((o2v16_bwd_scores_kernel<H>), grid, dim3(O16_THREADS), lds1, st, pk, tps);
-    hipLaunchKernelGGL((o2v16_bwd_apply_kernel<H>), grid, dim3(O16_THREADS), lds2, st, pk, tps);
+    hipLaunchKernelGGL((o2v16_bwd_apply_kernel<H, NSL>), dim3(a->B, a->nsplit, count * NSL), dim3(64 * GA::NW), lds2, st, pk, tps);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DLSG_OK : DLSG_ELAUNCH;
 }
