@@ -386,7 +386,8 @@ def spawn_ranks(n, argv):
     import socket
     import subprocess
     ndev = torch.cuda.device_count()
-    if ndev < n:
+    rehearsal = os.environ.get('DLSG_BENCH_ALL_RANKS_ON_DEVICE0') == '1'      # tests: every rank on device 0 over gloo
+    if ndev < n and not rehearsal:
         sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible: refusing to run a smaller job under that label\n' % (n, ndev))
         return 3
     sk = socket.socket()

@@ -939,7 +939,19 @@ class Trainer(object):
                 self._capture(frames, regions, captions, cap_lens, hook)
             else:
                 try:
-                    self._capture(frames, regions, captions, cap_lens, hook)
+                    try:
+                        self._capture(frames, regions, captions, cap_lens, hook)
+                    except RuntimeError as e1:
+                        if self._comm_mode() != 'rccl' or self.world_size <= 1:
+                            raise
+                        # the in-graph RCCL capture was refused: before giving up on graphs altogether, the segmented form
+                        # (torch.distributed collectives issued by the host between graph segments)
+                        import warnings
+                        warnings.warn('capture with in-graph RCCL collectives failed (%s: %s); retrying with host-issued '
+                                      'torch.distributed collectives between graph segments' % (type(e1).__name__, e1))
+                        torch.cuda.synchronize()
+                        self.comm = 'torch'
+                        self._capture(frames, regions, captions, cap_lens, hook)
                 except RuntimeError as e:   # opted in: keep the run alive on kernel-by-kernel launches
                     import warnings
                     warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
