@@ -540,6 +540,9 @@ def tun_bwd_tail(ops, m, pfx, regions, sv, G, defer_dw=None):
 
 
 # ================================================================================================ EncoderVisual
+BILSTM_ROWS = 64        # batch rows of one persistent BiLSTM launch (csrc/bilstm.hip BL_ROWS)
+
+
 def _bilstm_steps_fwd(ops, xg, Whh, bih, bhh, out, hprev, cst, gates, B, T, H, ref):
     """the BiLSTM recurrence step by step: per step one grouped K-split skinny GEMM (both directions) + one pointwise launch"""
     ns = _nsplit_for(B, 4 * H, 2)
@@ -586,10 +589,14 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
     hprev = [_zeros(ref, B, T, H), _zeros(ref, B, T, H)]       # h of the previous step of each direction
     cst = [_empty(ref, B, T, H), _empty(ref, B, T, H)]
     gates = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
-    if getattr(ops, 'bilstm_supported', None) is not None and ops.bilstm_supported(B, T, H):
+    if getattr(ops, 'bilstm_supported', None) is not None and ops.bilstm_supported(min(B, BILSTM_ROWS), T, H):
         # the whole recurrence of both directions as ONE persistent launch: W_hh slices resident in LDS, h_t exchanged through
-        # L2 (csrc/bilstm.hip) -- instead of 25 x (grouped skinny GEMM + pointwise launch)
-        ops.bilstm_fwd(xg, Whh, bih, bhh, out, hprev, cst, gates)
+        # L2 (csrc/bilstm.hip) -- instead of 25 x (grouped skinny GEMM + pointwise launch).  The kernel takes 64 rows; a larger
+        # batch runs it once per 64-row chunk (128 clips: 0.74 ms against 1.04 ms step by step, tools/bilstm_bench.py 128)
+        for b0 in range(0, B, BILSTM_ROWS):
+            b1 = min(B, b0 + BILSTM_ROWS)
+            ops.bilstm_fwd([x.view(B, T, 4 * H)[b0:b1].reshape(-1, 4 * H) for x in xg], Whh, bih, bhh, out[b0:b1],
+                           [h_[b0:b1] for h_ in hprev], [c_[b0:b1] for c_ in cst], [g_[b0:b1] for g_ in gates])
     else:
         _bilstm_steps_fwd(ops, xg, Whh, bih, bhh, out, hprev, cst, gates, B, T, H, ref)
     out2 = out.view(B * T, 2 * H)
@@ -726,7 +733,9 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     gates, cst, hprev = s['gates'], s['cst'], s['hprev']
     dG = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
     if getattr(ops, 'bilstm_supported', None) is not None and ops.bilstm_supported(B, T, H):
-        ops.bilstm_bwd(gates, cst, dout3, Whh, dG)          # all steps of both directions: one persistent launch
+        # all steps of both directions: one persistent launch (beyond 64 rows the chunked form only ties with the per-step
+        # schedule -- 0.997 against 0.990 ms at 128 clips -- so that case stays step by step)
+        ops.bilstm_bwd(gates, cst, dout3, Whh, dG)
     else:
         _bilstm_steps_bwd(ops, gates, cst, dout3, Whh, dG, B, T, H, ref)
     de = _empty(ref, B * T, H)

@@ -27,8 +27,14 @@ cst = [torch.empty(B, T, H, device=dev) for _ in range(2)]
 gates = [torch.empty(B, T, 4 * H, device=dev) for _ in range(2)]
 
 
+def chunks():
+    return [(b0, min(B, b0 + 64)) for b0 in range(0, B, 64)]
+
+
 def persistent():
-    ops.bilstm_fwd(xg, Whh, bih, bhh, out, hprev, cst, gates)
+    for b0, b1 in chunks():          # the kernel takes <= 64 rows: larger batches run it once per 64-row chunk
+        ops.bilstm_fwd([x.view(B, T, 4 * H)[b0:b1].view(-1, 4 * H) for x in xg], Whh, bih, bhh, out[b0:b1], [h[b0:b1] for h in hprev],
+                       [c[b0:b1] for c in cst], [g_[b0:b1] for g_ in gates])
 
 
 def steps():
@@ -64,7 +70,8 @@ dG = [torch.empty(B, T, 4 * H, device=dev) for _ in range(2)]
 
 
 def persistent_bwd():
-    ops.bilstm_bwd(gates, cst, dout, Whh, dG)
+    for b0, b1 in chunks():
+        ops.bilstm_bwd([g_[b0:b1] for g_ in gates], [c[b0:b1] for c in cst], dout[b0:b1], Whh, [d_[b0:b1] for d_ in dG])
 
 
 def steps_bwd():
