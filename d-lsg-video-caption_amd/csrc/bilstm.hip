@@ -427,8 +427,17 @@ int launch_bwd(const dlsg_bilstm_bwd_args* a, hipStream_t st) {
 
 }  // namespace
 
+// Every workgroup of the launch must be resident at once (they wait for each other inside the kernel): the current device
+// needs at least 2 * H / 8 compute units (a partitioned or CU-masked device with fewer gets the per-step schedule instead).
+static int device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return cus;
+}
 extern "C" int dlsg_bilstm_supported(int B, int T, int H) {
-    return (B >= 1 && B <= BL_ROWS && T >= 1 && T <= 4096 && (H == 64 || H == 512 || H == 1024)) ? 1 : 0;
+    if (!(B >= 1 && B <= BL_ROWS && T >= 1 && T <= 4096 && (H == 64 || H == 512 || H == 1024))) return 0;
+    return device_cus() >= 2 * (H / 8) ? 1 : 0;
 }
 extern "C" int64_t dlsg_bilstm_hx_floats(int T, int H) { return (int64_t)2 * T * H * BL_ROWS; }
 extern "C" int64_t dlsg_bilstm_flag_words(int T, int H) { return ((int64_t)2 * T * (H / 8) + 3) / 4 * 4; }

@@ -478,7 +478,8 @@ int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr,
  * first step of a direction is never written); c[d] (B, T, H); gates[d] (B, T, 4H) activated gates (what the backward reads).
  * Scratch owned by the caller: hx = dlsg_bilstm_hx_floats(T, H) floats, flags = dlsg_bilstm_flag_words(T, H) 32-bit words
  * (zeroed by the call itself), err = optional int32 that is set to 1 if a workgroup timed out waiting for another (the result
- * is then invalid; the device is never left spinning).  dlsg_bilstm_supported: B <= 64, H in {64, 512, 1024}. */
+ * is then invalid; the device is never left spinning).  dlsg_bilstm_supported: B <= 64, H in {64, 512, 1024} and the current
+ * device has at least 2 * H/8 compute units (all workgroups must be resident together). */
 typedef struct {
     const float* xg[2];
     int64_t ldxg;
