@@ -641,6 +641,145 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ skinny GEMM, NT, generation 3
+// Register-direct: no LDS staging at all.  With both operands k-contiguous (x W^T) a lane's MFMA fragment of four consecutive k
+// IS 16 contiguous bytes in memory: lane (r, kg) of a v_mfma_f32_16x16x4_f32 loads A[row 16 i + r][k0 + 4 kg .. + 3] for the four
+// 16-row blocks i and B[col 16 cb + r][k0 + 4 kg .. + 3] for the two 16-column blocks with one `global_load_dwordx4` each -- six
+// loads feed 32 MFMAs.  A wave keeps up to 48 such loads (48 KB per wave, 192 KB per CU at two workgroups) in flight, double
+// buffered by 4-block chunks, against 18 KB per wave in the LDS-DMA ring of generation 2; the persistent BiLSTM kernel
+// (bilstm.hip) showed the same structure streaming 256 KB per CU under 7.8 us of MFMAs.  The four waves split K, their partials
+// are summed through 24 KB of LDS (wave w ends with row block w).  256 registers per wave -> two workgroups per CU, so one
+// workgroup's load prologue sits under the other's MFMA phase.
+constexpr int S3_CH = 4;                     // 16-deep blocks per chunk (two chunks in flight)
+
+// Loads are unconditional (clamped addresses, the value zeroed afterwards): a load under a branch or an exec mask makes the
+// compiler's wait insertion give up counting and emit vmcnt(0), which would drain the chunk that was just issued.
+__device__ __forceinline__ void s3_load(f32x4 (&a)[S3_CH][4], f32x4 (&b)[S3_CH][2], const float* A, const float* B, int64_t lda,
+                                        int64_t ldb, int M, int Ncols, int K, int n0, int blk0, int nblk, int r, int kg) {
+#pragma unroll
+    for (int j = 0; j < S3_CH; ++j) {
+        const int k = 16 * (blk0 + j) + 4 * kg;
+        const int kc = min(k, K - 4);
+        if (lda < 0) {
+            // TIMING PROBE ONLY (DLSG_SKINNY_GEN3=2, wrong values): the same bytes addressed as if the activations were stored
+            // k-quad-major [k/4][64 rows][4] and the weights packed in fragment order [col block][k block][kg][col][4] -- every
+            // load instruction then reads four 256-byte runs (A) or one 1-KB run (B) instead of 64 scattered 64-byte segments
+            const int blk = min(blk0 + j, (K - 4) / 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[j][i] = *reinterpret_cast<const f32x4*>(A + ((int64_t)(kc / 4) * 64 + 16 * i + r) * 4);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                b[j][cb] = *reinterpret_cast<const f32x4*>(B + (((int64_t)(min(n0, Ncols - 32) / 16 + cb) * (K / 16) + blk) * 64 + kg * 16 + r) * 4);
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(16 * i + r, M - 1);
+            a[j][i] = *reinterpret_cast<const f32x4*>(A + (int64_t)row * lda + kc);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = min(n0 + 16 * cb + r, Ncols - 1);
+            b[j][cb] = *reinterpret_cast<const f32x4*>(B + (int64_t)col * ldb + kc);
+        }
+    }
+}
+// zero what lies beyond the contraction (rows / columns beyond M / N only produce outputs that are never stored)
+__device__ __forceinline__ void s3_mask(f32x4 (&a)[S3_CH][4], int K, int blk0, int nblk, int kg) {
+#pragma unroll
+    for (int j = 0; j < S3_CH; ++j) {
+        const bool kin = (blk0 + j) < nblk && 16 * (blk0 + j) + 4 * kg < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[j][i] = kin ? a[j][i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__global__ __launch_bounds__(NT, 2) void skinny3_nt_kernel(const KArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 8 * 64];
+    if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
+    const int z = blockIdx.y;
+    const int gi = z % p.ngroups, bi = z / p.ngroups;
+    const dlsg_gemm_group grp = p.g[gi];
+    const float* A = grp.A + (int64_t)bi * p.bsa;
+    const float* B = grp.B + (int64_t)bi * p.bsb;
+    float* C = grp.C + (int64_t)bi * p.bsc;
+    const int K = grp.K, M = p.M, N = grp.N > 0 ? grp.N : p.N;
+    const int n0 = blockIdx.x * 32;
+    if (n0 >= N) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 15, kg = lane >> 4;
+    // this wave's 16-deep blocks of the contraction
+    const int nb = (K + 15) / 16, nbw = (nb + 3) / 4;
+    const int b_lo = w * nbw, b_hi = min(nb, b_lo + nbw);
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
+    f32x4 a0[S3_CH][4], b0[S3_CH][2], a1[S3_CH][4], b1[S3_CH][2];
+    auto mma = [&](const f32x4 (&a)[S3_CH][4], const f32x4 (&b)[S3_CH][2]) {
+#pragma unroll
+        for (int j = 0; j < S3_CH; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i][s], b[j][0][s], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i][s], b[j][1][s], acc[i][1], 0, 0, 0);
+                }
+    };
+    s3_load(a0, b0, A, B, grp.lda, grp.ldb, M, N, K, n0, b_lo, b_hi, r, kg);
+    for (int blk = b_lo; blk < b_hi; blk += 2 * S3_CH) {
+        s3_load(a1, b1, A, B, grp.lda, grp.ldb, M, N, K, n0, blk + S3_CH, b_hi, r, kg);
+        __builtin_amdgcn_sched_barrier(0);
+        s3_mask(a0, K, blk, b_hi, kg);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        s3_load(a0, b0, A, B, grp.lda, grp.ldb, M, N, K, n0, blk + 2 * S3_CH, b_hi, r, kg);
+        __builtin_amdgcn_sched_barrier(0);
+        s3_mask(a1, K, blk + S3_CH, b_hi, kg);
+        mma(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the four K-partials: wave `dst` ends with row block `dst` (rows 16 dst + 4 q + reg of the C layout)
+#pragma unroll
+    for (int dst = 0; dst < 4; ++dst)
+        if (dst != w) {
+            float* q = red + ((dst * 3 + (w - (w > dst))) * 8) * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { q[e * 64] = acc[dst][0][e]; q[(4 + e) * 64] = acc[dst][1][e]; }
+        }
+    __syncthreads();
+    f32x4 own[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i == w) { own[0] = acc[i][0]; own[1] = acc[i][1]; }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const float* q = red + ((w * 3 + s3) * 8) * 64 + lane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { own[0][e] += q[e * 64]; own[1][e] += q[(4 + e) * 64]; }
+    }
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, do_tanh = p.flags & DLSG_GEMM_TANH;
+    const float* bias = (p.flags & DLSG_GEMM_BIAS) ? (grp.bias ? grp.bias : p.bias) : nullptr;
+    const int64_t ldc = grp.ldc ? grp.ldc : (int64_t)p.ldc;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = n0 + 16 * cb + r;
+        if (col >= N) continue;
+        const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 16 * w + 4 * kg + e;
+            if (row >= M) continue;
+            float v = p.alpha * own[cb][e] + bv;
+            float* cp = C + (int64_t)row * ldc + col;
+            if (accum) v += *cp;
+            if (do_tanh) v = tanhf(v);
+            *cp = v;
+        }
+    }
+}
+
 int launch_skinny(const dlsg_gemm_args* a, hipStream_t st) {
     KArgs k;
     k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
@@ -656,7 +795,12 @@ int launch_skinny(const dlsg_gemm_args* a, hipStream_t st) {
             ok = (g.K % 4 == 0) && g.K >= S2_STAGE && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
                  ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
         }
-        if (ok) {
+        static const int gen3 = getenv("DLSG_SKINNY_GEN3") ? atoi(getenv("DLSG_SKINNY_GEN3")) : 0;   // A/B switch: the register-direct kernel
+        if (ok && gen3) {
+            if (gen3 == 2)                       // timing probe of a coalesced operand layout (values are wrong): see s3_load
+                for (int i = 0; i < a->ngroups; ++i) k.g[i].lda = -1;
+            hipLaunchKernelGGL(skinny3_nt_kernel, grid, block, 0, st, k);
+        } else if (ok) {
             static std::once_flag once;
             std::call_once(once, [] {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<1>),
