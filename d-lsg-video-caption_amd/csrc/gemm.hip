@@ -650,6 +650,12 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
 // (bilstm.hip) showed the same structure streaming 256 KB per CU under 7.8 us of MFMAs.  The four waves split K, their partials
 // are summed through 24 KB of LDS (wave w ends with row block w).  256 registers per wave -> two workgroups per CU, so one
 // workgroup's load prologue sits under the other's MFMA phase.
+// MEASURED AND NOT USED (tools/recurrent_gemm_bench.py; env DLSG_SKINNY_GEN3=1 selects it): query gates 28.1 us against 22.3 for
+// generation 2, language gates 39.0 against 28.1, BiLSTM step 23.5 against 17.2.  A timing probe with the same bytes addressed as
+// fully coalesced runs (DLSG_SKINNY_GEN3=2: activations as if k-quad-major, weights as if packed in fragment order) changes nothing
+// (32.1 / 42.9 / 24.2): neither the staging mechanism nor the 64-byte row segments bound these launches -- the 196 MB a 64 x 32
+// tiling moves from L2 into the CUs per language-gate launch (two thirds of it re-fetched activations) do, at the ~7-10 TB/s the
+// chip sustains on that path; the LDS-DMA ring simply costs fewer issue slots for the same bytes.
 constexpr int S3_CH = 4;                     // 16-deep blocks per chunk (two chunks in flight)
 
 // Loads are unconditional (clamped addresses, the value zeroed afterwards): a load under a branch or an exec mask makes the
