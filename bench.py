@@ -248,7 +248,8 @@ def gemm_roofline(prof, nsteps, root=ROOT):
         a_s = d['work_total'] / (d['ms_total'] * 1e-3) / 1e12
         shapes.append({'shape': shp, 'launches_timed': d['launches'], 'avg_launch_ms': round(d['ms_total'] / d['launches'], 4),
                        'achieved': round(a_s, 2), 'frac': round(a_s / peak, 4), 'traffic': tb,
-                       'algorithmic_bytes': ent.get('algorithmic_bytes') if ent else None})
+                       'operand_bytes': d.get('operand_bytes'),
+                       'traffic_over_operand_bytes': round(tb / d['operand_bytes'], 2) if (tb and d.get('operand_bytes')) else None})
     # symbol under which rocprofv3 lists this kernel (profiles/*kernel_stats*.csv)
     parts = gk.split('_')              # gemm_{f32|bf16x3}_mfma_{tile}_{nt|nn|tn}
     tile, mode = parts[3], parts[-1]
@@ -261,8 +262,10 @@ def gemm_roofline(prof, nsteps, root=ROOT):
         sym = ('skinny_x3_kernel' if is_x3 else 'skinny_kernel') + ('<false>' if mode == 'nt' else '<true>')
     return {'kernel': gk + (' (3 x v_mfma_f32_32x32x16_bf16 per product; peak = 2500/3)' if is_x3
                             else ' (v_mfma_f32_32x32x2_f32)') + '; rocprof symbol: ' + sym,
-            'traffic_note': 'HBM-side bytes/launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, keyed by '
-                            'kernel + launch shape), mean over the timed launches; null unless every launch shape of this kernel is in the file',
+            'traffic_note': 'HBM-side bytes/launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the real '
+                            'step, keyed by kernel + launch shape; Infinity-Cache hits are counted), mean over the timed launches; null '
+                            'unless every launch shape of this kernel is in the file.  operand_bytes counts every group\'s operands on '
+                            'their own',
             'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'traffic': round(tsum / tn) if (all_known and tn) else None, 'launches_timed': g['launches'],
             'avg_launch_ms': round(g['ms_total'] / g['launches'], 4),

@@ -318,12 +318,12 @@ class HipOps(object):
         e0.record()
         return e0
 
-    def _prof_end(self, key, e0, work, shape=''):
+    def _prof_end(self, key, e0, work, shape='', operand_bytes=None):
         if e0 is None:
             return
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.prof.setdefault(key, []).append((e0, e1, work, shape))
+        self.prof.setdefault(key, []).append((e0, e1, work, shape, operand_bytes))
 
     def prof_summary(self):
         """key -> dict(launches, ms_total, work_total, shapes: launch shape -> the same three); call after
@@ -332,10 +332,10 @@ class HipOps(object):
         for key, rec in (self.prof or {}).items():
             shapes = {}
             tot = 0.0
-            for a, b, w, shp in rec:
+            for a, b, w, shp, ob in rec:
                 ms = a.elapsed_time(b)
                 tot += ms
-                d = shapes.setdefault(shp, dict(launches=0, ms_total=0.0, work_total=0.0))
+                d = shapes.setdefault(shp, dict(launches=0, ms_total=0.0, work_total=0.0, operand_bytes=ob))
                 d['launches'] += 1; d['ms_total'] += ms; d['work_total'] += float(w)
             out[key] = dict(launches=len(rec), ms_total=tot, work_total=float(sum(r[2] for r in rec)), shapes=shapes)
         return out
@@ -416,7 +416,14 @@ class HipOps(object):
             # one key per kernel symbol (arithmetic, tile, operand layout), as rocprofv3 --stats lists them
             ks = sorted(set(a.g[i].K for i in range(len(groups))))
             shape = '%s M=%d N=%d K=%s groups=%d batch=%d' % (('NT', 'NN', 'TN')[mode], M, N, '/'.join(map(str, ks)), len(groups), nb)
-            self._prof_end('gemm_%s_mfma_%s_%s' % ('bf16x3' if x3 else 'f32', variant, ('nt', 'nn', 'tn')[mode]), e0, flops, shape)
+            # bytes of the operands and results of one launch, every group's counted on its own (groups that share an operand --
+            # the two streams' region projections read the same regions -- make the unique bytes smaller than this)
+            ob = 0
+            for i, grp_ in enumerate(groups):
+                Ng = grp_[2].shape[-1]
+                Kg = a.g[i].K
+                ob += 4 * nb * (M * Kg + Ng * Kg + M * Ng * (2 if (a.flags & F_ACCUM) else 1))
+            self._prof_end('gemm_%s_mfma_%s_%s' % ('bf16x3' if x3 else 'f32', variant, ('nt', 'nn', 'tn')[mode]), e0, flops, shape, ob)
 
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""

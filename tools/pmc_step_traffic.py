@@ -1,0 +1,65 @@
+"""Attribute the per-dispatch FETCH_SIZE / WRITE_SIZE counters of tools/pmc_step_target.py (two rocprofv3 --pmc passes) to the
+launches bench.py's roofline objects time, keyed by kernel + launch shape, and print the `per_launch_shape` block of
+profiles/traffic.json.  HBM-side bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024 (MI355X_MICROARCH.md, HBM section:
+FETCH_SIZE reports half the bytes of 16-byte-per-lane streaming reads on gfx950; Infinity-Cache hits are counted).
+usage: python3 tools/pmc_step_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <calls.json>"""
+import collections
+import csv
+import json
+import sys
+
+SYMS = {   # prof key -> (kernel symbols of one launch group, in dispatch order; '?' = optional follower)
+    'gemm_f32_mfma_128x128_tn': ['gemm_kernel_w3<128, 128, true, true, 32>'],
+    'gemm_f32_mfma_128x128_nt': ['gemm_kernel_w3<128, 128, false, false, 32>'],
+    'gemm_f32_mfma_128x128_nn': ['gemm_kernel_w3<128, 128, false, true, 32>'],
+    'o2v_graph_fwd': ['o2v16_kernel<', '?o2v_combine_multi_kernel'],
+    'o2v_graph_bwd': ['o2v16_bwd_scores_kernel<', 'o2v16_bwd_apply_kernel<', '?o2v_combine_multi_kernel'],
+}
+
+
+def last_step(path):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+    a, b = adam[-2], adam[-1]
+    return rows[a + 1:b + 1]
+
+
+fetch, write, calls = last_step(sys.argv[1]), last_step(sys.argv[2]), json.load(open(sys.argv[3]))
+out = collections.OrderedDict()
+for key, syms in SYMS.items():
+    mine = [c for c in calls if c['key'] == key]
+    if not mine:
+        continue
+    per = []
+    for rows, cname in ((fetch, 'FETCH_SIZE'), (write, 'WRITE_SIZE')):
+        # walk the step: every dispatch of syms[0] opens a launch group, followers join it
+        groups, cur = [], None
+        for r in rows:
+            n = r['Kernel_Name']
+            if syms[0] in n:
+                cur = [float(r['Counter_Value'])]
+                groups.append(cur)
+            elif cur is not None and any(s.lstrip('?') in n for s in syms[1:]):
+                cur.append(float(r['Counter_Value']))
+            elif cur is not None and not any(s.lstrip('?') in n for s in syms):
+                if key.startswith('o2v'):
+                    cur = None          # a foreign kernel ends the group
+        per.append([sum(g) for g in groups])
+    if len(per[0]) != len(mine) or len(per[1]) != len(mine):
+        print('skip %s: %d logged launches, %d / %d dispatch groups' % (key, len(mine), len(per[0]), len(per[1])), file=sys.stderr)
+        continue
+    agg = collections.OrderedDict()
+    for c, f, w in zip(mine, per[0], per[1]):
+        d = agg.setdefault(key + ' | ' + c['shape'], {'launches': 0, 'FETCH_SIZE_KiB': 0.0, 'WRITE_SIZE_KiB': 0.0, 'work': c['algorithmic_work']})
+        d['launches'] += 1; d['FETCH_SIZE_KiB'] += f; d['WRITE_SIZE_KiB'] += w
+    for k, d in agg.items():
+        n = d['launches']
+        hb = (2 * d['FETCH_SIZE_KiB'] + d['WRITE_SIZE_KiB']) * 1024 / n
+        ent = {'launches_in_step': n, 'FETCH_SIZE_KiB': round(d['FETCH_SIZE_KiB'] / n, 1), 'WRITE_SIZE_KiB': round(d['WRITE_SIZE_KiB'] / n, 1),
+               'hbm_bytes_per_launch': int(hb)}
+        if key.startswith('o2v'):
+            ent['algorithmic_bytes'] = int(d['work'])
+            ent['ratio'] = round(hb / d['work'], 2)
+        out[k] = ent
+print(json.dumps(out, indent=1))
