@@ -813,6 +813,7 @@ extern "C" int dlsg_struct_size(int which) {
         case 18: return (int)sizeof(dlsg_latent_psl_bwd_args);
         case 19: return (int)sizeof(dlsg_bilstm_args);
         case 20: return (int)sizeof(dlsg_bilstm_bwd_args);
+        case 21: return (int)sizeof(dlsg_colsum_desc);
         default: return -1;
     }
 }

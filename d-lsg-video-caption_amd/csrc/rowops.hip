@@ -233,6 +233,51 @@ __global__ __launch_bounds__(1024) void colsum_v4_kernel(const float* __restrict
     }
 }
 
+// Several short column sums in ONE launch (blockIdx.y picks the descriptor): the backward of a train step folds ~25 small
+// partial arrays (LayerNorm dgamma | dbeta partials, bias gradients) of a few hundred to a few thousand rows each -- 8-9 us per
+// launch on their own, almost all of it launch floor.  Same arithmetic and order of additions as colsum_v4_kernel with one chunk.
+struct ColsumPack {
+    dlsg_colsum_desc d[DLSG_COLSUM_MAXMULTI];
+};
+__global__ __launch_bounds__(1024) void colsum_multi_kernel(const ColsumPack pk) {
+    __shared__ float red[64][65];
+    const dlsg_colsum_desc& a = pk.d[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= a.n) return;
+    const float* __restrict__ part = a.part;
+    const int64_t ld = a.ld;
+    const int rows = a.rows, n = a.n;
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + cg * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (col < n) {
+        int r = rl;
+        for (; r + 192 < rows; r += 256) {
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(part + (int64_t)r * ld + col);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(part + (int64_t)(r + 64) * ld + col);
+            const f32x4 t2 = *reinterpret_cast<const f32x4*>(part + (int64_t)(r + 128) * ld + col);
+            const f32x4 t3 = *reinterpret_cast<const f32x4*>(part + (int64_t)(r + 192) * ld + col);
+            acc += (t0 + t1) + (t2 + t3);
+        }
+        for (; r < rows; r += 64) acc += *reinterpret_cast<const f32x4*>(part + (int64_t)r * ld + col);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rl][cg * 4 + e] = acc[e];
+    __syncthreads();
+    const int c = threadIdx.x >> 4, part16 = threadIdx.x & 15;
+    float t = red[part16][c] + red[part16 + 16][c] + red[part16 + 32][c] + red[part16 + 48][c];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    const int oc = blockIdx.x * 64 + c;
+    if (part16 == 0 && oc < n) {
+        const int mode = a.out_b ? (a.dup ? 1 : 0) : 0;
+        const int split = a.out_b ? (a.dup ? n : a.split) : n;
+        float* d0 = (mode == 0 && oc >= split) ? a.out_b + (oc - split) : a.out_a + oc;
+        float* d1 = mode == 1 ? a.out_b + oc : nullptr;
+        *d0 = a.accum ? *d0 + t : t;
+        if (d1) *d1 = a.accum ? *d1 + t : t;
+    }
+}
+
 // chunk partials ws (chunks, n) -> destinations, chunks added in order (bit-reproducible, unlike the atomic combine)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ ws, int chunks, int n, float* __restrict__ out,
                                                             float* __restrict__ out2, int split, int mode, int accum) {
@@ -914,6 +959,24 @@ static int colsum_launch(const float* part, int64_t ld, int rows, int n, float* 
         hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out, accum, rpc, none);
         hipLaunchKernelGGL(colsum_kernel, dim3((n + 63) / 64, chunks), dim3(1024), 0, ST(stream), part, ld, rows, n, out2, accum, rpc, none);
     }
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+extern "C" int dlsg_colsum_multi_ok(const float* part, int64_t ld, int rows, int n) {
+    return (colsum_chunks(rows) == 1 && n % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0) ? 1 : 0;
+}
+extern "C" int dlsg_colsum_multi(const dlsg_colsum_desc* d, int count, void* stream) {
+    if (!d || count < 1 || count > DLSG_COLSUM_MAXMULTI) return DLSG_EINVAL;
+    ColsumPack pk;
+    int maxn = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!d[i].part || !d[i].out_a || d[i].n < 1 || d[i].rows < 0) return DLSG_EINVAL;
+        if (!dlsg_colsum_multi_ok(d[i].part, d[i].ld, d[i].rows, d[i].n)) return DLSG_EALIGN;
+        if (d[i].out_b && !d[i].dup && (d[i].split < 0 || d[i].split > d[i].n)) return DLSG_EINVAL;
+        pk.d[i] = d[i];
+        maxn = d[i].n > maxn ? d[i].n : maxn;
+    }
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3((maxn + 63) / 64, count), dim3(1024), 0, ST(stream), pk);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

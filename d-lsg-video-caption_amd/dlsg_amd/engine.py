@@ -586,7 +586,8 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
     xg = [_empty(ref, B * T, 4 * H), _empty(ref, B * T, 4 * H)]
     ops.gemm(GEMM_NT, [(e, Wih[0], xg[0]), (e, Wih[1], xg[1])])
     out = _empty(ref, B, T, 2 * H)
-    hprev = [_zeros(ref, B, T, H), _zeros(ref, B, T, H)]       # h of the previous step of each direction
+    hz = _zeros(ref, 2, B, T, H)
+    hprev = [hz[0], hz[1]]                                     # h of the previous step of each direction
     cst = [_empty(ref, B, T, H), _empty(ref, B, T, H)]
     gates = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
     if getattr(ops, 'bilstm_supported', None) is not None and ops.bilstm_supported(min(B, BILSTM_ROWS), T, H):
@@ -857,10 +858,12 @@ def dec_alloc(dec, s, ref, B, L):
     H, W, Q, D, ns = plan.H, plan.W, plan.Q, plan.D, plan.ns
     V = dec.vocab_size
     P = s['Kp'][0].shape[1]
-    s['LHP'] = _zeros(ref, L + 1, B, D)
-    s['QH'] = _zeros(ref, L + 1, B, Q)
-    s['QC'] = _zeros(ref, L + 1, B, Q)
-    s['LC'] = _zeros(ref, L + 1, B, D)
+    # the four recurrent state arrays start at zero: ONE fill (each torch.zeros is a 5-us launch in the replayed step)
+    zst = _zeros(ref, (L + 1) * B * (2 * D + 2 * Q))
+    o = 0
+    for key, wd in (('LHP', D), ('QH', Q), ('QC', Q), ('LC', D)):
+        s[key] = zst[o:o + (L + 1) * B * wd].view(L + 1, B, wd)
+        o += (L + 1) * B * wd
     s['WE'] = _empty(ref, L + 1, B, W)
     s['IDS'] = _zeros(ref, L + 1, B, dtype=torch.int64)
     s['QCUR'] = _empty(ref, L, B, Q)

@@ -103,6 +103,11 @@ class BilstmBwdArgs(C.Structure):
                 ('B', i32), ('T', i32), ('H', i32), ('pad_', i32)]
 
 
+class ColsumDesc(C.Structure):
+    _fields_ = [('part', c_f32p), ('ld', i64), ('out_a', c_f32p), ('out_b', c_f32p), ('rows', i32), ('n', i32), ('split', i32),
+                ('dup', i32), ('accum', i32), ('pad_', i32)]
+
+
 class DecAttArgs(C.Structure):
     _fields_ = [('Kp', c_f32p * 2), ('Vp', c_f32p * 2), ('q', c_f32p), ('ldq', i64), ('c', c_f32p * 2), ('ldc', i64),
                 ('alpha', c_f32p), ('B', i32), ('P', i32), ('Q', i32), ('H', i32), ('nstream', i32), ('scale', f32)]
@@ -165,7 +170,7 @@ class DecattCacheGradsArgs(C.Structure):
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
-           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_colsum_ws_floats', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
+           'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_colsum_ws_floats', 'dlsg_colsum_multi', 'dlsg_colsum_multi_ok', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_softmax_bwd2', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
@@ -198,6 +203,8 @@ def load_library(path=LIB_PATH):
         'dlsg_colsum_ws_floats': [i32, i32],
         'dlsg_colsum': [vp, i64, i32, i32, vp, i32, vp, vp],
         'dlsg_colsum2': [vp, i64, i32, i32, vp, vp, i32, i32, i32, vp, vp],
+        'dlsg_colsum_multi': [P(ColsumDesc), i32, vp],
+        'dlsg_colsum_multi_ok': [vp, i64, i32, i32],
         'dlsg_o2v_workspace_bytes': [i32, i32, i32, i32],
         'dlsg_o2v_fwd': [P(O2VArgs), vp],
         'dlsg_o2v_fwd_multi': [P(O2VArgs), i32, vp],
@@ -270,7 +277,7 @@ def load_library(path=LIB_PATH):
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
            SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs,
-           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs]
+           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs, ColsumDesc]
 
 
 def _p(t):
@@ -473,9 +480,39 @@ class HipOps(object):
         k = int(self.lib.dlsg_colsum_ws_floats(part.size(0), part.size(1)))
         return torch.empty(k, dtype=torch.float32, device=part.device) if k else None
 
+    # Short column sums can be collected and launched together (`colsum_defer = []` starts collecting, `colsum_flush()` launches
+    # and stops): the backward of a step folds ~25 small partial arrays, each 8-9 us on its own.
+    colsum_defer = None
+
+    def _colsum_try_defer(self, part, out_a, out_b, split, dup, accum):
+        if self.colsum_defer is None or not self.lib.dlsg_colsum_multi_ok(_p(part), i64(part.stride(0)), part.size(0), part.size(1)):
+            return False
+        self.colsum_defer.append((part, out_a, out_b, split, dup, accum))
+        return True
+
+    def colsum_flush(self, keep_collecting=False):
+        """launch the collected column sums: descriptors that write the same destination go into different launches, in order"""
+        items, self.colsum_defer = (self.colsum_defer or []), ([] if keep_collecting else None)
+        while items:
+            batch, rest, seen = [], [], set()
+            for it in items:
+                dests = {it[1].data_ptr()} | ({it[2].data_ptr()} if it[2] is not None else set())
+                if len(batch) < 32 and not (dests & seen) and not rest:
+                    batch.append(it); seen |= dests
+                else:
+                    rest.append(it)
+            arr = (ColsumDesc * len(batch))()
+            for d, (part, out_a, out_b, split, dup, accum) in zip(arr, batch):
+                d.part, d.ld, d.out_a, d.out_b = _p(part), part.stride(0), _p(out_a), _p(out_b)
+                d.rows, d.n, d.split, d.dup, d.accum = part.size(0), part.size(1), split, int(dup), int(accum)
+            self._check(self.lib.dlsg_colsum_multi(arr, len(batch), self._stream()), 'dlsg_colsum_multi')
+            items = rest
+
     def colsum(self, part, out, accum=False):
         """out[j] (+)= sum over rows of part (rows, n) view."""
         _chk2(part)
+        if self._colsum_try_defer(part, out, None, part.size(1), False, accum):
+            return
         ws = self._colsum_ws(part)
         self._check(self.lib.dlsg_colsum(_p(part), i64(part.stride(0)), part.size(0), part.size(1), _p(out), int(accum),
                                          _p(ws), self._stream()), 'dlsg_colsum')
@@ -484,6 +521,8 @@ class HipOps(object):
         """one pass, two destinations: split=k -> columns [0,k) to out_a and [k,n) to out_b; split=None -> every column
         to both out_a and out_b."""
         _chk2(part)
+        if self._colsum_try_defer(part, out_a, out_b, 0 if split is None else split, split is None, accum):
+            return
         ws = self._colsum_ws(part)
         self._check(self.lib.dlsg_colsum2(_p(part), i64(part.stride(0)), part.size(0), part.size(1), _p(out_a), _p(out_b),
                                           0 if split is None else split, int(split is None), int(accum), _p(ws), self._stream()),

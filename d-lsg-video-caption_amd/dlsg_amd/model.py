@@ -8,6 +8,7 @@ fused ragged cross-entropy, hand-scheduled backward into a flat gradient arena, 
 overlaps the encoder backward, and one fused Adam kernel over the flat parameter arena.
 """
 import math
+import os
 import random
 
 import torch
@@ -229,6 +230,8 @@ class CapGnnModel(_HipModel):
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
         ops = self.ops
         ops.extra_flags = self._gemm_flags(False)
+        if getattr(ops, 'colsum_defer', None) is not None:
+            ops.colsum_defer = None         # (a backward that raised half-way must not leave the collector armed)
         frames = frames.contiguous().float()
         regions = regions.contiguous().float()
         obj, mot = self._encode(frames, regions, training, seed, sv)
@@ -252,6 +255,9 @@ class CapGnnModel(_HipModel):
         ops.fill(self._gflat, 0.0)
         if self.merge_weight_grads and self._defer_ok:
             sv['tn_defer'] = []             # mid-size weight gradients of every module: launched together at the end
+        collect = hasattr(ops, 'colsum_flush') and not os.environ.get('DLSG_NO_COLSUM_MULTI')      # (env: A/B measurements)
+        if collect:
+            ops.colsum_defer = []           # short column sums (LayerNorm / bias gradients): grouped launches (hip.py)
         frames, regions = sv['frames'], sv['regions']
         B, T, F = frames.shape
         H = self.decoder.visual_hidden_size
@@ -261,9 +267,12 @@ class CapGnnModel(_HipModel):
             # a bucket's gradients must be complete when it is handed to the all-reduce: the weight gradients deferred so far
             # go out now, as one grouped launch per height (with one process nothing is reduced and they wait for the end)
             if on_bucket:
-                if sv.get('tn_defer') and self._flush_at_buckets:
-                    E.tn_grouped(ops, sv['tn_defer'])
-                    sv['tn_defer'] = []
+                if self._flush_at_buckets:
+                    if sv.get('tn_defer'):
+                        E.tn_grouped(ops, sv['tn_defer'])
+                        sv['tn_defer'] = []
+                    if collect:
+                        ops.colsum_flush(keep_collecting=True)
                 on_bucket(key)
         bucket('decoder')
         dob, dmo = dmems
@@ -291,6 +300,8 @@ class CapGnnModel(_HipModel):
         E.gemm_tn_deep(ops, deep, frames)
         if 'tn_defer' in sv:
             E.tn_grouped(ops, sv.pop('tn_defer'))
+        if collect:
+            ops.colsum_flush()
         if on_bucket:
             on_bucket(('encoder.motion_encoder', 'encoder.obj_encoder'))
 

@@ -30,7 +30,7 @@ int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
  * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args, 15 beam_select_args,
- * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args, 19 bilstm_args, 20 bilstm_bwd_args): lets a binding verify its
+ * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args, 19 bilstm_args, 20 bilstm_bwd_args, 21 colsum_desc): lets a binding verify its
  * struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
@@ -124,6 +124,18 @@ int dlsg_colsum(const float* part, int64_t ld, int rows, int n, float* out, int 
  * LayerNorm partials); dup != 0 -> all n columns to both (bias_ih / bias_hh of an LSTM receive the same gradient). */
 int dlsg_colsum2(const float* part, int64_t ld, int rows, int n, float* out_a, float* out_b, int split, int dup, int accum,
                  float* ws, void* stream);
+/* `count` (<= DLSG_COLSUM_MAXMULTI) short column sums in one launch: each descriptor is one dlsg_colsum (out_b NULL) or
+ * dlsg_colsum2 (out_b set; dup != 0: every column to both destinations, else columns [0, split) to out_a and the rest to out_b).
+ * Only inputs dlsg_colsum_multi_ok() accepts (fewer than 4096 rows, 16-byte aligned, n and ld multiples of 4); no two descriptors of
+ * one call may write the same destination.  Same additions in the same order as the single launches. */
+#define DLSG_COLSUM_MAXMULTI 32
+typedef struct {
+    const float* part; int64_t ld;
+    float* out_a; float* out_b;
+    int32_t rows, n, split, dup, accum, pad_;
+} dlsg_colsum_desc;
+int dlsg_colsum_multi_ok(const float* part, int64_t ld, int rows, int n);
+int dlsg_colsum_multi(const dlsg_colsum_desc* d, int count, void* stream);
 
 /* ---------------------------------------------------------------- object->frame conditional graph (layer.py:184-193)
  * y (B, NO, H) = tanh(obj_embed(regions)) (the GEMM epilogue applied tanh); LayerNorm(obj_norm) is applied on the

@@ -1040,3 +1040,44 @@ def test_persistent_bilstm_backward(hip, B, T, H):
             ref = want[d]
             e = (ref - dG[d].cpu()).abs().max().item()
             assert e <= 2e-5 * max(1.0, ref.abs().max().item()), (rep, d, e, ref.abs().max().item())
+
+
+def test_grouped_column_sums_equal_the_single_launches(hip):
+    """dlsg_colsum_multi: the short column sums of a backward collected into grouped launches -- bit-identical to launching each
+    on its own (same additions, same order), including two sums that accumulate into the same destination (kept in order, in
+    different launches), the two-destination forms, strided inputs and an input too tall for the grouped kernel."""
+    g = torch.Generator().manual_seed(5)
+    cases = []
+    for rows, n, kind in ((37, 128, 'one'), (1664, 4096, 'dup'), (200, 2048, 'split'), (64, 64, 'one'), (3000, 1024, 'one'),
+                          (5000, 256, 'one'), (333, 512, 'strided'), (90, 128, 'same_dest'), (91, 128, 'same_dest')):
+        part = rnd(g, rows, n + (64 if kind == 'strided' else 0)).cuda()
+        cases.append((part[:, :n] if kind == 'strided' else part, n, kind))
+
+    def run(defer):
+        outs = []
+        shared = torch.zeros(128, device='cuda')
+        if defer:
+            hip.colsum_defer = []
+        for part, n, kind in cases:
+            if kind == 'dup':
+                a, b = torch.ones(n, device='cuda'), torch.ones(n, device='cuda')
+                hip.colsum2(part, a, b, accum=True); outs += [a, b]
+            elif kind == 'split':
+                a, b = torch.zeros(n // 2, device='cuda'), torch.zeros(n // 2, device='cuda')
+                hip.colsum2(part, a, b, split=n // 2); outs += [a, b]
+            elif kind == 'same_dest':
+                hip.colsum(part, shared, accum=True)
+            else:
+                a = torch.full((n,), 0.5, device='cuda')
+                hip.colsum(part, a, accum=(kind == 'strided')); outs.append(a)
+        if defer:
+            assert len(hip.colsum_defer) == len(cases) - 1          # the 5000-row input went out on its own
+            hip.colsum_flush()
+            assert hip.colsum_defer is None
+        torch.cuda.synchronize()
+        return outs + [shared]
+    single, grouped = run(False), run(True)
+    for a, b in zip(single, grouped):
+        assert torch.equal(a, b)
+    ref = cases[1][0].double().sum(0).float().cpu() + 1.0
+    assert (single[1].cpu() - ref).abs().max().item() <= 1e-3
