@@ -595,6 +595,7 @@ def main():
       except Exception as e:                 # noqa: BLE001
         b128 = {'error': '%s: %s' % (type(e).__name__, e)}
         torch.cuda.synchronize()
+    tr.check()                             # persistent kernels: no hand-off timed out anywhere above
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist

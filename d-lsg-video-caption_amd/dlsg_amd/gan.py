@@ -88,24 +88,35 @@ def _hip_ops():
     return _HIP[0]
 
 
+def _seq_kernels(ops, L, n, H):
+    """whole-sequence launches where the op set has them and the shape fits (n <= 256, H in {64, 512}, enough CUs)"""
+    f = getattr(ops, 'lstm_seq_supported', None)
+    return f is not None and f(L, n, H)
+
+
 class _LstmSeq(torch.autograd.Function):
     """The critic's whole LSTM layer as ONE autograd node per differentiation level (zero initial state, gates i,f,g,o):
         a_t = xin_t + h_{t-1} W^T,  (h_t, c_t) = cell(a_t, c_{t-1})        xin (L, n, 4H) already holds x W_ih^T + b
     returns (Hs, As, Cs); As and Cs are outputs so that the backward's backward can hand its gradients w.r.t. the saved
-    pre-activations and cell states back to this node.  Per word step every level is one recurrent product plus one cell
-    kernel (csrc/critic.hip); weight gradients are single products over all steps -- no per-step gradient accumulation."""
+    pre-activations and cell states back to this node.  Every level is ONE persistent launch over all word steps
+    (csrc/critic_lstm.hip) where the shape fits, else one recurrent product plus one cell kernel per step (csrc/critic.hip);
+    weight gradients are single products over all steps -- no per-step gradient accumulation."""
 
     @staticmethod
     def forward(ctx, ops, xin, W):
         L, n, G = xin.shape
         H = G // 4
-        As = xin.clone()
         Hs, Cs = xin.new_empty(L, n, H), xin.new_empty(L, n, H)
-        Wt = W.t()
-        for t in range(L):
-            if t:
-                As[t].addmm_(Hs[t - 1], Wt)
-            ops.lstm_cell_fwd(As[t], Cs[t - 1] if t else None, Hs[t], Cs[t])
+        if _seq_kernels(ops, L, n, H):                  # all L steps in one launch (csrc/critic_lstm.hip)
+            As = torch.empty_like(xin, memory_format=torch.contiguous_format)
+            ops.lstm_seq_fwd(xin.contiguous(), W.contiguous(), As, Hs, Cs)
+        else:
+            As = xin.clone()
+            Wt = W.t()
+            for t in range(L):
+                if t:
+                    As[t].addmm_(Hs[t - 1], Wt)
+                ops.lstm_cell_fwd(As[t], Cs[t - 1] if t else None, Hs[t], Cs[t])
         ctx.ops = ops
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(As, Cs, Hs, W)
@@ -138,14 +149,17 @@ class _LstmSeqBwd(torch.autograd.Function):
         H = G // 4
         DA = torch.empty_like(As)
         DH, DC = torch.empty_like(Hs), torch.empty_like(Hs)          # the summed dh_t / dc_t each step was differentiated at
-        s_buf = [torch.empty_like(Hs[0]), torch.empty_like(Hs[0])]
-        r = torch.empty_like(Hs[0])
-        for t in range(L - 1, -1, -1):
-            last = t == L - 1
-            ops.lstm_cell_bwd_seq(As[t], Cs[t - 1] if t else None, dHs[t], None if last else r, None if last else s_buf[(t + 1) & 1],
-                                  None if dCs is None else dCs[t], None if dAs is None else dAs[t], DA[t], s_buf[t & 1], DH[t], DC[t])
-            if t:
-                torch.mm(DA[t], W, out=r)
+        if _seq_kernels(ops, L, n, H):
+            ops.lstm_seq_bwd(As, Cs, W.contiguous(), dHs, dAs, dCs, DA, DH, DC)
+        else:
+            s_buf = [torch.empty_like(Hs[0]), torch.empty_like(Hs[0])]
+            r = torch.empty_like(Hs[0])
+            for t in range(L - 1, -1, -1):
+                last = t == L - 1
+                ops.lstm_cell_bwd_seq(As[t], Cs[t - 1] if t else None, dHs[t], None if last else r, None if last else s_buf[(t + 1) & 1],
+                                      None if dCs is None else dCs[t], None if dAs is None else dAs[t], DA[t], s_buf[t & 1], DH[t], DC[t])
+                if t:
+                    torch.mm(DA[t], W, out=r)
         dW = DA[1:].reshape(-1, G).t() @ Hs[:-1].reshape(-1, H) if L > 1 else torch.zeros_like(W)
         ctx.ops = ops
         ctx.set_materialize_grads(False)
@@ -159,16 +173,19 @@ class _LstmSeqBwd(torch.autograd.Function):
         L, n, G = As.shape
         H = G // 4
         ops = ctx.ops
-        Ubar = torch.zeros_like(As) if Uxin is None else Uxin.clone()
+        Ubar = torch.zeros_like(As) if Uxin is None else Uxin.clone(memory_format=torch.contiguous_format)
         if UW is not None and L > 1:
             Ubar[1:].view(-1, G).addmm_(Hs[:-1].reshape(-1, H), UW.t())
         gA, gC, gDH, gDC = torch.empty_like(As), torch.zeros_like(Cs), torch.empty_like(Hs), torch.empty_like(Hs)
-        Wt = W.t()
-        for t in range(L):
-            if t:
-                Ubar[t].addmm_(gDH[t - 1], Wt)
-            ops.lstm_cell_bwd2(As[t], Cs[t - 1] if t else None, DH[t], DC[t], Ubar[t], gDC[t - 1] if t else None, gA[t],
-                               gC[t - 1] if t else None, gDH[t], gDC[t])
+        if _seq_kernels(ops, L, n, H):
+            ops.lstm_seq_bwd2(As, Cs, W.contiguous(), DH, DC, Ubar, gA, gC, gDH, gDC)
+        else:
+            Wt = W.t()
+            for t in range(L):
+                if t:
+                    Ubar[t].addmm_(gDH[t - 1], Wt)
+                ops.lstm_cell_bwd2(As[t], Cs[t - 1] if t else None, DH[t], DC[t], Ubar[t], gDC[t - 1] if t else None, gA[t],
+                                   gC[t - 1] if t else None, gDH[t], gDC[t])
         gW = gHs = None
         if L > 1:
             gW = DA[1:].reshape(-1, G).t() @ gDH[:-1].reshape(-1, H)
@@ -647,6 +664,9 @@ class GanTrainer(object):
                    loss_D=loss_D, wasserstein=wass)
         out['total_loss'] = out['cap_loss'] + out['loss_G'] * out['gan_lambda']
         out.pop('cap_loss_dev')
+        check = getattr(model.ops, 'check_persistent', None)
+        if check is not None:
+            check()                        # the losses above were read back: the device is idle, the time-out words are final
         return out
 
 

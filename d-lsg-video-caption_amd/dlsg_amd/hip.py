@@ -103,6 +103,12 @@ class BilstmBwdArgs(C.Structure):
                 ('B', i32), ('T', i32), ('H', i32), ('pad_', i32)]
 
 
+class LstmSeqArgs(C.Structure):
+    _fields_ = [(n, c_f32p) for n in ('addend', 'addend_out', 'W', 'As', 'Hs', 'Cs', 'dHs', 'dAs', 'dCs', 'DA', 'DH', 'DC',
+                                      'gA', 'gC', 'gDH', 'gDC', 'xbuf', 'xbuf2', 'flags', 'err')] + \
+               [('L', i32), ('n', i32), ('H', i32), ('pad_', i32)]
+
+
 class ColsumDesc(C.Structure):
     _fields_ = [('part', c_f32p), ('ld', i64), ('out_a', c_f32p), ('out_b', c_f32p), ('rows', i32), ('n', i32), ('split', i32),
                 ('dup', i32), ('accum', i32), ('pad_', i32)]
@@ -180,6 +186,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2', 'dlsg_lstm_cell_bwd_seq',
            'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2',
            'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd', 'dlsg_bilstm_bwd_x_floats', 'dlsg_bilstm_bwd',
+           'dlsg_lstm_seq_supported', 'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_lstm_seq',
            'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
            'dlsg_allreduce_buckets']
 
@@ -259,6 +266,10 @@ def load_library(path=LIB_PATH):
         'dlsg_bilstm_bwd_x_floats': [i32, i32],
         'dlsg_bilstm_bwd': [P(BilstmBwdArgs), vp],
         'dlsg_comm_unique_id': [vp],
+        'dlsg_lstm_seq_supported': [i32, i32, i32],
+        'dlsg_lstm_seq_x_floats': [i32, i32, i32],
+        'dlsg_lstm_seq_flag_words': [i32, i32, i32],
+        'dlsg_lstm_seq': [P(LstmSeqArgs), i32, vp],
         'dlsg_comm_init': [P(vp), vp, i32, i32],
         'dlsg_comm_destroy': [vp],
         'dlsg_comm_info': [vp, P(i32), P(i32), P(i32)],
@@ -270,14 +281,15 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats', 'dlsg_colsum_ws_floats',
-                                            'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_bwd_x_floats') else C.c_int
+                                            'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_bwd_x_floats',
+                                            'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words') else C.c_int
     return lib
 
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
            SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs,
-           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs, ColsumDesc]
+           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs, ColsumDesc, LstmSeqArgs]
 
 
 def _p(t):
@@ -793,6 +805,20 @@ class HipOps(object):
         a.L, a.B, a.Q, a.H, a.P, a.nstream = L, B, Q, dVp[0].size(2), dKp[0].size(1), ns
         self._check(self.lib.dlsg_decatt_cache_grads(C.byref(a), self._stream()), 'dlsg_decatt_cache_grads')
 
+    # ------------------------------------------------------------------ persistent kernels: time-out word
+    def check_persistent(self):
+        """Read the error words of the persistent recurrent kernels (csrc/bilstm.hip, csrc/critic_lstm.hip): a workgroup that
+        waited ~1 s for another one's flag (the launch was not fully co-resident) sets it and the results since then are
+        invalid.  A host synchronisation: the trainers call it where they read a loss back anyway."""
+        for name in ('_bilstm_err', '_lstm_seq_err'):
+            w = getattr(self, name, None)
+            if w is not None:
+                code = int(w.item())
+                if code:
+                    w.zero_()
+                    raise RuntimeError('persistent kernel hand-off timed out (%s = %d): the launch was not co-resident on this '
+                                       'device; set ops.persistent_bilstm / ops.persistent_lstm_seq = False' % (name[1:], code))
+
     # ------------------------------------------------------------------ persistent BiLSTM recurrence
     persistent_bilstm = True      # False: the per-step schedule (grouped skinny GEMM + pointwise launch per step)
 
@@ -844,6 +870,48 @@ class HipOps(object):
         a.B, a.T, a.H = B, T, H
         self._check(self.lib.dlsg_bilstm_bwd(C.byref(a), self._stream()), 'dlsg_bilstm_bwd')
         return self._bilstm_err
+
+    # ------------------------------------------------------------------ critic LSTM, a whole sequence per launch
+    persistent_lstm_seq = True    # False: gan.py's per-step loops (one product + one cell launch per word step)
+
+    def lstm_seq_supported(self, L, n, H):
+        return self.persistent_lstm_seq and bool(self.lib.dlsg_lstm_seq_supported(L, n, H))
+
+    def _lstm_seq(self, level, W, L, n, H, **t):
+        a = LstmSeqArgs()
+        dev = W.device
+        nx = int(self.lib.dlsg_lstm_seq_x_floats(L, n, H))
+        xbuf = torch.empty(nx, dtype=torch.float32, device=dev)
+        xbuf2 = torch.empty(nx, dtype=torch.float32, device=dev) if level == 1 else None
+        flags = torch.empty(int(self.lib.dlsg_lstm_seq_flag_words(L, n, H)), dtype=torch.int32, device=dev)
+        if getattr(self, '_lstm_seq_err', None) is None or self._lstm_seq_err.device != dev:
+            self._lstm_seq_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        _chkc(W)
+        for name, v in t.items():
+            if v is not None:
+                _chkc(v)
+                assert v.dtype == torch.float32 and v.shape[:2] == (L, n) and v.shape[2] in (H, 4 * H), (name, v.shape)
+            setattr(a, name, _p(v))
+        a.W, a.xbuf, a.xbuf2, a.flags, a.err = _p(W), _p(xbuf), _p(xbuf2), _p(flags), _p(self._lstm_seq_err)
+        a.L, a.n, a.H = L, n, H
+        self._check(self.lib.dlsg_lstm_seq(C.byref(a), level, self._stream()), 'dlsg_lstm_seq(level %d)' % level)
+        return self._lstm_seq_err
+
+    def lstm_seq_fwd(self, xin, W, As, Hs, Cs):
+        """h_t, c_t for all L steps in one launch: xin (L, n, 4H) = x W_ih^T + b; W = weight_hh (4H, H)."""
+        L, n, H = Hs.shape
+        return self._lstm_seq(0, W, L, n, H, addend=xin, As=As, Hs=Hs, Cs=Cs)
+
+    def lstm_seq_bwd(self, As, Cs, W, dHs, dAs, dCs, DA, DH, DC):
+        """backward through time with the injected gradients dAs / dCs (None = none) in one launch."""
+        L, n, H = dHs.shape
+        return self._lstm_seq(1, W, L, n, H, As=As, Cs=Cs, dHs=dHs, dAs=dAs, dCs=dCs, DA=DA, DH=DH, DC=DC)
+
+    def lstm_seq_bwd2(self, As, Cs, W, DH, DC, ubar, gA, gC, gDH, gDC):
+        """backward of lstm_seq_bwd in one launch; ubar (L, n, 4H) holds the gradient w.r.t. DA on entry and the gradient
+        w.r.t. dAs on return; row L-1 of gC is left as the caller set it (zero)."""
+        L, n, H = DH.shape
+        return self._lstm_seq(2, W, L, n, H, As=As, Cs=Cs, DH=DH, DC=DC, addend=ubar, addend_out=ubar, gA=gA, gC=gC, gDH=gDH, gDC=gDC)
 
     # ------------------------------------------------------------------ LSTM pointwise
     @staticmethod

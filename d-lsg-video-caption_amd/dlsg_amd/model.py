@@ -790,8 +790,16 @@ class Trainer(object):
             info['rccl_version'] = self._rccl.rccl_version
         return info
 
+    def check(self):
+        """Raise if a persistent kernel's inter-workgroup wait timed out since the last call (ops.check_persistent).  A host
+        synchronisation: call it where the loss is read back (per logging interval / epoch), not per step."""
+        chk = getattr(self.model.ops, 'check_persistent', None)
+        if chk is not None:
+            chk()
+
     def close(self):
         """destroy the RCCL communicator (collective: every rank calls it)"""
+        self.check()
         if self._rccl is not None:
             torch.cuda.synchronize()
             self._rccl.close()

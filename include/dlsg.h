@@ -530,6 +530,37 @@ typedef struct {
 int64_t dlsg_bilstm_bwd_x_floats(int T, int H);
 int dlsg_bilstm_bwd(const dlsg_bilstm_bwd_args* a, void* stream);
 
+/* ---------------------------------------------------------------- DiscV2's LSTM, a whole sequence per launch
+ * Replaces `self.lstm = nn.LSTM(512, 512, batch_first=True)` of DiscV2 (models/model.py:122,139) inside a WGAN-GP critic
+ * update (run_gun.py:352-371), where autograd differentiates it twice: level 0 = the forward recurrence, level 1 = its
+ * backward through time (with the extra gradient inputs the gradient penalty's graph feeds in), level 2 = the backward of
+ * that backward.  One persistent launch per level for all L steps (csrc/critic_lstm.hip; the per-step forms are
+ * dlsg_lstm_cell_fwd / _bwd_seq / _bwd2 above).  Tensors are time-major and contiguous: (L, n, 4H) gate tensors (gate order
+ * i, f, g, o), (L, n, H) states.  n <= 256, H in {64, 512}; W = weight_hh (4H, H).
+ *   level 0: addend = x W_ih^T + b_ih + b_hh  ->  As (pre-activations), Hs, Cs
+ *   level 1: As, Cs, dHs, optional dAs / dCs  ->  DA (d As, injections included), DH, DC (total gradients reaching h_t, c_t)
+ *   level 2: As, Cs, DH, DC, addend = gradient w.r.t. DA  ->  addend_out = Ubar (gradient w.r.t. dAs; may alias addend), gA, gC
+ *            (row L-1 of gC is not written: zero it), gDH (gradient w.r.t. dHs), gDC (w.r.t. dCs)
+ * xbuf / xbuf2: dlsg_lstm_seq_x_floats floats each (xbuf2 only at level 1), 16-byte aligned; flags: dlsg_lstm_seq_flag_words
+ * words, zeroed by the call; err (optional): set non-zero if a workgroup timed out waiting (result then invalid). */
+typedef struct {
+    const float* addend;
+    float* addend_out;
+    const float* W;
+    float* As; float* Hs; float* Cs;                 /* level 0 writes, levels 1-2 read As, Cs */
+    const float* dHs; const float* dAs; const float* dCs;
+    float* DA; float* DH; float* DC;                 /* level 1 writes, level 2 reads DH, DC */
+    float* gA; float* gC; float* gDH; float* gDC;
+    float* xbuf; float* xbuf2;
+    uint32_t* flags;
+    int32_t* err;
+    int32_t L, n, H, pad_;
+} dlsg_lstm_seq_args;
+int dlsg_lstm_seq_supported(int L, int n, int H);
+int64_t dlsg_lstm_seq_x_floats(int L, int n, int H);
+int64_t dlsg_lstm_seq_flag_words(int L, int n, int H);
+int dlsg_lstm_seq(const dlsg_lstm_seq_args* a, int level, void* stream);
+
 /* ---------------------------------------------------------------- gradient all-reduce over RCCL / xGMI
  * Replaces the gradient exchange of `DistributedDataParallel(model, find_unused_parameters=True)` over NCCL
  * (run_gun.py:63-64, train_debug.py:20): one process per GPU, sum of ranges of the flat gradient arena over all ranks,

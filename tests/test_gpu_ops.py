@@ -1081,3 +1081,111 @@ def test_grouped_column_sums_equal_the_single_launches(hip):
         assert torch.equal(a, b)
     ref = cases[1][0].double().sum(0).float().cpu() + 1.0
     assert (single[1].cpu() - ref).abs().max().item() <= 1e-3
+
+
+def _plain_lstm(xin, W):
+    """nn.LSTM's recurrence with the input products already in xin (L, n, 4H): plain torch, differentiable"""
+    L, n, G = xin.shape
+    H = G // 4
+    h = xin.new_zeros(n, H); c = xin.new_zeros(n, H)
+    hs = []
+    for t in range(L):
+        i, f, g, o = (xin[t] + h @ W.t()).split(H, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        hs.append(h)
+    return torch.stack(hs)
+
+
+def _gp_like(hs_of, xin, W, r1, r2):
+    """a scalar that differentiates the LSTM twice, as the critic's gradient penalty does (run_gun.py:362-371)"""
+    hs = hs_of(xin, W)
+    g, = torch.autograd.grad((hs * r1).sum(), xin, create_graph=True)
+    pen = ((g.reshape(g.shape[0], g.shape[1], -1).norm(dim=-1) - 1.0) ** 2).mean()
+    return pen * 10.0 + (hs * r2).sum() * 0.01
+
+
+@pytest.mark.parametrize('L,n,H', [(26, 192, 512), (26, 5, 64), (7, 70, 64), (1, 3, 64), (26, 256, 64), (3, 130, 512)])
+def test_critic_lstm_sequence_kernels_against_autograd(hip, L, n, H):
+    """csrc/critic_lstm.hip: DiscV2's LSTM over all word steps as ONE persistent launch per differentiation level -- forward,
+    backward through time with injected gradients, backward of the backward -- through dlsg_amd.gan's autograd nodes, against
+    (a) the per-step launches it replaces and (b) torch autograd's own double backward of the plain recurrence on the CPU.
+    Twice (reused exchange buffers / flags); the time-out word must stay 0."""
+    from dlsg_amd.gan import _LstmSeq
+    assert hip.lib.dlsg_lstm_seq_supported(L, n, H) == 1
+    assert hip.lib.dlsg_lstm_seq_supported(L, 257, H) == 0 and hip.lib.dlsg_lstm_seq_supported(L, n, 96) == 0
+    g = torch.Generator().manual_seed(23)
+    sc = 1.0 / math.sqrt(H)
+    xin0, W0 = rnd(g, L, n, 4 * H), rnd(g, 4 * H, H, scale=2 * sc)
+    r1, r2 = rnd(g, L, n, H), rnd(g, L, n, H)
+
+    def run(hs_of, dev):
+        xin = xin0.to(dev).requires_grad_(True)
+        W = W0.to(dev).requires_grad_(True)
+        loss = _gp_like(hs_of, xin, W, r1.to(dev), r2.to(dev))
+        gx, gw = torch.autograd.grad(loss, (xin, W))
+        return loss.detach().cpu(), gx.cpu(), gw.cpu()
+    want = run(_plain_lstm, 'cpu')
+    node = lambda xin, W: _LstmSeq.apply(hip, xin, W)[0]
+    assert hip.persistent_lstm_seq
+    try:
+        hip.persistent_lstm_seq = False
+        steps = run(node, 'cuda')
+    finally:
+        hip.persistent_lstm_seq = True
+    for rep in range(2):
+        got = run(node, 'cuda')
+        hip.check_persistent()
+        for name, a, b, c in zip(('loss', 'd xin', 'd W_hh'), want, steps, got):
+            s = max(1.0, a.abs().max().item())
+            assert (a - c).abs().max().item() <= 2e-4 * s, (rep, name, (a - c).abs().max().item(), s)
+            assert (b - c).abs().max().item() <= 2e-5 * s, (rep, name, 'vs per-step launches', (b - c).abs().max().item(), s)
+
+
+def test_critic_lstm_sequence_levels_against_step_kernels(hip):
+    """each level of csrc/critic_lstm.hip against the loop over csrc/critic.hip's cell kernels + products, every output tensor
+    (also the ones the autograd comparison above only sees summed: DH, DC, gC, gDC)"""
+    L, n, H = 9, 150, 64
+    g = torch.Generator().manual_seed(29)
+    cu = lambda *s, **k: rnd(g, *s, **k).cuda()
+    xin, W = cu(L, n, 4 * H), cu(4 * H, H, scale=0.25)
+    new = lambda last: torch.full((L, n, last), float('nan'), device='cuda')
+    # level 0
+    As, Hs, Cs = new(4 * H), new(H), new(H)
+    hip.lstm_seq_fwd(xin, W, As, Hs, Cs)
+    As_, Hs_, Cs_ = xin.clone(), new(H), new(H)
+    for t in range(L):
+        if t:
+            As_[t].addmm_(Hs_[t - 1], W.t())
+        hip.lstm_cell_fwd(As_[t], Cs_[t - 1] if t else None, Hs_[t], Cs_[t])
+    for name, a, b in (('As', As_, As), ('Hs', Hs_, Hs), ('Cs', Cs_, Cs)):
+        assert (a - b).abs().max().item() <= 2e-5, (name, (a - b).abs().max().item())
+    # level 1, with and without injections
+    for inj in (True, False):
+        dHs, dAs, dCs = cu(L, n, H), (cu(L, n, 4 * H) if inj else None), (cu(L, n, H) if inj else None)
+        DA, DH, DC = new(4 * H), new(H), new(H)
+        hip.lstm_seq_bwd(As_, Cs_, W, dHs, dAs, dCs, DA, DH, DC)
+        DA_, DH_, DC_ = new(4 * H), new(H), new(H)
+        s_buf = [torch.empty(n, H, device='cuda'), torch.empty(n, H, device='cuda')]
+        r = torch.empty(n, H, device='cuda')
+        for t in range(L - 1, -1, -1):
+            last = t == L - 1
+            hip.lstm_cell_bwd_seq(As_[t], Cs_[t - 1] if t else None, dHs[t], None if last else r, None if last else s_buf[(t + 1) & 1],
+                                  None if dCs is None else dCs[t], None if dAs is None else dAs[t], DA_[t], s_buf[t & 1], DH_[t], DC_[t])
+            if t:
+                torch.mm(DA_[t], W, out=r)
+        for name, a, b in (('DA', DA_, DA), ('DH', DH_, DH), ('DC', DC_, DC)):
+            assert (a - b).abs().max().item() <= 3e-5 * max(1.0, a.abs().max().item()), (inj, name, (a - b).abs().max().item())
+    # level 2
+    U0 = cu(L, n, 4 * H)
+    Ubar, gA, gC, gDH, gDC = U0.clone(), new(4 * H), torch.zeros(L, n, H, device='cuda'), new(H), new(H)
+    hip.lstm_seq_bwd2(As_, Cs_, W, DH_, DC_, Ubar, gA, gC, gDH, gDC)
+    Ubar_, gA_, gC_, gDH_, gDC_ = U0.clone(), new(4 * H), torch.zeros(L, n, H, device='cuda'), new(H), new(H)
+    for t in range(L):
+        if t:
+            Ubar_[t].addmm_(gDH_[t - 1], W.t())
+        hip.lstm_cell_bwd2(As_[t], Cs_[t - 1] if t else None, DH_[t], DC_[t], Ubar_[t], gDC_[t - 1] if t else None, gA_[t],
+                           gC_[t - 1] if t else None, gDH_[t], gDC_[t])
+    hip.check_persistent()
+    for name, a, b in (('Ubar', Ubar_, Ubar), ('gA', gA_, gA), ('gC', gC_, gC), ('gDH', gDH_, gDH), ('gDC', gDC_, gDC)):
+        assert (a - b).abs().max().item() <= 3e-5 * max(1.0, a.abs().max().item()), (name, (a - b).abs().max().item())

@@ -1,6 +1,7 @@
 """One RunGAN iteration (run_gun.py:147-234) at the bench shape: generator on the HIP path, DiscV2 critic on PyTorch-ROCm
 (dlsg_amd/gan.py).  Prints ms per phase (no-grad generator forward, num_D critic updates, generator step incl. the GAN
-term) and clips/s of the whole iteration.  usage: python tools/gan_bench.py [batch=64] [iters=8] [num_D=5]"""
+term) and clips/s of the whole iteration.  usage: python tools/gan_bench.py [batch=64] [iters=8] [num_D=5] [lstm=seq|steps]
+(lstm=steps: the critic's LSTM as one product + one cell launch per word step instead of csrc/critic_lstm.hip's launches)"""
 import json
 import os
 import random
@@ -17,6 +18,9 @@ from dlsg_amd.synth import synth_state_dict, synth_batch  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 num_D = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+if len(sys.argv) > 4 and sys.argv[4] == 'steps':
+    from dlsg_amd.hip import HipOps
+    HipOps.persistent_lstm_seq = False
 V = 1000
 args = dlsg_amd.msvd_shaped(use_visual_gan=True)
 torch.manual_seed(0)
@@ -54,5 +58,5 @@ for i in range(iters):
     ph['generator_forward_nograd'] += (t1 - t) / iters
     ph['critic_updates'] += (t2 - t1) / iters
 ph['generator_step'] = whole - ph['generator_forward_nograd'] - ph['critic_updates']
-print(json.dumps({'batch': B, 'num_D': num_D, 'ms_per_iteration': round(whole * 1e3, 2), 'clips_per_s': round(B / whole, 1),
+print(json.dumps({'batch': B, 'num_D': num_D, 'critic_lstm': sys.argv[4] if len(sys.argv) > 4 else 'seq', 'ms_per_iteration': round(whole * 1e3, 2), 'clips_per_s': round(B / whole, 1),
                   'phase_ms': {k: round(v * 1e3, 2) for k, v in ph.items()}}))
