@@ -815,6 +815,7 @@ extern "C" int dlsg_struct_size(int which) {
         case 20: return (int)sizeof(dlsg_bilstm_bwd_args);
         case 21: return (int)sizeof(dlsg_colsum_desc);
         case 22: return (int)sizeof(dlsg_lstm_seq_args);
+        case 23: return (int)sizeof(dlsg_gemm_narrow_args);
         default: return -1;
     }
 }

@@ -88,6 +88,136 @@ def _hip_ops():
     return _HIP[0]
 
 
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2          # include/dlsg.h: C = A B^T | A B | A^T B (row-major operands)
+
+
+def _row_major(t):
+    """an operand csrc/gemm.hip can address: unit stride along the last axis (any row / batch stride)"""
+    return t if (t.stride(-1) == 1 or t.size(-1) == 1) else t.contiguous()
+
+
+def _tn_chunks(M, N, K):
+    """A^T B with a deep contraction and a small output (the weight gradients over all 4 992 caption rows: 512 x 512 is 64
+    tiles on 256 CUs): the K rows go to this many groups of one launch, each writing its own slab"""
+    if K < 2048:
+        return 1
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    return max(1, min(16, 768 // tiles, K // 256))
+
+
+def _gemm_tn_split(ops, A, B, C, alpha):
+    K = A.shape[0]
+    ks = _tn_chunks(C.shape[0], C.shape[1], K)
+    step = ((K + ks - 1) // ks + 31) // 32 * 32
+    bounds = [(k, min(K, k + step)) for k in range(0, K, step)]
+    slabs = C.new_empty(len(bounds), C.shape[0], C.shape[1])
+    ops.gemm(GEMM_TN, [(A[k0:k1], B[k0:k1], slabs[i]) for i, (k0, k1) in enumerate(bounds)], alpha=alpha)
+    ops.slab_reduce(slabs, C)
+
+
+def _product(ops, mode, A, B, C, alpha=1.0, bias=None):
+    """C = alpha op(A) op(B) (+ bias) on the kernel that fits the shape: narrow (one side <= 32), deep TN split, or the tiled GEMM"""
+    K = A.shape[-2] if mode == GEMM_TN else A.shape[-1]
+    nb = C.shape[0] if C.dim() == 3 else 1
+    kind = ops.gemm_narrow_kind(mode, C.shape[-2], C.shape[-1], K, nb) if hasattr(ops, 'gemm_narrow_kind') else 0
+    if kind and not (kind == 3 and bias is not None):
+        ops.gemm_narrow(mode, A, B, C, alpha, bias)
+    elif mode == GEMM_TN and A.dim() == 2 and bias is None and _tn_chunks(C.shape[0], C.shape[1], K) > 1:
+        _gemm_tn_split(ops, A, B, C, alpha)
+    else:
+        ops.gemm(mode, [(A, B, C)], alpha=alpha, bias=bias)
+
+
+class _Gemm(torch.autograd.Function):
+    """C = alpha * op(A) op(B) (+ bias) on this repo's GEMM (csrc/gemm.hip, exact fp32 MFMA) instead of rocBLAS: 2-D operands, or
+    3-D ones as a batch.  The two gradient products are `_Gemm` nodes again (the three layouts are closed under
+    differentiation), so the gradient penalty's double backward runs on the same kernel."""
+
+    @staticmethod
+    def forward(ctx, ops, mode, A, B, bias, alpha):
+        A, B = _row_major(A), _row_major(B)
+        if mode == GEMM_NT:
+            M, N = A.shape[-2], B.shape[-2]
+        elif mode == GEMM_NN:
+            M, N = A.shape[-2], B.shape[-1]
+        else:
+            M, N = A.shape[-1], B.shape[-1]
+        C = A.new_empty(*A.shape[:-2], M, N)
+        _product(ops, mode, A, B, C, alpha, None if bias is None else bias.contiguous())
+        ctx.ops, ctx.mode, ctx.alpha, ctx.has_bias = ops, mode, alpha, bias is not None
+        ctx.save_for_backward(A, B)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, B = ctx.saved_tensors
+        ops, mode, al = ctx.ops, ctx.mode, ctx.alpha
+        dA = dB = db = None
+        need_a, need_b = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        dC = _row_major(dC)
+        if mode == GEMM_NT:          # C = A B^T
+            if need_a:
+                dA = _mm(ops, GEMM_NN, dC, B, al)
+            if need_b:
+                dB = _mm(ops, GEMM_TN, dC, A, al)
+        elif mode == GEMM_NN:        # C = A B
+            if need_a:
+                dA = _mm(ops, GEMM_NT, dC, B, al)
+            if need_b:
+                dB = _mm(ops, GEMM_TN, A, dC, al)
+        else:                        # C = A^T B
+            if need_a:
+                dA = _mm(ops, GEMM_NT, B, dC, al)
+            if need_b:
+                dB = _mm(ops, GEMM_NN, A, dC, al)
+        if ctx.has_bias and ctx.needs_input_grad[4]:
+            db = dC.reshape(-1, dC.shape[-1]).sum(0)
+        return None, None, dA, dB, db, None
+
+
+def _gemm_ops(ops, mode, A, B):
+    """which backend multiplies: the kernel interface (returned) or ATen / rocBLAS (None).  DLSG_CRITIC_GEMM = rocblas (default) |
+    dlsg (every product of a critic update on csrc/gemm.hip + csrc/gemm_narrow.hip: no vendor GEMM on the path; parity-tested,
+    tests/test_gpu_gan.py).  Measured on an MI355X at batch 64 (tools/critic_gemm_census.py, profiles/r03k_critic_gemm_census.txt):
+    the 175 products of an update take 4.1 ms on rocBLAS and 5.4 ms on this repo's kernels, which are tuned for the generator's
+    shapes (26 624-row projections, 64-row recurrences) -- they win the tall 4 992 x 512 x 512 products (36 vs 43 us) and lose the
+    deep 512 x 512 x 4 992 weight gradients (44 vs 35 us), the 576-row ones (16 vs 8 us: a 64 x 64 fp32-MFMA tile needs 7 us for
+    K = 512) and most 26 x 26 / 26 x 3 batched ones; 5 critic updates: 55 ms against 44.  A per-shape mix of the two measured
+    no better than rocBLAS alone (44.2 vs 44.3 ms), so the default stays one backend.
+    A kernel interface that is not the HIP library (the tests' emulation) always takes the products, so the CPU tests cover the
+    whole three-level algebra of `_Gemm`."""
+    if ops is None or not hasattr(ops, 'gemm'):
+        return None
+    if getattr(ops, 'name', '') != 'hip':
+        return ops
+    if A.dtype != torch.float32 or B.dtype != torch.float32:
+        return None
+    return ops if os.environ.get('DLSG_CRITIC_GEMM', 'rocblas') == 'dlsg' else None
+
+
+def _mm(ops, mode, A, B, alpha=1.0, bias=None):
+    """alpha * op(A) op(B) (+ bias): both 2-D or both 3-D (a batch), on the backend `_gemm_ops` picks for the shape"""
+    g = _gemm_ops(ops, mode, A, B)
+    if g is not None:
+        return _Gemm.apply(g, mode, A, B, bias, alpha)
+    if mode == GEMM_NT:
+        if bias is not None and alpha == 1.0 and A.dim() == 2:
+            return F.linear(A, B, bias)
+        r = A @ B.transpose(-1, -2)
+    elif mode == GEMM_NN:
+        r = A @ B
+    else:
+        r = A.transpose(-1, -2) @ B
+    r = r if alpha == 1.0 else r * alpha
+    return r if bias is None else r + bias
+
+
+def _linear(ops, x, W, b=None):
+    """F.linear over the last axis, the bias added in the product's epilogue"""
+    y = _mm(ops, GEMM_NT, x.reshape(-1, x.shape[-1]), W, 1.0, b)
+    return y.view(*x.shape[:-1], W.shape[0])
+
+
 def _seq_kernels(ops, L, n, H):
     """whole-sequence launches where the op set has them and the shape fits (n <= 256, H in {64, 512}, enough CUs)"""
     f = getattr(ops, 'lstm_seq_supported', None)
@@ -310,7 +440,7 @@ class DiscV2(nn.Module):
 
     def project(self, x):
         """(B,L,V) logits or any dense caption representation -> (B,L,512)"""
-        return F.linear(x, self.vocab_matrix(), self.conv1d.bias)
+        return _linear(self._cell_ops(x), x, self.vocab_matrix(), self.conv1d.bias)
 
     def project_ids(self, captions):
         """real captions (B,L) int64: the one-hot product of run_gun.py:447-451 as a gather of weight columns"""
@@ -341,7 +471,7 @@ class DiscV2(nn.Module):
         out = []
         if ops is not None:
             # the whole recurrence as one node per differentiation level (time-major: a step's rows are dense)
-            xin = F.linear(x.transpose(0, 1), w_ih, bias).contiguous()
+            xin = _linear(ops, x.transpose(0, 1).contiguous(), w_ih, bias)
             return _LstmSeq.apply(ops, xin, w_hh)[0].transpose(0, 1)
         xin = F.linear(x, w_ih, bias)                              # all steps' input gates in one product
         for t in range(L):
@@ -355,16 +485,17 @@ class DiscV2(nn.Module):
         """PSLScore2.forward (layer.py:690-715): words (n,L,512) attended by the (top-k) proposals"""
         n = psl.shape[0]
         ops = self._cell_ops(psl)
-        e = _tanh_ln(m.psl_embed[0](psl), m.psl_embed[2], ops)
+        lin = lambda layer, x: _linear(ops, x, layer.weight, layer.bias)
+        e = _tanh_ln(lin(m.psl_embed[0], psl), m.psl_embed[2], ops)
         if m.select:
             top = alpha.sum(dim=1).topk(m.num_top, dim=-1).indices
             e = e.gather(1, top.unsqueeze(-1).expand(n, m.num_top, WIDTH))
-        a = _tanh_ln(m.att_norm[0](words), m.att_norm[2], ops)
-        adj = _softmax(a @ e.transpose(1, 2) / math.sqrt(WIDTH), 1, ops) * word_mask          # mask after the softmax (:703-704)
+        a = _tanh_ln(lin(m.att_norm[0], words), m.att_norm[2], ops)
+        adj = _softmax(_mm(ops, GEMM_NT, a, e, 1.0 / math.sqrt(WIDTH)), 1, ops) * word_mask     # mask after the softmax (:703-704)
         weight = adj.sum(dim=1)
-        agg = _dropout(_tanh_ln(adj.transpose(1, 2) @ a, m.psl_norm[1], ops), 0.3, self.training)
+        agg = _dropout(_tanh_ln(_mm(ops, GEMM_TN, adj, a), m.psl_norm[1], ops), 0.3, self.training)
         sc = m.psl_scorer
-        pair = sc.classify(torch.tanh(sc.visual_embed[0](e)) * torch.tanh(sc.sent_embed[0](agg))).squeeze(-1)
+        pair = lin(sc.classify, torch.tanh(lin(sc.visual_embed[0], e)) * torch.tanh(lin(sc.sent_embed[0], agg))).squeeze(-1)
         return (pair * weight).sum(dim=-1) / weight.sum(dim=-1)                                   # (n,)
 
     def score_projected(self, h, obj, mot, att_mask, alpha_all, groups=1):
@@ -382,15 +513,16 @@ class DiscV2(nn.Module):
         # (MIOpen's choice for this shape is an im2col + GEMM per sample: 2 x 192 launches per call)
         xp = F.pad(x, (0, 0, 1, 1))
         taps = torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=2)                          # (n, L, 3 x 512): x[t-1] | x[t] | x[t+1]
-        x = x + 0.3 * F.linear(taps, conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1), conv.bias)
         ops = self._cell_ops(h)
+        x = x + 0.3 * _linear(ops, taps, conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1), conv.bias)
         y = _dropout(_tanh_ln(self._lstm(x), self.layer_norm, ops, pre_tanh=False),
                      0.3, self.training)
         mask = rep(att_mask)
         sa = self.att
-        logits = sa.K(y) @ sa.Q(y).transpose(1, 2) / math.sqrt(sa.attention_size)
+        logits = _mm(ops, GEMM_NT, _linear(ops, y, sa.K.weight), _linear(ops, y, sa.Q.weight), 1.0 / math.sqrt(sa.attention_size))
         w = _softmax(torch.where(mask > 0, logits, torch.full_like(logits, -9e15)), -1, ops)
-        words = _tanh_ln(_dropout(sa.output_layer[0](w @ sa.V(y)), sa.dropout, self.training), self.att_norm[1], ops)
+        ctx_ = _linear(ops, _mm(ops, GEMM_NN, w, _linear(ops, y, sa.V.weight)), sa.output_layer[0].weight)
+        words = _tanh_ln(_dropout(ctx_, sa.dropout, self.training), self.att_norm[1], ops)
         word_mask = mask[:, 0, :].unsqueeze(2)                     # (n,L,1)
         alpha = rep(alpha_all) * word_mask
         P = self.num_psl
@@ -401,9 +533,9 @@ class DiscV2(nn.Module):
         so = so.view(groups, B).mean(dim=1).repeat_interleave(B)
         sm = sm.view(groups, B).mean(dim=1).repeat_interleave(B)
         ts = self.text_sum
-        adj = _softmax(words @ ts.theta.t(), 1, ops)               # LatentPSL(512, 1): one latent node over the words
-        sent = _dropout(_tanh_ln(adj.transpose(1, 2) @ words, ts.out_norm[1], ops), 0.3, self.training).squeeze(1)
-        fus = _softmax(sent @ self.fusion.t(), -1, ops)
+        adj = _softmax(_linear(ops, words, ts.theta), 1, ops)      # LatentPSL(512, 1): one latent node over the words
+        sent = _dropout(_tanh_ln(_mm(ops, GEMM_TN, adj, words), ts.out_norm[1], ops), 0.3, self.training).squeeze(1)
+        fus = _softmax(_linear(ops, sent, self.fusion), -1, ops)
         return so * fus[:, 0] + sm * fus[:, 1]
 
     def forward(self, inputs, obj_proposals, motion_proposals, att_mask=None, alpha_all=None):
@@ -427,11 +559,12 @@ def critic_step_losses(D, captions, f_caption, obj, mot, att_mask, alpha, eps_gp
     r_logit, f_logit, m_logit = scores[:B], scores[B:2 * B], scores[2 * B:]
     g = torch.autograd.grad(m_logit.sum(), h_m, create_graph=True, retain_graph=True)[0]        # (B,L,512)
     W = D.vocab_matrix()
-    gram = W @ W.t()
+    ops = D._cell_ops(g)
+    gram = _mm(ops, GEMM_NT, W, W)
     # |d mixed_logit / d mixed_captions|_2 per sample.  The floor keeps sqrt's derivative finite where a sample's critic
     # gradient is exactly zero / underflows (torch's .norm(2) of the reference, run_gun.py:366-371, has subgradient 0 there;
     # an unclamped sqrt would put NaN into every critic parameter through the double backward)
-    gn = torch.sqrt(((g @ gram) * g).sum(dim=(1, 2)).clamp_min(1e-24))
+    gn = torch.sqrt(((_linear(ops, g, gram)) * g).sum(dim=(1, 2)).clamp_min(1e-24))
     gp = ((gn - 1) * (gn - 1)).mean()
     r_loss, f_loss = r_logit.mean(), f_logit.mean()
     return f_loss - r_loss + 10 * gp, r_loss, f_loss, gp, (r_logit, f_logit, m_logit)
@@ -550,15 +683,20 @@ class GanTrainer(object):
         dev = inputs[1].device
         st = [t.clone() for t in inputs] + [torch.empty(inputs[0].shape[0], 1, 1, device=dev)]
         params = [p for p in D.parameters() if p.grad is not None]
-        grads = [p.grad for p in params]
         out = {}
         torch.cuda.synchronize()
         gA, gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(gA, capture_error_mode='thread_local'):   # other threads (RCCL watchdog, loaders) keep working
-            opt.zero_grad(set_to_none=False)
+            # no zero fill + accumulate: with .grad unset the first gradient that reaches a parameter BECOMES its .grad (a
+            # buffer of this graph's pool, the same address on every replay) -- one launch less per parameter than adding
+            # into a zeroed buffer, ~50 of the ~1 000 launches of an update
+            for p in params:
+                p.grad = None
             loss_D, r_loss, f_loss, gp, _ = critic_step_losses(D, *st)
             loss_D.backward()
             out['loss_D'], out['w'] = loss_D.detach(), (r_loss - f_loss).detach()
+        assert all(p.grad is not None for p in params)
+        grads = [p.grad for p in params]
         with torch.cuda.graph(gB, pool=gA.pool(), capture_error_mode='thread_local'):
             opt.step()
         cg = dict(st=st, params=params, grads=grads, out=out, graphs=(gA, gB))

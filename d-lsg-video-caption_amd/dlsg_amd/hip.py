@@ -109,6 +109,12 @@ class LstmSeqArgs(C.Structure):
                [('L', i32), ('n', i32), ('H', i32), ('pad_', i32)]
 
 
+class GemmNarrowArgs(C.Structure):
+    _fields_ = [('A', c_f32p), ('B', c_f32p), ('C', c_f32p), ('bias', c_f32p), ('ws', c_f32p), ('ws_floats', i64),
+                ('lda', i64), ('ldb', i64), ('ldc', i64), ('bsa', i64), ('bsb', i64), ('bsc', i64),
+                ('mode', i32), ('M', i32), ('N', i32), ('K', i32), ('nbatch', i32), ('pad_', i32), ('alpha', f32), ('pad2_', i32)]
+
+
 class ColsumDesc(C.Structure):
     _fields_ = [('part', c_f32p), ('ld', i64), ('out_a', c_f32p), ('out_b', c_f32p), ('rows', i32), ('n', i32), ('split', i32),
                 ('dup', i32), ('accum', i32), ('pad_', i32)]
@@ -187,6 +193,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2',
            'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd', 'dlsg_bilstm_bwd_x_floats', 'dlsg_bilstm_bwd',
            'dlsg_lstm_seq_supported', 'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_lstm_seq',
+           'dlsg_gemm_narrow_kind', 'dlsg_gemm_narrow_ws_floats', 'dlsg_gemm_narrow',
            'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
            'dlsg_allreduce_buckets']
 
@@ -270,6 +277,9 @@ def load_library(path=LIB_PATH):
         'dlsg_lstm_seq_x_floats': [i32, i32, i32],
         'dlsg_lstm_seq_flag_words': [i32, i32, i32],
         'dlsg_lstm_seq': [P(LstmSeqArgs), i32, vp],
+        'dlsg_gemm_narrow_kind': [i32, i32, i32, i32, i32],
+        'dlsg_gemm_narrow_ws_floats': [i32, i32, i32, i32, i32],
+        'dlsg_gemm_narrow': [P(GemmNarrowArgs), vp],
         'dlsg_comm_init': [P(vp), vp, i32, i32],
         'dlsg_comm_destroy': [vp],
         'dlsg_comm_info': [vp, P(i32), P(i32), P(i32)],
@@ -282,14 +292,14 @@ def load_library(path=LIB_PATH):
         fn.argtypes = args
         fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats', 'dlsg_colsum_ws_floats',
                                             'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_bwd_x_floats',
-                                            'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words') else C.c_int
+                                            'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_gemm_narrow_ws_floats') else C.c_int
     return lib
 
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
            SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs,
-           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs, ColsumDesc, LstmSeqArgs]
+           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs, ColsumDesc, LstmSeqArgs, GemmNarrowArgs]
 
 
 def _p(t):
@@ -443,6 +453,34 @@ class HipOps(object):
                 Kg = a.g[i].K
                 ob += 4 * nb * (M * Kg + Ng * Kg + M * Ng * (2 if (a.flags & F_ACCUM) else 1))
             self._prof_end('gemm_%s_mfma_%s_%s' % ('bf16x3' if x3 else 'f32', variant, ('nt', 'nn', 'tn')[mode]), e0, flops, shape, ob)
+
+    def gemm_narrow_kind(self, mode, M, N, K, nbatch=1):
+        """which narrow-product kernel (csrc/gemm_narrow.hip) takes this shape; 0 = none (use gemm)"""
+        return int(self.lib.dlsg_gemm_narrow_kind(mode, M, N, K, nbatch))
+
+    def gemm_narrow(self, mode, A, B, Cc, alpha=1.0, bias=None):
+        """Cc = alpha * op(A) op(B) (+ bias) for a shape gemm_narrow_kind() accepts; 2-d operands, or 3-d as a batch."""
+        a = GemmNarrowArgs()
+        nb = Cc.size(0) if Cc.dim() == 3 else 1
+        M, N = Cc.shape[-2], Cc.shape[-1]
+        K = A.shape[-2] if mode == GEMM_TN else A.shape[-1]
+        for t in (A, B, Cc):
+            assert t.dtype == torch.float32 and (t.stride(-1) == 1 or t.size(-1) == 1), (t.shape, t.stride())
+        if mode == GEMM_TN:
+            assert A.shape[-1] == M and B.shape[-2] == K and B.shape[-1] == N, (A.shape, B.shape, Cc.shape)
+        elif mode == GEMM_NN:
+            assert A.shape[-2] == M and B.shape[-2] == K and B.shape[-1] == N, (A.shape, B.shape, Cc.shape)
+        else:
+            assert A.shape[-2] == M and B.shape[-1] == K and B.shape[-2] == N, (A.shape, B.shape, Cc.shape)
+        a.A, a.B, a.C, a.bias = _p(A), _p(B), _p(Cc), _p(bias)
+        a.lda, a.ldb, a.ldc = A.stride(-2), B.stride(-2), Cc.stride(-2)
+        if nb > 1:
+            a.bsa, a.bsb, a.bsc = A.stride(0), B.stride(0), Cc.stride(0)
+        a.mode, a.M, a.N, a.K, a.nbatch, a.alpha = mode, M, N, K, nb, alpha
+        nws = int(self.lib.dlsg_gemm_narrow_ws_floats(mode, M, N, K, nb))
+        ws = torch.empty(nws, dtype=torch.float32, device=Cc.device) if nws else None
+        a.ws, a.ws_floats = _p(ws), nws
+        self._check(self.lib.dlsg_gemm_narrow(C.byref(a), self._stream()), 'dlsg_gemm_narrow')
 
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""

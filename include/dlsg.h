@@ -530,6 +530,25 @@ typedef struct {
 int64_t dlsg_bilstm_bwd_x_floats(int T, int H);
 int dlsg_bilstm_bwd(const dlsg_bilstm_bwd_args* a, void* stream);
 
+/* ---------------------------------------------------------------- narrow products (one side <= 32 wide)
+ * The critic's small matmuls (`DiscV2`, models/model.py:143-166; `PSLScore2`, layer.py:697-713; `SelfAttention`,
+ * sublayer.py:69-78; their first and second gradient products under run_gun.py:362-371), which torch sends to rocBLAS:
+ * C = alpha * op(A) op(B) (+ bias over columns), same modes / row-major operands / batch strides as dlsg_gemm, one group.
+ * dlsg_gemm_narrow_kind() says which kernel takes a shape (0 = none: use dlsg_gemm):
+ *   1: K <= 32, modes NN / TN        2: N <= 32, mode NT        3: M <= 4, mode TN, K > 32, nbatch == 1 (needs ws:
+ *   dlsg_gemm_narrow_ws_floats() floats of scratch; the K chunks are folded in a fixed order, bit-reproducible). */
+typedef struct {
+    const float* A; const float* B; float* C;
+    const float* bias;                 /* optional, N values (kinds 1 and 2) */
+    float* ws; int64_t ws_floats;      /* kind 3 */
+    int64_t lda, ldb, ldc, bsa, bsb, bsc;
+    int32_t mode, M, N, K, nbatch, pad_;
+    float alpha; int32_t pad2_;
+} dlsg_gemm_narrow_args;
+int dlsg_gemm_narrow_kind(int mode, int M, int N, int K, int nbatch);
+int64_t dlsg_gemm_narrow_ws_floats(int mode, int M, int N, int K, int nbatch);
+int dlsg_gemm_narrow(const dlsg_gemm_narrow_args* a, void* stream);
+
 /* ---------------------------------------------------------------- DiscV2's LSTM, a whole sequence per launch
  * Replaces `self.lstm = nn.LSTM(512, 512, batch_first=True)` of DiscV2 (models/model.py:122,139) inside a WGAN-GP critic
  * update (run_gun.py:352-371), where autograd differentiates it twice: level 0 = the forward recurrence, level 1 = its

@@ -13,8 +13,11 @@ from helpers import load_gan_case, check_post
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('tag', ['gan_msvd', 'gan_msrvtt'])
-def test_gan_iteration_matches_reference(tag):
+@pytest.mark.parametrize('tag,critic_gemm', [('gan_msvd', 'rocblas'), ('gan_msrvtt', 'rocblas'), ('gan_msvd', 'dlsg'), ('gan_msrvtt', 'dlsg')])
+def test_gan_iteration_matches_reference(tag, critic_gemm, monkeypatch):
+    """critic_gemm: which backend multiplies inside the critic (dlsg_amd.gan._gemm_ops) -- rocBLAS through torch (default), or
+    every product on this repo's kernels (no vendor GEMM in the update)."""
+    monkeypatch.setenv('DLSG_CRITIC_GEMM', critic_gemm)
     args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case(tag, dlsg_amd.CapGnnModel, dlsg_amd.DiscV2)
     G, D = G.cuda(), D.cuda()
     frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()

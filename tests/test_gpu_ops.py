@@ -1189,3 +1189,34 @@ def test_critic_lstm_sequence_levels_against_step_kernels(hip):
     hip.check_persistent()
     for name, a, b in (('Ubar', Ubar_, Ubar), ('gA', gA_, gA), ('gC', gC_, gC), ('gDH', gDH_, gDH), ('gDC', gDC_, gDC)):
         assert (a - b).abs().max().item() <= 3e-5 * max(1.0, a.abs().max().item()), (name, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize('mode,M,N,K,nb', [
+    (GEMM_NN, 26, 512, 26, 192), (GEMM_NN, 26, 512, 3, 192), (GEMM_NN, 26, 512, 1, 7), (GEMM_NN, 4992, 512, 1, 1), (GEMM_NN, 192, 512, 2, 1),
+    (GEMM_NN, 33, 1000, 32, 3), (GEMM_TN, 26, 512, 26, 192), (GEMM_TN, 3, 512, 26, 192), (GEMM_TN, 1, 512, 26, 5), (GEMM_TN, 40, 70, 9, 2),
+    (GEMM_NT, 26, 26, 512, 192), (GEMM_NT, 26, 3, 512, 192), (GEMM_NT, 26, 1, 512, 4), (GEMM_NT, 4992, 1, 512, 1), (GEMM_NT, 576, 1, 512, 1),
+    (GEMM_NT, 192, 2, 512, 1), (GEMM_NT, 70, 32, 100, 3), (GEMM_TN, 1, 512, 4992, 1), (GEMM_TN, 1, 512, 576, 1), (GEMM_TN, 2, 512, 192, 1),
+    (GEMM_TN, 4, 300, 33, 1), (GEMM_TN, 3, 64, 50, 1)])
+def test_narrow_products_against_matmul(hip, mode, M, N, K, nb):
+    """csrc/gemm_narrow.hip (the critic's products with one side <= 32 wide, batched or not) against a float64 matmul; operands
+    as strided views (row strides wider than the rows), with alpha and -- where the kernel takes one -- a bias."""
+    kind = hip.gemm_narrow_kind(mode, M, N, K, nb)
+    assert kind in (1, 2, 3), (mode, M, N, K, nb)
+    g = torch.Generator().manual_seed(31)
+    lead = (nb,) if nb > 1 else ()
+    sa = (K, M) if mode == GEMM_TN else (M, K)
+    sb = (N, K) if mode == GEMM_NT else (K, N)
+    A = rnd(g, *lead, sa[0], sa[1] + 3).cuda()[..., :sa[1]]
+    Bm = rnd(g, *lead, sb[0], sb[1] + 5).cuda()[..., :sb[1]]
+    Cbuf = torch.full((*lead, M, N + 2), float('nan'), device='cuda')
+    Cc = Cbuf[..., :N]
+    bias = rnd(g, N).cuda() if kind != 3 else None
+    hip.gemm_narrow(mode, A, Bm, Cc, alpha=0.7, bias=bias)
+    a64, b64 = A.double().cpu(), Bm.double().cpu()
+    want = 0.7 * (a64 @ b64.transpose(-1, -2) if mode == GEMM_NT else (a64 @ b64 if mode == GEMM_NN else a64.transpose(-1, -2) @ b64))
+    if bias is not None:
+        want = want + bias.double().cpu()
+    err = (Cc.double().cpu() - want).abs().max().item()
+    assert err <= 2e-6 * max(1.0, want.abs().max().item()) * math.sqrt(K), (kind, err)
+    assert torch.isnan(Cbuf[..., N:]).all()                 # nothing written past the view
+    assert hip.gemm_narrow_kind(GEMM_NT, 64, 64, 64, 1) == 0 and hip.gemm_narrow_kind(GEMM_NN, 64, 64, 33, 1) == 0
