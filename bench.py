@@ -456,6 +456,12 @@ def main():
     rehearsal = os.environ.get('DLSG_BENCH_ALL_RANKS_ON_DEVICE0') == '1'
     if rehearsal:
         local = 0
+        # the persistent recurrent kernels need every workgroup of a launch resident at once (one per CU); two processes
+        # sharing one device can each hold half of the CUs and wait for the other half: shared-device rehearsals use the
+        # per-step schedule
+        from dlsg_amd.hip import HipOps
+        HipOps.persistent_bilstm = False
+        HipOps.persistent_lstm_seq = False
     backend = os.environ.get('DLSG_BENCH_BACKEND', 'nccl')
     if not rehearsal and torch.cuda.device_count() <= local:
         sys.stderr.write('bench.py: rank %d has no device %d (%d visible)\n' % (rank, local, torch.cuda.device_count()))
