@@ -1,4 +1,5 @@
-"""Target for rocprofv3 --kernel-trace --stats: beam-5 inference, batch 128, MSVD-shaped (3 calls)."""
+"""Target for rocprofv3 --kernel-trace --stats: inference (BASELINE.json configs[4]), MSVD-shaped, 3 eager calls.
+usage: python3 tools/profile_beam.py [batch=128] [beam=5]   (beam=1: greedy)"""
 import os
 import sys
 
@@ -17,7 +18,7 @@ net.load_state_dict(synth_state_dict(net.state_dict(), 0))
 net = net.cuda().eval()
 frames, regions, caps, lens = synth_batch(args, 1000, B, 1)
 frames, regions = frames.cuda(), regions.cuda()
-net.update_beam_size(5)
+net.update_beam_size(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 with torch.no_grad():
     for _ in range(3):
         ids = net(frames, regions, None)[0]
