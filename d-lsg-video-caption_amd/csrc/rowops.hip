@@ -747,19 +747,77 @@ __global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restric
 // indices that reorder the recurrent state.  Ties resolve to the lower index.
 constexpr int BEAM_MAXK = 8;
 
+// (value, index) order of the search: larger value first, ties to the smaller index (torch.topk on equal log-probs is not
+// specified; the oracle and the reference fixtures agree with this rule on every golden case)
+__device__ __forceinline__ bool beam_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ int wave_min_i32(int v) {
+    v = min(v, dpp_i32<0xB1>(v));
+    v = min(v, dpp_i32<0x4E>(v));
+    v = min(v, dpp_i32<0x141>(v));
+    v = min(v, dpp_i32<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// the best (value, index) pair of the wave, to every lane: two DPP reductions instead of twelve ds_bpermute round trips
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
+    const float m = dlsg::wave_max(v);
+    i = wave_min_i32(v == m ? i : 0x7fffffff);
+    v = m;
+}
+
+// One row of the search: the K best classes of a V-wide logit row and the row's log-sum-exp, ONE wave.  The row is read twice
+// (maximum + each lane's own K best in the first pass, the exponential sum in the second -- same summation order as a plain
+// strided loop, so the log-probs are bit-identical to the previous 2 + K pass form), then K merge rounds over the lanes' heads.
+template <int K>
+__device__ __forceinline__ void beam_row_topk(const float* x, int V, int lane, float& lse, float (&outv)[K], int (&outi)[K]) {
+    float tv[K];
+    int ti[K];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(i, o, 64);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    for (int q = 0; q < K; ++q) { tv[q] = -INFINITY; ti[q] = 0x7fffffff; }
+    float m = -INFINITY;
+    for (int j = lane; j < V; j += 64) {
+        float cv = x[j];
+        int ci = j;
+        m = fmaxf(m, cv);
+        if (beam_better(cv, ci, tv[K - 1], ti[K - 1])) {
+#pragma unroll
+            for (int q = 0; q < K; ++q) {                       // one bubble pass keeps tv sorted
+                const bool up = beam_better(cv, ci, tv[q], ti[q]);
+                const float nv = up ? tv[q] : cv;
+                const int ni = up ? ti[q] : ci;
+                tv[q] = up ? cv : tv[q];
+                ti[q] = up ? ci : ti[q];
+                cv = nv; ci = ni;
+            }
+        }
+    }
+    m = dlsg::wave_max(m);
+    float sum = 0.f;
+    for (int j = lane; j < V; j += 64) sum += expf(x[j] - m);
+    sum = dlsg::wave_sum(sum);
+    lse = logf(sum) + m;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+        float bv = tv[0];
+        int bi = ti[0];
+        wave_argmax(bv, bi);
+        outv[c] = bv; outi[c] = bi;
+        if (ti[0] == bi && bi != 0x7fffffff) {                  // the winning lane pops its head
+#pragma unroll
+            for (int q = 0; q + 1 < K; ++q) { tv[q] = tv[q + 1]; ti[q] = ti[q + 1]; }
+            tv[K - 1] = -INFINITY; ti[K - 1] = 0x7fffffff;
+        }
     }
 }
 
-__global__ __launch_bounds__(64 * BEAM_MAXK) void beam_select_kernel(const dlsg_beam_select_args a) {
-    __shared__ float cand_lp[BEAM_MAXK * BEAM_MAXK];
-    __shared__ int cand_cls[BEAM_MAXK * BEAM_MAXK];
-    const int b = blockIdx.x, k = a.k, V = a.V;
+template <int K>
+__global__ __launch_bounds__(64 * K) void beam_select_kernel(const dlsg_beam_select_args a) {
+    __shared__ float cand_lp[K * K];
+    __shared__ int cand_cls[K * K];
+    const int b = blockIdx.x, k = K, V = a.V;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int nbeam = a.first ? 1 : k;                      // step 0: the k rows of a group are identical, use row 0
     if (w < nbeam) {
@@ -773,28 +831,14 @@ __global__ __launch_bounds__(64 * BEAM_MAXK) void beam_select_kernel(const dlsg_
                 cand_cls[w * k + lane] = lane == 0 ? a.end : (lane - 1 < a.end ? lane - 1 : lane);
             }
         } else {
-            float m = -INFINITY;
-            for (int j = lane; j < V; j += 64) m = fmaxf(m, x[j]);
-            m = wave_max(m);
-            float sum = 0.f;
-            for (int j = lane; j < V; j += 64) sum += expf(x[j] - m);
-            sum = wave_sum(sum);
-            const float lse = logf(sum) + m;
-            int chosen[BEAM_MAXK];
-            for (int c = 0; c < k; ++c) {
-                float bv = -INFINITY;
-                int bi = 0x7fffffff;
-                for (int j = lane; j < V; j += 64) {
-                    bool taken = false;
-                    for (int q = 0; q < c; ++q) taken = taken || (chosen[q] == j);
-                    const float v = x[j];
-                    if (!taken && (v > bv || (v == bv && j < bi))) { bv = v; bi = j; }
-                }
-                wave_argmax(bv, bi);
-                chosen[c] = bi;
-                if (lane == 0) {
-                    cand_lp[w * k + c] = (bv - lse) + base;
-                    cand_cls[w * k + c] = bi;
+            float lse, bv[K];
+            int bi[K];
+            beam_row_topk<K>(x, V, lane, lse, bv, bi);
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    cand_lp[w * k + c] = (bv[c] - lse) + base;
+                    cand_cls[w * k + c] = bi[c];
                 }
             }
         }
@@ -1138,7 +1182,16 @@ extern "C" int dlsg_log_softmax(const float* logits, float* out, int rows, int V
 extern "C" int dlsg_beam_select(const dlsg_beam_select_args* a, void* stream) {
     if (!a || a->k < 1 || a->k > BEAM_MAXK || a->V < a->k) return DLSG_EINVAL;
     if (a->B == 0) return DLSG_OK;
-    hipLaunchKernelGGL(beam_select_kernel, dim3(a->B), dim3(64 * a->k), 0, ST(stream), *a);
+    switch (a->k) {
+        case 1: hipLaunchKernelGGL(beam_select_kernel<1>, dim3(a->B), dim3(64), 0, ST(stream), *a); break;
+        case 2: hipLaunchKernelGGL(beam_select_kernel<2>, dim3(a->B), dim3(128), 0, ST(stream), *a); break;
+        case 3: hipLaunchKernelGGL(beam_select_kernel<3>, dim3(a->B), dim3(192), 0, ST(stream), *a); break;
+        case 4: hipLaunchKernelGGL(beam_select_kernel<4>, dim3(a->B), dim3(256), 0, ST(stream), *a); break;
+        case 5: hipLaunchKernelGGL(beam_select_kernel<5>, dim3(a->B), dim3(320), 0, ST(stream), *a); break;
+        case 6: hipLaunchKernelGGL(beam_select_kernel<6>, dim3(a->B), dim3(384), 0, ST(stream), *a); break;
+        case 7: hipLaunchKernelGGL(beam_select_kernel<7>, dim3(a->B), dim3(448), 0, ST(stream), *a); break;
+        default: hipLaunchKernelGGL(beam_select_kernel<8>, dim3(a->B), dim3(512), 0, ST(stream), *a); break;
+    }
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

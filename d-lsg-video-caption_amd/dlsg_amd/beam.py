@@ -130,7 +130,8 @@ def beam_finish(model, preds, backs, lps, ended, done, B, k, R, L, extras):
         rec.append(P[0].gather(1, cur).unsqueeze(2))
         all_preds = torch.cat(list(reversed(rec)), 2)
     best = last_lp.topk(1)[1].squeeze(1)                          # layer.py:456-460
-    out = torch.stack([all_preds[i, best[i], :] for i in range(B)])
+    # (one gather: indexing clip by clip reads best[i] back to the host B times -- 128 synchronisations per batch)
+    out = all_preds.gather(1, best.view(B, 1, 1).expand(B, 1, all_preds.shape[2])).squeeze(1)
     if extras is not None:
         return out, extras[0], extras[1], []
     return out, 0, 0, 0

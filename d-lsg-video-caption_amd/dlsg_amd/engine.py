@@ -919,7 +919,8 @@ def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed, dev_coins=No
             ops.argmax(s['LOGITS'][t], ids[t + 1])
             # same (seed, site, row) mask stream as the bulk call above: rows (t+1)*B.. of the WE matrix
             ops.embed_fwd(E, ids[t + 1], s['WE'][t + 1], p=pw, seed=seed, site=SITE_WORD, row0=(t + 1) * B)
-    dec_logits(ops, dec, s, 0, L)
+    if any(coins[t] for t in range(L)):
+        dec_logits(ops, dec, s, 0, L)          # (greedy inference: every step's logits were already written above)
     return s
 
 
