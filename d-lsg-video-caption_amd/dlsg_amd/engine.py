@@ -733,7 +733,7 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     dout3 = dout.view(B, T, D2)
     gates, cst, hprev = s['gates'], s['cst'], s['hprev']
     dG = [_empty(ref, B, T, 4 * H), _empty(ref, B, T, 4 * H)]
-    if getattr(ops, 'bilstm_supported', None) is not None and ops.bilstm_supported(B, T, H):
+    if getattr(ops, 'bilstm_supported', None) is not None and getattr(ops, 'persistent_bilstm_bwd', True) and ops.bilstm_supported(B, T, H):
         # all steps of both directions: one persistent launch (beyond 64 rows the chunked form only ties with the per-step
         # schedule -- 0.997 against 0.990 ms at 128 clips -- so that case stays step by step)
         ops.bilstm_bwd(gates, cst, dout3, Whh, dG)

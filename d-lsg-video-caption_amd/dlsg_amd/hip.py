@@ -859,6 +859,7 @@ class HipOps(object):
 
     # ------------------------------------------------------------------ persistent BiLSTM recurrence
     persistent_bilstm = True      # False: the per-step schedule (grouped skinny GEMM + pointwise launch per step)
+    persistent_bilstm_bwd = True  # False: only the backward through time step by step (Trainer sets it when world_size > 1)
 
     def bilstm_supported(self, B, T, H):
         return self.persistent_bilstm and bool(self.lib.dlsg_bilstm_supported(B, T, H))

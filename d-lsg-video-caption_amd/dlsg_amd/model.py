@@ -596,6 +596,15 @@ class Trainer(object):
         self._graphs = None
         self._hook_mode, self._hook_sv = False, None
         self.m = self.v = None
+        if world_size > 1 and hasattr(model.ops, 'persistent_bilstm_bwd'):
+            # The persistent BiLSTM kernels need all of their workgroups (one per CU at H = 1024, 152 KB of LDS each) resident
+            # together.  The encoder's backward runs while the decoder bucket's all-reduce is in flight: a CU that hosts an
+            # RCCL workgroup has no room for a 152-KB one, so the launch would sit half-resident, its workgroups polling for
+            # partners that cannot start, until the collective ends -- no deadlock (RCCL does not depend on it), but the CUs
+            # it holds and the overlap window are lost.  With several ranks the backward through time therefore runs step by
+            # step (0.60 against 0.50 ms); the forward keeps the persistent launch (no collective is in flight there: the
+            # previous step's all-reduces are joined before its Adam).
+            model.ops.persistent_bilstm_bwd = False
         self._bind()
 
     def _bind(self):
