@@ -172,6 +172,9 @@ __global__ __launch_bounds__(256) void tanh_ln_fwd_kernel(const float* __restric
                                                           const float* __restrict__ beta, float* __restrict__ y, int rows, int E,
                                                           float eps) {
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, N = 64 * E;
+    // blockIdx.y = row group: `rows` consecutive rows with their own gamma / beta (several same-shape LayerNorms in one launch)
+    x += (int64_t)blockIdx.y * rows * N; y += (int64_t)blockIdx.y * rows * N;
+    gamma += blockIdx.y * N; beta += blockIdx.y * N;
     float t[EMAX];
     for (int row = gw; row < rows; row += nw) {
         const RowStats st = load_row<TANH, EMAX>(x + (int64_t)row * N, E, lane, eps, t);
@@ -189,6 +192,9 @@ __global__ __launch_bounds__(256) void tanh_ln_bwd_kernel(const float* __restric
                                                           const float* __restrict__ dy, float* __restrict__ dx,
                                                           float* __restrict__ part, int rows, int E, float eps) {
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, N = 64 * E;
+    x += (int64_t)blockIdx.y * rows * N; dy += (int64_t)blockIdx.y * rows * N; dx += (int64_t)blockIdx.y * rows * N;
+    gamma += blockIdx.y * N;
+    part += (int64_t)blockIdx.y * 2 * gridDim.x * N;                    // [group][dgamma | dbeta][workgroup][N]
     float t[EMAX], gam[EMAX], pg[EMAX], pb[EMAX];
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
@@ -242,6 +248,12 @@ __global__ __launch_bounds__(256) void tanh_ln_bwd2_kernel(const float* __restri
                                                            float* __restrict__ gx, float* __restrict__ gdy,
                                                            float* __restrict__ part, int rows, int E, float eps) {
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4, N = 64 * E;
+    {
+        const int64_t o = (int64_t)blockIdx.y * rows * N;
+        x += o; dy += o; U += o; gx += o; gdy += o;
+        gamma += blockIdx.y * N; vg += blockIdx.y * N; vb += blockIdx.y * N;
+        part += (int64_t)blockIdx.y * gridDim.x * N;                    // [group][workgroup][N]
+    }
     float t[EMAX], gam[EMAX], vgl[EMAX], vbl[EMAX], pgg[EMAX];
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
@@ -308,12 +320,13 @@ __global__ __launch_bounds__(256) void tanh_ln_bwd2_kernel(const float* __restri
         part[(int64_t)blockIdx.x * N + j] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
 }
 
-// out_k[j] = sum_w part[k][w][j], w in order (deterministic); grid (N / 64, K)
+// out_k[g][j] = sum_w part[g][k][w][j], w in order (deterministic); grid (N / 64, K, groups)
 __global__ __launch_bounds__(256) void ln_colsum_kernel(const float* __restrict__ part, int nw, int N, float* __restrict__ o0,
                                                         float* __restrict__ o1) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
-    const float* p = part + (int64_t)blockIdx.y * nw * N;
+    const float* p = part + ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * nw * N;
+    o0 += blockIdx.z * N; o1 += blockIdx.z * N;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int w = q;
     for (; w + 28 < nw; w += 32) {                       // 8 independent loads in flight per thread
@@ -383,34 +396,39 @@ extern "C" int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_p
 
 extern "C" int64_t dlsg_tanh_ln_ws_floats(int rows, int N) { return (int64_t)2 * ln_blocks(rows) * N; }
 
+// groups > 1: `groups` consecutive blocks of `rows` rows, block g normalised with gamma[g], beta[g] ((groups, N) arrays) -- the
+// same-shape LayerNorms of the critic's two proposal scorers in one launch.  ws: groups * dlsg_tanh_ln_ws_floats(rows, N).
 extern "C" int dlsg_tanh_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int N, float eps,
-                                int pre_tanh, void* stream) {
-    if (!x || !gamma || !beta || !y || rows < 0 || N < 64 || N % 64 || N > 64 * LN_MAXE) return DLSG_EINVAL;
+                                int pre_tanh, int groups, void* stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || N < 64 || N % 64 || N > 64 * LN_MAXE || groups < 1 || groups > 64) return DLSG_EINVAL;
     if (rows == 0) return DLSG_OK;
-    const dim3 grid(ln_blocks(rows)), block(256);
+    const dim3 grid(ln_blocks(rows), groups), block(256);
     LN_DISPATCH(tanh_ln_fwd_kernel, x, gamma, beta, y, rows, N / 64, eps);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
 extern "C" int dlsg_tanh_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
-                                float* ws, int rows, int N, float eps, int pre_tanh, void* stream) {
-    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !ws || rows < 1 || N < 64 || N % 64 || N > 64 * LN_MAXE) return DLSG_EINVAL;
+                                float* ws, int rows, int N, float eps, int pre_tanh, int groups, void* stream) {
+    if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !ws || rows < 1 || N < 64 || N % 64 || N > 64 * LN_MAXE || groups < 1 ||
+        groups > 64)
+        return DLSG_EINVAL;
     const int nb = ln_blocks(rows);
-    const dim3 grid(nb), block(256);
+    const dim3 grid(nb, groups), block(256);
     LN_DISPATCH(tanh_ln_bwd_kernel, x, gamma, dy, dx, ws, rows, N / 64, eps);
-    hipLaunchKernelGGL(ln_colsum_kernel, dim3(N / 64, 2), block, 0, ST(stream), ws, nb, N, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_colsum_kernel, dim3(N / 64, 2, groups), block, 0, ST(stream), ws, nb, N, dgamma, dbeta);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
 extern "C" int dlsg_tanh_ln_bwd2(const float* x, const float* gamma, const float* dy, const float* U, const float* vg, const float* vb,
                                  float* gx, float* ggamma, float* gdy, float* ws, int rows, int N, float eps, int pre_tanh,
-                                 void* stream) {
-    if (!x || !gamma || !dy || !U || !vg || !vb || !gx || !ggamma || !gdy || !ws || rows < 1 || N < 64 || N % 64 || N > 64 * LN_MAXE)
+                                 int groups, void* stream) {
+    if (!x || !gamma || !dy || !U || !vg || !vb || !gx || !ggamma || !gdy || !ws || rows < 1 || N < 64 || N % 64 || N > 64 * LN_MAXE ||
+        groups < 1 || groups > 64)
         return DLSG_EINVAL;
     const int nb = ln_blocks(rows);
-    const dim3 grid(nb), block(256);
+    const dim3 grid(nb, groups), block(256);
     LN_DISPATCH(tanh_ln_bwd2_kernel, x, gamma, dy, U, vg, vb, gx, gdy, ws, rows, N / 64, eps);
-    hipLaunchKernelGGL(ln_colsum_kernel, dim3(N / 64, 1), block, 0, ST(stream), ws, nb, N, ggamma, ggamma);
+    hipLaunchKernelGGL(ln_colsum_kernel, dim3(N / 64, 1, groups), block, 0, ST(stream), ws, nb, N, ggamma, ggamma);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -74,6 +74,22 @@ def _tanh_ln(x, ln, ops=None, pre_tanh=True):
     return F.layer_norm(torch.tanh(x) if pre_tanh else x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
 
 
+def _tanh_ln_stacked(x, gamma, beta, eps, ops):
+    """x (G, R, N), gamma / beta (G, N): G same-shape LayerNorm(tanh(x[g])) in one launch per differentiation level"""
+    return _TanhLN.apply(ops, x, gamma, beta, eps, True)
+
+
+def _linear_stacked(ops, x, W, b=None):
+    """x (G, R, K) @ W (G, N, K)^T + b (G, N): G same-shape linear layers as one batched product"""
+    g = _gemm_ops(ops, GEMM_NT, x, W)
+    if g is not None:
+        y = _Gemm.apply(g, GEMM_NT, x, W, None, 1.0)
+        return y if b is None else y + b.unsqueeze(1)
+    if b is None:
+        return torch.bmm(x, W.transpose(1, 2))
+    return torch.baddbmm(b.unsqueeze(1), x, W.transpose(1, 2))
+
+
 def _dropout(x, p, on):
     return F.dropout(x, p, True) if on and p > 0 else x
 
@@ -498,6 +514,41 @@ class DiscV2(nn.Module):
         pair = lin(sc.classify, torch.tanh(lin(sc.visual_embed[0], e)) * torch.tanh(lin(sc.sent_embed[0], agg))).squeeze(-1)
         return (pair * weight).sum(dim=-1) / weight.sum(dim=-1)                                   # (n,)
 
+    def _proposal_scores(self, psl_o, psl_m, alpha_o, alpha_m, words, word_mask):
+        """both PSLScore2 heads (object and motion proposals: same shapes, different weights) side by side: every product is one
+        batched launch over the two heads, every LayerNorm one grouped launch, every element-wise op one launch on the stacked
+        tensor -- half the launches of two `_proposal_score` calls at each differentiation level.  Same arithmetic per head."""
+        mo, mm = self.obj_psl_score, self.motion_psl_score
+        ops = self._cell_ops(words)
+        n, L, _ = words.shape
+        P = psl_o.shape[1]
+
+        def st(f):
+            return torch.stack([f(mo), f(mm)])
+
+        def lin(x, layer):
+            bias = layer(mo).bias
+            return _linear_stacked(ops, x, st(lambda m: layer(m).weight), None if bias is None else st(lambda m: layer(m).bias))
+
+        def ln(x, layer):
+            return _tanh_ln_stacked(x, st(lambda m: layer(m).weight), st(lambda m: layer(m).bias), layer(mo).eps, ops)
+        e = ln(lin(torch.stack([psl_o, psl_m]).view(2, n * P, -1), lambda m: m.psl_embed[0]), lambda m: m.psl_embed[2])
+        e = e.view(2 * n, P, WIDTH)
+        if mo.select:
+            top = torch.cat([alpha_o, alpha_m], 0).sum(dim=1).topk(mo.num_top, dim=-1).indices               # (2n, top)
+            e = e.gather(1, top.unsqueeze(-1).expand(2 * n, mo.num_top, WIDTH))
+        T = e.shape[1]
+        a = ln(lin(words.reshape(1, n * L, WIDTH).expand(2, n * L, WIDTH), lambda m: m.att_norm[0]), lambda m: m.att_norm[2])
+        a = a.view(2 * n, L, WIDTH)
+        adj = _softmax(_mm(ops, GEMM_NT, a, e, 1.0 / math.sqrt(WIDTH)), 1, ops)                            # (2n, L, T)
+        adj = (adj.view(2, n, L, T) * word_mask).view(2 * n, L, T)                                          # mask after the softmax
+        weight = adj.sum(dim=1)                                                                             # (2n, T)
+        agg = _dropout(ln(_mm(ops, GEMM_TN, adj, a).view(2, n * T, WIDTH), lambda m: m.psl_norm[1]), 0.3, self.training)
+        v = torch.tanh(lin(e.reshape(2, n * T, WIDTH), lambda m: m.psl_scorer.visual_embed[0]))
+        s_ = torch.tanh(lin(agg, lambda m: m.psl_scorer.sent_embed[0]))
+        pair = lin(v * s_, lambda m: m.psl_scorer.classify).view(2 * n, T)
+        return ((pair * weight).sum(dim=-1) / weight.sum(dim=-1)).view(2, n)                               # [object | motion] x (n,)
+
     def score_projected(self, h, obj, mot, att_mask, alpha_all, groups=1):
         """h (n,L,512) = projected captions, n = groups * B rows (`groups` caption sets scored against the same clips in one
         pass).  PSLScore2 ends with a mean over ITS batch (layer.py:714: `.mean(axis=-1)` on a (B,) tensor), so the two
@@ -519,24 +570,30 @@ class DiscV2(nn.Module):
                      0.3, self.training)
         mask = rep(att_mask)
         sa = self.att
-        logits = _mm(ops, GEMM_NT, _linear(ops, y, sa.K.weight), _linear(ops, y, sa.Q.weight), 1.0 / math.sqrt(sa.attention_size))
+        # K, Q, V: three same-shape projections of y as one batched product
+        kqv = _linear_stacked(ops, y.reshape(1, n * y.shape[1], WIDTH).expand(3, -1, -1), torch.stack([sa.K.weight, sa.Q.weight, sa.V.weight]))
+        kqv = kqv.view(3, n, y.shape[1], -1)
+        logits = _mm(ops, GEMM_NT, kqv[0], kqv[1], 1.0 / math.sqrt(sa.attention_size))
         w = _softmax(torch.where(mask > 0, logits, torch.full_like(logits, -9e15)), -1, ops)
-        ctx_ = _linear(ops, _mm(ops, GEMM_NN, w, _linear(ops, y, sa.V.weight)), sa.output_layer[0].weight)
+        ctx_ = _linear(ops, _mm(ops, GEMM_NN, w, kqv[2]), sa.output_layer[0].weight)
         words = _tanh_ln(_dropout(ctx_, sa.dropout, self.training), self.att_norm[1], ops)
         word_mask = mask[:, 0, :].unsqueeze(2)                     # (n,L,1)
         alpha = rep(alpha_all) * word_mask
         P = self.num_psl
         # (the two proposal scores and the text summary are independent; recorded on forked streams during the graph capture
         # they replay SLOWER -- 14.8 ms against 11.8 ms per critic update: cross-queue joins cost more than the launch floor saves)
-        so = self._proposal_score(self.obj_psl_score, rep(obj), alpha[:, :, :P], words, word_mask)
-        sm = self._proposal_score(self.motion_psl_score, rep(mot), alpha[:, :, -P:], words, word_mask)
-        so = so.view(groups, B).mean(dim=1).repeat_interleave(B)
-        sm = sm.view(groups, B).mean(dim=1).repeat_interleave(B)
+        if ops is not None and self.obj_psl_score.select == self.motion_psl_score.select and obj.shape == mot.shape and \
+                not os.environ.get('DLSG_CRITIC_PSL_SEPARATE'):
+            both = self._proposal_scores(rep(obj), rep(mot), alpha[:, :, :P], alpha[:, :, -P:], words, word_mask)     # (2, n)
+        else:
+            both = torch.stack([self._proposal_score(self.obj_psl_score, rep(obj), alpha[:, :, :P], words, word_mask),
+                                self._proposal_score(self.motion_psl_score, rep(mot), alpha[:, :, -P:], words, word_mask)])
+        both = both.view(2, groups, B).mean(dim=2).repeat_interleave(B, dim=1)                                        # (2, n)
         ts = self.text_sum
         adj = _softmax(_linear(ops, words, ts.theta), 1, ops)      # LatentPSL(512, 1): one latent node over the words
         sent = _dropout(_tanh_ln(_mm(ops, GEMM_TN, adj, words), ts.out_norm[1], ops), 0.3, self.training).squeeze(1)
         fus = _softmax(_linear(ops, sent, self.fusion), -1, ops)
-        return so * fus[:, 0] + sm * fus[:, 1]
+        return (both * fus.t()).sum(dim=0)
 
     def forward(self, inputs, obj_proposals, motion_proposals, att_mask=None, alpha_all=None):
         return self.score_projected(self.project(inputs), obj_proposals, motion_proposals, att_mask, alpha_all)

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 
-ABI_VERSION = 2            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
+ABI_VERSION = 3            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3 = 256, 512, 1024
@@ -241,9 +241,9 @@ def load_library(path=LIB_PATH):
         'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp, vp],
         'dlsg_fill': [vp, i64, f32, vp],
         'dlsg_tanh_ln_ws_floats': [i32, i32],
-        'dlsg_tanh_ln_fwd': [vp, vp, vp, vp, i32, i32, f32, i32, vp],
-        'dlsg_tanh_ln_bwd': [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
-        'dlsg_tanh_ln_bwd2': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, vp],
+        'dlsg_tanh_ln_fwd': [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
+        'dlsg_tanh_ln_bwd': [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
+        'dlsg_tanh_ln_bwd2': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
         'dlsg_lstm_cell_fwd': [vp, i64, vp, vp, vp, i32, i32, vp],
         'dlsg_lstm_cell_bwd_seq': [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
         'dlsg_lstm_cell_bwd': [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp],
@@ -1099,33 +1099,42 @@ class HipOps(object):
                                                  _p(gc_prev), _p(gdh), _p(gdc), n, H, self._stream()), 'lstm_cell_bwd2')
 
     # ------------------------------------------------------------------ critic (tanh +) LayerNorm, three levels
-    def _ln_ws(self, x):
+    @staticmethod
+    def _ln_geom(x, gamma):
+        """(rows per group, N, groups): gamma (N,) = one LayerNorm over all rows of x; gamma (G, N) = G LayerNorms over G
+        consecutive equal blocks of rows"""
         rows, N = x.shape
-        return torch.empty(int(self.lib.dlsg_tanh_ln_ws_floats(rows, N)), dtype=torch.float32, device=x.device)
+        G = 1 if gamma.dim() == 1 else gamma.shape[0]
+        assert rows % G == 0 and gamma.shape[-1] == N, (x.shape, gamma.shape)
+        return rows // G, N, G
+
+    def _ln_ws(self, x, gamma):
+        rows, N, G = self._ln_geom(x, gamma)
+        return torch.empty(G * int(self.lib.dlsg_tanh_ln_ws_floats(rows, N)), dtype=torch.float32, device=x.device)
 
     def tanh_ln_fwd(self, x, gamma, beta, y, eps, pre_tanh):
-        """x, y (rows, N) dense: y = LayerNorm(tanh(x) if pre_tanh else x) * gamma + beta"""
-        rows, N = x.shape
+        """x, y (rows, N) dense: y = LayerNorm(tanh(x) if pre_tanh else x) * gamma + beta; gamma / beta (G, N): G LayerNorms"""
+        rows, N, G = self._ln_geom(x, gamma)
         for t in (x, gamma, beta, y):
             _chkc(t)
-        self._check(self.lib.dlsg_tanh_ln_fwd(_p(x), _p(gamma), _p(beta), _p(y), rows, N, f32(eps), int(pre_tanh), self._stream()),
+        self._check(self.lib.dlsg_tanh_ln_fwd(_p(x), _p(gamma), _p(beta), _p(y), rows, N, f32(eps), int(pre_tanh), G, self._stream()),
                     'tanh_ln_fwd')
 
     def tanh_ln_bwd(self, x, gamma, dy, dx, dgamma, dbeta, eps, pre_tanh):
-        rows, N = x.shape
+        rows, N, G = self._ln_geom(x, gamma)
         for t in (x, gamma, dy, dx, dgamma, dbeta):
             _chkc(t)
-        ws = self._ln_ws(x)
+        ws = self._ln_ws(x, gamma)
         self._check(self.lib.dlsg_tanh_ln_bwd(_p(x), _p(gamma), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(ws), rows, N, f32(eps),
-                                              int(pre_tanh), self._stream()), 'tanh_ln_bwd')
+                                              int(pre_tanh), G, self._stream()), 'tanh_ln_bwd')
 
     def tanh_ln_bwd2(self, x, gamma, dy, U, vg, vb, gx, ggamma, gdy, eps, pre_tanh):
-        rows, N = x.shape
+        rows, N, G = self._ln_geom(x, gamma)
         for t in (x, gamma, dy, U, vg, vb, gx, ggamma, gdy):
             _chkc(t)
-        ws = self._ln_ws(x)
+        ws = self._ln_ws(x, gamma)
         self._check(self.lib.dlsg_tanh_ln_bwd2(_p(x), _p(gamma), _p(dy), _p(U), _p(vg), _p(vb), _p(gx), _p(ggamma), _p(gdy), _p(ws),
-                                               rows, N, f32(eps), int(pre_tanh), self._stream()), 'tanh_ln_bwd2')
+                                               rows, N, f32(eps), int(pre_tanh), G, self._stream()), 'tanh_ln_bwd2')
 
     def gather_rows(self, src, idx, dst):
         """dst[r] = src[idx[r]] (2-d views; dst must not alias src)."""

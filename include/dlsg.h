@@ -18,7 +18,7 @@ extern "C" {
 /* Bumped whenever the signature or the meaning of an existing entry point changes (2: dlsg_colsum / dlsg_colsum2 take a
  * workspace pointer before the stream; the RCCL communicator entry points and the persistent BiLSTM were added).  A binding
  * must refuse a library whose version differs from the header it was written against. */
-#define DLSG_ABI_VERSION 2
+#define DLSG_ABI_VERSION 3
 int dlsg_abi_version(void);
 
 /* Return codes of every entry point that returns int: 0 or one of these. */
@@ -439,12 +439,16 @@ int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_prev, const 
  * (x, gamma, dy) for cotangents (U on dx, vg on dgamma, vb on dbeta).  ws: caller scratch of dlsg_tanh_ln_ws_floats(rows, N)
  * floats (per-workgroup column partials, summed in a fixed order). */
 int64_t dlsg_tanh_ln_ws_floats(int rows, int N);
+/* groups (ABI 3): 1 = one LayerNorm over `rows` rows.  groups = G > 1: G same-shape LayerNorms in one launch (the two
+ * proposal scorers of DiscV2, layer.py:661-689, side by side): x / y / dy / ... hold G consecutive blocks of `rows` rows, gamma,
+ * beta, dgamma, dbeta, vg, vb, ggamma are (G, N); ws = G * dlsg_tanh_ln_ws_floats(rows, N) floats. */
 int dlsg_tanh_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int N, float eps, int pre_tanh,
-                     void* stream);
+                     int groups, void* stream);
 int dlsg_tanh_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* ws,
-                     int rows, int N, float eps, int pre_tanh, void* stream);
+                     int rows, int N, float eps, int pre_tanh, int groups, void* stream);
 int dlsg_tanh_ln_bwd2(const float* x, const float* gamma, const float* dy, const float* U, const float* vg, const float* vb,
-                      float* gx, float* ggamma, float* gdy, float* ws, int rows, int N, float eps, int pre_tanh, void* stream);
+                      float* gx, float* ggamma, float* gdy, float* ws, int rows, int N, float eps, int pre_tanh, int groups,
+                      void* stream);
 
 /* ---------------------------------------------------------------- loss + optimizer (run_gun.py:189-198, :91)
  * Ragged CrossEntropy: row (b,t) counts iff t < lens[b]; loss = mean over counted rows; dlogits written for all

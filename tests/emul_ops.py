@@ -542,17 +542,35 @@ class EmulOps(object):
         r = (((t - mu) ** 2).mean(1, keepdim=True) + eps).rsqrt()
         return t, r, (t - mu) * r, ((1 - t * t) if pre_tanh else torch.ones_like(t))
 
+    @staticmethod
+    def _ln_groups(gamma, *rowwise):
+        """gamma (G, N): the row tensors as G consecutive blocks (csrc/critic.hip blockIdx.y)"""
+        G = gamma.shape[0]
+        return [[t.view(G, -1, t.shape[-1])[g] for t in rowwise] for g in range(G)]
+
     def tanh_ln_fwd(self, x, gamma, beta, y, eps, pre_tanh):
+        if gamma.dim() == 2:
+            for g, (xg, yg) in enumerate(self._ln_groups(gamma, x, y)):
+                self.tanh_ln_fwd(xg, gamma[g], beta[g], yg, eps, pre_tanh)
+            return
         t, r, n, s = self._ln_stats(x, eps, pre_tanh)
         y.copy_(n * gamma + beta)
 
     def tanh_ln_bwd(self, x, gamma, dy, dx, dgamma, dbeta, eps, pre_tanh):
+        if gamma.dim() == 2:
+            for g, (xg, dyg, dxg) in enumerate(self._ln_groups(gamma, x, dy, dx)):
+                self.tanh_ln_bwd(xg, gamma[g], dyg, dxg, dgamma[g], dbeta[g], eps, pre_tanh)
+            return
         t, r, n, s = self._ln_stats(x, eps, pre_tanh)
         a = dy * gamma
         dt = r * (a - a.mean(1, keepdim=True) - n * (a * n).mean(1, keepdim=True))
         dx.copy_(dt * s); dgamma.copy_((dy * n).sum(0)); dbeta.copy_(dy.sum(0))
 
     def tanh_ln_bwd2(self, x, gamma, dy, U, vg, vb, gx, ggamma, gdy, eps, pre_tanh):
+        if gamma.dim() == 2:
+            for g, (xg, dyg, Ug, gxg, gdyg) in enumerate(self._ln_groups(gamma, x, dy, U, gx, gdy)):
+                self.tanh_ln_bwd2(xg, gamma[g], dyg, Ug, vg[g], vb[g], gxg, ggamma[g], gdyg, eps, pre_tanh)
+            return
         N = x.shape[1]
         t, r, n, s = self._ln_stats(x, eps, pre_tanh)
         a = dy * gamma

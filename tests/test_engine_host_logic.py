@@ -489,4 +489,5 @@ def test_critic_fused_cell_and_conv_follow_the_plain_recurrence():
     for k in p0:
         assert (p0[k] - p1[k]).abs().max().item() <= 1e-9 * max(1.0, p0[k].abs().max().item()), k
     # every product of the critic went through the kernel interface's GEMM, at all three differentiation levels (gan._Gemm)
-    assert D1._ops.calls.get('gemm', 0) + D1._ops.calls.get('gemm_narrow', 0) >= 150 and D1._ops.calls.get('gemm_narrow', 0) >= 50, D1._ops.calls
+    # (119 products per update since the two proposal scorers and the K / Q / V projections run as batched products; 175 one by one)
+    assert D1._ops.calls.get('gemm', 0) + D1._ops.calls.get('gemm_narrow', 0) >= 100 and D1._ops.calls.get('gemm_narrow', 0) >= 50, D1._ops.calls
