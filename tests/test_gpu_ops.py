@@ -871,6 +871,23 @@ def test_critic_tanh_layernorm_three_levels(hip, rows, N, pre_tanh):
     both(hip, build, run, ['y', 'dx', 'dg', 'db', 'gx', 'gg', 'gdy'], tol=3e-5, name='critic ln %d x %d' % (rows, N))
 
 
+@pytest.mark.parametrize('rows,N,G,pre_tanh', [(576, 512, 2, True), (4992, 512, 2, True), (2100, 512, 3, False), (5, 64, 4, True)])
+def test_critic_tanh_layernorm_grouped(hip, rows, N, G, pre_tanh):
+    """`groups` of csrc/critic.hip's LayerNorm kernels (ABI 3): G same-shape LayerNorms with their own gamma / beta over G
+    consecutive row blocks in one launch per level (the critic's two proposal scorers side by side), against the ATen formulas
+    applied block by block"""
+    def build(g):
+        return dict(x=rnd(g, G * rows, N, scale=1.5), gam=rnd(g, G, N), bet=rnd(g, G, N), dy=rnd(g, G * rows, N), U=rnd(g, G * rows, N),
+                    vg=rnd(g, G, N), vb=rnd(g, G, N), y=torch.zeros(G * rows, N), dx=torch.zeros(G * rows, N), dg=torch.zeros(G, N),
+                    db=torch.zeros(G, N), gx=torch.zeros(G * rows, N), gg=torch.zeros(G, N), gdy=torch.zeros(G * rows, N))
+
+    def run(ops, t):
+        ops.tanh_ln_fwd(t['x'], t['gam'], t['bet'], t['y'], 1e-5, pre_tanh)
+        ops.tanh_ln_bwd(t['x'], t['gam'], t['dy'], t['dx'], t['dg'], t['db'], 1e-5, pre_tanh)
+        ops.tanh_ln_bwd2(t['x'], t['gam'], t['dy'], t['U'], t['vg'], t['vb'], t['gx'], t['gg'], t['gdy'], 1e-5, pre_tanh)
+    both(hip, build, run, ['y', 'dx', 'dg', 'db', 'gx', 'gg', 'gdy'], tol=3e-5, name='critic ln %d x %d x %d groups' % (rows, N, G))
+
+
 def test_critic_lstm_cell_sequence_step(hip):
     """the backward step of the whole-sequence op: optional second dh / dc pieces and injection on da, NULL = zero"""
     n, H = 192, 512
