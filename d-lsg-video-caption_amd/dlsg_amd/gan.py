@@ -475,9 +475,10 @@ class DiscV2(nn.Module):
             ops = _hip_ops()                                       # raises if libdlsg_hip.so is missing: no silent fallback on a GPU
         return ops
 
-    def _lstm(self, x):
+    def _lstm(self, x, time_major=False):
         """single-layer LSTM, zero initial state, gate order i,f,g,o; unrolled so that autograd can differentiate it twice:
-        the recurrent product is an ordinary matmul per step, the cell's pointwise part one fused op per step."""
+        the recurrent product is an ordinary matmul per step, the cell's pointwise part one fused op per step.
+        time_major (kernel path only): return the (L, n, 512) array the recurrence writes instead of its (n, L, 512) view."""
         w_ih, w_hh = self.lstm.weight_ih_l0, self.lstm.weight_hh_l0
         bias = self.lstm.bias_ih_l0 + self.lstm.bias_hh_l0
         n, L, _ = x.shape
@@ -488,7 +489,8 @@ class DiscV2(nn.Module):
         if ops is not None:
             # the whole recurrence as one node per differentiation level (time-major: a step's rows are dense)
             xin = _linear(ops, x.transpose(0, 1).contiguous(), w_ih, bias)
-            return _LstmSeq.apply(ops, xin, w_hh)[0].transpose(0, 1)
+            hs = _LstmSeq.apply(ops, xin, w_hh)[0]
+            return hs if time_major else hs.transpose(0, 1)
         xin = F.linear(x, w_ih, bias)                              # all steps' input gates in one product
         for t in range(L):
             i, f, g, o = (xin[:, t] + F.linear(h, w_hh)).chunk(4, dim=1)
@@ -566,14 +568,22 @@ class DiscV2(nn.Module):
         taps = torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=2)                          # (n, L, 3 x 512): x[t-1] | x[t] | x[t+1]
         ops = self._cell_ops(h)
         x = x + 0.3 * _linear(ops, taps, conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1), conv.bias)
-        y = _dropout(_tanh_ln(self._lstm(x), self.layer_norm, ops, pre_tanh=False),
-                     0.3, self.training)
         mask = rep(att_mask)
         sa = self.att
+        Lw = x.shape[1]
+        if ops is not None:
+            # LayerNorm, dropout and the K / Q / V projections are row-wise: they run on the time-major rows the recurrence
+            # wrote (no transposed copy of the sequence at any differentiation level); the attention products below read the
+            # per-caption (L, 512) blocks as strided views
+            y = _dropout(_tanh_ln(self._lstm(x, time_major=True), self.layer_norm, ops, pre_tanh=False), 0.3, self.training)
+            rows = y.reshape(1, Lw * n, WIDTH)
+        else:
+            y = _dropout(_tanh_ln(self._lstm(x), self.layer_norm, ops, pre_tanh=False), 0.3, self.training)
+            rows = y.reshape(1, n * Lw, WIDTH)
         # K, Q, V: three same-shape projections of y as one batched product
-        kqv = _linear_stacked(ops, y.reshape(1, n * y.shape[1], WIDTH).expand(3, -1, -1), torch.stack([sa.K.weight, sa.Q.weight, sa.V.weight]))
-        kqv = kqv.view(3, n, y.shape[1], -1)
-        logits = _mm(ops, GEMM_NT, kqv[0], kqv[1], 1.0 / math.sqrt(sa.attention_size))
+        kqv = _linear_stacked(ops, rows.expand(3, -1, -1), torch.stack([sa.K.weight, sa.Q.weight, sa.V.weight]))
+        kqv = kqv.view(3, Lw, n, -1).transpose(1, 2).unbind(0) if ops is not None else kqv.view(3, n, Lw, -1).unbind(0)
+        logits = _mm(ops, GEMM_NT, kqv[0], kqv[1], 1.0 / math.sqrt(sa.attention_size))                    # (n, L, L)
         w = _softmax(torch.where(mask > 0, logits, torch.full_like(logits, -9e15)), -1, ops)
         ctx_ = _linear(ops, _mm(ops, GEMM_NN, w, kqv[2]), sa.output_layer[0].weight)
         words = _tanh_ln(_dropout(ctx_, sa.dropout, self.training), self.att_norm[1], ops)
