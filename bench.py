@@ -431,6 +431,8 @@ def main():
     ap.add_argument('--no-batch128', action='store_true', help='skip the extra N = 1 measurement at 128 clips per GPU')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
     ap.add_argument('--no-gan', action='store_true', help='skip the GAN-iteration leg (SURVEY.md 8f rank 1)')
+    ap.add_argument('--leg', default=None, choices=['gan_iteration'],
+                    help='(internal) run only this side leg and print its JSON: the parent bench starts it as a child process')
     ap.add_argument('--no-inference', action='store_true', help='skip the inference leg (BASELINE configs[4])')
     ap.add_argument('--no-msrvtt', action='store_true', help='skip the MSR-VTT-shaped batch-64 leg (BASELINE configs[2] per GPU)')
     ap.add_argument('--comm', default='auto', choices=['auto', 'rccl', 'torch'],
@@ -440,6 +442,9 @@ def main():
     if a.gpus < 1:
         ap.error('--gpus must be >= 1')
 
+    if a.leg == 'gan_iteration':
+        print(json.dumps(gan_iteration_leg(torch.device('cuda', 0), a.batch, with_eager=not a.no_eager_baseline)))
+        return
     if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
         sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -696,7 +701,10 @@ def main():
         if world == 1 and not a.no_eager_baseline and a.shape == 'msvd':
             leg('vs_pytorch_rocm_eager', eager_leg)
         if world == 1 and not a.no_gan and a.shape == 'msvd' and a.gemm == 'fp32' and not a.no_graphs:
-            leg('gan_iteration', lambda: gan_iteration_leg(dev, a.batch, with_eager=not a.no_eager_baseline))
+            # in a child process: this leg is PyTorch autograd + rocBLAS + captured graphs around this repo's kernels; whatever
+            # happens in there (an abort inside a vendor library included) must not cost the line
+            leg('gan_iteration', lambda: child_leg('gan_iteration', ['--batch', str(a.batch)] +
+                                                   (['--no-eager-baseline'] if a.no_eager_baseline else []), 900))
         if world == 1 and not a.no_cpu_baseline:
             leg('cpu_baseline', cpu_baseline)
         out['dtype_note'] = {'fp32': 'all products on fp32-input MFMA (exact fp32)',
@@ -711,6 +719,21 @@ def main():
         dist.barrier()
         tr.close()
         dist.destroy_process_group()
+
+
+def child_leg(name, extra, timeout_s):
+    """run `bench.py --leg name` as a child process (started with Popen, never exec'd over this process) and return the JSON
+    object it prints; a crash or a time-out becomes an {'error': ...} field of the parent's line"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--leg', name] + extra
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {'error': 'child process timed out after %d s' % timeout_s}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    if r.returncode != 0 or not lines:
+        return {'error': 'child process exited with code %d' % r.returncode, 'stderr_tail': r.stderr[-400:]}
+    return json.loads(lines[-1])
 
 
 def socket_hostname():
