@@ -516,7 +516,7 @@ class DiscV2(nn.Module):
         pair = lin(sc.classify, torch.tanh(lin(sc.visual_embed[0], e)) * torch.tanh(lin(sc.sent_embed[0], agg))).squeeze(-1)
         return (pair * weight).sum(dim=-1) / weight.sum(dim=-1)                                   # (n,)
 
-    def _proposal_scores(self, psl_o, psl_m, alpha_o, alpha_m, words, word_mask):
+    def _proposal_scores(self, psl_o, psl_m, alpha_o, alpha_m, words, word_mask, groups=1):
         """both PSLScore2 heads (object and motion proposals: same shapes, different weights) side by side: every product is one
         batched launch over the two heads, every LayerNorm one grouped launch, every element-wise op one launch on the stacked
         tensor -- half the launches of two `_proposal_score` calls at each differentiation level.  Same arithmetic per head."""
@@ -524,6 +524,7 @@ class DiscV2(nn.Module):
         ops = self._cell_ops(words)
         n, L, _ = words.shape
         P = psl_o.shape[1]
+        assert n == groups * psl_o.shape[0]
 
         def st(f):
             return torch.stack([f(mo), f(mm)])
@@ -534,8 +535,10 @@ class DiscV2(nn.Module):
 
         def ln(x, layer):
             return _tanh_ln_stacked(x, st(lambda m: layer(m).weight), st(lambda m: layer(m).bias), layer(mo).eps, ops)
-        e = ln(lin(torch.stack([psl_o, psl_m]).view(2, n * P, -1), lambda m: m.psl_embed[0]), lambda m: m.psl_embed[2])
-        e = e.view(2 * n, P, WIDTH)
+        # the proposals are the clips' (B rows), the same for every caption set scored against them: embedded once, then repeated
+        Bc = psl_o.shape[0]
+        e = ln(lin(torch.stack([psl_o, psl_m]).view(2, Bc * P, -1), lambda m: m.psl_embed[0]), lambda m: m.psl_embed[2])
+        e = e.view(2, 1, Bc, P, WIDTH).expand(2, groups, Bc, P, WIDTH).reshape(2 * n, P, WIDTH)
         if mo.select:
             top = torch.cat([alpha_o, alpha_m], 0).sum(dim=1).topk(mo.num_top, dim=-1).indices               # (2n, top)
             e = e.gather(1, top.unsqueeze(-1).expand(2 * n, mo.num_top, WIDTH))
@@ -594,7 +597,7 @@ class DiscV2(nn.Module):
         # they replay SLOWER -- 14.8 ms against 11.8 ms per critic update: cross-queue joins cost more than the launch floor saves)
         if ops is not None and self.obj_psl_score.select == self.motion_psl_score.select and obj.shape == mot.shape and \
                 not os.environ.get('DLSG_CRITIC_PSL_SEPARATE'):
-            both = self._proposal_scores(rep(obj), rep(mot), alpha[:, :, :P], alpha[:, :, -P:], words, word_mask)     # (2, n)
+            both = self._proposal_scores(obj, mot, alpha[:, :, :P], alpha[:, :, -P:], words, word_mask, groups)       # (2, n)
         else:
             both = torch.stack([self._proposal_score(self.obj_psl_score, rep(obj), alpha[:, :, :P], words, word_mask),
                                 self._proposal_score(self.motion_psl_score, rep(mot), alpha[:, :, -P:], words, word_mask)])
