@@ -339,6 +339,36 @@ __global__ __launch_bounds__(256) void ln_colsum_kernel(const float* __restrict_
     if (q == 0) (blockIdx.y == 0 ? o0 : o1)[j] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
+// ------------------------------------------------------------------------------------------------ Conv1d(k = 3) taps
+// DiscV2's ResBlock convolution (sublayer.py:107-119, Conv1d(512, 512, 3, padding = 1) over the word axis) is ONE product on the
+// three shifted copies of the sequence:  taps[b, t, k C + c] = x[b, t + k - 1, c]  (zero outside the caption).  Built from ATen
+// ops (pad + three slices + cat) that is 5 launches forward and ~10 per backward level (every slice gradient is a zero-filled
+// (n, L + 2, C) array plus a copy); here it is one launch, and so is its adjoint
+//    dx[b, t, c] = sum_k d[b, t - k + 1, k C + c],
+// the two being each other's backward (both are linear maps).
+__global__ __launch_bounds__(256) void conv_taps_kernel(const float* __restrict__ x, float* __restrict__ y, int n, int L, int C4,
+                                                        int adjoint) {
+    const int64_t total = (int64_t)n * L * (adjoint ? C4 : 3 * C4);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        if (!adjoint) {
+            const int c = (int)(i % C4), k = (int)((i / C4) % 3);
+            const int64_t row = i / (3 * C4);
+            const int t = (int)(row % L) + k - 1;
+            y4[i] = (t >= 0 && t < L) ? x4[(row + k - 1) * C4 + c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            const int c = (int)(i % C4);
+            const int64_t row = i / C4;
+            const int t = (int)(row % L);
+            f32x4 acc = x4[row * 3 * C4 + C4 + c];                                   // k = 1: d[b, t]
+            if (t + 1 < L) acc += x4[(row + 1) * 3 * C4 + c];                        // k = 0: d[b, t + 1]
+            if (t > 0) acc += x4[(row - 1) * 3 * C4 + 2 * C4 + c];                   // k = 2: d[b, t - 1]
+            y4[i] = acc;
+        }
+    }
+}
+
 inline int ln_blocks(int rows) { return rows < 2048 ? (rows + 3) / 4 : 512; }
 
 // rows of up to 512 columns keep 8 values per lane in registers, wider ones 16
@@ -390,6 +420,16 @@ extern "C" int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_p
     if (rows == 0) return DLSG_OK;
     hipLaunchKernelGGL(cell_bwd2_kernel, dim3((rows * H + 255) / 256), dim3(256), 0, ST(stream), a, lda, c_prev, dh, dc, u, uc, ga,
                        gc_prev, gdh, gdc, rows, H);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+extern "C" int dlsg_conv_taps(const float* x, float* y, int n, int L, int C, int adjoint, void* stream) {
+    if (!x || !y || n < 0 || L < 1 || C < 4 || (C & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)) return DLSG_EINVAL;
+    if (n == 0) return DLSG_OK;
+    const int64_t total = (int64_t)n * L * (adjoint ? C / 4 : 3 * (C / 4));
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_taps_kernel, dim3(blocks), dim3(256), 0, ST(stream), x, y, n, L, C / 4, adjoint);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

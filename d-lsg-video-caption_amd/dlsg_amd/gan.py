@@ -74,6 +74,25 @@ def _tanh_ln(x, ln, ops=None, pre_tanh=True):
     return F.layer_norm(torch.tanh(x) if pre_tanh else x, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
 
 
+class _Taps(torch.autograd.Function):
+    """x (n, L, C) -> (n, L, 3C) = [x[t-1] | x[t] | x[t+1]] (adjoint=False) or the transposed map (adjoint=True): one launch each
+    (csrc/critic.hip conv_taps_kernel), each the other's backward -- instead of pad + three slices + cat and, per backward level,
+    three zero-filled (n, L + 2, C) slice gradients with their copies and adds."""
+
+    @staticmethod
+    def forward(ctx, ops, x, adjoint):
+        x = x.contiguous()
+        C_ = x.shape[2] // 3 if adjoint else x.shape[2]
+        y = x.new_empty(x.shape[0], x.shape[1], C_ if adjoint else 3 * C_)
+        ops.conv_taps(x, y, adjoint)
+        ctx.ops, ctx.adjoint = ops, adjoint
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return None, _Taps.apply(ctx.ops, dy, not ctx.adjoint), None
+
+
 def _tanh_ln_stacked(x, gamma, beta, eps, ops):
     """x (G, R, N), gamma / beta (G, N): G same-shape LayerNorm(tanh(x[g])) in one launch per differentiation level"""
     return _TanhLN.apply(ops, x, gamma, beta, eps, True)
@@ -567,9 +586,12 @@ class DiscV2(nn.Module):
         conv = self.block[0].res_block[1]
         # Conv1d(512, 512, 3, padding=1) over the word axis as ONE product on the three shifted copies of the sequence
         # (MIOpen's choice for this shape is an im2col + GEMM per sample: 2 x 192 launches per call)
-        xp = F.pad(x, (0, 0, 1, 1))
-        taps = torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=2)                          # (n, L, 3 x 512): x[t-1] | x[t] | x[t+1]
         ops = self._cell_ops(h)
+        if ops is not None and hasattr(ops, 'conv_taps') and (x.dtype == torch.float32 or getattr(ops, 'name', '') != 'hip'):
+            taps = _Taps.apply(ops, x, False)                                                   # (n, L, 3 x 512): x[t-1] | x[t] | x[t+1]
+        else:
+            xp = F.pad(x, (0, 0, 1, 1))
+            taps = torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=2)
         x = x + 0.3 * _linear(ops, taps, conv.weight.permute(0, 2, 1).reshape(conv.weight.shape[0], -1), conv.bias)
         mask = rep(att_mask)
         sa = self.att

@@ -190,7 +190,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd', 'dlsg_o2v_bwd_multi', 'dlsg_o2v_bwd_gen1',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
            'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2', 'dlsg_lstm_cell_bwd_seq',
-           'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2',
+           'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2', 'dlsg_conv_taps',
            'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd', 'dlsg_bilstm_bwd_x_floats', 'dlsg_bilstm_bwd',
            'dlsg_lstm_seq_supported', 'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_lstm_seq',
            'dlsg_gemm_narrow_kind', 'dlsg_gemm_narrow_ws_floats', 'dlsg_gemm_narrow',
@@ -240,6 +240,7 @@ def load_library(path=LIB_PATH):
         'dlsg_copy2d': [vp, i64, vp, i64, i32, i32, i32, vp],
         'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp, vp],
         'dlsg_fill': [vp, i64, f32, vp],
+        'dlsg_conv_taps': [vp, vp, i32, i32, i32, i32, vp],
         'dlsg_tanh_ln_ws_floats': [i32, i32],
         'dlsg_tanh_ln_fwd': [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
         'dlsg_tanh_ln_bwd': [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
@@ -1099,6 +1100,14 @@ class HipOps(object):
                                                  _p(gc_prev), _p(gdh), _p(gdc), n, H, self._stream()), 'lstm_cell_bwd2')
 
     # ------------------------------------------------------------------ critic (tanh +) LayerNorm, three levels
+    def conv_taps(self, x, y, adjoint):
+        """adjoint False: x (n, L, C) -> y (n, L, 3C) = [x[t-1] | x[t] | x[t+1]] (zeros outside the sequence); True: the transpose"""
+        n, L = x.shape[:2]
+        C_ = y.shape[2] if adjoint else x.shape[2]
+        assert (x.shape[2], y.shape[2]) == ((3 * C_, C_) if adjoint else (C_, 3 * C_)) and y.shape[:2] == x.shape[:2]
+        _chkc(x); _chkc(y)
+        self._check(self.lib.dlsg_conv_taps(_p(x), _p(y), n, L, C_, int(adjoint), self._stream()), 'conv_taps')
+
     @staticmethod
     def _ln_geom(x, gamma):
         """(rows per group, N, groups): gamma (N,) = one LayerNorm over all rows of x; gamma (G, N) = G LayerNorms over G

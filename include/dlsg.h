@@ -433,6 +433,12 @@ int dlsg_lstm_cell_bwd_seq(const float* a, int64_t lda, const float* c_prev, con
 int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, const float* u,
                         const float* uc, float* ga, float* gc_prev, float* gdh, float* gdc, int rows, int H, void* stream);
 
+/* The three shifted copies of a sequence that turn DiscV2's ResBlock convolution (Conv1d(512, 512, 3, padding = 1) over the word
+ * axis, sublayer.py:107-119) into one product: adjoint == 0: x (n, L, C) -> y (n, L, 3C), y[b, t, k C + c] = x[b, t + k - 1, c]
+ * (zero outside 0 <= t + k - 1 < L); adjoint != 0: x (n, L, 3C) -> y (n, L, C), the transposed map (the gradient of the first).
+ * Dense arrays, C % 4 == 0, 16-byte aligned. */
+int dlsg_conv_taps(const float* x, float* y, int n, int L, int C, int adjoint, void* stream);
+
 /* The critic's normalisations y = LayerNorm(tanh(x)) (pre_tanh = 1) or LayerNorm(x) over dense rows of N = 64..1024 columns
  * (N % 64 == 0), eps inside the square root, biased variance (models/model.py:124-131, layer.py:661-689), again at the three
  * levels of the WGAN-GP update: fwd; bwd = (dx, dgamma, dbeta) from dy; bwd2 = vector-Jacobian product of bwd w.r.t.

@@ -542,6 +542,15 @@ class EmulOps(object):
         r = (((t - mu) ** 2).mean(1, keepdim=True) + eps).rsqrt()
         return t, r, (t - mu) * r, ((1 - t * t) if pre_tanh else torch.ones_like(t))
 
+    def conv_taps(self, x, y, adjoint):
+        C = y.shape[2] if adjoint else x.shape[2]
+        if not adjoint:
+            xp = torch.nn.functional.pad(x, (0, 0, 1, 1))
+            y.copy_(torch.cat([xp[:, :-2], xp[:, 1:-1], xp[:, 2:]], dim=2))
+        else:
+            dp = torch.nn.functional.pad(x, (0, 0, 1, 1))                      # d[t+1, 0:C] + d[t, C:2C] + d[t-1, 2C:3C]
+            y.copy_(dp[:, 2:, :C] + dp[:, 1:-1, C:2 * C] + dp[:, :-2, 2 * C:])
+
     @staticmethod
     def _ln_groups(gamma, *rowwise):
         """gamma (G, N): the row tensors as G consecutive blocks (csrc/critic.hip blockIdx.y)"""

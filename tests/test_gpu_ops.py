@@ -1237,3 +1237,23 @@ def test_narrow_products_against_matmul(hip, mode, M, N, K, nb):
     assert err <= 2e-6 * max(1.0, want.abs().max().item()) * math.sqrt(K), (kind, err)
     assert torch.isnan(Cbuf[..., N:]).all()                 # nothing written past the view
     assert hip.gemm_narrow_kind(GEMM_NT, 64, 64, 64, 1) == 0 and hip.gemm_narrow_kind(GEMM_NN, 64, 64, 33, 1) == 0
+
+
+@pytest.mark.parametrize('n,L,C', [(192, 26, 512), (3, 1, 8), (5, 2, 64), (64, 26, 512)])
+def test_conv_taps_and_adjoint(hip, n, L, C):
+    """csrc/critic.hip conv_taps_kernel: the three shifted copies of a sequence (DiscV2's k = 3 convolution as one product) and
+    the transposed map, against pad + slices + cat; <A x, d> == <x, A^T d> ties the two launches to each other"""
+    def build(g):
+        return dict(x=rnd(g, n, L, C), d=rnd(g, n, L, 3 * C), y=torch.zeros(n, L, 3 * C), dx=torch.zeros(n, L, C))
+
+    def run(ops, t):
+        ops.conv_taps(t['x'], t['y'], False)
+        ops.conv_taps(t['d'], t['dx'], True)
+    both(hip, build, run, ['y', 'dx'], tol=1e-6, name='conv taps %d x %d x %d' % (n, L, C))
+    g = torch.Generator().manual_seed(5)
+    x, d = rnd(g, n, L, C).cuda(), rnd(g, n, L, 3 * C).cuda()
+    y, dx = torch.empty(n, L, 3 * C, device='cuda'), torch.empty(n, L, C, device='cuda')
+    hip.conv_taps(x, y, False)
+    hip.conv_taps(d, dx, True)
+    a, b = (y.double() * d.double()).sum().item(), (x.double() * dx.double()).sum().item()
+    assert abs(a - b) <= 1e-5 * max(1.0, abs(a), float(n * L * C) ** 0.5)          # dx sums three floats in fp32
