@@ -116,6 +116,7 @@ __global__ __launch_bounds__(DT) void dec_mid_fwd_kernel(const dlsg_dec_mid_args
     __shared__ float sc[2 * MAXP], wt[2 * MAXP];
     __shared__ float red[32];
     const int b = blockIdx.x;
+    const int bk = a.kv_div > 1 ? b / a.kv_div : b;          // the block of K', V' this row attends over
     const int Q = a.Q, H = a.H, P = a.P, ns = a.nstream;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(DT) void dec_mid_fwd_kernel(const dlsg_dec_mid_args
     // ---- attention scores of every stream: score_p = K'[b,p,:] . q * scale  (one wave per dot)
     for (int d = w; d < ns * P; d += DT / 64) {
         const int s = d / P, p = d % P;
-        const float* kp = a.Kp[s] + ((int64_t)b * P + p) * Q;
+        const float* kp = a.Kp[s] + ((int64_t)bk * P + p) * Q;
         float acc = 0.f;
 #pragma unroll 4
         for (int j = lane * V; j < Q; j += 64 * V) {
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(DT) void dec_mid_fwd_kernel(const dlsg_dec_mid_args
     float* cb = gb;
     for (int it = threadIdx.x * V; it < ns * H; it += DT * V) {
         const int s = it / H, j = it % H;
-        const float* vp = a.Vp[s] + (int64_t)b * P * H + j;
+        const float* vp = a.Vp[s] + (int64_t)bk * P * H + j;
         float acc[V], t[4][V];
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;

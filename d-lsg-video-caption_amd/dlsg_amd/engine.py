@@ -829,7 +829,7 @@ def dec_step(ops, dec, s, t, ref, training, seed, B, word_dropout=True):
                     [s['CPRE'][i][t] for i in range(ns)], [s['CTX'][i][t] for i in range(ns)],
                     [s['ST_C'][i][t] for i in range(ns)], s['ALPHA'][t],
                     [a.dropout if training else 0.0 for a in atts], [site + SITE_ATT1 + i for i in range(ns)],
-                    1.0 / math.sqrt(H), seed=seed)
+                    1.0 / math.sqrt(H), seed=seed, **({'kv_div': s['kv_div']} if s.get('kv_div', 1) > 1 else {}))
     # ---- language LSTM
     segs = [(s['CTX'][i][t], ll.weight_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]]) for i in range(ns)]
     segs.append((s['QCUR'][t], ll.weight_ih[:, plan.l_q[0]:plan.l_q[1]]))

@@ -153,7 +153,7 @@ class DecMidArgs(C.Structure):
                 ('Kp', C.c_void_p * 2), ('Vp', C.c_void_p * 2), ('lnc_g', C.c_void_p * 2), ('lnc_b', C.c_void_p * 2),
                 ('cpre', C.c_void_p * 2), ('ctx', C.c_void_p * 2), ('st_c', C.c_void_p * 2), ('alpha', c_f32p),
                 ('p_att', f32 * 2), ('site_att', u32 * 2), ('B', i32), ('Q', i32), ('H', i32), ('P', i32), ('nstream', i32),
-                ('scale', f32), ('eps', f32), ('seed', u64), ('seed_ptr', c_f32p)]
+                ('scale', f32), ('eps', f32), ('kv_div', i32), ('seed', u64), ('seed_ptr', c_f32p)]
 
 
 class DecTailArgs(C.Structure):
@@ -763,10 +763,13 @@ class HipOps(object):
 
     # ------------------------------------------------------------------ fused decoder step
     def dec_mid_fwd(self, slabs, addend, b_ih, b_hh, c_prev, c, h, gates, lnq, qcur, st_q, p_q, site_q, Kp, Vp, lnc, cpre,
-                    ctx, st_c, alpha, p_att, site_att, scale, seed=0, eps=1e-5):
+                    ctx, st_c, alpha, p_att, site_att, scale, seed=0, eps=1e-5, kv_div=1):
         """query cell pointwise -> LN(+dropout) -> attention over Kp/Vp (per stream) -> tanh -> LN(+dropout); one launch.
-        lnq = (gamma, beta); lnc = [(gamma, beta)] per stream."""
+        lnq = (gamma, beta); lnc = [(gamma, beta)] per stream.  kv_div = k > 1: Kp / Vp hold one block per k consecutive rows
+        (beam search: the k beams of a clip share their clip's K', V')."""
         a = DecMidArgs()
+        a.kv_div = kv_div
+        assert Kp[0].size(0) * max(1, kv_div) == c.size(0), (Kp[0].shape, c.shape, kv_div)
         a.slabs, a.nslab, a.slab_stride = _p(slabs), slabs.size(0), slabs.stride(0)
         a.addend, a.ldadd = _p(addend), (addend.stride(0) if addend is not None else 0)
         a.b_ih, a.b_hh, a.c_prev, a.c, a.h, a.gates = _p(b_ih), _p(b_hh), _p(c_prev), _p(c), _p(h), _p(gates)

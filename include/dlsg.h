@@ -286,6 +286,10 @@ typedef struct {
     float p_att[2]; uint32_t site_att[2];
     int32_t B, Q, H, P, nstream;
     float scale, eps;
+    int32_t kv_div;                              /* <= 1: row b attends over K'[b], V'[b].  k > 1 (beam search: the k beams of a
+                                                    clip are consecutive rows): row b attends over K'[b / k], V'[b / k], which
+                                                    then hold one block per CLIP -- the beams share the lines in L2 instead of
+                                                    each streaming its own expanded copy */
     uint64_t seed; const uint64_t* seed_ptr;
 } dlsg_dec_mid_args;
 int dlsg_dec_mid_fwd(const dlsg_dec_mid_args* a, void* stream);

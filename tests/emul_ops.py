@@ -352,9 +352,12 @@ class EmulOps(object):
 
     # ------------------------------------------------------------------ LSTM pointwise
     def dec_mid_fwd(self, slabs, addend, b_ih, b_hh, c_prev, c, h, gates, lnq, qcur, st_q, p_q, site_q, Kp, Vp, lnc, cpre,
-                    ctx, st_c, alpha, p_att, site_att, scale, seed=0, eps=1e-5):
+                    ctx, st_c, alpha, p_att, site_att, scale, seed=0, eps=1e-5, kv_div=1):
         # the fused launch is, by definition, the unfused chain
         B, Q = c.shape
+        if kv_div > 1:                                              # the k beams of a clip attend over the clip's K', V'
+            Kp = [x.repeat_interleave(kv_div, dim=0) for x in Kp]
+            Vp = [x.repeat_interleave(kv_div, dim=0) for x in Vp]
         self.lstm_pw_fwd(slabs, c, B, Q, addend=addend, b_ih=b_ih, b_hh=b_hh, c_prev=c_prev, h=h, gates=gates)
         self.rowln_fwd(h, lnq[0], lnq[1], qcur, st_q, p1=p_q, site1=site_q, seed=seed, eps=eps)
         self.decatt_fwd(Kp, Vp, qcur, cpre, alpha, scale)
