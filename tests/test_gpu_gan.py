@@ -56,6 +56,32 @@ def test_gan_iteration_matches_reference(tag, critic_gemm, monkeypatch):
     check_post(G.named_parameters(), g, 'post.', 1e-4)
 
 
+def test_stacked_proposal_heads_equal_the_heads_one_by_one(monkeypatch):
+    """DiscV2 scores both PSLScore2 heads side by side (batched products, grouped LayerNorms: gan._proposal_scores); the
+    one-head-at-a-time form (DLSG_CRITIC_PSL_SEPARATE=1, what the reference computes, layer.py:690-715) must give the same
+    losses and parameter gradients on the GPU kernels"""
+    import copy
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case('gan_msvd', dlsg_amd.CapGnnModel, dlsg_amd.DiscV2)
+    G, D = G.cuda(), D.cuda()
+    frames, regions, caps = frames.cuda(), regions.cuda(), caps.cuda()
+    eps = torch.from_numpy(g['eps_gp']).cuda()
+    with torch.no_grad():
+        f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)
+    res = []
+    for separate in (False, True):
+        if separate:
+            monkeypatch.setenv('DLSG_CRITIC_PSL_SEPARATE', '1')
+        Dk = copy.deepcopy(D)
+        loss_D, r_loss, f_loss, gp, _ = gan.critic_step_losses(Dk, caps, f_caption, obj, mot, gan.attention_mask(caps), alpha, eps[0])
+        loss_D.backward()
+        res.append((loss_D.item(), gp.item(), {n: p.grad.clone() for n, p in Dk.named_parameters() if p.grad is not None}))
+    (l0, g0, p0), (l1, g1, p1) = res
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)) and abs(g0 - g1) <= 1e-5 * max(1.0, abs(g0)), (l0, l1, g0, g1)
+    assert p0.keys() == p1.keys()
+    for k in p0:
+        assert (p0[k] - p1[k]).abs().max().item() <= 2e-5 * max(1.0, p0[k].abs().max().item()), k
+
+
 def test_proposal_and_attention_gradients_reach_the_encoder():
     """`obj_proposals`, `motion_proposals` and `alpha_all` are graph-attached outputs of forward() (models/model.py:36-40):
     a caller that does NOT detach them (unlike run_gun.py:172-174) sends d(obj), d(mot), d(alpha) back through the
