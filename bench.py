@@ -442,6 +442,9 @@ def main():
     if a.gpus < 1:
         ap.error('--gpus must be >= 1')
 
+    # dmabuf IPC between the ranks' processes (the host driver supports nothing else): must be in the environment before the
+    # first HIP call of this process, i.e. before torch.cuda.set_device below
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if a.leg == 'gan_iteration':
         print(json.dumps(gan_iteration_leg(torch.device('cuda', 0), a.batch, with_eager=not a.no_eager_baseline)))
         return
