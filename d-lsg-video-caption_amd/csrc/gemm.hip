@@ -910,9 +910,9 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     // workgroups of the square tile) wins 3-8 % over the 64 x 64 one; below that only the small tile fills the chip.
     const int padM = (a->M + 127) / 128 * 128;
     if ((padM - a->M) * 10 <= a->M) {
-        // (700-999 tiles: only the TN form gains from the square tile -- 2048 x 2048 x 1664 x 3: 343 us against 354; the BiLSTM's
+        // (500-999 tiles: only the TN form gains from the square tile -- 2048 x 2048 x 1664 x 3: 343 us against 354; the BiLSTM's
         // input projection NT 1664 x 4096 x 1024 x 2 runs 264 us on 128 x 64 against 284, tools/gemm_mid_probe.py)
-        if (tilesL >= 700 && a->mode == 2) return launch<128, 128, 32>(a, st);
+        if (tilesL >= 500 && a->mode == 2) return launch<128, 128, 32>(a, st);       // (1024 x 1024 x 512 x 8 groups: 82 us against 100)
         if (tilesL >= 200) return launch<128, 64, 64>(a, st);
     }
     return launch<64, 64, 64>(a, st);

@@ -440,7 +440,7 @@ class HipOps(object):
             elif tiles_l >= 1000:
                 variant = '128x128'
             elif not x3 and ((M + 127) // 128 * 128 - M) * 10 <= M and tiles_l >= 200:
-                variant = '128x128' if (tiles_l >= 700 and mode == GEMM_TN) else '128x64'
+                variant = '128x128' if (tiles_l >= 500 and mode == GEMM_TN) else '128x64'
             else:
                 variant = '64x64'
             # one key per kernel symbol (arithmetic, tile, operand layout), as rocprofv3 --stats lists them
