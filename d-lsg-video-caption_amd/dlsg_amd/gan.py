@@ -785,6 +785,26 @@ class GanTrainer(object):
         self._cg.clear()
         self._cg_seen.clear()
 
+    # ------------------------------------------------------------------ the critic's optimizer (run_gun.py:100)
+    def optimizer_d_state_dict(self):
+        """`optimizer_d_state_dict` of a checkpoint (run_gun.py:307): torch.optim.Adam layout"""
+        sd = self.opt_D.state_dict()
+        for st in sd['state'].values():
+            st['step'] = st['step'].detach().cpu().reshape(())
+        sd['param_groups'][0]['capturable'] = False
+        return sd
+
+    def load_optimizer_d_state_dict(self, sd):
+        self.opt_D.load_state_dict(sd)
+        self.opt_D.param_groups[0]['capturable'] = self.use_graphs
+        self.reset_graphs()
+
+    def critic_adam_step(self, grads):
+        """one Adam step of the critic's optimizer on given gradients {parameter name: tensor}"""
+        for n, p in self.D.named_parameters():
+            p.grad = grads[n].to(p.device) if n in grads else None
+        self.opt_D.step()
+
     def _rank_mean(self, value):
         """run_gun.py:433-437 `reduce_tensor`: the mean over ranks of a logged scalar.  Every rank then sees the same caption
         loss, so GANLambdaHandler switches its schedule at the same step everywhere (run_gun.py:202-203,212)."""
@@ -965,7 +985,7 @@ def save_checkpoint(path, epoch, gan):
                 'model_state_dict': {k: v.detach().cpu() for k, v in gan.model.state_dict().items()},
                 'optimizer_state_dict': gan.trainer.optimizer_state_dict(),
                 'model_d_state_dict': {k: v.detach().cpu() for k, v in gan.D.state_dict().items()},
-                'optimizer_d_state_dict': gan.opt_D.state_dict(),
+                'optimizer_d_state_dict': gan.optimizer_d_state_dict(),
                 'cap_list': np.array(gan.lambda_handler.cap_list)}, path)
 
 
@@ -975,8 +995,7 @@ def load_checkpoint(path, gan, map_location=None):
     gan.model.load_state_dict(ck['model_state_dict'])
     gan.trainer.load_optimizer_state_dict(ck['optimizer_state_dict'])
     gan.D.load_state_dict(ck['model_d_state_dict'])
-    gan.opt_D.load_state_dict(ck['optimizer_d_state_dict'])
-    gan.reset_graphs()
+    gan.load_optimizer_d_state_dict(ck['optimizer_d_state_dict'])
     h = gan.lambda_handler
     gan.lambda_handler = GANLambdaHandler(h.total_step, h.start_gan_lambda, cap_list=ck['cap_list'])
     return ck['epoch']

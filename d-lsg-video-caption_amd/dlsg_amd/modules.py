@@ -123,6 +123,9 @@ class Decoder(nn.Module):
         self.baseline = baseline
         H, W, Q, D = args.visual_hidden_size, args.word_size, args.query_hidden_size, args.decode_hidden_size
         self.word_embed = nn.Embedding(self.vocab_size, W)
+        self.dataset = getattr(args, 'dataset', 'msvd')
+        if getattr(args, 'use_glove', False):
+            self.get_glove_embedding()
         q_in = H + W + D + (0 if baseline else H)
         self.query_lstm = nn.LSTMCell(q_in, Q)
         self.query_lstm_layernorm = nn.LayerNorm(Q)
@@ -135,6 +138,35 @@ class Decoder(nn.Module):
             self.context_att_2 = AttentionShare(H, Q, H)
         self.word_restore = nn.Linear(D, self.vocab_size)
         nn.init.xavier_normal_(self.word_restore.weight)
+
+    def get_glove_embedding(self, data_dir='./data'):
+        """models/layer.py:352-385 (`--use_glove`): the word embedding starts from `./data/{dataset}_glove.npy` (one row per
+        vocabulary id); when that file is missing it is built from `./data/glove.42B.300d.txt` -- a word with a trailing comma
+        is looked up without it, a word GloVe does not have gets N(0, 0.6) -- and written for the next run, as the reference
+        does.  Neither file present: an error naming both (the reference dies on the open())"""
+        import os
+        import numpy as np
+        npy = os.path.join(data_dir, '%s_glove.npy' % self.dataset)
+        V, W = self.word_embed.num_embeddings, self.word_embed.embedding_dim
+        if os.path.exists(npy):
+            weight = np.load(npy)
+        else:
+            txt = os.path.join(data_dir, 'glove.42B.300d.txt')
+            if not os.path.exists(txt):
+                raise FileNotFoundError('use_glove: neither %s nor %s exists (models/layer.py:353-359)' % (npy, txt))
+            wanted = {}
+            for i, word in enumerate(self.vocab.idx2word):
+                wanted.setdefault(word[:-1] if word.endswith(',') else word, []).append(i)
+            weight = np.random.normal(scale=0.6, size=(V, W))
+            with open(txt, 'rb') as f:
+                for line in f:
+                    parts = line.decode().split()
+                    for i in wanted.get(parts[0], ()):
+                        weight[i] = np.array(parts[1:]).astype(np.float64)
+            np.save(npy, weight)
+        if weight.shape != (V, W):
+            raise ValueError('%s holds %s, the word embedding is (%d, %d)' % (npy, weight.shape, V, W))
+        self.word_embed.load_state_dict({'weight': torch.from_numpy(np.asarray(weight))})
 
     def update_beam_size(self, beam_size):
         """models/layer.py:348-350"""

@@ -9,7 +9,8 @@ import torch
 
 import dlsg_amd
 from emul_ops import EmulOps
-from helpers import load_case, weights_and_inputs
+import os
+from helpers import load_case, weights_and_inputs, small_args
 
 SMALL = ['small_msvd', 'small_msrvtt', 'small_noobj', 'small_baseline1', 'small_baselinemodel']
 MODELS = {'capgnn': dlsg_amd.CapGnnModel, 'baseline1': dlsg_amd.CapBaseline1, 'baselinemodel': dlsg_amd.CapBaselineModel}
@@ -491,3 +492,30 @@ def test_critic_fused_cell_and_conv_follow_the_plain_recurrence():
     # every product of the critic went through the kernel interface's GEMM, at all three differentiation levels (gan._Gemm)
     # (119 products per update since the two proposal scorers and the K / Q / V projections run as batched products; 175 one by one)
     assert D1._ops.calls.get('gemm', 0) + D1._ops.calls.get('gemm_narrow', 0) >= 100 and D1._ops.calls.get('gemm_narrow', 0) >= 50, D1._ops.calls
+
+
+def test_use_glove_initialises_the_word_embedding(tmp_path, monkeypatch):
+    """models/layer.py:310-311,352-385: `./data/{dataset}_glove.npy` if present, else built from the GloVe text file (trailing
+    comma stripped, unknown words random) and saved; neither file: an error, not a silently ignored flag."""
+    from dlsg_amd.config import Vocabulary
+    monkeypatch.chdir(tmp_path)
+    args = small_args(use_glove=True, word_size=5)
+    vocab = Vocabulary()
+    for w in ('cat', 'dog,', 'zebra'):
+        vocab.add_word(w)
+    with pytest.raises(FileNotFoundError):
+        dlsg_amd.CapGnnModel(args, vocab)
+    os.makedirs('data')
+    with open('data/glove.42B.300d.txt', 'w') as f:
+        f.write('dog 1 2 3 4 5\ncat 0.5 0.25 0 -1 -2\nhorse 9 9 9 9 9\n')
+    net = dlsg_amd.CapGnnModel(args, vocab)
+    E_ = net.decoder.word_embed.weight.detach()
+    assert E_[vocab('cat')].tolist() == [0.5, 0.25, 0.0, -1.0, -2.0] and E_[vocab('dog,')].tolist() == [1, 2, 3, 4, 5]
+    saved = np.load('data/msvd_glove.npy')
+    assert saved.shape == (len(vocab), 5) and np.allclose(saved, E_.numpy())
+    os.remove('data/glove.42B.300d.txt')
+    net2 = dlsg_amd.CapGnnModel(args, vocab)                      # second run: from the .npy, unknown words included
+    assert torch.equal(net2.decoder.word_embed.weight.detach(), E_)
+    np.save('data/msvd_glove.npy', saved[:-1])
+    with pytest.raises(ValueError):
+        dlsg_amd.CapGnnModel(args, vocab)
