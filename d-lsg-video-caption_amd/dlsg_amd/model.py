@@ -25,8 +25,9 @@ def _default_ops():
     return HipOps()
 
 
-class _HipModel(nn.Module):
-    """Shared machinery: flat parameter / gradient arenas, ops handle, autograd bridge."""
+class _ArenaModule(nn.Module):
+    """A module whose parameters are views of ONE flat fp32 arena (plus a gradient arena of the same layout) and that launches
+    kernels through an `ops` handle: shared by the generator models and the critic (gan.DiscV2)."""
 
     def __init__(self):
         super().__init__()
@@ -34,12 +35,6 @@ class _HipModel(nn.Module):
         self._flat = None
         self._gflat = None
         self._offsets = None
-        self.rng = random          # scheduled-sampling coins come from Python's `random`, like layer.py:432
-        self.seed_counter = 0
-        self.fused_o2v = True
-        # GEMM arithmetic: 'fp32' = exact fp32 MFMA everywhere; 'x3_bwd' = split-bf16 (3 bf16 MFMAs per product,
-        # ~1e-5 relative error) for the backward products only; 'x3_all' = split-bf16 for forward and backward.
-        self.gemm_precision = 'fp32'
 
     # ------------------------------------------------------------------ copy / pickle
     def __getstate__(self):
@@ -47,26 +42,16 @@ class _HipModel(nn.Module):
         the arenas are rebuilt on first use (flatten_parameters_ notices that the copied parameters are not its views)."""
         st = dict(self.__dict__)
         st['_ops_obj'] = None
-        st['rng'] = None
+        if 'rng' in st:
+            st['rng'] = None
         for k in ('_flat', '_gflat', '_offsets', '_G'):
             st[k] = None
         return st
 
     def __setstate__(self, st):
         self.__dict__.update(st)
-        self.rng = random
-
-    @staticmethod
-    def check_kernel_limits(args, attended_rows, what):
-        """The fused decoder-step kernels (csrc/decstep.hip: MAXW, MAXP) hold one batch row's vectors in LDS: widths up to
-        2048, at most 72 attended rows per attention stream (72 = the longest clip the reference's positional
-        encoding admits, sublayer.py:87; the baseline decoders attend over the frame nodes).  Checked at construction, with names, instead of an EINVAL
-        from the first launch."""
-        for k in ('query_hidden_size', 'decode_hidden_size', 'visual_hidden_size'):
-            if getattr(args, k) > 2048:
-                raise ValueError('%s = %d: the fused decoder step supports widths up to 2048' % (k, getattr(args, k)))
-        if attended_rows > 72:
-            raise ValueError('%s = %d: the fused decoder step attends over at most 72 rows per stream' % (what, attended_rows))
+        if 'rng' in st:
+            self.rng = random
 
     # ------------------------------------------------------------------ kernels handle
     @property
@@ -77,6 +62,7 @@ class _HipModel(nn.Module):
 
     def set_ops(self, ops):
         self._ops_obj = ops
+        return self
 
     # ------------------------------------------------------------------ arenas
     def _arena_ok(self):
@@ -110,6 +96,31 @@ class _HipModel(nn.Module):
 
     def grad_views(self):
         return self._G
+
+
+class _HipModel(_ArenaModule):
+    """Shared machinery of the generator models: arenas, ops handle, autograd bridge."""
+
+    def __init__(self):
+        super().__init__()
+        self.rng = random          # scheduled-sampling coins come from Python's `random`, like layer.py:432
+        self.seed_counter = 0
+        self.fused_o2v = True
+        # GEMM arithmetic: 'fp32' = exact fp32 MFMA everywhere; 'x3_bwd' = split-bf16 (3 bf16 MFMAs per product,
+        # ~1e-5 relative error) for the backward products only; 'x3_all' = split-bf16 for forward and backward.
+        self.gemm_precision = 'fp32'
+
+    @staticmethod
+    def check_kernel_limits(args, attended_rows, what):
+        """The fused decoder-step kernels (csrc/decstep.hip: MAXW, MAXP) hold one batch row's vectors in LDS: widths up to
+        2048, at most 72 attended rows per attention stream (72 = the longest clip the reference's positional
+        encoding admits, sublayer.py:87; the baseline decoders attend over the frame nodes).  Checked at construction, with names, instead of an EINVAL
+        from the first launch."""
+        for k in ('query_hidden_size', 'decode_hidden_size', 'visual_hidden_size'):
+            if getattr(args, k) > 2048:
+                raise ValueError('%s = %d: the fused decoder step supports widths up to 2048' % (k, getattr(args, k)))
+        if attended_rows > 72:
+            raise ValueError('%s = %d: the fused decoder step attends over at most 72 rows per stream' % (what, attended_rows))
 
     def _gemm_flags(self, backward):
         from .hip import F_BF16X3
@@ -969,7 +980,7 @@ class Trainer(object):
         self._adam_in_graph = mode != 'torch'
 
     @torch.no_grad()
-    def forward_only(self, frames, regions, captions, tf_ratio, max_len=26):
+    def forward_only(self, frames, regions, captions, tf_ratio, max_len=26, time_major=False):
         """The no-grad generator forward of the GAN iteration (run_gun.py:167) from the captured step's FIRST graph (forward +
         CrossEntropy): same coin / dropout-seed draws as `model(frames, regions, captions, max_len, tf_ratio)`, returns
         (logits (B,L,V), obj, mot, alpha (B,L,2P)) as views of the graphs' static buffers -- valid until the next replay --
@@ -992,7 +1003,9 @@ class Trainer(object):
         st['seed'].copy_(torch.tensor([seed], dtype=torch.int64), non_blocking=True)
         self._graphs[0][0].replay()
         logits_tm, sv = self._hook_sv
-        return logits_tm.transpose(0, 1), sv['dec_gsrc'][0], sv['dec_gsrc'][1], sv['dec']['ALPHA'].transpose(0, 1)
+        # time_major: the logits as the decoder wrote them, (L,B,V) -- what the critic's schedule reads (gan.GanTrainer)
+        return (logits_tm if time_major else logits_tm.transpose(0, 1)), sv['dec_gsrc'][0], sv['dec_gsrc'][1], \
+            sv['dec']['ALPHA'].transpose(0, 1)
 
     def static_inputs(self):
         """The captured graphs read their batch from these device buffers: (frames, regions, captions, cap_lens), or None
@@ -1045,8 +1058,10 @@ class Trainer(object):
         for g, key in self._graphs:
             g.replay()
             if key == 'hook':
-                res = extra_dlogits(*self._hook_sv)
-                st['extra'].copy_(res)
+                if getattr(extra_dlogits, 'takes_dst', False):
+                    extra_dlogits(*self._hook_sv, dst=st['extra'])         # writes the static buffer itself: no staging copy
+                else:
+                    st['extra'].copy_(extra_dlogits(*self._hook_sv))
             elif key is not None:
                 self._allreduce(key)
         if not self._adam_in_graph:

@@ -10,6 +10,8 @@ import math
 import numpy as np
 import torch
 
+from emul_critic import CriticEmul
+
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3 = 256, 512, 1024     # tile / precision selectors: no effect on the emulation
@@ -46,7 +48,7 @@ def _mask(seed, site, rows, n, p, row0=0):
     return drop_scale(seed, site, idx, p)
 
 
-class EmulOps(object):
+class EmulOps(CriticEmul):
     name = 'emul'
 
     def __init__(self, fused_supported=True):
@@ -172,7 +174,14 @@ class EmulOps(object):
                 dgb_part[b, 0] = (g[sel] * xh[sel]).sum(0)
                 dgb_part[b, 1] = g[sel].sum(0)
 
-    def colsum(self, part, out, accum=False):
+    def colsum(self, part, out, accum=False, scale=1.0):
+        if scale != 1.0:
+            r = part.sum(0) * scale
+            out.copy_(out + r if accum else r)
+            return
+        return self._colsum1(part, out, accum)
+
+    def _colsum1(self, part, out, accum=False):
         self._count('colsum')
         r = part.sum(0)
         out.copy_(r + out if accum else r)

@@ -122,7 +122,7 @@ def _gan_build():
         m = dlsg_amd.CapGnnModel(args, vocab)
         m.set_ops(EmulOps())
         return m
-    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case('gan_msrvtt', mk, dlsg_amd.DiscV2)     # batch 4
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case('gan_msrvtt', mk, lambda a, v: dlsg_amd.DiscV2(a, v).set_ops(EmulOps()))     # batch 4
     return G, D.eval(), frames, regions, caps, lens, torch.from_numpy(g['eps_gp'])
 
 
@@ -171,10 +171,13 @@ def test_two_rank_gan_iteration_keeps_generator_and_critic_replicas_identical(tm
     with torch.no_grad():
         f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)          # rows are independent: one call, then slices
     losses = []
+    eng = D.engine
     for r in range(2):
         sl = slice(r * 2, r * 2 + 2)
-        losses.append(gan.critic_step_losses(D, caps[sl], f_caption[sl], obj[sl], mot[sl], gan.attention_mask(caps[sl]), alpha[sl],
-                                             eps[0][sl])[0].item())
+        smask = (caps[sl] > 0).float()
+        ws = eng.prepare(caps.device, 2, caps.shape[1], f_caption.shape[2], smask, 4)
+        eng.proposals(ws, obj[sl].contiguous(), mot[sl].contiguous(), alpha[sl], smask)
+        losses.append(float(eng.update_gradients(ws, caps[sl], f_caption[sl].transpose(0, 1).contiguous(), eps[0][sl].reshape(2), 0)[0]))
     want = 0.5 * (losses[0] + losses[1])
     for r in range(2):
         assert abs(np.load(tmp_path / ('lossd%d.npy' % r))[0] - want) <= 1e-5 * max(1.0, abs(want))

@@ -348,23 +348,29 @@ def test_gan_iteration_matches_reference(tag):
         m = dlsg_amd.CapGnnModel(args, vocab)
         m.set_ops(EmulOps())
         return m
-    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case(tag, mk, dlsg_amd.DiscV2)
+    args, vocab, g, G, D, frames, regions, caps, lens = load_gan_case(tag, mk, lambda a, v: dlsg_amd.DiscV2(a, v).set_ops(EmulOps()))
     assert sorted(D.state_dict().keys()) == sorted([k[len('dpost.'):] for k in g if k.startswith('dpost.')] + ['att.pe.pe'])
     eps = torch.from_numpy(g['eps_gp'])
     with torch.no_grad():
         f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)
-    D0 = copy.deepcopy(D)
-    loss_D, r_loss, f_loss, gp, (rl, fl, ml) = gan.critic_step_losses(D0, caps, f_caption, obj, mot, gan.attention_mask(caps),
-                                                                     alpha, eps[0])
-    assert np.abs(rl.detach().numpy() - g['d0.r_logit']).max() <= 5e-5
-    assert np.abs(fl.detach().numpy() - g['d0.f_logit']).max() <= 5e-5
-    assert np.abs(ml.detach().numpy() - g['d0.mixed_logit']).max() <= 5e-5
-    assert abs(gp.item() - float(g['d0.gp'])) <= 2e-4 * max(1.0, float(g['d0.gp']))
-    assert abs(loss_D.item() - float(g['d0.loss_D'])) <= 5e-4
-    loss_D.backward()
+    # one critic update's losses and gradients on a copy (critic.CriticEngine: F, B1, T, B2), against the reference's first update
+    D0 = copy.deepcopy(D).set_ops(EmulOps())
+    B, L, V = caps.shape[0], caps.shape[1], int(g['meta.V'])
+    smask = (caps > 0).float()
+    eng = D0.engine
+    ws = eng.prepare(caps.device, B, L, V, smask, 4)
+    eng.proposals(ws, obj, mot, alpha, smask)
+    stats = eng.update_gradients(ws, caps, f_caption.transpose(0, 1).contiguous(), eps[0].reshape(B), 0)
+    outv = eng._bufs(ws)['outv'].numpy()
+    assert np.abs(outv[:B] - g['d0.r_logit']).max() <= 5e-5
+    assert np.abs(outv[B:2 * B] - g['d0.f_logit']).max() <= 5e-5
+    assert np.abs(outv[2 * B:] - g['d0.mixed_logit']).max() <= 5e-5
+    assert abs(float(stats[3]) - float(g['d0.gp'])) <= 2e-4 * max(1.0, float(g['d0.gp']))
+    assert abs(float(stats[0]) - float(g['d0.loss_D'])) <= 5e-4
+    Gd = D0.grad_views()
     for n, p in D0.named_parameters():
-        ref = float(g['d0.gnorm.' + n])
-        got = float(p.grad.double().norm()) if p.grad is not None else -1.0
+        ref = max(float(g['d0.gnorm.' + n]), 0.0)                 # -1 in the fixture: the reference left .grad unset
+        got = float(Gd[n].double().norm())
         assert abs(got - ref) <= 1e-3 * max(abs(ref), 1e-3), (n, got, ref)
     # the dense forward (reference call signature) agrees with the gather path
     with torch.no_grad():
@@ -454,44 +460,6 @@ def test_proposal_and_attention_gradients_reach_the_encoder():
             continue
         err = (grads[1][k] - ref).abs().max().item()
         assert err <= 2e-5 + 2e-4 * ref.abs().max().item(), (k, err)
-
-
-def test_critic_fused_cell_and_conv_follow_the_plain_recurrence():
-    """DiscV2 with the fused LSTM-cell and (tanh +) LayerNorm ops (emulated kernels: level 0 / 1 / 2 formulas of
-    csrc/critic.hip) against the same critic on plain ATen ops: critic scores, gradient penalty (first derivative) and every parameter gradient of loss_D
-    (second derivative through the penalty) must agree."""
-    import copy
-    from helpers import gan_args
-    from dlsg_amd import gan
-    args = gan_args()
-    torch.manual_seed(5)
-    V, B, L, P = 30, 3, 26, args.num_proposals
-    D0 = dlsg_amd.DiscV2(args, V).double().eval()
-    D1 = copy.deepcopy(D0).set_ops(EmulOps())
-    caps = torch.randint(1, V, (B, L))
-    caps[0, 9:] = 0
-    caps[2, 20:] = 0
-    f_caption = torch.randn(B, L, V, dtype=torch.float64)
-    obj, mot = torch.randn(B, P, 1024, dtype=torch.float64), torch.randn(B, P, 1024, dtype=torch.float64)
-    alpha = torch.rand(B, L, 2 * P, dtype=torch.float64)
-    mask = gan.attention_mask(caps).double()
-    eps = torch.rand(B, 1, 1, dtype=torch.float64)
-    res = []
-    for D in (D0, D1):
-        loss_D, r_loss, f_loss, gp, logits = gan.critic_step_losses(D, caps, f_caption, obj, mot, mask, alpha, eps)
-        loss_D.backward()
-        res.append((loss_D.item(), gp.item(), [x.detach() for x in logits], {k: p.grad.clone() for k, p in D.named_parameters()
-                                                                           if p.grad is not None}))
-    (l0, g0, s0, p0), (l1, g1, s1, p1) = res
-    assert abs(l0 - l1) <= 1e-10 * max(1, abs(l0)) and abs(g0 - g1) <= 1e-10 * max(1, abs(g0)), (l0, l1, g0, g1)
-    for a, b in zip(s0, s1):
-        assert (a - b).abs().max().item() <= 1e-10
-    assert p0.keys() == p1.keys() and 'lstm.weight_hh_l0' in p0
-    for k in p0:
-        assert (p0[k] - p1[k]).abs().max().item() <= 1e-9 * max(1.0, p0[k].abs().max().item()), k
-    # every product of the critic went through the kernel interface's GEMM, at all three differentiation levels (gan._Gemm)
-    # (119 products per update since the two proposal scorers and the K / Q / V projections run as batched products; 175 one by one)
-    assert D1._ops.calls.get('gemm', 0) + D1._ops.calls.get('gemm_narrow', 0) >= 100 and D1._ops.calls.get('gemm_narrow', 0) >= 50, D1._ops.calls
 
 
 def test_use_glove_initialises_the_word_embedding(tmp_path, monkeypatch):
