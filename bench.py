@@ -159,8 +159,8 @@ def gpu_eager_baseline(dev, batch, steps=4, warmup=2):
 
 def gan_iteration_leg(dev, batch, with_eager=True, iters=6):
     """SURVEY.md 8(f) rank 1, what train_debug.py really trains: one RunGAN iteration (run_gun.py:147-234 -- no-grad generator
-    forward, 5 critic updates with gradient penalty, generator step with the GAN term) at the bench shape.  The generator runs
-    on the HIP path, the DiscV2 critic on PyTorch-ROCm launches replayed from hipGraphs (dlsg_amd/gan.py); the comparator is
+    forward, 5 critic updates with gradient penalty, generator step with the GAN term) at the bench shape.  The generator and the
+    DiscV2 critic run on the HIP kernels as hand-written launch schedules replayed from hipGraphs (dlsg_amd/gan.py, critic.py); the comparator is
     the oracle's restatement of the reference (oracle/gan_ref.py, kind 'port') stepped by PyTorch-ROCm eager."""
     import dlsg_amd
     from dlsg_amd.synth import synth_state_dict, synth_batch

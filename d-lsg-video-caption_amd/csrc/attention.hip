@@ -815,7 +815,12 @@ extern "C" int dlsg_struct_size(int which) {
         case 20: return (int)sizeof(dlsg_bilstm_bwd_args);
         case 21: return (int)sizeof(dlsg_colsum_desc);
         case 22: return (int)sizeof(dlsg_lstm_seq_args);
-        case 23: return (int)sizeof(dlsg_gemm_narrow_args);
+        case 23: return (int)sizeof(dlsg_cln_args);
+        case 24: return (int)sizeof(dlsg_crit_sa_args);
+        case 25: return (int)sizeof(dlsg_crit_pattn_args);
+        case 26: return (int)sizeof(dlsg_crit_tsum_args);
+        case 27: return (int)sizeof(dlsg_crit_score_args);
+        case 28: return (int)sizeof(dlsg_crit_colsum_desc);
         default: return -1;
     }
 }

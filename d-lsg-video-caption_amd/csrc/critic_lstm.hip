@@ -1,21 +1,30 @@
 // DiscV2's LSTM (nn.LSTM(512, 512), models/model.py:122) as persistent launches at the three differentiation levels of a WGAN-GP
 // critic update (run_gun.py:362-371: the gradient penalty differentiates the critic twice).
 //
-// dlsg_amd/gan.py keeps the whole LSTM layer as ONE autograd node per level (_LstmSeq, _LstmSeqBwd); per word step every level was
-// one rocBLAS product (192 x 2048 x 512, 10-15 us) plus one cell launch (critic.hip) = 78 products and 104 cell launches of the
-// ~1 180 launches of an update.  Here every level is ONE launch for all 26 steps, on the scheme of bilstm.hip (persist.hpp): a
+// Step by step every level is one 192 x 2048 x 512 product (10-15 us) plus one cell launch per word = 78 products and 104 cell
+// launches per critic update.  Here every level is ONE launch for all 26 steps, on the scheme of bilstm.hip (persist.hpp): a
 // workgroup per (64-row group, 8 hidden units), its 32 x H slice of W_hh (or W_hh^T) resident in LDS, the recurrent vector exchanged
-// between the workgroups through L2 with write-through stores and per-step flags.  Tensors are time-major, as gan.py holds them:
-// (L, n, 4H) pre-activations / their gradients, (L, n, H) states.  n <= 256 rows = up to four row groups; the row groups are
-// independent recurrences sharing the weights (the real, fake and mixed captions of one critic pass).
+// between the workgroups through L2 with write-through stores and per-step flags.  Tensors are batch-major, as critic.py holds
+// them ((n, L, 4H) pre-activations / their gradients, (n, L, H) states: a caption's words are consecutive rows), or time-major
+// ((L, n, .), batch_major = 0).  n <= 256 rows = up to four row groups; the row groups are independent recurrences sharing the
+// weights (the real, fake and mixed captions of one critic pass).
 //
-//   level 0  dlsg_lstm_seq_fwd  :  a_t = xin_t + h_{t-1} W^T,  (h_t, c_t) = cell(a_t, c_{t-1})
+//   level 0  dlsg_lstm_seq_fwd  :  a_t = xin_t (+ b_ih + b_hh) + h_{t-1} W^T,  (h_t, c_t) = cell(a_t, c_{t-1});  Hprev_t = h_{t-1}
 //   level 1  dlsg_lstm_seq_bwd  :  dh_t = dHs_t + DA_{t+1} W,  dc_t = s_t + dCs_t,  (da_t, s_{t-1}) = cell'(a_t, c_{t-1}; dh_t, dc_t),
 //                                  DA_t = da_t + dAs_t           (backwards in time; DH_t = dh_t and DC_t = dc_t are kept)
 //   level 2  dlsg_lstm_seq_bwd2 :  ubar_t = Ubar_t + gdh_{t-1} W^T,
 //                                  (ga_t, gc_{t-1}, gdh_t, gdc_t) = cell''(a_t, c_{t-1}, DH_t, DC_t; ubar_t, gdc_{t-1})    (forwards)
-// Cell formulas: critic.hip (checked there against autograd's own double backward).  The weight-gradient products over all steps
-// stay single GEMMs in gan.py.
+//                                  gDHprev_t = gdh_{t-1}
+// Cell formulas: below, with i = s(a_i), f = s(a_f), g = tanh(a_g), o = s(a_o), c = f c_prev + i g, tc = tanh(c), q = 1 - tc^2,
+// s_i = i(1-i), s_f = f(1-f), s_o = o(1-o), s_g = 1 - g^2:
+//   level 1:  dct = dc + dh o q;  da_i = dct g s_i;  da_f = dct c_prev s_f;  da_g = dct i s_g;  da_o = dh tc s_o;  dc_prev = dct f
+//   level 2:  A  = u_i g s_i + u_f c_prev s_f + u_g i s_g + uc f            (= dL/d dct)
+//             Gc = q (u_o dh s_o - 2 A dh o tc)                              (= dL/dc through tc)
+//             ga_i = dct s_i (u_i g (1-2i) + u_g s_g) + Gc g s_i;   ga_f = dct s_f (u_f c_prev (1-2f) + uc) + Gc c_prev s_f
+//             ga_g = dct s_g (u_i s_i - 2 u_g i g) + Gc i s_g;      ga_o = s_o dh (A q + u_o tc (1-2o))
+//             gc_prev = dct u_f s_f + Gc f;   gdh = A o q + u_o tc s_o;   gdc = A
+// (checked against autograd's own double backward of the unrolled cell, tests/test_gpu_ops.py).  The weight-gradient products over
+// all steps are single GEMMs of the caller (critic.py): Hprev / gDHprev are their operands.
 #include <mutex>
 
 #include "dlsg.h"
@@ -51,6 +60,8 @@ __global__ __launch_bounds__(THREADS) void lstm_seq_fwdlike_kernel(const dlsg_ls
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int L = a.L, n = a.n;
+    const bool bm = a.batch_major != 0;
+    const int pstep = bm ? 1 : n;                           // rows between step t and step t - 1 of one sequence
     const bool cell_lane = c < 8;
     const int unit = u0 + (c & 7);
     const int row0 = rg * ROWS + 16 * q + 4 * w;            // this lane's 4 consecutive rows (of the whole batch)
@@ -60,6 +71,12 @@ __global__ __launch_bounds__(THREADS) void lstm_seq_fwdlike_kernel(const dlsg_ls
     const int RG = (n + ROWS - 1) / ROWS;
     const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, RG * L * H * ROWS * 4, 0x00020000);
     float st[4] = {0.f, 0.f, 0.f, 0.f};                     // MODE 0: cell state c;  MODE 2: gdc of the previous step
+    float xprev[4] = {0.f, 0.f, 0.f, 0.f};                  // h_{t-1} / gdh_{t-1} of this lane's cells
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0 && a.b_ih && cell_lane) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias[g] = a.b_ih[g * H + unit] + a.b_hh[g * H + unit];
+    }
     __syncthreads();
 
     for (int t = 0; t < L; ++t) {
@@ -70,13 +87,13 @@ __global__ __launch_bounds__(THREADS) void lstm_seq_fwdlike_kernel(const dlsg_ls
         for (int i = 0; i < 4; ++i) {
             const int row = row0 + i;
             const bool on = cell_lane && row < n;
-            const int64_t rt = (int64_t)t * n + row;
+            const int64_t rt = bm ? (int64_t)row * L + t : (int64_t)t * n + row;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g][i] = on ? a.addend[rt * (4 * H) + g * H + unit] : 0.f;
+            for (int g = 0; g < 4; ++g) pre[g][i] = on ? a.addend[rt * (4 * H) + g * H + unit] + bias[g] : 0.f;
             if (MODE == 2) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) sa[g][i] = on ? a.As[rt * (4 * H) + g * H + unit] : 0.f;
-                cp[i] = (on && t > 0) ? a.Cs[(rt - n) * H + unit] : 0.f;
+                cp[i] = (on && t > 0) ? a.Cs[(rt - pstep) * H + unit] : 0.f;
                 dh[i] = on ? a.DH[rt * H + unit] : 0.f;
                 dc[i] = on ? a.DC[rt * H + unit] : 0.f;
             }
@@ -128,22 +145,26 @@ __global__ __launch_bounds__(THREADS) void lstm_seq_fwdlike_kernel(const dlsg_ls
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + i;
                 if (row >= n) continue;
-                const int64_t rt = (int64_t)t * n + row;
+                const int64_t rt = bm ? (int64_t)row * L + t : (int64_t)t * n + row;
                 if (MODE == 0) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) a.As[rt * (4 * H) + g * H + unit] = pre[g][i];
                     a.Hs[rt * H + unit] = xv[i];
                     a.Cs[rt * H + unit] = st[i];
+                    if (a.Hprev) a.Hprev[rt * H + unit] = xprev[i];
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         a.gA[rt * (4 * H) + g * H + unit] = o0[g][i];
-                        a.addend_out[rt * (4 * H) + g * H + unit] = pre[g][i];          // ubar_t (the gradient w.r.t. dAs)
+                        if (a.addend_out) a.addend_out[rt * (4 * H) + g * H + unit] = pre[g][i];   // ubar_t (the gradient w.r.t. dAs)
                     }
-                    if (t > 0) a.gC[(rt - n) * H + unit] = o1[i];
+                    if (t > 0) a.gC[(rt - pstep) * H + unit] = o1[i];
+                    if (t == L - 1) a.gC[rt * H + unit] = 0.f;                          // nothing follows the last step
                     a.gDH[rt * H + unit] = xv[i];
                     a.gDC[rt * H + unit] = o2[i];
+                    if (a.gDHprev) a.gDHprev[rt * H + unit] = xprev[i];
                 }
+                xprev[i] = xv[i];
             }
         }
     }
@@ -160,6 +181,8 @@ __global__ __launch_bounds__(THREADS) void lstm_seq_bwd_kernel(const dlsg_lstm_s
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = lane & 15, q = lane >> 4;
     const int L = a.L, n = a.n;
+    const bool bm = a.batch_major != 0;
+    const int pstep = bm ? 1 : n;
     const int pj = threadIdx.x >> 5, pp = threadIdx.x & 31, punit = 8 * wg + pj;       // pointwise cells: rows 2 pp, 2 pp + 1
 
     fill_wimage_cols<J>(wimg, a.W, H, kq * H, 32 * nn);
@@ -179,13 +202,13 @@ __global__ __launch_bounds__(THREADS) void lstm_seq_bwd_kernel(const dlsg_lstm_s
         for (int i = 0; i < 2; ++i) {
             const int row = rg * ROWS + 2 * pp + i;
             const bool on = row < n;
-            const int64_t rt = (int64_t)t * n + row;
+            const int64_t rt = bm ? (int64_t)row * L + t : (int64_t)t * n + row;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 sa[g][i] = on ? a.As[rt * (4 * H) + g * H + punit] : 0.f;
                 inj[g][i] = (on && a.dAs) ? a.dAs[rt * (4 * H) + g * H + punit] : 0.f;
             }
-            cp[i] = (on && t > 0) ? a.Cs[(rt - n) * H + punit] : 0.f;
+            cp[i] = (on && t > 0) ? a.Cs[(rt - pstep) * H + punit] : 0.f;
             dhv[i] = on ? a.dHs[rt * H + punit] : 0.f;
             dcv[i] = sdc[i] + ((on && a.dCs) ? a.dCs[rt * H + punit] : 0.f);
         }
@@ -220,7 +243,7 @@ __global__ __launch_bounds__(THREADS) void lstm_seq_bwd_kernel(const dlsg_lstm_s
         for (int i = 0; i < 2; ++i) {
             const int row = rg * ROWS + 2 * pp + i;
             if (row >= n) continue;
-            const int64_t rt = (int64_t)t * n + row;
+            const int64_t rt = bm ? (int64_t)row * L + t : (int64_t)t * n + row;
 #pragma unroll
             for (int g = 0; g < 4; ++g) a.DA[rt * (4 * H) + g * H + punit] = da[g][i];
             a.DH[rt * H + punit] = dhv[i];
@@ -265,8 +288,8 @@ extern "C" int dlsg_lstm_seq(const dlsg_lstm_seq_args* a, int level, void* strea
     if (!a || level < 0 || level > 2 || !dlsg_lstm_seq_supported(a->L, a->n, a->H) || !a->W || !a->xbuf || !a->flags) return DLSG_EINVAL;
     if (level == 0 && (!a->addend || !a->As || !a->Hs || !a->Cs)) return DLSG_EINVAL;
     if (level == 1 && (!a->As || !a->Cs || !a->dHs || !a->DA || !a->DH || !a->DC || !a->xbuf2)) return DLSG_EINVAL;
-    if (level == 2 && (!a->As || !a->Cs || !a->DH || !a->DC || !a->addend || !a->addend_out || !a->gA || !a->gC || !a->gDH || !a->gDC))
-        return DLSG_EINVAL;
+    if (level == 2 && (!a->As || !a->Cs || !a->DH || !a->DC || !a->addend || !a->gA || !a->gC || !a->gDH || !a->gDC)) return DLSG_EINVAL;
+    if ((a->b_ih == nullptr) != (a->b_hh == nullptr)) return DLSG_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a->xbuf) & 15) || (reinterpret_cast<uintptr_t>(a->xbuf2) & 15) || (reinterpret_cast<uintptr_t>(a->W) & 15))
         return DLSG_EALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);

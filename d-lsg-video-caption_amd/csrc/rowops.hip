@@ -339,31 +339,6 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     }
 }
 
-// backward of softmax_bwd (the critic differentiates its softmaxes twice, csrc/critic.hip): with dx = y (dy - s), s = sum y dy
-// and a cotangent u on dx:  t = sum u y,  gdy = y (u - t),  gy = u (dy - s) - dy t
-__global__ __launch_bounds__(256) void softmax_bwd2_kernel(const float* __restrict__ y, const float* __restrict__ dy,
-                                                           const float* __restrict__ u, float* __restrict__ gy,
-                                                           float* __restrict__ gdy, int64_t outer, int n, int inner) {
-    const int lane = threadIdx.x & 63;
-    const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (line >= outer * inner) return;
-    const int64_t o = line / inner, in = line % inner;
-    const int64_t base = o * n * inner + in;
-    float s = 0.f, t = 0.f;
-    for (int j = lane; j < n; j += 64) {
-        const int64_t k = base + (int64_t)j * inner;
-        s += y[k] * dy[k];
-        t += y[k] * u[k];
-    }
-    s = wave_sum(s);
-    t = wave_sum(t);
-    for (int j = lane; j < n; j += 64) {
-        const int64_t k = base + (int64_t)j * inner;
-        gdy[k] = y[k] * (u[k] - t);
-        gy[k] = u[k] * (dy[k] - s) - dy[k] * t;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ LSTM pointwise
 // blockIdx.z selects one of up to two descriptors: the two directions of a BiLSTM step run as one launch.
 struct PwFwdSet { dlsg_lstm_pw_args a[2]; };
@@ -1048,15 +1023,6 @@ extern "C" int dlsg_softmax_bwd(const float* y, const float* dy, float* dx, int6
     const int64_t lines = outer * inner;
     if (lines == 0) return DLSG_OK;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, ST(stream), y, dy, dx, outer, n,
-                       inner);
-    DLSG_CHECK_LAUNCH();
-    return DLSG_OK;
-}
-extern "C" int dlsg_softmax_bwd2(const float* y, const float* dy, const float* u, float* gy, float* gdy, int64_t outer, int n,
-                                 int inner, void* stream) {
-    const int64_t lines = outer * inner;
-    if (lines == 0) return DLSG_OK;
-    hipLaunchKernelGGL(softmax_bwd2_kernel, dim3((unsigned)((lines + 3) / 4)), dim3(256), 0, ST(stream), y, dy, u, gy, gdy, outer, n,
                        inner);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;

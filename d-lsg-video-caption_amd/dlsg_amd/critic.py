@@ -124,7 +124,7 @@ class CriticEngine(object):
         ws.select = D.num_psl > D.num_top
         if ws.select:
             idx = ws.get('idx', 2, B, T, dtype=torch.int64)
-            ops.crit_topk(alpha.contiguous(), smask, P, T, idx)
+            ops.crit_topk(alpha, smask, P, T, idx)
 
     def _embed_proposals(self, ws, p):
         """psl_embed + visual_embed of both heads (layer.py:692-696,709): they depend on the critic's weights, so once per update"""
@@ -326,7 +326,7 @@ class CriticEngine(object):
         ops.crit_tsum_bwd2(M('words'), p['theta'], p['ts_g'], p['ts_b'], p['fusion'], Tn('c_fus'), Tn('words'), Tn('fus'), cw[0, m0:m1],
                            ws.get('ts_part2', B, 5, C), p=pd, site=SITE_TSUM, seed=seed, row0=m0)
         v2 = [ws.vv[k].view(B, T, C) for k in range(2)]
-        ops.crit_score_bwd2(v2, M2('s'), p['wc'], p['bcl'], M2('wgt'), M('fus'), ws.ones_B, [uspre[0], uspre[1]], T2('wgt'), Tn('fus'),
+        ops.crit_score_bwd2(v2, M2('s'), p['wc'], p['bcl'], M2('wgt'), M('fus'), M2('pair'), M2('score'), ws.ones_B, [uspre[0], uspre[1]], T2('wgt'), Tn('fus'),
                             M('c_fus'), M2('c_spre'), T2('c_vcap'), M2('c_wgt'), [ws.get('part_wc2', 2, B, C)[k] for k in range(2)],
                             ws.get('dbc2', 2))
 
@@ -358,7 +358,7 @@ class CriticEngine(object):
         ops.gemm(GEMM_TN, [(c_vpre[k], ws.esel[k], g['Wv'][k]) for k in range(2)])
         if ws.select:
             c_e = ws.get('c_e', 2, B * P, C)
-            ops.crit_unselect(c_esel.view(2 * B * T, C), ws.get('idx', 2, B, T, dtype=torch.int64).view(-1), c_e.view(2 * B * P, C))
+            ops.crit_unselect(c_esel.view(2 * B * T, C), ws.get('idx', 2, B, T, dtype=torch.int64).view(-1), c_e.view(2 * B * P, C), P)
         else:
             c_e = c_esel
         c_epre = ws.get('c_epre', 2, B * P, C)
@@ -369,39 +369,34 @@ class CriticEngine(object):
         dhr, dhf = (ws.get('dhr', B, L, C) if second else None), ws.get('dhf_tm', L, B, C)
         ops.crit_embed_mix_bwd(b['c_h'].view(min(S, 3), B, L, C), eps, dhr, dhf)
         ops.gemm(GEMM_TN, [(dhf.view(L * B, C), logits_tm.reshape(L * B, V), g['Wvoc'])])
-        cs = ops.colsum
-        cs(dhf.view(L * B, C), g['bvoc'])
         if second:
             Mg = ws.get('Mg', C, C)
             ops.gemm(GEMM_TN, [(ws.get('gsc', B, L, C).view(B * L, C), ws.get('g', B, L, C).view(B * L, C), Mg)])
             ops.gemm(GEMM_NN, [(Mg, p['Wvoc'], g['Wvoc'])], alpha=2.0, flags=F_ACCUM)
             ops.crit_vocab_scatter(dhr, ids, g['Wvoc'])
-            cs(dhr.view(B * L, C), g['bvoc'], accum=True)
-        # ---- biases and per-caption partials: column sums
-        ops.colsum2(f2(b['DA'][:npr], Rp), g['b_ih'], g['b_hh'])
-        cs(f2(b['c_x1'][:npr], Rp), g['bc'], scale=0.3)
+        # ---- biases and the fused kernels' per-caption partials: ONE launch of column sums (a descriptor: sources, out, copy, scale)
+        cs = []
+        cs.append(([dhf.view(L * B, C)] + ([dhr.view(B * L, C)] if second else []), g['bvoc'], None, 1.0))
+        cs.append(([f2(b['DA'][:npr], Rp)], g['b_ih'], g['b_hh'], 1.0))
+        cs.append(([f2(b['c_x1'][:npr], Rp)], g['bc'], None, 0.3))
         for k in range(2):
-            cs(f2(b['c_apre'][k, :npr], Rp), g['ba'][k])
-            cs(f2(b['c_spre'][k, :npr], Rtp), g['bs'][k])
-            cs(c_vpre[k], g['bv'][k])
-            cs(c_epre[k], g['be'][k])
-        # fused kernels' partials: the last pass's over its captions (+ the T pass's over the mixed captions)
+            cs.append(([f2(b['c_apre'][k, :npr], Rp)], g['ba'][k], None, 1.0))
+            cs.append(([f2(b['c_spre'][k, :npr], Rtp)], g['bs'][k], None, 1.0))
+            cs.append(([c_vpre[k]], g['bv'][k], None, 1.0))
+            cs.append(([c_epre[k]], g['be'][k], None, 1.0))
+        # the last pass's partials over its captions (+ the T pass's over the mixed captions)
         tp = ws.get('ts_part', 3 * B, 5, C)[:npr]
         tp2 = ws.get('ts_part2', B, 5, C) if second else None
         for j, dst in enumerate((g['theta'].view(-1), g['ts_g'], g['ts_b'], g['fusion'][0], g['fusion'][1])):
-            cs(tp[:, j], dst)
-            if second:
-                cs(tp2[:, j], dst, accum=True)
+            cs.append(([tp[:, j]] + ([tp2[:, j]] if second else []), dst, None, 1.0))
         pw = ws.get('part_wc', 2, 3 * B, C)
         pw2 = ws.get('part_wc2', 2, B, C) if second else None
         dbc = ws.get('dbc', 2)
         dbc2 = ws.get('dbc2', 2) if second else None
         for k in range(2):
-            cs(pw[k, :npr], g['wc'][k].view(-1))
-            ops.copy2d(dbc[k:k + 1].view(1, 1), g['bcl'][k].view(1, 1))
-            if second:
-                cs(pw2[k], g['wc'][k].view(-1), accum=True)
-                ops.copy2d(dbc2[k:k + 1].view(1, 1), g['bcl'][k].view(1, 1), accum=True)
+            cs.append(([pw[k, :npr]] + ([pw2[k]] if second else []), g['wc'][k].view(-1), None, 1.0))
+            cs.append(([dbc[k:k + 1].view(1, 1)] + ([dbc2[k:k + 1].view(1, 1)] if second else []), g['bcl'][k].view(-1), None, 1.0))
+        ops.crit_colsum(cs)
 
     # ------------------------------------------------------------------ one critic update (run_gun.py:343-381)
     @torch.no_grad()

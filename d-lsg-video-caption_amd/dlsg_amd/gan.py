@@ -283,7 +283,7 @@ class GanTrainer(object):
         for n, t in grads.items():
             G[n].copy_(t)
         self.t_D += 1
-        self._adam_D()
+        self._adam_D(hyper=torch.tensor(self._hyper_D(), dtype=torch.float32).to(self.D._flat.device))
 
     def reset_graphs(self):
         """Drop the captured critic graphs (a changed arena / optimizer state layout invalidates their pointers)."""
@@ -378,7 +378,8 @@ class GanTrainer(object):
             else:
                 stats = eng.update_gradients(ws, captions, logits_tm, eps, seed)
                 self._allreduce_D()
-                self._adam_D()
+                # (the bias corrections as the replayed launch reads them: a device word, so both forms give the same bits)
+                self._adam_D(hyper=torch.tensor(self._hyper_D(), dtype=torch.float32).to(dev))
                 acc += stats
         acc /= self.num_D
         return self._rank_mean(acc[0]), self._rank_mean(acc[4])

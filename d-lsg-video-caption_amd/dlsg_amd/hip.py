@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 
-ABI_VERSION = 3            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
+ABI_VERSION = 4            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3 = 256, 512, 1024
@@ -106,13 +106,50 @@ class BilstmBwdArgs(C.Structure):
 class LstmSeqArgs(C.Structure):
     _fields_ = [(n, c_f32p) for n in ('addend', 'addend_out', 'W', 'As', 'Hs', 'Cs', 'dHs', 'dAs', 'dCs', 'DA', 'DH', 'DC',
                                       'gA', 'gC', 'gDH', 'gDC', 'xbuf', 'xbuf2', 'flags', 'err')] + \
-               [('L', i32), ('n', i32), ('H', i32), ('pad_', i32)]
+               [('L', i32), ('n', i32), ('H', i32), ('batch_major', i32)] + \
+               [(n, c_f32p) for n in ('b_ih', 'b_hh', 'Hprev', 'gDHprev')]
 
 
-class GemmNarrowArgs(C.Structure):
-    _fields_ = [('A', c_f32p), ('B', c_f32p), ('C', c_f32p), ('bias', c_f32p), ('ws', c_f32p), ('ws_floats', i64),
-                ('lda', i64), ('ldb', i64), ('ldc', i64), ('bsa', i64), ('bsb', i64), ('bsc', i64),
-                ('mode', i32), ('M', i32), ('N', i32), ('K', i32), ('nbatch', i32), ('pad_', i32), ('alpha', f32), ('pad2_', i32)]
+_P4 = c_f32p * 4
+_P2 = c_f32p * 2
+
+
+class ClnArgs(C.Structure):
+    _fields_ = [('x', _P4), ('gamma', _P4), ('beta', _P4), ('y', _P4), ('dy', _P4 * 3), ('dx', _P4), ('dgamma', _P4), ('dbeta', _P4),
+                ('extra', _P4), ('U', _P4), ('gx', _P4), ('gdy', _P4), ('gpart', _P4), ('ws', c_f32p),
+                ('rows', i32), ('N', i32), ('groups', i32), ('pre_tanh', i32), ('ndy', i32), ('acc_lo', i32), ('acc_hi', i32), ('pad_', i32),
+                ('eps', f32), ('p_pre', f32), ('p_post', f32), ('site_pre', u32), ('site_post', u32), ('pad2_', u32),
+                ('seed', u64), ('seed_ptr', C.c_void_p), ('row0', i64)]
+
+
+class CritSaArgs(C.Structure):
+    _fields_ = [(n, c_f32p) for n in ('KQV', 'smask', 'w', 'ctx', 'dctx', 'dKQV', 'U', 'Uctx', 'gKQV')] + \
+               [('n', i32), ('B', i32), ('L', i32), ('acc_lo', i32), ('acc_hi', i32), ('pad_', i32), ('scale', f32), ('pad2_', f32)]
+
+
+class CritPattnArgs(C.Structure):
+    _fields_ = [('a', _P2), ('e', _P2), ('smask', c_f32p), ('P', _P2), ('wgt', _P2), ('aggpre', _P2), ('d_agg', _P2), ('d_wgt', _P2),
+                ('da', _P2), ('de', _P2), ('Ua', _P2), ('Uagg', _P2), ('Uwgt', _P2), ('ga', _P2), ('ge', _P2),
+                ('n', i32), ('B', i32), ('L', i32), ('T', i32), ('acc_lo', i32), ('acc_hi', i32), ('scale', f32), ('pad_', f32)]
+
+
+class CritTsumArgs(C.Structure):
+    _fields_ = [(n, c_f32p) for n in ('words', 'theta', 'gamma', 'beta', 'fusion', 'adj', 'u', 'sent', 'fus', 'd_fus', 'dwords', 'part',
+                                      'U', 'Ufus', 'gwords', 'gpart')] + \
+               [('n', i32), ('L', i32), ('acc_lo', i32), ('acc_hi', i32), ('eps', f32), ('p', f32), ('site', u32), ('pad_', u32),
+                ('seed', u64), ('seed_ptr', C.c_void_p), ('row0', i64)]
+
+
+class CritScoreArgs(C.Structure):
+    _fields_ = [('v', _P2), ('s', _P2), ('wc', _P2), ('bc', _P2), ('wgt', _P2), ('fus', c_f32p), ('pair', _P2), ('score', _P2),
+                ('both', c_f32p), ('out', c_f32p), ('d_out', c_f32p), ('d_fus', c_f32p), ('c_spre', _P2), ('c_vpre', _P2), ('d_wgt', _P2),
+                ('part_wc', _P2), ('dbc', c_f32p), ('Uspre', _P2), ('Uwgt', _P2), ('Ufus', c_f32p), ('scratch', c_f32p),
+                ('n', i32), ('B', i32), ('T', i32), ('ng', i32), ('acc_lo', i32), ('acc_hi', i32)]
+
+
+class CritColsumDesc(C.Structure):
+    _fields_ = [('part', c_f32p), ('ld', i64), ('rows', i32), ('n', i32), ('part_b', c_f32p), ('ld_b', i64), ('rows_b', i32), ('pad_', i32),
+                ('out', c_f32p), ('out_b', c_f32p), ('scale', f32), ('pad2_', f32)]
 
 
 class ColsumDesc(C.Structure):
@@ -183,17 +220,20 @@ class DecattCacheGradsArgs(C.Structure):
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
 SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
            'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_colsum_ws_floats', 'dlsg_colsum_multi', 'dlsg_colsum_multi_ok', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
-           'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_softmax_bwd2', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
+           'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd', 'dlsg_o2v_bwd_multi', 'dlsg_o2v_bwd_gen1',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
-           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_lstm_cell_fwd', 'dlsg_lstm_cell_bwd', 'dlsg_lstm_cell_bwd2', 'dlsg_lstm_cell_bwd_seq',
-           'dlsg_tanh_ln_ws_floats', 'dlsg_tanh_ln_fwd', 'dlsg_tanh_ln_bwd', 'dlsg_tanh_ln_bwd2', 'dlsg_conv_taps',
+           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd',
+           'dlsg_crit_embed_mix', 'dlsg_crit_embed_mix_bwd', 'dlsg_crit_vocab_scatter', 'dlsg_crit_relu_taps', 'dlsg_crit_relu_taps_bwd',
+           'dlsg_cln_ws_floats', 'dlsg_cln_fwd', 'dlsg_cln_bwd', 'dlsg_cln_bwd2', 'dlsg_crit_sa_fwd', 'dlsg_crit_sa_bwd', 'dlsg_crit_sa_bwd2',
+           'dlsg_crit_pattn_fwd', 'dlsg_crit_pattn_bwd', 'dlsg_crit_pattn_bwd2', 'dlsg_crit_tsum_fwd', 'dlsg_crit_tsum_bwd',
+           'dlsg_crit_tsum_bwd2', 'dlsg_crit_score_fwd', 'dlsg_crit_score_bwd', 'dlsg_crit_score_bwd2', 'dlsg_crit_gp', 'dlsg_crit_topk',
+           'dlsg_crit_unselect', 'dlsg_crit_colsum',
            'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd', 'dlsg_bilstm_bwd_x_floats', 'dlsg_bilstm_bwd',
            'dlsg_lstm_seq_supported', 'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_lstm_seq',
-           'dlsg_gemm_narrow_kind', 'dlsg_gemm_narrow_ws_floats', 'dlsg_gemm_narrow',
            'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
            'dlsg_allreduce_buckets']
 
@@ -224,7 +264,6 @@ def load_library(path=LIB_PATH):
         'dlsg_o2v_fwd_multi': [P(O2VArgs), i32, vp],
         'dlsg_softmax_fwd': [vp, vp, vp, i64, i32, i32, vp],
         'dlsg_softmax_bwd': [vp, vp, vp, i64, i32, i32, vp],
-        'dlsg_softmax_bwd2': [vp, vp, vp, vp, vp, i64, i32, i32, vp],
         'dlsg_decatt_fwd': [P(DecAttArgs), vp],
         'dlsg_decatt_bwd': [P(DecAttBwdArgs), vp],
         'dlsg_lstm_pw_fwd': [P(LstmPwArgs), vp],
@@ -240,15 +279,6 @@ def load_library(path=LIB_PATH):
         'dlsg_copy2d': [vp, i64, vp, i64, i32, i32, i32, vp],
         'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp, vp],
         'dlsg_fill': [vp, i64, f32, vp],
-        'dlsg_conv_taps': [vp, vp, i32, i32, i32, i32, vp],
-        'dlsg_tanh_ln_ws_floats': [i32, i32],
-        'dlsg_tanh_ln_fwd': [vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
-        'dlsg_tanh_ln_bwd': [vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
-        'dlsg_tanh_ln_bwd2': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp],
-        'dlsg_lstm_cell_fwd': [vp, i64, vp, vp, vp, i32, i32, vp],
-        'dlsg_lstm_cell_bwd_seq': [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
-        'dlsg_lstm_cell_bwd': [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp],
-        'dlsg_lstm_cell_bwd2': [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
         'dlsg_ce_ragged': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         'dlsg_log_softmax': [vp, vp, i32, i32, vp],
         'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
@@ -278,9 +308,23 @@ def load_library(path=LIB_PATH):
         'dlsg_lstm_seq_x_floats': [i32, i32, i32],
         'dlsg_lstm_seq_flag_words': [i32, i32, i32],
         'dlsg_lstm_seq': [P(LstmSeqArgs), i32, vp],
-        'dlsg_gemm_narrow_kind': [i32, i32, i32, i32, i32],
-        'dlsg_gemm_narrow_ws_floats': [i32, i32, i32, i32, i32],
-        'dlsg_gemm_narrow': [P(GemmNarrowArgs), vp],
+        'dlsg_crit_embed_mix': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        'dlsg_crit_embed_mix_bwd': [vp, vp, vp, vp, i32, i32, i32, vp],
+        'dlsg_crit_vocab_scatter': [vp, vp, vp, i32, i32, vp],
+        'dlsg_crit_relu_taps': [vp, vp, vp, f32, vp, vp, i32, i32, vp],
+        'dlsg_crit_relu_taps_bwd': [vp, vp, vp, vp, i32, i32, vp],
+        'dlsg_cln_ws_floats': [i32, i32],
+        'dlsg_cln_fwd': [P(ClnArgs), vp], 'dlsg_cln_bwd': [P(ClnArgs), vp], 'dlsg_cln_bwd2': [P(ClnArgs), vp],
+        'dlsg_crit_sa_fwd': [P(CritSaArgs), vp], 'dlsg_crit_sa_bwd': [P(CritSaArgs), vp], 'dlsg_crit_sa_bwd2': [P(CritSaArgs), vp],
+        'dlsg_crit_pattn_fwd': [P(CritPattnArgs), vp], 'dlsg_crit_pattn_bwd': [P(CritPattnArgs), vp],
+        'dlsg_crit_pattn_bwd2': [P(CritPattnArgs), vp],
+        'dlsg_crit_tsum_fwd': [P(CritTsumArgs), vp], 'dlsg_crit_tsum_bwd': [P(CritTsumArgs), vp], 'dlsg_crit_tsum_bwd2': [P(CritTsumArgs), vp],
+        'dlsg_crit_score_fwd': [P(CritScoreArgs), vp], 'dlsg_crit_score_bwd': [P(CritScoreArgs), vp],
+        'dlsg_crit_score_bwd2': [P(CritScoreArgs), vp],
+        'dlsg_crit_gp': [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp],
+        'dlsg_crit_topk': [vp, i64, i64, i32, vp, vp, i32, i32, i32, i32, vp],
+        'dlsg_crit_unselect': [vp, vp, vp, i32, i32, i32, i32, vp],
+        'dlsg_crit_colsum': [P(CritColsumDesc), i32, vp],
         'dlsg_comm_init': [P(vp), vp, i32, i32],
         'dlsg_comm_destroy': [vp],
         'dlsg_comm_info': [vp, P(i32), P(i32), P(i32)],
@@ -291,16 +335,17 @@ def load_library(path=LIB_PATH):
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_tanh_ln_ws_floats', 'dlsg_colsum_ws_floats',
+        fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_cln_ws_floats', 'dlsg_colsum_ws_floats',
                                             'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_bwd_x_floats',
-                                            'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_gemm_narrow_ws_floats') else C.c_int
+                                            'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words') else C.c_int
     return lib
 
 
 STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs, LstmPwArgs, LstmPwBwdArgs, DecMidArgs,
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
            SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs,
-           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs, ColsumDesc, LstmSeqArgs, GemmNarrowArgs]
+           LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs, ColsumDesc, LstmSeqArgs, ClnArgs, CritSaArgs, CritPattnArgs, CritTsumArgs,
+           CritScoreArgs, CritColsumDesc]
 
 
 def _p(t):
@@ -455,34 +500,6 @@ class HipOps(object):
                 ob += 4 * nb * (M * Kg + Ng * Kg + M * Ng * (2 if (a.flags & F_ACCUM) else 1))
             self._prof_end('gemm_%s_mfma_%s_%s' % ('bf16x3' if x3 else 'f32', variant, ('nt', 'nn', 'tn')[mode]), e0, flops, shape, ob)
 
-    def gemm_narrow_kind(self, mode, M, N, K, nbatch=1):
-        """which narrow-product kernel (csrc/gemm_narrow.hip) takes this shape; 0 = none (use gemm)"""
-        return int(self.lib.dlsg_gemm_narrow_kind(mode, M, N, K, nbatch))
-
-    def gemm_narrow(self, mode, A, B, Cc, alpha=1.0, bias=None):
-        """Cc = alpha * op(A) op(B) (+ bias) for a shape gemm_narrow_kind() accepts; 2-d operands, or 3-d as a batch."""
-        a = GemmNarrowArgs()
-        nb = Cc.size(0) if Cc.dim() == 3 else 1
-        M, N = Cc.shape[-2], Cc.shape[-1]
-        K = A.shape[-2] if mode == GEMM_TN else A.shape[-1]
-        for t in (A, B, Cc):
-            assert t.dtype == torch.float32 and (t.stride(-1) == 1 or t.size(-1) == 1), (t.shape, t.stride())
-        if mode == GEMM_TN:
-            assert A.shape[-1] == M and B.shape[-2] == K and B.shape[-1] == N, (A.shape, B.shape, Cc.shape)
-        elif mode == GEMM_NN:
-            assert A.shape[-2] == M and B.shape[-2] == K and B.shape[-1] == N, (A.shape, B.shape, Cc.shape)
-        else:
-            assert A.shape[-2] == M and B.shape[-1] == K and B.shape[-2] == N, (A.shape, B.shape, Cc.shape)
-        a.A, a.B, a.C, a.bias = _p(A), _p(B), _p(Cc), _p(bias)
-        a.lda, a.ldb, a.ldc = A.stride(-2), B.stride(-2), Cc.stride(-2)
-        if nb > 1:
-            a.bsa, a.bsb, a.bsc = A.stride(0), B.stride(0), Cc.stride(0)
-        a.mode, a.M, a.N, a.K, a.nbatch, a.alpha = mode, M, N, K, nb, alpha
-        nws = int(self.lib.dlsg_gemm_narrow_ws_floats(mode, M, N, K, nb))
-        ws = torch.empty(nws, dtype=torch.float32, device=Cc.device) if nws else None
-        a.ws, a.ws_floats = _p(ws), nws
-        self._check(self.lib.dlsg_gemm_narrow(C.byref(a), self._stream()), 'dlsg_gemm_narrow')
-
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         """slabs (S, rows, n) contiguous per slab; out (rows, n) view."""
         S, rows, n = slabs.shape
@@ -584,10 +601,6 @@ class HipOps(object):
 
     def softmax_bwd(self, y, dy, dx, outer, n, inner):
         self._check(self.lib.dlsg_softmax_bwd(_p(y), _p(dy), _p(dx), i64(outer), n, inner, self._stream()), 'softmax_bwd')
-
-    def softmax_bwd2(self, y, dy, u, gy, gdy, outer, n, inner):
-        self._check(self.lib.dlsg_softmax_bwd2(_p(y), _p(dy), _p(u), _p(gy), _p(gdy), i64(outer), n, inner, self._stream()),
-                    'softmax_bwd2')
 
     # ------------------------------------------------------------------ o2v graph
     def o2v_supported(self, T, H):
@@ -915,46 +928,52 @@ class HipOps(object):
         return self._bilstm_err
 
     # ------------------------------------------------------------------ critic LSTM, a whole sequence per launch
-    persistent_lstm_seq = True    # False: gan.py's per-step loops (one product + one cell launch per word step)
-
     def lstm_seq_supported(self, L, n, H):
-        return self.persistent_lstm_seq and bool(self.lib.dlsg_lstm_seq_supported(L, n, H))
+        """the persistent launches take up to 256 sequences; more run as consecutive launches over caption chunks"""
+        return bool(self.lib.dlsg_lstm_seq_supported(L, min(n, 256), H))
 
-    def _lstm_seq(self, level, W, L, n, H, **t):
-        a = LstmSeqArgs()
+    def _lstm_seq(self, level, W, b_ih=None, b_hh=None, **t):
+        """batch-major arrays (n, L, .): chunks of <= 256 sequences are independent recurrences, one persistent launch each"""
+        ref = next(v for v in t.values() if v is not None)
+        n, L = ref.shape[0], ref.shape[1]
+        H = W.shape[1]
         dev = W.device
-        nx = int(self.lib.dlsg_lstm_seq_x_floats(L, n, H))
-        xbuf = torch.empty(nx, dtype=torch.float32, device=dev)
-        xbuf2 = torch.empty(nx, dtype=torch.float32, device=dev) if level == 1 else None
-        flags = torch.empty(int(self.lib.dlsg_lstm_seq_flag_words(L, n, H)), dtype=torch.int32, device=dev)
+        if not self.lib.dlsg_lstm_seq_supported(L, min(n, 256), H):
+            raise RuntimeError('dlsg_lstm_seq does not take L = %d, H = %d on this device (H in {64, 512}, >= 4 * H / 8 compute units)'
+                               % (L, H))
         if getattr(self, '_lstm_seq_err', None) is None or self._lstm_seq_err.device != dev:
             self._lstm_seq_err = torch.zeros(1, dtype=torch.int32, device=dev)
         _chkc(W)
         for name, v in t.items():
             if v is not None:
                 _chkc(v)
-                assert v.dtype == torch.float32 and v.shape[:2] == (L, n) and v.shape[2] in (H, 4 * H), (name, v.shape)
-            setattr(a, name, _p(v))
-        a.W, a.xbuf, a.xbuf2, a.flags, a.err = _p(W), _p(xbuf), _p(xbuf2), _p(flags), _p(self._lstm_seq_err)
-        a.L, a.n, a.H = L, n, H
-        self._check(self.lib.dlsg_lstm_seq(C.byref(a), level, self._stream()), 'dlsg_lstm_seq(level %d)' % level)
+                assert v.dtype == torch.float32 and v.shape[:2] == (n, L) and v.shape[2] in (H, 4 * H), (name, v.shape)
+        for lo in range(0, n, 256):
+            hi = min(n, lo + 256)
+            a = LstmSeqArgs()
+            nx = int(self.lib.dlsg_lstm_seq_x_floats(L, hi - lo, H))
+            xbuf = torch.empty(nx, dtype=torch.float32, device=dev)
+            xbuf2 = torch.empty(nx, dtype=torch.float32, device=dev) if level == 1 else None
+            flags = torch.empty(int(self.lib.dlsg_lstm_seq_flag_words(L, hi - lo, H)), dtype=torch.int32, device=dev)
+            for name, v in t.items():
+                setattr(a, name, _p(None if v is None else v[lo:hi]))
+            a.W, a.xbuf, a.xbuf2, a.flags, a.err = _p(W), _p(xbuf), _p(xbuf2), _p(flags), _p(self._lstm_seq_err)
+            a.b_ih, a.b_hh = _p(b_ih), _p(b_hh)
+            a.L, a.n, a.H, a.batch_major = L, hi - lo, H, 1
+            self._check(self.lib.dlsg_lstm_seq(C.byref(a), level, self._stream()), 'dlsg_lstm_seq(level %d)' % level)
         return self._lstm_seq_err
 
-    def lstm_seq_fwd(self, xin, W, As, Hs, Cs):
-        """h_t, c_t for all L steps in one launch: xin (L, n, 4H) = x W_ih^T + b; W = weight_hh (4H, H)."""
-        L, n, H = Hs.shape
-        return self._lstm_seq(0, W, L, n, H, addend=xin, As=As, Hs=Hs, Cs=Cs)
+    def lstm_seq_fwd(self, xin, W, b_ih, b_hh, As, Hs, Cs, Hprev):
+        """h_t, c_t for all L steps in one launch: xin (n, L, 4H) = x W_ih^T; W = weight_hh (4H, H); Hprev[:, t] = h_{t-1}."""
+        return self._lstm_seq(0, W, b_ih, b_hh, addend=xin, As=As, Hs=Hs, Cs=Cs, Hprev=Hprev)
 
     def lstm_seq_bwd(self, As, Cs, W, dHs, dAs, dCs, DA, DH, DC):
         """backward through time with the injected gradients dAs / dCs (None = none) in one launch."""
-        L, n, H = dHs.shape
-        return self._lstm_seq(1, W, L, n, H, As=As, Cs=Cs, dHs=dHs, dAs=dAs, dCs=dCs, DA=DA, DH=DH, DC=DC)
+        return self._lstm_seq(1, W, As=As, Cs=Cs, dHs=dHs, dAs=dAs, dCs=dCs, DA=DA, DH=DH, DC=DC)
 
-    def lstm_seq_bwd2(self, As, Cs, W, DH, DC, ubar, gA, gC, gDH, gDC):
-        """backward of lstm_seq_bwd in one launch; ubar (L, n, 4H) holds the gradient w.r.t. DA on entry and the gradient
-        w.r.t. dAs on return; row L-1 of gC is left as the caller set it (zero)."""
-        L, n, H = DH.shape
-        return self._lstm_seq(2, W, L, n, H, As=As, Cs=Cs, DH=DH, DC=DC, addend=ubar, addend_out=ubar, gA=gA, gC=gC, gDH=gDH, gDC=gDC)
+    def lstm_seq_bwd2(self, As, Cs, W, DH, DC, ubar, gA, gC, gDH, gDHprev, gDC):
+        """derivative of lstm_seq_bwd along ubar (n, L, 4H), the tangent of the input gates, in one launch"""
+        return self._lstm_seq(2, W, As=As, Cs=Cs, DH=DH, DC=DC, addend=ubar, gA=gA, gC=gC, gDH=gDH, gDC=gDC, gDHprev=gDHprev)
 
     # ------------------------------------------------------------------ LSTM pointwise
     @staticmethod
@@ -1064,89 +1083,263 @@ class HipOps(object):
         assert t.is_contiguous()
         self._check(self.lib.dlsg_fill(_p(t), i64(t.numel()), f32(value), self._stream()), 'fill')
 
-    # ------------------------------------------------------------------ critic LSTM cell (three differentiation levels)
-    def lstm_cell_fwd(self, a, c_prev, h, c):
-        """a (n, 4H) rows strided, c_prev (or None = zero state) / h / c (n, H) dense: (h, c) = LSTM cell pointwise, gates i,f,g,o"""
-        n, H = c.shape
-        _chk2(a); _chkc(h); _chkc(c)
-        if c_prev is not None:
-            _chkc(c_prev)
-        self._check(self.lib.dlsg_lstm_cell_fwd(_p(a), i64(a.stride(0)), _p(c_prev), _p(h), _p(c), n, H, self._stream()),
-                    'lstm_cell_fwd')
+    # ------------------------------------------------------------------ critic schedule blocks (csrc/critic_sched.hip)
+    def crit_embed_mix(self, proj_tm, ids, W, bias, eps, h):
+        ng, B, L, _ = h.shape
+        self._check(self.lib.dlsg_crit_embed_mix(_p(proj_tm), _p(ids), _p(W), _p(bias), _p(eps), _p(h), ng, B, L, W.shape[1],
+                                                 self._stream()), 'crit_embed_mix')
 
-    def lstm_cell_bwd(self, a, c_prev, dh, dc, da, dc_prev):
-        n, H = c_prev.shape
-        _chk2(a)
-        for t in (c_prev, dh, dc, da, dc_prev):
+    def crit_embed_mix_bwd(self, ch, eps, dhr, dhf_tm):
+        ng, B, L, _ = ch.shape
+        self._check(self.lib.dlsg_crit_embed_mix_bwd(_p(ch), _p(eps), _p(dhr), _p(dhf_tm), ng, B, L, self._stream()), 'crit_embed_mix_bwd')
+
+    def crit_vocab_scatter(self, dhr, ids, dW):
+        _chkc(dhr); _chkc(ids); _chkc(dW)
+        self._check(self.lib.dlsg_crit_vocab_scatter(_p(dhr), _p(ids), _p(dW), ids.numel(), dW.shape[1], self._stream()), 'crit_vocab_scatter')
+
+    def crit_relu_taps(self, x, ref, bias, bias_scale, y, taps):
+        n, L, _ = x.shape
+        for t in (x, ref, y, taps):
             _chkc(t)
-        self._check(self.lib.dlsg_lstm_cell_bwd(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh), _p(dc), _p(da), _p(dc_prev), n, H,
-                                                self._stream()), 'lstm_cell_bwd')
+        self._check(self.lib.dlsg_crit_relu_taps(_p(x), _p(ref), _p(bias), f32(bias_scale), _p(y), _p(taps), n, L, self._stream()),
+                    'crit_relu_taps')
 
-    def lstm_cell_bwd_seq(self, a, c_prev, dh1, dh2, dc1, dc2, da_inj, da, dc_prev, dh_tot, dc_tot):
-        """one backward step of the whole-sequence op: sums of the optional pieces, cell backward, optional injection on da"""
-        n, H = dh1.shape
-        _chk2(a)
-        for t in (c_prev, dh1, dh2, dc1, dc2, da_inj, da, dc_prev, dh_tot, dc_tot):
-            if t is not None:
-                _chkc(t)
-        self._check(self.lib.dlsg_lstm_cell_bwd_seq(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh1), _p(dh2), _p(dc1), _p(dc2), _p(da_inj),
-                                                    _p(da), _p(dc_prev), _p(dh_tot), _p(dc_tot), n, H, self._stream()),
-                    'lstm_cell_bwd_seq')
+    def crit_relu_taps_bwd(self, dy, dtaps, ref, dx):
+        n, L, _ = dy.shape
+        for t in (dy, dtaps, ref, dx):
+            _chkc(t)
+        self._check(self.lib.dlsg_crit_relu_taps_bwd(_p(dy), _p(dtaps), _p(ref), _p(dx), n, L, self._stream()), 'crit_relu_taps_bwd')
 
-    def lstm_cell_bwd2(self, a, c_prev, dh, dc, u, uc, ga, gc_prev, gdh, gdc):
-        n, H = dh.shape
-        _chk2(a)
-        for t in (c_prev, dh, dc, u, uc, ga, gc_prev, gdh, gdc):
-            if t is not None:
-                _chkc(t)
-        self._check(self.lib.dlsg_lstm_cell_bwd2(_p(a), i64(a.stride(0)), _p(c_prev), _p(dh), _p(dc), _p(u), _p(uc), _p(ga),
-                                                 _p(gc_prev), _p(gdh), _p(gdc), n, H, self._stream()), 'lstm_cell_bwd2')
+    def _cln_args(self, x, gamma, pre_tanh, eps, p_pre, site_pre, p_post, site_post, seed, row0):
+        a = ClnArgs()
+        G = len(x)
+        rows, N = x[0].shape
+        for g in range(G):
+            _chkc(x[g]); _chkc(gamma[g])
+            assert x[g].shape == (rows, N) and x[g].dtype == torch.float32
+            a.x[g], a.gamma[g] = _p(x[g]), _p(gamma[g])
+        a.rows, a.N, a.groups, a.pre_tanh, a.eps = rows, N, G, int(pre_tanh), eps
+        a.p_pre, a.site_pre, a.p_post, a.site_post, a.row0 = p_pre, site_pre, p_post, site_post, row0
+        a.seed, a.seed_ptr = _seed(seed)
+        a.acc_lo = a.acc_hi = 0
+        return a
 
-    # ------------------------------------------------------------------ critic (tanh +) LayerNorm, three levels
-    def conv_taps(self, x, y, adjoint):
-        """adjoint False: x (n, L, C) -> y (n, L, 3C) = [x[t-1] | x[t] | x[t+1]] (zeros outside the sequence); True: the transpose"""
-        n, L = x.shape[:2]
-        C_ = y.shape[2] if adjoint else x.shape[2]
-        assert (x.shape[2], y.shape[2]) == ((3 * C_, C_) if adjoint else (C_, 3 * C_)) and y.shape[:2] == x.shape[:2]
-        _chkc(x); _chkc(y)
-        self._check(self.lib.dlsg_conv_taps(_p(x), _p(y), n, L, C_, int(adjoint), self._stream()), 'conv_taps')
+    def _cln_ws(self, a, dev):
+        return torch.empty(a.groups * int(self.lib.dlsg_cln_ws_floats(a.rows, a.N)), dtype=torch.float32, device=dev)
 
     @staticmethod
-    def _ln_geom(x, gamma):
-        """(rows per group, N, groups): gamma (N,) = one LayerNorm over all rows of x; gamma (G, N) = G LayerNorms over G
-        consecutive equal blocks of rows"""
-        rows, N = x.shape
-        G = 1 if gamma.dim() == 1 else gamma.shape[0]
-        assert rows % G == 0 and gamma.shape[-1] == N, (x.shape, gamma.shape)
-        return rows // G, N, G
+    def _cln_dys(a, dys):
+        a.ndy = len(dys)
+        for k, lst in enumerate(dys):
+            for g, t in enumerate(lst):
+                _chkc(t)
+                a.dy[k][g] = _p(t)
 
-    def _ln_ws(self, x, gamma):
-        rows, N, G = self._ln_geom(x, gamma)
-        return torch.empty(G * int(self.lib.dlsg_tanh_ln_ws_floats(rows, N)), dtype=torch.float32, device=x.device)
+    def cln_fwd(self, x, gamma, beta, y, pre_tanh, eps=1e-5, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, seed=0, row0=0):
+        a = self._cln_args(x, gamma, pre_tanh, eps, p_pre, site_pre, p_post, site_post, seed, row0)
+        for g in range(len(x)):
+            _chkc(y[g])
+            a.beta[g], a.y[g] = _p(beta[g]), _p(y[g])
+        self._check(self.lib.dlsg_cln_fwd(C.byref(a), self._stream()), 'cln_fwd')
 
-    def tanh_ln_fwd(self, x, gamma, beta, y, eps, pre_tanh):
-        """x, y (rows, N) dense: y = LayerNorm(tanh(x) if pre_tanh else x) * gamma + beta; gamma / beta (G, N): G LayerNorms"""
-        rows, N, G = self._ln_geom(x, gamma)
-        for t in (x, gamma, beta, y):
+    def cln_bwd(self, x, gamma, dys, dx, dgamma, dbeta, pre_tanh, eps=1e-5, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, seed=0,
+                row0=0, acc=None, extra=None):
+        a = self._cln_args(x, gamma, pre_tanh, eps, p_pre, site_pre, p_post, site_post, seed, row0)
+        self._cln_dys(a, dys)
+        for g in range(len(x)):
+            _chkc(dx[g])
+            a.dx[g] = _p(dx[g])
+            if dgamma:
+                a.dgamma[g], a.dbeta[g] = _p(dgamma[g]), _p(dbeta[g])
+                if extra is not None:
+                    _chkc(extra[g])
+                    a.extra[g] = _p(extra[g])
+        if acc is not None:
+            a.acc_lo, a.acc_hi = acc
+        ws = self._cln_ws(a, x[0].device) if dgamma else None
+        a.ws = _p(ws)
+        self._check(self.lib.dlsg_cln_bwd(C.byref(a), self._stream()), 'cln_bwd')
+
+    def cln_bwd2(self, x, gamma, dys, U, gx, gdy, gpart, pre_tanh, eps=1e-5, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, seed=0,
+                 row0=0):
+        a = self._cln_args(x, gamma, pre_tanh, eps, p_pre, site_pre, p_post, site_post, seed, row0)
+        self._cln_dys(a, dys)
+        for g in range(len(x)):
+            for t in (U[g], gx[g], gdy[g], gpart[g]):
+                _chkc(t)
+            a.U[g], a.gx[g], a.gdy[g], a.gpart[g] = _p(U[g]), _p(gx[g]), _p(gdy[g]), _p(gpart[g])
+        ws = self._cln_ws(a, x[0].device)
+        a.ws = _p(ws)
+        self._check(self.lib.dlsg_cln_bwd2(C.byref(a), self._stream()), 'cln_bwd2')
+
+    def _sa_args(self, KQV, smask, scale, acc=None):
+        a = CritSaArgs()
+        _chkc(KQV); _chkc(smask)
+        a.KQV, a.smask = _p(KQV), _p(smask)
+        a.n, a.L, a.B, a.scale = KQV.shape[0], KQV.shape[1], smask.shape[0], scale
+        a.acc_lo, a.acc_hi = acc if acc is not None else (0, 0)
+        return a
+
+    def crit_sa_fwd(self, KQV, smask, w, ctx, scale):
+        a = self._sa_args(KQV, smask, scale)
+        _chkc(w); _chkc(ctx)
+        a.w, a.ctx = _p(w), _p(ctx)
+        self._check(self.lib.dlsg_crit_sa_fwd(C.byref(a), self._stream()), 'crit_sa_fwd')
+
+    def crit_sa_bwd(self, KQV, smask, w, dctx, dKQV, scale, acc=None):
+        a = self._sa_args(KQV, smask, scale, acc)
+        for t in (w, dctx, dKQV):
             _chkc(t)
-        self._check(self.lib.dlsg_tanh_ln_fwd(_p(x), _p(gamma), _p(beta), _p(y), rows, N, f32(eps), int(pre_tanh), G, self._stream()),
-                    'tanh_ln_fwd')
+        a.w, a.dctx, a.dKQV = _p(w), _p(dctx), _p(dKQV)
+        self._check(self.lib.dlsg_crit_sa_bwd(C.byref(a), self._stream()), 'crit_sa_bwd')
 
-    def tanh_ln_bwd(self, x, gamma, dy, dx, dgamma, dbeta, eps, pre_tanh):
-        rows, N, G = self._ln_geom(x, gamma)
-        for t in (x, gamma, dy, dx, dgamma, dbeta):
+    def crit_sa_bwd2(self, KQV, smask, dctx, U, Uctx, gKQV, scale):
+        a = self._sa_args(KQV, smask, scale)
+        for t in (dctx, U, Uctx, gKQV):
             _chkc(t)
-        ws = self._ln_ws(x, gamma)
-        self._check(self.lib.dlsg_tanh_ln_bwd(_p(x), _p(gamma), _p(dy), _p(dx), _p(dgamma), _p(dbeta), _p(ws), rows, N, f32(eps),
-                                              int(pre_tanh), G, self._stream()), 'tanh_ln_bwd')
+        a.dctx, a.U, a.Uctx, a.gKQV = _p(dctx), _p(U), _p(Uctx), _p(gKQV)
+        self._check(self.lib.dlsg_crit_sa_bwd2(C.byref(a), self._stream()), 'crit_sa_bwd2')
 
-    def tanh_ln_bwd2(self, x, gamma, dy, U, vg, vb, gx, ggamma, gdy, eps, pre_tanh):
-        rows, N, G = self._ln_geom(x, gamma)
-        for t in (x, gamma, dy, U, vg, vb, gx, ggamma, gdy):
+    @staticmethod
+    def _set2(a, **kw):
+        for name, pair in kw.items():
+            if pair is None:
+                continue
+            arr = getattr(a, name)
+            for h in range(2):
+                _chkc(pair[h])
+                arr[h] = _p(pair[h])
+
+    def _pattn_args(self, a_, e, smask, scale, acc=None):
+        a = CritPattnArgs()
+        self._set2(a, a=a_, e=e)
+        _chkc(smask)
+        a.smask = _p(smask)
+        a.n, a.L, a.B, a.T, a.scale = a_[0].shape[0], a_[0].shape[1], smask.shape[0], e[0].shape[1], scale
+        a.acc_lo, a.acc_hi = acc if acc is not None else (0, 0)
+        return a
+
+    def crit_pattn_fwd(self, a_, e, smask, P, wgt, aggpre, scale):
+        a = self._pattn_args(a_, e, smask, scale)
+        self._set2(a, P=P, wgt=wgt, aggpre=aggpre)
+        self._check(self.lib.dlsg_crit_pattn_fwd(C.byref(a), self._stream()), 'crit_pattn_fwd')
+
+    def crit_pattn_bwd(self, a_, e, smask, P, d_agg, d_wgt, da, de, scale, acc=None):
+        a = self._pattn_args(a_, e, smask, scale, acc)
+        self._set2(a, P=P, d_agg=d_agg, d_wgt=d_wgt, da=da, de=de)
+        self._check(self.lib.dlsg_crit_pattn_bwd(C.byref(a), self._stream()), 'crit_pattn_bwd')
+
+    def crit_pattn_bwd2(self, a_, e, smask, d_agg, d_wgt, Ua, Uagg, Uwgt, ga, ge, scale):
+        a = self._pattn_args(a_, e, smask, scale)
+        self._set2(a, d_agg=d_agg, d_wgt=d_wgt, Ua=Ua, Uagg=Uagg, Uwgt=Uwgt, ga=ga, ge=ge)
+        self._check(self.lib.dlsg_crit_pattn_bwd2(C.byref(a), self._stream()), 'crit_pattn_bwd2')
+
+    def _tsum_args(self, words, theta, gamma, beta, fusion, eps, p, site, seed, row0, acc=None):
+        a = CritTsumArgs()
+        for t in (words, theta, gamma, fusion):
             _chkc(t)
-        ws = self._ln_ws(x, gamma)
-        self._check(self.lib.dlsg_tanh_ln_bwd2(_p(x), _p(gamma), _p(dy), _p(U), _p(vg), _p(vb), _p(gx), _p(ggamma), _p(gdy), _p(ws),
-                                               rows, N, f32(eps), int(pre_tanh), G, self._stream()), 'tanh_ln_bwd2')
+        a.words, a.theta, a.gamma, a.beta, a.fusion = _p(words), _p(theta), _p(gamma), _p(beta if beta is not None else gamma), _p(fusion)
+        a.n, a.L, a.eps, a.p, a.site, a.row0 = words.shape[0], words.shape[1], eps, p, site, row0
+        a.seed, a.seed_ptr = _seed(seed)
+        a.acc_lo, a.acc_hi = acc if acc is not None else (0, 0)
+        return a
+
+    def crit_tsum_fwd(self, words, theta, gamma, beta, fusion, adj, u, sent, fus, eps=1e-5, p=0.0, site=0, seed=0, row0=0):
+        a = self._tsum_args(words, theta, gamma, beta, fusion, eps, p, site, seed, row0)
+        for t in (adj, u, sent, fus):
+            _chkc(t)
+        a.adj, a.u, a.sent, a.fus = _p(adj), _p(u), _p(sent), _p(fus)
+        self._check(self.lib.dlsg_crit_tsum_fwd(C.byref(a), self._stream()), 'crit_tsum_fwd')
+
+    def crit_tsum_bwd(self, words, theta, gamma, fusion, adj, u, sent, fus, d_fus, dwords, part, eps=1e-5, p=0.0, site=0, seed=0,
+                      row0=0, acc=None):
+        """(adj, u, sent, fus of the forward are recomputed by the kernel: accepted for interface symmetry, not read)"""
+        a = self._tsum_args(words, theta, gamma, None, fusion, eps, p, site, seed, row0, acc)
+        _chkc(d_fus); _chkc(dwords)
+        a.d_fus, a.dwords, a.part = _p(d_fus), _p(dwords), _p(part)
+        self._check(self.lib.dlsg_crit_tsum_bwd(C.byref(a), self._stream()), 'crit_tsum_bwd')
+
+    def crit_tsum_bwd2(self, words, theta, gamma, beta, fusion, d_fus, U, Ufus, gwords, gpart, eps=1e-5, p=0.0, site=0, seed=0, row0=0):
+        a = self._tsum_args(words, theta, gamma, beta, fusion, eps, p, site, seed, row0)
+        for t in (d_fus, U, Ufus, gwords, gpart):
+            _chkc(t)
+        a.d_fus, a.U, a.Ufus, a.gwords, a.gpart = _p(d_fus), _p(U), _p(Ufus), _p(gwords), _p(gpart)
+        self._check(self.lib.dlsg_crit_tsum_bwd2(C.byref(a), self._stream()), 'crit_tsum_bwd2')
+
+    def _score_args(self, v, s, wc, wgt, fus, pair, score, ng, acc=None):
+        a = CritScoreArgs()
+        self._set2(a, v=v, s=s, wc=wc, wgt=wgt, pair=pair, score=score)
+        _chkc(fus)
+        a.fus = _p(fus)
+        a.n, a.B, a.T, a.ng = s[0].shape[0], v[0].shape[0], v[0].shape[1], ng
+        a.acc_lo, a.acc_hi = acc if acc is not None else (0, 0)
+        return a
+
+    def crit_score_fwd(self, v, s, wc, bc, wgt, fus, pair, score, both, out, ng):
+        a = self._score_args(v, s, wc, wgt, fus, pair, score, ng)
+        self._set2(a, bc=bc)
+        _chkc(both); _chkc(out)
+        a.both, a.out = _p(both), _p(out)
+        self._check(self.lib.dlsg_crit_score_fwd(C.byref(a), self._stream()), 'crit_score_fwd')
+
+    def crit_score_bwd(self, v, s, wc, wgt, fus, pair, score, both, d_out, d_fus, c_spre, c_vpre, d_wgt, part_wc, dbc, ng, acc=None):
+        a = self._score_args(v, s, wc, wgt, fus, pair, score, ng, acc)
+        self._set2(a, c_spre=c_spre, c_vpre=c_vpre, d_wgt=d_wgt, part_wc=part_wc)
+        for t in (both, d_out, d_fus):
+            _chkc(t)
+        a.both, a.d_out, a.d_fus, a.dbc = _p(both), _p(d_out), _p(d_fus), _p(dbc)
+        scratch = torch.empty(4 * ng + 16, dtype=torch.float32, device=fus.device)
+        a.scratch = _p(scratch)
+        self._check(self.lib.dlsg_crit_score_bwd(C.byref(a), self._stream()), 'crit_score_bwd')
+
+    def crit_score_bwd2(self, v, s, wc, bc, wgt, fus, pair, score, d_out, Uspre, Uwgt, Ufus, g_fus, g_spre, g_vpre, g_wgt, gpart_wc, g_dbc):
+        a = self._score_args(v, s, wc, wgt, fus, pair, score, 1)
+        self._set2(a, Uspre=Uspre, Uwgt=Uwgt, c_spre=g_spre, c_vpre=g_vpre, d_wgt=g_wgt, part_wc=gpart_wc)
+        for t in (d_out, Ufus, g_fus, g_dbc):
+            _chkc(t)
+        a.d_out, a.Ufus, a.d_fus, a.dbc = _p(d_out), _p(Ufus), _p(g_fus), _p(g_dbc)
+        n = s[0].shape[0]
+        scratch = torch.empty(16 + 2 * n + 2 * n * 8, dtype=torch.float32, device=fus.device)
+        a.scratch = _p(scratch)
+        self._check(self.lib.dlsg_crit_score_bwd2(C.byref(a), self._stream()), 'crit_score_bwd2')
+
+    def crit_gp(self, g, gG, out, stats, vseed, gsc):
+        B, L, _ = g.shape
+        for t in (g, gG, out, stats, vseed, gsc):
+            _chkc(t)
+        q = torch.empty(B, dtype=torch.float32, device=g.device)
+        self._check(self.lib.dlsg_crit_gp(_p(g), _p(gG), _p(out), _p(stats), _p(vseed), _p(gsc), _p(q), B, L, self._stream()), 'crit_gp')
+
+    def crit_topk(self, alpha, smask, P, T, idx):
+        B, L, na = alpha.shape
+        assert alpha.stride(2) == 1 and alpha.dtype == torch.float32
+        _chkc(smask); _chkc(idx)
+        self._check(self.lib.dlsg_crit_topk(_p(alpha), i64(alpha.stride(0)), i64(alpha.stride(1)), na, _p(smask), _p(idx), B, L, P, T,
+                                            self._stream()), 'crit_topk')
+
+    def crit_unselect(self, src, idx, dst, per):
+        """dst (R, n): row idx[r] = src[r], every other row zero; dst is groups of `per` rows, idx holds the selected rows of each
+        group (the same number per group), group by group"""
+        _chkc(src); _chkc(idx); _chkc(dst)
+        self._check(self.lib.dlsg_crit_unselect(_p(src), _p(idx), _p(dst), src.shape[0], dst.shape[0], per, dst.shape[1], self._stream()),
+                    'crit_unselect')
+
+    def crit_colsum(self, descs):
+        """descs: list of (sources, out, out_b, scale): out = scale * sum over the rows of the one or two 2-d sources (unit column
+        stride); out_b (or None) receives a copy.  One launch per 32 descriptors, fixed order of additions."""
+        for lo in range(0, len(descs), 32):
+            chunk = descs[lo:lo + 32]
+            arr = (CritColsumDesc * len(chunk))()
+            for d, (srcs, out, out_b, scale) in zip(arr, chunk):
+                a = srcs[0]
+                assert a.dim() == 2 and (a.stride(1) == 1 or a.shape[1] == 1) and out.numel() == a.shape[1] and out.is_contiguous()
+                d.part, d.ld, d.rows, d.n = _p(a), a.stride(0), a.shape[0], a.shape[1]
+                if len(srcs) > 1:
+                    b = srcs[1]
+                    assert b.dim() == 2 and (b.stride(1) == 1 or b.shape[1] == 1) and b.shape[1] == a.shape[1]
+                    d.part_b, d.ld_b, d.rows_b = _p(b), b.stride(0), b.shape[0]
+                d.out, d.out_b, d.scale = _p(out), _p(out_b), scale
+            self._check(self.lib.dlsg_crit_colsum(arr, len(chunk), self._stream()), 'crit_colsum')
 
     def gather_rows(self, src, idx, dst):
         """dst[r] = src[idx[r]] (2-d views; dst must not alias src)."""

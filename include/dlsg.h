@@ -17,8 +17,10 @@ extern "C" {
 
 /* Bumped whenever the signature or the meaning of an existing entry point changes (2: dlsg_colsum / dlsg_colsum2 take a
  * workspace pointer before the stream; the RCCL communicator entry points and the persistent BiLSTM were added).  A binding
- * must refuse a library whose version differs from the header it was written against. */
-#define DLSG_ABI_VERSION 3
+ * must refuse a library whose version differs from the header it was written against.  (4: the critic's per-op entry points --
+ * dlsg_lstm_cell_*, dlsg_tanh_ln_*, dlsg_conv_taps, dlsg_softmax_bwd2, dlsg_gemm_narrow -- gave way to the blocks of its schedule,
+ * dlsg_crit_* / dlsg_cln_*; dlsg_lstm_seq takes batch-major arrays.) */
+#define DLSG_ABI_VERSION 4
 int dlsg_abi_version(void);
 
 /* Return codes of every entry point that returns int: 0 or one of these. */
@@ -236,10 +238,6 @@ int dlsg_sa_core_bwd(const dlsg_sa_core_bwd_args* a, void* stream);
 int dlsg_softmax_fwd(const float* x, const float* mask, float* y, int64_t outer, int n, int inner, void* stream);
 /* dx = y * (dy - sum_n y*dy) */
 int dlsg_softmax_bwd(const float* y, const float* dy, float* dx, int64_t outer, int n, int inner, void* stream);
-/* backward of dlsg_softmax_bwd w.r.t. (y, dy) for a cotangent u on dx (the DiscV2 critic's softmaxes are differentiated
- * twice, run_gun.py:362-371): t = sum u y, gdy = y (u - t), gy = u (dy - s) - dy t */
-int dlsg_softmax_bwd2(const float* y, const float* dy, const float* u, float* gy, float* gdy, int64_t outer, int n, int inner,
-                      void* stream);
 
 /* ---------------------------------------------------------------- decoder attention over cached K', V' (sublayer.py:28-43)
  * For stream s in {0,1}: score_p = K'_s[b,p,:].q[b,:] * scale; w = softmax over p; c = sum_p w_p V'_s[b,p,:].
@@ -417,48 +415,163 @@ int dlsg_gather_rows(const float* src, int64_t lds, const int64_t* idx, float* d
 /* dst[b,t,:] = src[t,b,:]: time-major decoder buffers -> the (B,L,V) layout Decoder.forward returns (layer.py:447) */
 int dlsg_permute_tb(const float* src, float* dst, int T, int B, int n, void* stream);
 
-/* ---------------------------------------------------------------- DiscV2 critic
- * Pointwise part of one step of the critic's nn.LSTM(512, 512) (models/model.py:122,147-150), at the three levels the
- * WGAN-GP critic update differentiates it (run_gun.py:362-371: gradient penalty with create_graph=True, then loss backward):
- *   a (rows, 4H) row stride lda = x W_ih^T + h_prev W_hh^T + b, gate order i,f,g,o; every other array dense (rows, H) / (rows, 4H).
- *   fwd : (h, c) = cell(a, c_prev)                 (c_prev NULL: zero state)
- *   bwd : (da, dc_prev) = cell'(a, c_prev; dh, dc)
- *   bwd2: vector-Jacobian product of bwd w.r.t. (a, c_prev, dh, dc) for cotangents (u on da, uc on dc_prev)
- * The recurrent products stay GEMMs of the caller (dlsg_gemm or the framework's matmul). */
-int dlsg_lstm_cell_fwd(const float* a, int64_t lda, const float* c_prev, float* h, float* c, int rows, int H, void* stream);
-int dlsg_lstm_cell_bwd(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, float* da,
-                       float* dc_prev, int rows, int H, void* stream);
-/* bwd inside the whole-sequence op (dlsg_amd/gan.py _LstmSeq): dh = dh1 + dh2, dc = dc1 + dc2, da = cell'(a, c_prev; dh, dc) + da_inj;
- * dh2, dc1, dc2, da_inj and c_prev may be NULL (= 0); the summed dh / dc are written to dh_tot / dc_tot. */
-int dlsg_lstm_cell_bwd_seq(const float* a, int64_t lda, const float* c_prev, const float* dh1, const float* dh2, const float* dc1,
-                           const float* dc2, const float* da_inj, float* da, float* dc_prev, float* dh_tot, float* dc_tot, int rows,
-                           int H, void* stream);
-/* c_prev / uc NULL: zeros (first step); gc_prev NULL: not wanted */
-int dlsg_lstm_cell_bwd2(const float* a, int64_t lda, const float* c_prev, const float* dh, const float* dc, const float* u,
-                        const float* uc, float* ga, float* gc_prev, float* gdh, float* gdc, int rows, int H, void* stream);
+/* ---------------------------------------------------------------- DiscV2 critic: the blocks of its schedule
+ * `DiscV2.forward` (models/model.py:143-166), `PSLScore2.forward` (models/layer.py:690-715), `SelfAttention` with the caption mask
+ * (models/sublayer.py:63-82), `LatentPSL` (sublayer.py:189-198), `ResBlock` (sublayer.py:107-119) and the WGAN-GP critic update
+ * around them (run_gun.py:339-381: three critic forwards, gradient penalty with create_graph=True, loss backward) as explicit
+ * passes of dlsg_amd/critic.py.  Every block exists at three levels:
+ *   fwd   the block's forward;
+ *   bwd   its vector-Jacobian product (inputs; parameters where it has any);
+ *   bwd2  the DIRECTIONAL DERIVATIVE of (fwd, bwd) along a tangent U of the block's input at fixed output cotangent -- what the
+ *         gradient penalty's second-order term needs of a block: the derivative of fwd is the tangent handed to the next block,
+ *         the derivative of bwd's input gradient an extra cotangent on the block's input, the derivative of bwd's parameter
+ *         gradient an extra parameter gradient.
+ * Activations are batch-major: (captions, L words, 512) dense; `captions` = n blocks of B ("caption sets" scored against the same
+ * B clips: caption i belongs to clip i % B).  acc_lo / acc_hi: a caption (or row) range whose outputs are ADDED to what the
+ * buffer holds (the extra cotangents of the bwd2 pass) instead of written.  Dropout is the stateless mask of the generator path
+ * (keyed by seed + *seed_ptr, site, element index); p = 0 switches it off.  L <= 32, T <= 8 proposals, width 512. */
+#define DLSG_CRIT_C 512
+#define DLSG_CRIT_LMAX 32
+#define DLSG_CRIT_TMAX 8
 
-/* The three shifted copies of a sequence that turn DiscV2's ResBlock convolution (Conv1d(512, 512, 3, padding = 1) over the word
- * axis, sublayer.py:107-119) into one product: adjoint == 0: x (n, L, C) -> y (n, L, 3C), y[b, t, k C + c] = x[b, t + k - 1, c]
- * (zero outside 0 <= t + k - 1 < L); adjoint != 0: x (n, L, 3C) -> y (n, L, C), the transposed map (the gradient of the first).
- * Dense arrays, C % 4 == 0, 16-byte aligned. */
-int dlsg_conv_taps(const float* x, float* y, int n, int L, int C, int adjoint, void* stream);
+/* Vocabulary projection glue (models/model.py:143-144 on one-hot / logit inputs, run_gun.py:447-451,358-360).
+ * embed_mix: proj_tm (L,B,512) = logits W^T without bias; ids (B,L) or NULL; W (512,V); eps (B) or NULL.
+ *   ng = 3: h[0] = W[:, ids] + bias (real captions as a gather of weight columns), h[1] = proj + bias, h[2] = eps h[0] + (1-eps) h[1];
+ *   ng = 1: h[0] = proj + bias.   h (ng, B, L, 512).
+ * embed_mix_bwd: ch (ng,B,L,512) -> dhr (B,L,512) = ch[0] + eps ch[2] and dhf_tm (L,B,512) = ch[1] + (1-eps) ch[2]  (ng = 1: dhf_tm = ch[0]^T).
+ * vocab_scatter: dW[:, ids[b,l]] += dhr[b,l,:] in a fixed order (the first row carrying an id adds all rows of that id). */
+int dlsg_crit_embed_mix(const float* proj_tm, const int64_t* ids, const float* W, const float* bias, const float* eps, float* h,
+                        int ng, int B, int L, int V, void* stream);
+int dlsg_crit_embed_mix_bwd(const float* ch, const float* eps, float* dhr, float* dhf_tm, int ng, int B, int L, void* stream);
+int dlsg_crit_vocab_scatter(const float* dhr, const int64_t* ids, float* dW, int rows, int V, void* stream);
 
-/* The critic's normalisations y = LayerNorm(tanh(x)) (pre_tanh = 1) or LayerNorm(x) over dense rows of N = 64..1024 columns
- * (N % 64 == 0), eps inside the square root, biased variance (models/model.py:124-131, layer.py:661-689), again at the three
- * levels of the WGAN-GP update: fwd; bwd = (dx, dgamma, dbeta) from dy; bwd2 = vector-Jacobian product of bwd w.r.t.
- * (x, gamma, dy) for cotangents (U on dx, vg on dgamma, vb on dbeta).  ws: caller scratch of dlsg_tanh_ln_ws_floats(rows, N)
- * floats (per-workgroup column partials, summed in a fixed order). */
-int64_t dlsg_tanh_ln_ws_floats(int rows, int N);
-/* groups (ABI 3): 1 = one LayerNorm over `rows` rows.  groups = G > 1: G same-shape LayerNorms in one launch (the two
- * proposal scorers of DiscV2, layer.py:661-689, side by side): x / y / dy / ... hold G consecutive blocks of `rows` rows, gamma,
- * beta, dgamma, dbeta, vg, vb, ggamma are (G, N); ws = G * dlsg_tanh_ln_ws_floats(rows, N) floats. */
-int dlsg_tanh_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, int rows, int N, float eps, int pre_tanh,
-                     int groups, void* stream);
-int dlsg_tanh_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* ws,
-                     int rows, int N, float eps, int pre_tanh, int groups, void* stream);
-int dlsg_tanh_ln_bwd2(const float* x, const float* gamma, const float* dy, const float* U, const float* vg, const float* vb,
-                      float* gx, float* ggamma, float* gdy, float* ws, int rows, int N, float eps, int pre_tanh, int groups,
-                      void* stream);
+/* ResBlock head (sublayer.py:110-119; its ReLU is in place, so the skip carries relu(x)): z = x * [ref > 0];
+ * y = z (+ bias_scale * bias); taps[i, l, 3 c + k] = z[i, l + k - 1, c] (zero outside the caption): the three shifted copies that
+ * turn Conv1d(512, 512, 3, padding = 1) into ONE product with conv.weight viewed as (512, 1536).  x, ref, y (n, L, 512), taps (n, L, 1536).
+ * bwd: dx = (dy + sum_k dtaps[i, l - k + 1, 3 c + k]) * [ref > 0]. */
+int dlsg_crit_relu_taps(const float* x, const float* ref, const float* bias, float bias_scale, float* y, float* taps, int n, int L,
+                        void* stream);
+int dlsg_crit_relu_taps_bwd(const float* dy, const float* dtaps, const float* ref, float* dx, int n, int L, void* stream);
+
+/* (tanh +) LayerNorm with dropouts: z = drop_pre(x); t = pre_tanh ? tanh(z) : z; y = drop_post(LN(t) gamma + beta), rows of N = 64..1024
+ * columns (N % 64 == 0), `groups` <= 4 same-shape blocks of `rows` rows with their own arrays (the critic's two proposal heads side
+ * by side); block g uses dropout sites site_* + g; the mask of element (r, j) is keyed by (row0 + r) * N + j.
+ *   bwd : dy = sum of ndy <= 3 arrays; dx (rows [acc_lo, acc_hi) of every block added to), dgamma / dbeta (NULL: not wanted;
+ *         extra[g] (2, N), optional, is added to (dgamma, dbeta)); ws = dlsg_cln_ws_floats(rows, N) * groups floats of scratch
+ *   bwd2: U = tangent of x -> gdy = tangent of y, gx = derivative of dx, gpart[g] (2, N) = derivative of (dgamma, dbeta) */
+#define DLSG_CLN_MAXG 4
+typedef struct {
+    const float* x[DLSG_CLN_MAXG]; const float* gamma[DLSG_CLN_MAXG]; const float* beta[DLSG_CLN_MAXG];
+    float* y[DLSG_CLN_MAXG];
+    const float* dy[3][DLSG_CLN_MAXG]; float* dx[DLSG_CLN_MAXG];
+    float* dgamma[DLSG_CLN_MAXG]; float* dbeta[DLSG_CLN_MAXG]; const float* extra[DLSG_CLN_MAXG];
+    const float* U[DLSG_CLN_MAXG]; float* gx[DLSG_CLN_MAXG]; float* gdy[DLSG_CLN_MAXG]; float* gpart[DLSG_CLN_MAXG];
+    float* ws;
+    int32_t rows, N, groups, pre_tanh, ndy, acc_lo, acc_hi, pad_;
+    float eps, p_pre, p_post; uint32_t site_pre, site_post, pad2_;
+    uint64_t seed; const uint64_t* seed_ptr; int64_t row0;
+} dlsg_cln_args;
+int64_t dlsg_cln_ws_floats(int rows, int N);
+int dlsg_cln_fwd(const dlsg_cln_args* a, void* stream);
+int dlsg_cln_bwd(const dlsg_cln_args* a, void* stream);
+int dlsg_cln_bwd2(const dlsg_cln_args* a, void* stream);
+
+/* Masked self-attention core of one caption on rows [K | Q | V] (n, L, 1536) (sublayer.py:66-78 with att_mask[b,i,j] =
+ * smask[b,i] smask[b,j], run_gun.py:164-166; smask (B, L), caption i uses smask[i % B]):
+ *   w = softmax_j(scale K_i . Q_j, masked entries -9e15), ctx = w V.     bwd: dctx -> dKQV.
+ *   bwd2: U (n, L, 1536) tangent of [K | Q | V], dctx fixed -> Uctx (tangent of ctx), gKQV (derivative of dKQV; w varies with K, Q). */
+typedef struct {
+    const float* KQV; const float* smask; float* w; float* ctx;
+    const float* dctx; float* dKQV;
+    const float* U; float* Uctx; float* gKQV;
+    int32_t n, B, L, acc_lo, acc_hi, pad_;
+    float scale, pad2_;
+} dlsg_crit_sa_args;
+int dlsg_crit_sa_fwd(const dlsg_crit_sa_args* a, void* stream);
+int dlsg_crit_sa_bwd(const dlsg_crit_sa_args* a, void* stream);
+int dlsg_crit_sa_bwd2(const dlsg_crit_sa_args* a, void* stream);
+
+/* PSLScore2's word -> proposal graph (layer.py:697-707), both heads per launch: a[h] (n, L, 512) words, e[h] (B, T, 512) proposals
+ * of the clips (caption i scores clip i % B):
+ *   P = softmax over the words of scale a e^T (n, L, T); adj = P * smask (mask AFTER the softmax, :703-704); wgt = sum_l adj (n, T);
+ *   aggpre = adj^T a (n, T, 512).
+ *   bwd : d_agg (n, T, 512), d_wgt (n, T) -> da (n, L, 512), de (n, T, 512) per caption (NULL: not wanted; the caller sums a clip's captions)
+ *   bwd2: Ua = tangent of a -> Uagg, Uwgt (tangents), ga, ge (derivatives of da, de) */
+typedef struct {
+    const float* a[2]; const float* e[2]; const float* smask;
+    float* P[2]; float* wgt[2]; float* aggpre[2];
+    const float* d_agg[2]; const float* d_wgt[2]; float* da[2]; float* de[2];
+    const float* Ua[2]; float* Uagg[2]; float* Uwgt[2]; float* ga[2]; float* ge[2];
+    int32_t n, B, L, T, acc_lo, acc_hi;
+    float scale, pad_;
+} dlsg_crit_pattn_args;
+int dlsg_crit_pattn_fwd(const dlsg_crit_pattn_args* a, void* stream);
+int dlsg_crit_pattn_bwd(const dlsg_crit_pattn_args* a, void* stream);
+int dlsg_crit_pattn_bwd2(const dlsg_crit_pattn_args* a, void* stream);
+
+/* Text summary (LatentPSL(512, 1), sublayer.py:189-198, no mask) and the fusion weights (models/model.py:163-165):
+ *   adj = softmax_l(words theta) (n, L); u = adj^T words (n, 512); sent = drop(LN(tanh(u))); fus = softmax(sent fusion^T) (n, 2)
+ *   bwd : d_fus (n, 2) -> dwords (n, L, 512), part (n, 5, 512) per-caption partials of [dtheta, dgamma, dbeta, dfusion_0, dfusion_1]
+ *         (NULL: not wanted)
+ *   bwd2: U (n, L, 512) tangent of words -> Ufus, gwords, gpart (n, 5, 512) */
+typedef struct {
+    const float* words; const float* theta; const float* gamma; const float* beta; const float* fusion;
+    float* adj; float* u; float* sent; float* fus;
+    const float* d_fus; float* dwords; float* part;
+    const float* U; float* Ufus; float* gwords; float* gpart;
+    int32_t n, L, acc_lo, acc_hi;
+    float eps, p; uint32_t site, pad_;
+    uint64_t seed; const uint64_t* seed_ptr; int64_t row0;
+} dlsg_crit_tsum_args;
+int dlsg_crit_tsum_fwd(const dlsg_crit_tsum_args* a, void* stream);
+int dlsg_crit_tsum_bwd(const dlsg_crit_tsum_args* a, void* stream);
+int dlsg_crit_tsum_bwd2(const dlsg_crit_tsum_args* a, void* stream);
+
+/* Pair scores, batch means, critic output (sublayer.py:304-306, layer.py:709-714, models/model.py:165-166), heads h = 0, 1:
+ *   pair[h][i,t] = sum_c v[h][i % B,t,c] s[h][i,t,c] wc[h][c] + bc[h];  score[h][i] = sum_t pair wgt / sum_t wgt;
+ *   both[g][h] = mean over the B captions of set g of score[h] (PSLScore2 ends with a mean over ITS batch);  out[i] = sum_h both[g(i)][h] fus[i][h]
+ *   v = tanh(v_pre) (B, T, 512), s = tanh(s_pre) (n, T, 512): the backward returns the gradients of the PRE-activations.
+ *   bwd : d_out (n) -> d_fus (n, 2), c_spre[h] (n, T, 512), c_vpre[h] (n, T, 512) per caption (NULL: not wanted), d_wgt[h] (n, T),
+ *         part_wc[h] (n, 512) per-caption partials of classify.weight's gradient and dbc (2) (NULL: not wanted); scratch (4 ng + 8) floats
+ *   bwd2: ONE caption set (n == B); tangents Uspre[h] (n, T, 512) of s_pre, Uwgt[h] (n, T), Ufus (n, 2) -> the derivatives of bwd's
+ *         outputs: g_fus, g_spre, g_vpre, g_wgt, gpart_wc, g_dbc; scratch (2 n + 16) floats */
+typedef struct {
+    const float* v[2]; const float* s[2]; const float* wc[2]; const float* bc[2]; const float* wgt[2]; const float* fus;
+    float* pair[2]; float* score[2]; float* both; float* out;
+    const float* d_out; float* d_fus; float* c_spre[2]; float* c_vpre[2]; float* d_wgt[2]; float* part_wc[2]; float* dbc;
+    const float* Uspre[2]; const float* Uwgt[2]; const float* Ufus;
+    float* scratch;
+    int32_t n, B, T, ng, acc_lo, acc_hi;
+} dlsg_crit_score_args;
+int dlsg_crit_score_fwd(const dlsg_crit_score_args* a, void* stream);
+int dlsg_crit_score_bwd(const dlsg_crit_score_args* a, void* stream);
+int dlsg_crit_score_bwd2(const dlsg_crit_score_args* a, void* stream);
+
+/* Gradient penalty and the update's loss values (run_gun.py:362-375) from g = d(sum mixed scores)/d(mixed projection) (B, L, 512) and
+ * gG = g (W W^T): q_b = sum g gG = |d mixed score_b / d mixed caption_b|^2, gn = sqrt(max(q, 1e-24)), penalty = mean (gn - 1)^2,
+ * c_b = d penalty / d q_b (0 where q was clamped).  out (3B): scores of [real | fake | mixed].
+ * stats[0..5) = loss_D = mean fake - mean real + 10 penalty, mean real, mean fake, penalty, mean real - mean fake;
+ * vseed = 20 c_b gG (= 10 d penalty / d g), gsc = 10 c_b g.  q: B floats of scratch. */
+int dlsg_crit_gp(const float* g, const float* gG, const float* out, float* stats, float* vseed, float* gsc, float* q, int B, int L,
+                 void* stream);
+
+/* Top-k proposals of a clip by attention mass (layer.py:694-696): head 0 = the first P columns of alpha (B, L, 2P) (row stride lda,
+ * clip stride sa), head 1 = the last P; idx (2, B, T) int64 = rows (h B + b) P + p of the (2 B P, .) proposal embeddings, by
+ * decreasing sum_l alpha smask (ties: the lower p).  unselect: dst (R, n) row idx[r] = src[r], every other row zero. */
+int dlsg_crit_topk(const float* alpha, int64_t sa, int64_t lda, int na, const float* smask, int64_t* idx, int B, int L, int P, int T,
+                   void* stream);
+int dlsg_crit_unselect(const float* src, const int64_t* idx, float* dst, int rows_src, int rows_dst, int per, int n, void* stream);
+
+/* `count` <= 32 column sums in one launch: out[j] = scale * (sum_r part[r, j] + sum_r part_b[r, j]) (part_b optional), also written
+ * to out_b when set (bias_ih / bias_hh of an LSTM receive the same gradient).  Fixed order of additions.  n <= 2048. */
+#define DLSG_CRIT_COLSUM_MAX 32
+typedef struct {
+    const float* part; int64_t ld; int32_t rows, n;
+    const float* part_b; int64_t ld_b; int32_t rows_b, pad_;
+    float* out; float* out_b;
+    float scale, pad2_;
+} dlsg_crit_colsum_desc;
+int dlsg_crit_colsum(const dlsg_crit_colsum_desc* d, int count, void* stream);
 
 /* ---------------------------------------------------------------- loss + optimizer (run_gun.py:189-198, :91)
  * Ragged CrossEntropy: row (b,t) counts iff t < lens[b]; loss = mean over counted rows; dlogits written for all
@@ -544,36 +657,17 @@ typedef struct {
 int64_t dlsg_bilstm_bwd_x_floats(int T, int H);
 int dlsg_bilstm_bwd(const dlsg_bilstm_bwd_args* a, void* stream);
 
-/* ---------------------------------------------------------------- narrow products (one side <= 32 wide)
- * The critic's small matmuls (`DiscV2`, models/model.py:143-166; `PSLScore2`, layer.py:697-713; `SelfAttention`,
- * sublayer.py:69-78; their first and second gradient products under run_gun.py:362-371), which torch sends to rocBLAS:
- * C = alpha * op(A) op(B) (+ bias over columns), same modes / row-major operands / batch strides as dlsg_gemm, one group.
- * dlsg_gemm_narrow_kind() says which kernel takes a shape (0 = none: use dlsg_gemm):
- *   1: K <= 32, modes NN / TN        2: N <= 32, mode NT        3: M <= 4, mode TN, K > 32, nbatch == 1 (needs ws:
- *   dlsg_gemm_narrow_ws_floats() floats of scratch; the K chunks are folded in a fixed order, bit-reproducible). */
-typedef struct {
-    const float* A; const float* B; float* C;
-    const float* bias;                 /* optional, N values (kinds 1 and 2) */
-    float* ws; int64_t ws_floats;      /* kind 3 */
-    int64_t lda, ldb, ldc, bsa, bsb, bsc;
-    int32_t mode, M, N, K, nbatch, pad_;
-    float alpha; int32_t pad2_;
-} dlsg_gemm_narrow_args;
-int dlsg_gemm_narrow_kind(int mode, int M, int N, int K, int nbatch);
-int64_t dlsg_gemm_narrow_ws_floats(int mode, int M, int N, int K, int nbatch);
-int dlsg_gemm_narrow(const dlsg_gemm_narrow_args* a, void* stream);
-
 /* ---------------------------------------------------------------- DiscV2's LSTM, a whole sequence per launch
  * Replaces `self.lstm = nn.LSTM(512, 512, batch_first=True)` of DiscV2 (models/model.py:122,139) inside a WGAN-GP critic
  * update (run_gun.py:352-371), where autograd differentiates it twice: level 0 = the forward recurrence, level 1 = its
  * backward through time (with the extra gradient inputs the gradient penalty's graph feeds in), level 2 = the backward of
  * that backward.  One persistent launch per level for all L steps (csrc/critic_lstm.hip; the per-step forms are
- * dlsg_lstm_cell_fwd / _bwd_seq / _bwd2 above).  Tensors are time-major and contiguous: (L, n, 4H) gate tensors (gate order
- * i, f, g, o), (L, n, H) states.  n <= 256, H in {64, 512}; W = weight_hh (4H, H).
+ * cell formulas in that file's header).  Tensors are contiguous, time-major (L, n, .) or batch-major (n, L, .) (`batch_major`):
+ * gate tensors 4H wide (gate order i, f, g, o), states H wide.  n <= 256, H in {64, 512}; W = weight_hh (4H, H).
  *   level 0: addend = x W_ih^T + b_ih + b_hh  ->  As (pre-activations), Hs, Cs
  *   level 1: As, Cs, dHs, optional dAs / dCs  ->  DA (d As, injections included), DH, DC (total gradients reaching h_t, c_t)
- *   level 2: As, Cs, DH, DC, addend = gradient w.r.t. DA  ->  addend_out = Ubar (gradient w.r.t. dAs; may alias addend), gA, gC
- *            (row L-1 of gC is not written: zero it), gDH (gradient w.r.t. dHs), gDC (w.r.t. dCs)
+ *   level 2: As, Cs, DH, DC, addend = gradient w.r.t. DA  ->  addend_out = Ubar (gradient w.r.t. dAs; optional, may alias addend),
+ *            gA, gC (its last step is zero), gDH (gradient w.r.t. dHs), gDC (w.r.t. dCs)
  * xbuf / xbuf2: dlsg_lstm_seq_x_floats floats each (xbuf2 only at level 1), 16-byte aligned; flags: dlsg_lstm_seq_flag_words
  * words, zeroed by the call; err (optional): set non-zero if a workgroup timed out waiting (result then invalid). */
 typedef struct {
@@ -587,7 +681,11 @@ typedef struct {
     float* xbuf; float* xbuf2;
     uint32_t* flags;
     int32_t* err;
-    int32_t L, n, H, pad_;
+    int32_t L, n, H;
+    int32_t batch_major;                             /* 0: (L, n, .) arrays; 1: (n, L, .) -- a sequence's steps are consecutive rows */
+    const float* b_ih; const float* b_hh;            /* level 0, optional (both or neither): added to the addend */
+    float* Hprev;                                    /* level 0, optional: Hprev_t = h_{t-1} (zeros at t = 0), layout of Hs */
+    float* gDHprev;                                  /* level 2, optional: gDHprev_t = gDH_{t-1} */
 } dlsg_lstm_seq_args;
 int dlsg_lstm_seq_supported(int L, int n, int H);
 int64_t dlsg_lstm_seq_x_floats(int L, int n, int H);

@@ -406,7 +406,7 @@ class CriticEmul(object):
         if dbc is not None:
             dbc.copy_(r[5])
 
-    def crit_score_bwd2(self, v, s, wc, bc, wgt, fus, d_out, Uspre, Uwgt, Ufus, g_fus, g_spre, g_vpre, g_wgt, gpart_wc, g_dbc):
+    def crit_score_bwd2(self, v, s, wc, bc, wgt, fus, pair, score, d_out, Uspre, Uwgt, Ufus, g_fus, g_spre, g_vpre, g_wgt, gpart_wc, g_dbc):
         """one caption group: tangents of s_pre (s = tanh(s_pre)), wgt, fus -> the derivatives of crit_score_bwd's outputs"""
         W = torch.stack([w.reshape(-1) for w in wc]).detach()
         bcv = torch.cat([b.reshape(1) for b in bc]).detach()
@@ -444,7 +444,16 @@ class CriticEmul(object):
             top = a[:, :, sl].sum(1).topk(T, dim=-1).indices                       # (B,T)
             idx[h].copy_((h * B + torch.arange(B).unsqueeze(1)) * P + top)
 
-    def crit_unselect(self, src, idx, dst):
+    def crit_colsum(self, descs):
+        for srcs, out, out_b, scale in descs:
+            r = srcs[0].sum(0)
+            if len(srcs) > 1:
+                r = r + srcs[1].sum(0)
+            out.copy_((scale * r).reshape(out.shape))
+            if out_b is not None:
+                out_b.copy_(out)
+
+    def crit_unselect(self, src, idx, dst, per):
         """dst (R, C): row idx[r] = src[r], every other row zero"""
         dst.zero_()
         dst[idx.reshape(-1)] = src.reshape(-1, src.shape[-1])

@@ -840,73 +840,6 @@ def test_large_gemm_launches_of_the_step(hip, mode):
             assert (slabs[i] - dY[i * 160:(i + 1) * 160].t() @ X[i * 160:(i + 1) * 160]).abs().max().item() <= 5e-4
 
 
-@pytest.mark.parametrize('n,H,pad', [(192, 512, 0), (5, 7, 3), (64, 96, 0)])
-def test_critic_lstm_cell_three_levels(hip, n, H, pad):
-    """csrc/critic.hip: cell forward, its backward, and the backward of its backward against the ATen formulas"""
-    def build(g):
-        return dict(a=rnd(g, n, 4 * H + pad), cp=rnd(g, n, H), dh=rnd(g, n, H), dc=rnd(g, n, H), u=rnd(g, n, 4 * H), uc=rnd(g, n, H),
-                    h=torch.zeros(n, H), c=torch.zeros(n, H), da=torch.zeros(n, 4 * H), dcp=torch.zeros(n, H),
-                    ga=torch.zeros(n, 4 * H), gcp=torch.zeros(n, H), gdh=torch.zeros(n, H), gdc=torch.zeros(n, H))
-
-    def run(ops, t):
-        a = t['a'][:, :4 * H]
-        ops.lstm_cell_fwd(a, t['cp'], t['h'], t['c'])
-        ops.lstm_cell_bwd(a, t['cp'], t['dh'], t['dc'], t['da'], t['dcp'])
-        ops.lstm_cell_bwd2(a, t['cp'], t['dh'], t['dc'], t['u'], t['uc'], t['ga'], t['gcp'], t['gdh'], t['gdc'])
-    both(hip, build, run, ['h', 'c', 'da', 'dcp', 'ga', 'gcp', 'gdh', 'gdc'], tol=2e-5, name='critic cell %d x %d' % (n, H))
-
-
-@pytest.mark.parametrize('rows,N,pre_tanh', [(4992, 512, True), (4992, 512, False), (7, 64, True), (1536, 1024, True), (513, 192, False)])
-def test_critic_tanh_layernorm_three_levels(hip, rows, N, pre_tanh):
-    """csrc/critic.hip: LayerNorm(tanh(x)) forward, backward, and the backward of the backward against the ATen formulas"""
-    def build(g):
-        return dict(x=rnd(g, rows, N, scale=1.5), gam=rnd(g, N), bet=rnd(g, N), dy=rnd(g, rows, N), U=rnd(g, rows, N), vg=rnd(g, N),
-                    vb=rnd(g, N), y=torch.zeros(rows, N), dx=torch.zeros(rows, N), dg=torch.zeros(N), db=torch.zeros(N),
-                    gx=torch.zeros(rows, N), gg=torch.zeros(N), gdy=torch.zeros(rows, N))
-
-    def run(ops, t):
-        ops.tanh_ln_fwd(t['x'], t['gam'], t['bet'], t['y'], 1e-5, pre_tanh)
-        ops.tanh_ln_bwd(t['x'], t['gam'], t['dy'], t['dx'], t['dg'], t['db'], 1e-5, pre_tanh)
-        ops.tanh_ln_bwd2(t['x'], t['gam'], t['dy'], t['U'], t['vg'], t['vb'], t['gx'], t['gg'], t['gdy'], 1e-5, pre_tanh)
-    both(hip, build, run, ['y', 'dx', 'dg', 'db', 'gx', 'gg', 'gdy'], tol=3e-5, name='critic ln %d x %d' % (rows, N))
-
-
-@pytest.mark.parametrize('rows,N,G,pre_tanh', [(576, 512, 2, True), (4992, 512, 2, True), (2100, 512, 3, False), (5, 64, 4, True)])
-def test_critic_tanh_layernorm_grouped(hip, rows, N, G, pre_tanh):
-    """`groups` of csrc/critic.hip's LayerNorm kernels (ABI 3): G same-shape LayerNorms with their own gamma / beta over G
-    consecutive row blocks in one launch per level (the critic's two proposal scorers side by side), against the ATen formulas
-    applied block by block"""
-    def build(g):
-        return dict(x=rnd(g, G * rows, N, scale=1.5), gam=rnd(g, G, N), bet=rnd(g, G, N), dy=rnd(g, G * rows, N), U=rnd(g, G * rows, N),
-                    vg=rnd(g, G, N), vb=rnd(g, G, N), y=torch.zeros(G * rows, N), dx=torch.zeros(G * rows, N), dg=torch.zeros(G, N),
-                    db=torch.zeros(G, N), gx=torch.zeros(G * rows, N), gg=torch.zeros(G, N), gdy=torch.zeros(G * rows, N))
-
-    def run(ops, t):
-        ops.tanh_ln_fwd(t['x'], t['gam'], t['bet'], t['y'], 1e-5, pre_tanh)
-        ops.tanh_ln_bwd(t['x'], t['gam'], t['dy'], t['dx'], t['dg'], t['db'], 1e-5, pre_tanh)
-        ops.tanh_ln_bwd2(t['x'], t['gam'], t['dy'], t['U'], t['vg'], t['vb'], t['gx'], t['gg'], t['gdy'], 1e-5, pre_tanh)
-    both(hip, build, run, ['y', 'dx', 'dg', 'db', 'gx', 'gg', 'gdy'], tol=3e-5, name='critic ln %d x %d x %d groups' % (rows, N, G))
-
-
-def test_critic_lstm_cell_sequence_step(hip):
-    """the backward step of the whole-sequence op: optional second dh / dc pieces and injection on da, NULL = zero"""
-    n, H = 192, 512
-
-    def build(g):
-        return dict(a=rnd(g, n, 4 * H), cp=rnd(g, n, H), dh1=rnd(g, n, H), dh2=rnd(g, n, H), dc1=rnd(g, n, H), dc2=rnd(g, n, H),
-                    inj=rnd(g, n, 4 * H), da=torch.zeros(n, 4 * H), dcp=torch.zeros(n, H), dht=torch.zeros(n, H), dct=torch.zeros(n, H),
-                    da2=torch.zeros(n, 4 * H), dcp2=torch.zeros(n, H), dht2=torch.zeros(n, H), dct2=torch.zeros(n, H),
-                    h=torch.zeros(n, H), c=torch.zeros(n, H), ga=torch.zeros(n, 4 * H), gdh=torch.zeros(n, H), gdc=torch.zeros(n, H))
-
-    def run(ops, t):
-        ops.lstm_cell_bwd_seq(t['a'], t['cp'], t['dh1'], t['dh2'], t['dc1'], t['dc2'], t['inj'], t['da'], t['dcp'], t['dht'], t['dct'])
-        ops.lstm_cell_bwd_seq(t['a'], None, t['dh1'], None, None, None, None, t['da2'], t['dcp2'], t['dht2'], t['dct2'])
-        ops.lstm_cell_fwd(t['a'], None, t['h'], t['c'])
-        ops.lstm_cell_bwd2(t['a'], None, t['dh1'], t['dc1'], t['inj'], None, t['ga'], None, t['gdh'], t['gdc'])
-    both(hip, build, run, ['da', 'dcp', 'dht', 'dct', 'da2', 'dcp2', 'dht2', 'dct2', 'h', 'c', 'ga', 'gdh', 'gdc'], tol=2e-5,
-         name='critic cell seq step')
-
-
 def test_colsum_tall_is_bit_reproducible(hip):
     """26 624-row column sums (the region projection's bias gradient): chunk partials are combined in a fixed order"""
     g = torch.Generator().manual_seed(3)
@@ -924,19 +857,17 @@ def test_colsum_tall_is_bit_reproducible(hip):
 
 
 @pytest.mark.parametrize('shape,dim', [((192, 26, 3), 1), ((192, 26, 26), 2), ((192, 26, 1), 1), ((192, 2), 1), ((5, 130, 7), 1)])
-def test_softmax_three_levels(hip, shape, dim):
-    """softmax forward / backward / backward of the backward over an inner or the last axis (the critic's five softmaxes)"""
+def test_softmax_forward_and_backward(hip, shape, dim):
+    """softmax forward / backward over an inner or the last axis"""
     outer = int(np.prod(shape[:dim])); n = shape[dim]; inner = int(np.prod(shape[dim + 1:]))
 
     def build(g):
-        return dict(x=rnd(g, *shape, scale=2.0), dy=rnd(g, *shape), u=rnd(g, *shape), y=torch.zeros(*shape), dx=torch.zeros(*shape),
-                    gy=torch.zeros(*shape), gdy=torch.zeros(*shape))
+        return dict(x=rnd(g, *shape, scale=2.0), dy=rnd(g, *shape), y=torch.zeros(*shape), dx=torch.zeros(*shape))
 
     def run(ops, t):
         ops.softmax_fwd(t['x'], t['y'], outer, n, inner)
         ops.softmax_bwd(t['y'], t['dy'], t['dx'], outer, n, inner)
-        ops.softmax_bwd2(t['y'], t['dy'], t['u'], t['gy'], t['gdy'], outer, n, inner)
-    both(hip, build, run, ['y', 'dx', 'gy', 'gdy'], tol=2e-5, name='softmax levels %s' % (shape,))
+    both(hip, build, run, ['y', 'dx'], tol=2e-5, name='softmax %s' % (shape,))
 
 
 def test_embed_bwd_with_a_dominant_id(hip):
@@ -1121,139 +1052,3 @@ def _gp_like(hs_of, xin, W, r1, r2):
     pen = ((g.reshape(g.shape[0], g.shape[1], -1).norm(dim=-1) - 1.0) ** 2).mean()
     return pen * 10.0 + (hs * r2).sum() * 0.01
 
-
-@pytest.mark.parametrize('L,n,H', [(26, 192, 512), (26, 5, 64), (7, 70, 64), (1, 3, 64), (26, 256, 64), (3, 130, 512)])
-def test_critic_lstm_sequence_kernels_against_autograd(hip, L, n, H):
-    """csrc/critic_lstm.hip: DiscV2's LSTM over all word steps as ONE persistent launch per differentiation level -- forward,
-    backward through time with injected gradients, backward of the backward -- through dlsg_amd.gan's autograd nodes, against
-    (a) the per-step launches it replaces and (b) torch autograd's own double backward of the plain recurrence on the CPU.
-    Twice (reused exchange buffers / flags); the time-out word must stay 0."""
-    from dlsg_amd.gan import _LstmSeq
-    assert hip.lib.dlsg_lstm_seq_supported(L, n, H) == 1
-    assert hip.lib.dlsg_lstm_seq_supported(L, 257, H) == 0 and hip.lib.dlsg_lstm_seq_supported(L, n, 96) == 0
-    g = torch.Generator().manual_seed(23)
-    sc = 1.0 / math.sqrt(H)
-    xin0, W0 = rnd(g, L, n, 4 * H), rnd(g, 4 * H, H, scale=2 * sc)
-    r1, r2 = rnd(g, L, n, H), rnd(g, L, n, H)
-
-    def run(hs_of, dev):
-        xin = xin0.to(dev).requires_grad_(True)
-        W = W0.to(dev).requires_grad_(True)
-        loss = _gp_like(hs_of, xin, W, r1.to(dev), r2.to(dev))
-        gx, gw = torch.autograd.grad(loss, (xin, W))
-        return loss.detach().cpu(), gx.cpu(), gw.cpu()
-    want = run(_plain_lstm, 'cpu')
-    node = lambda xin, W: _LstmSeq.apply(hip, xin, W)[0]
-    assert hip.persistent_lstm_seq
-    try:
-        hip.persistent_lstm_seq = False
-        steps = run(node, 'cuda')
-    finally:
-        hip.persistent_lstm_seq = True
-    for rep in range(2):
-        got = run(node, 'cuda')
-        hip.check_persistent()
-        for name, a, b, c in zip(('loss', 'd xin', 'd W_hh'), want, steps, got):
-            s = max(1.0, a.abs().max().item())
-            assert (a - c).abs().max().item() <= 2e-4 * s, (rep, name, (a - c).abs().max().item(), s)
-            assert (b - c).abs().max().item() <= 2e-5 * s, (rep, name, 'vs per-step launches', (b - c).abs().max().item(), s)
-
-
-def test_critic_lstm_sequence_levels_against_step_kernels(hip):
-    """each level of csrc/critic_lstm.hip against the loop over csrc/critic.hip's cell kernels + products, every output tensor
-    (also the ones the autograd comparison above only sees summed: DH, DC, gC, gDC)"""
-    L, n, H = 9, 150, 64
-    g = torch.Generator().manual_seed(29)
-    cu = lambda *s, **k: rnd(g, *s, **k).cuda()
-    xin, W = cu(L, n, 4 * H), cu(4 * H, H, scale=0.25)
-    new = lambda last: torch.full((L, n, last), float('nan'), device='cuda')
-    # level 0
-    As, Hs, Cs = new(4 * H), new(H), new(H)
-    hip.lstm_seq_fwd(xin, W, As, Hs, Cs)
-    As_, Hs_, Cs_ = xin.clone(), new(H), new(H)
-    for t in range(L):
-        if t:
-            As_[t].addmm_(Hs_[t - 1], W.t())
-        hip.lstm_cell_fwd(As_[t], Cs_[t - 1] if t else None, Hs_[t], Cs_[t])
-    for name, a, b in (('As', As_, As), ('Hs', Hs_, Hs), ('Cs', Cs_, Cs)):
-        assert (a - b).abs().max().item() <= 2e-5, (name, (a - b).abs().max().item())
-    # level 1, with and without injections
-    for inj in (True, False):
-        dHs, dAs, dCs = cu(L, n, H), (cu(L, n, 4 * H) if inj else None), (cu(L, n, H) if inj else None)
-        DA, DH, DC = new(4 * H), new(H), new(H)
-        hip.lstm_seq_bwd(As_, Cs_, W, dHs, dAs, dCs, DA, DH, DC)
-        DA_, DH_, DC_ = new(4 * H), new(H), new(H)
-        s_buf = [torch.empty(n, H, device='cuda'), torch.empty(n, H, device='cuda')]
-        r = torch.empty(n, H, device='cuda')
-        for t in range(L - 1, -1, -1):
-            last = t == L - 1
-            hip.lstm_cell_bwd_seq(As_[t], Cs_[t - 1] if t else None, dHs[t], None if last else r, None if last else s_buf[(t + 1) & 1],
-                                  None if dCs is None else dCs[t], None if dAs is None else dAs[t], DA_[t], s_buf[t & 1], DH_[t], DC_[t])
-            if t:
-                torch.mm(DA_[t], W, out=r)
-        for name, a, b in (('DA', DA_, DA), ('DH', DH_, DH), ('DC', DC_, DC)):
-            assert (a - b).abs().max().item() <= 3e-5 * max(1.0, a.abs().max().item()), (inj, name, (a - b).abs().max().item())
-    # level 2
-    U0 = cu(L, n, 4 * H)
-    Ubar, gA, gC, gDH, gDC = U0.clone(), new(4 * H), torch.zeros(L, n, H, device='cuda'), new(H), new(H)
-    hip.lstm_seq_bwd2(As_, Cs_, W, DH_, DC_, Ubar, gA, gC, gDH, gDC)
-    Ubar_, gA_, gC_, gDH_, gDC_ = U0.clone(), new(4 * H), torch.zeros(L, n, H, device='cuda'), new(H), new(H)
-    for t in range(L):
-        if t:
-            Ubar_[t].addmm_(gDH_[t - 1], W.t())
-        hip.lstm_cell_bwd2(As_[t], Cs_[t - 1] if t else None, DH_[t], DC_[t], Ubar_[t], gDC_[t - 1] if t else None, gA_[t],
-                           gC_[t - 1] if t else None, gDH_[t], gDC_[t])
-    hip.check_persistent()
-    for name, a, b in (('Ubar', Ubar_, Ubar), ('gA', gA_, gA), ('gC', gC_, gC), ('gDH', gDH_, gDH), ('gDC', gDC_, gDC)):
-        assert (a - b).abs().max().item() <= 3e-5 * max(1.0, a.abs().max().item()), (name, (a - b).abs().max().item())
-
-
-@pytest.mark.parametrize('mode,M,N,K,nb', [
-    (GEMM_NN, 26, 512, 26, 192), (GEMM_NN, 26, 512, 3, 192), (GEMM_NN, 26, 512, 1, 7), (GEMM_NN, 4992, 512, 1, 1), (GEMM_NN, 192, 512, 2, 1),
-    (GEMM_NN, 33, 1000, 32, 3), (GEMM_TN, 26, 512, 26, 192), (GEMM_TN, 3, 512, 26, 192), (GEMM_TN, 1, 512, 26, 5), (GEMM_TN, 40, 70, 9, 2),
-    (GEMM_NT, 26, 26, 512, 192), (GEMM_NT, 26, 3, 512, 192), (GEMM_NT, 26, 1, 512, 4), (GEMM_NT, 4992, 1, 512, 1), (GEMM_NT, 576, 1, 512, 1),
-    (GEMM_NT, 192, 2, 512, 1), (GEMM_NT, 70, 32, 100, 3), (GEMM_TN, 1, 512, 4992, 1), (GEMM_TN, 1, 512, 576, 1), (GEMM_TN, 2, 512, 192, 1),
-    (GEMM_TN, 4, 300, 33, 1), (GEMM_TN, 3, 64, 50, 1)])
-def test_narrow_products_against_matmul(hip, mode, M, N, K, nb):
-    """csrc/gemm_narrow.hip (the critic's products with one side <= 32 wide, batched or not) against a float64 matmul; operands
-    as strided views (row strides wider than the rows), with alpha and -- where the kernel takes one -- a bias."""
-    kind = hip.gemm_narrow_kind(mode, M, N, K, nb)
-    assert kind in (1, 2, 3), (mode, M, N, K, nb)
-    g = torch.Generator().manual_seed(31)
-    lead = (nb,) if nb > 1 else ()
-    sa = (K, M) if mode == GEMM_TN else (M, K)
-    sb = (N, K) if mode == GEMM_NT else (K, N)
-    A = rnd(g, *lead, sa[0], sa[1] + 3).cuda()[..., :sa[1]]
-    Bm = rnd(g, *lead, sb[0], sb[1] + 5).cuda()[..., :sb[1]]
-    Cbuf = torch.full((*lead, M, N + 2), float('nan'), device='cuda')
-    Cc = Cbuf[..., :N]
-    bias = rnd(g, N).cuda() if kind != 3 else None
-    hip.gemm_narrow(mode, A, Bm, Cc, alpha=0.7, bias=bias)
-    a64, b64 = A.double().cpu(), Bm.double().cpu()
-    want = 0.7 * (a64 @ b64.transpose(-1, -2) if mode == GEMM_NT else (a64 @ b64 if mode == GEMM_NN else a64.transpose(-1, -2) @ b64))
-    if bias is not None:
-        want = want + bias.double().cpu()
-    err = (Cc.double().cpu() - want).abs().max().item()
-    assert err <= 2e-6 * max(1.0, want.abs().max().item()) * math.sqrt(K), (kind, err)
-    assert torch.isnan(Cbuf[..., N:]).all()                 # nothing written past the view
-    assert hip.gemm_narrow_kind(GEMM_NT, 64, 64, 64, 1) == 0 and hip.gemm_narrow_kind(GEMM_NN, 64, 64, 33, 1) == 0
-
-
-@pytest.mark.parametrize('n,L,C', [(192, 26, 512), (3, 1, 8), (5, 2, 64), (64, 26, 512)])
-def test_conv_taps_and_adjoint(hip, n, L, C):
-    """csrc/critic.hip conv_taps_kernel: the three shifted copies of a sequence (DiscV2's k = 3 convolution as one product) and
-    the transposed map, against pad + slices + cat; <A x, d> == <x, A^T d> ties the two launches to each other"""
-    def build(g):
-        return dict(x=rnd(g, n, L, C), d=rnd(g, n, L, 3 * C), y=torch.zeros(n, L, 3 * C), dx=torch.zeros(n, L, C))
-
-    def run(ops, t):
-        ops.conv_taps(t['x'], t['y'], False)
-        ops.conv_taps(t['d'], t['dx'], True)
-    both(hip, build, run, ['y', 'dx'], tol=1e-6, name='conv taps %d x %d x %d' % (n, L, C))
-    g = torch.Generator().manual_seed(5)
-    x, d = rnd(g, n, L, C).cuda(), rnd(g, n, L, 3 * C).cuda()
-    y, dx = torch.empty(n, L, 3 * C, device='cuda'), torch.empty(n, L, C, device='cuda')
-    hip.conv_taps(x, y, False)
-    hip.conv_taps(d, dx, True)
-    a, b = (y.double() * d.double()).sum().item(), (x.double() * dx.double()).sum().item()
-    assert abs(a - b) <= 1e-5 * max(1.0, abs(a), float(n * L * C) ** 0.5)          # dx sums three floats in fp32

@@ -1,7 +1,6 @@
-"""One RunGAN iteration (run_gun.py:147-234) at the bench shape: generator on the HIP path, DiscV2 critic on PyTorch-ROCm
-(dlsg_amd/gan.py).  Prints ms per phase (no-grad generator forward, num_D critic updates, generator step incl. the GAN
-term) and clips/s of the whole iteration.  usage: python tools/gan_bench.py [batch=64] [iters=8] [num_D=5] [lstm=seq|steps]
-(lstm=steps: the critic's LSTM as one product + one cell launch per word step instead of csrc/critic_lstm.hip's launches)"""
+"""One RunGAN iteration (run_gun.py:147-234) at the bench shape: generator and DiscV2 critic on the HIP kernels
+(dlsg_amd/gan.py, dlsg_amd/critic.py).  Prints ms per phase (no-grad generator forward, num_D critic updates, generator step
+incl. the GAN term) and clips/s of the whole iteration.  usage: python tools/gan_bench.py [batch=64] [iters=8] [num_D=5]"""
 import json
 import os
 import random
@@ -18,9 +17,6 @@ from dlsg_amd.synth import synth_state_dict, synth_batch  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 num_D = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-if len(sys.argv) > 4 and sys.argv[4] == 'steps':
-    from dlsg_amd.hip import HipOps
-    HipOps.persistent_lstm_seq = False
 V = 1000
 args = dlsg_amd.msvd_shaped(use_visual_gan=True)
 torch.manual_seed(0)
@@ -46,17 +42,16 @@ for i in range(iters):
     it.iteration(frames, regions, caps, lens, eps, 0, i + 1)
 whole = (sync() - t0) / iters
 # phases, separately timed
-att_mask = gan.attention_mask(caps)
+smask = (caps > 0).float()
 ph = {'generator_forward_nograd': 0.0, 'critic_updates': 0.0, 'generator_step': 0.0}
 for i in range(iters):
     t = sync()
-    with torch.no_grad():
-        f_caption, obj, mot, alpha = G(frames, regions, caps, 26, eps)
+    logits_tm, obj, mot, alpha = it.trainer.forward_only(frames, regions, caps, eps, 26, time_major=True)
     t1 = sync()
-    it.train_disc(caps, f_caption, obj, mot, att_mask, alpha)
+    it.train_disc(caps, logits_tm, obj, mot, smask, alpha)
     t2 = sync()
     ph['generator_forward_nograd'] += (t1 - t) / iters
     ph['critic_updates'] += (t2 - t1) / iters
 ph['generator_step'] = whole - ph['generator_forward_nograd'] - ph['critic_updates']
-print(json.dumps({'batch': B, 'num_D': num_D, 'critic_lstm': sys.argv[4] if len(sys.argv) > 4 else 'seq', 'ms_per_iteration': round(whole * 1e3, 2), 'clips_per_s': round(B / whole, 1),
+print(json.dumps({'batch': B, 'num_D': num_D, 'ms_per_iteration': round(whole * 1e3, 2), 'clips_per_s': round(B / whole, 1),
                   'phase_ms': {k: round(v * 1e3, 2) for k, v in ph.items()}}))
