@@ -241,7 +241,7 @@ class CriticEngine(object):
                            part_wc, dbc, ng, acc=acc)
         cw = b['c_words']
         ts_part = ws.get('ts_part', 3 * B, 5, C)[:nb] if want else None
-        ops.crit_tsum_bwd(A('words'), p['theta'], p['ts_g'], p['fusion'], A('adj'), A('u'), A('sent'), A('fus'), Cc('c_fus'),
+        ops.crit_tsum_bwd(A('words'), p['theta'], p['ts_g'], p['ts_b'], p['fusion'], A('adj'), A('u'), A('sent'), A('fus'), Cc('c_fus'),
                           cw[0, c0:c1], ts_part, p=pd, site=SITE_TSUM, seed=seed, row0=a0, acc=acc)
         ops.gemm(GEMM_NN, [(b['c_spre'][k, c0:c1].view(Rt, C), p['Ws'][k], b['c_agg'][k, c0:c1].view(Rt, C)) for k in range(2)])
         x2 = self._x2(ws, 'pn') if want else None

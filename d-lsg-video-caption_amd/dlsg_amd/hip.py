@@ -1201,11 +1201,11 @@ class HipOps(object):
         self._check(self.lib.dlsg_crit_sa_bwd2(C.byref(a), self._stream()), 'crit_sa_bwd2')
 
     @staticmethod
-    def _set2(a, **kw):
+    def _set2(st_, **kw):
         for name, pair in kw.items():
             if pair is None:
                 continue
-            arr = getattr(a, name)
+            arr = getattr(st_, name)
             for h in range(2):
                 _chkc(pair[h])
                 arr[h] = _p(pair[h])
@@ -1238,7 +1238,7 @@ class HipOps(object):
         a = CritTsumArgs()
         for t in (words, theta, gamma, fusion):
             _chkc(t)
-        a.words, a.theta, a.gamma, a.beta, a.fusion = _p(words), _p(theta), _p(gamma), _p(beta if beta is not None else gamma), _p(fusion)
+        a.words, a.theta, a.gamma, a.beta, a.fusion = _p(words), _p(theta), _p(gamma), _p(beta), _p(fusion)
         a.n, a.L, a.eps, a.p, a.site, a.row0 = words.shape[0], words.shape[1], eps, p, site, row0
         a.seed, a.seed_ptr = _seed(seed)
         a.acc_lo, a.acc_hi = acc if acc is not None else (0, 0)
@@ -1251,10 +1251,10 @@ class HipOps(object):
         a.adj, a.u, a.sent, a.fus = _p(adj), _p(u), _p(sent), _p(fus)
         self._check(self.lib.dlsg_crit_tsum_fwd(C.byref(a), self._stream()), 'crit_tsum_fwd')
 
-    def crit_tsum_bwd(self, words, theta, gamma, fusion, adj, u, sent, fus, d_fus, dwords, part, eps=1e-5, p=0.0, site=0, seed=0,
+    def crit_tsum_bwd(self, words, theta, gamma, beta, fusion, adj, u, sent, fus, d_fus, dwords, part, eps=1e-5, p=0.0, site=0, seed=0,
                       row0=0, acc=None):
         """(adj, u, sent, fus of the forward are recomputed by the kernel: accepted for interface symmetry, not read)"""
-        a = self._tsum_args(words, theta, gamma, None, fusion, eps, p, site, seed, row0, acc)
+        a = self._tsum_args(words, theta, gamma, beta, fusion, eps, p, site, seed, row0, acc)
         _chkc(d_fus); _chkc(dwords)
         a.d_fus, a.dwords, a.part = _p(d_fus), _p(dwords), _p(part)
         self._check(self.lib.dlsg_crit_tsum_bwd(C.byref(a), self._stream()), 'crit_tsum_bwd')

@@ -352,7 +352,7 @@ class CriticEmul(object):
         for dst, src in zip((adj, u, sent, fus), r):
             dst.copy_(src)
 
-    def crit_tsum_bwd(self, words, theta, gamma, fusion, adj, u, sent, fus, d_fus, dwords, part, eps=1e-5, p=0.0, site=0, seed=0,
+    def crit_tsum_bwd(self, words, theta, gamma, beta, fusion, adj, u, sent, fus, d_fus, dwords, part, eps=1e-5, p=0.0, site=0, seed=0,
                       row0=0, acc=None):
         """part (n, 5, C) or None: per-caption partials of [dtheta, dgamma, dbeta, dfusion_0, dfusion_1]"""
         mp = _m(seed, site, words.shape[0], words.shape[2], p, row0, words)

@@ -187,8 +187,8 @@ def test_text_summary_levels(n, L, drop):
     both('crit_tsum_fwd', [words, theta, gamma, beta, fusion, adj, u, sent, fus], kw)
     EmulOps().crit_tsum_fwd(words, theta, gamma, beta, fusion, adj, u, sent, fus, **kw)
     d_fus = rnd(n, 2, seed=4)
-    both('crit_tsum_bwd', [words, theta, gamma, fusion, adj, u, sent, fus, d_fus, torch.zeros(n, L, C), torch.zeros(n, 5, C)], kw, tol=5e-4)
-    both('crit_tsum_bwd', [words, theta, gamma, fusion, adj, u, sent, fus, d_fus, rnd(n, L, C, seed=5), None], dict(kw, acc=(1, 3)), tol=5e-4)
+    both('crit_tsum_bwd', [words, theta, gamma, beta, fusion, adj, u, sent, fus, d_fus, torch.zeros(n, L, C), torch.zeros(n, 5, C)], kw, tol=5e-4)
+    both('crit_tsum_bwd', [words, theta, gamma, beta, fusion, adj, u, sent, fus, d_fus, rnd(n, L, C, seed=5), None], dict(kw, acc=(1, 3)), tol=5e-4)
     both('crit_tsum_bwd2', [words, theta, gamma, beta, fusion, d_fus, rnd(n, L, C, seed=6), torch.zeros(n, 2), torch.zeros(n, L, C),
                             torch.zeros(n, 5, C)], kw, tol=1e-3, atol=1e-4)
 
