@@ -22,38 +22,61 @@ __device__ __forceinline__ void st2(float* p, f32x2 v) { *reinterpret_cast<f32x2
 __device__ __forceinline__ float dot2(f32x2 a, f32x2 b) { return a.x * b.x + a.y * b.y; }
 
 // ---------------------------------------------------------------------------------------------- block-wide helpers (256 threads)
-// out[i * ldo + j] = alpha * sum_c A[i][c] B[j][c], i < RA, j < RB: contraction over the 512 channels.  A, B global rows (strides
-// lda, ldb); scratch: 4 * LMAX * RBM floats of LDS.  Ends with a barrier: `out` (LDS) is ready for every thread.
-template <int RBM>
+// Per-caption matrices live in LDS, zero-filled once (zero_lds), with row strides that are multiples of 4 floats: the helpers read
+// whole padded rows / columns without bounds tests (a test per element puts a branch between the LDS reads and every read then
+// waits out its own latency: 30+ us per product instead of ~3).
+constexpr int LDW = LMAX + 4;        // L x L matrices
+constexpr int LDT = TMAX + 4;        // L x T matrices
+constexpr int RED = 4 * 16 * 64;     // floats of LDS a pairdot needs to fold its four partial tiles
+
+__device__ __forceinline__ void zero_lds(float* m, int n) {
+    for (int k = threadIdx.x; k < n; k += NT) m[k] = 0.f;
+}
+
+// out[i * ldo + j] = alpha * sum_c A[i][c] B[j][c], i < RA <= 32, j < RB <= 32: contraction over the 512 channels as ONE 32 x 32 tile
+// of v_mfma_f32_32x32x2_f32 (exact fp32).  Wave w contracts channels [128 w, 128 w + 128): lane (r = lane & 31, h = lane >> 5) holds
+// A[r][128 w + 64 h + s] and B[r][...] for s < 64 (16 x 16-byte loads each, all in flight together); MFMA s contracts the channel
+// pair (128 w + s, 128 w + 64 + s) -- the same pair for both operands.  The four partial tiles meet in LDS (`red`, RED floats).
+// A, B global rows (strides lda, ldb, 16-byte aligned).  Ends with a barrier: `out` (LDS) is ready for every thread.
 __device__ __forceinline__ void pairdot(const float* __restrict__ A, int64_t lda, int RA, const float* __restrict__ B, int64_t ldb, int RB,
-                                        float alpha, float* out, int ldo, float* scratch) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    f32x2 b[RBM];
+                                        float alpha, float* out, int ldo, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+    f32x4 a[16], b[16];
+    const float* ap = A + (int64_t)r * lda + 128 * w + 64 * h;
+    const float* bp = B + (int64_t)r * ldb + 128 * w + 64 * h;
 #pragma unroll
-    for (int j = 0; j < RBM; ++j) b[j] = j < RB ? ld2(B + (int64_t)j * ldb + 2 * tid) : f32x2{0.f, 0.f};
-    for (int i = 0; i < RA; ++i) {
-        const f32x2 a = ld2(A + (int64_t)i * lda + 2 * tid);
-#pragma unroll
-        for (int j = 0; j < RBM; ++j)
-            if (j < RB) {
-                const float s = dlsg::wave_sum(dot2(a, b[j]));
-                if (lane == 0) scratch[(w * LMAX + i) * RBM + j] = s;
-            }
+    for (int q = 0; q < 16; ++q) {
+        a[q] = r < RA ? *reinterpret_cast<const f32x4*>(ap + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b[q] = r < RB ? *reinterpret_cast<const f32x4*>(bp + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][e], b[q][e], acc, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(w * 16 + e) * 64 + lane] = acc[e];
     __syncthreads();
-    for (int k = tid; k < RA * RB; k += NT) {
-        const int i = k / RB, j = k - i * RB;
-        out[i * ldo + j] = alpha * ((scratch[(0 * LMAX + i) * RBM + j] + scratch[(1 * LMAX + i) * RBM + j]) +
-                                    (scratch[(2 * LMAX + i) * RBM + j] + scratch[(3 * LMAX + i) * RBM + j]));
+    // C / D map of the 32 x 32 tile: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    for (int k = tid; k < 16 * 64; k += NT) {
+        const int e = k >> 6, ln = k & 63, i = (e & 3) + 8 * (e >> 2) + 4 * (ln >> 5), jj = ln & 31;
+        if (i < RA && jj < RB) out[i * ldo + jj] = alpha * ((red[k] + red[1024 + k]) + (red[2048 + k] + red[3072 + k]));
     }
     __syncthreads();
 }
 
-// dots[i] = sum_c X[i][c] v[c] for i < R (X global rows, v this thread's channel pair): R block reductions, result in LDS `out`.
+// dots[i] = sum_c X[i][c] v[c] for i < R <= LMAX (X global rows, v this thread's channel pair); all rows are requested before the
+// first reduction.  Result in LDS `out`; scratch: 4 * LMAX floats.
 __device__ __forceinline__ void rowdots(const float* __restrict__ X, int64_t ldx, int R, f32x2 v, float* out, float* scratch) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = 0; i < R; ++i) {
-        const float s = dlsg::wave_sum(dot2(ld2(X + (int64_t)i * ldx + 2 * tid), v));
+    f32x2 x[LMAX];
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) x[i] = i < R ? ld2(X + (int64_t)i * ldx + 2 * tid) : f32x2{0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < LMAX; ++i) {
+        const float s = dlsg::wave_sum(dot2(x[i], v));
         if (lane == 0) scratch[w * LMAX + i] = s;
     }
     __syncthreads();
@@ -70,31 +93,45 @@ __device__ __forceinline__ float bsum(float v, float* red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Y[i][c] (=|+=) alpha * sum_j M(i, j) X[j][c]  (+ alpha * sum_j M2(i, j) X2[j][c]), i < RI, j < RJ <= RJM: contraction over words /
-// proposals per channel.  M in LDS: M(i, j) = M[i * ldm + j], or M[j * ldm + i] when TR.  X rows global.
-template <int RJM, bool TR>
+// Y[i][c] (=|+=) alpha * (sum_j M(i, j) X[j][c] + sum_j M2(i, j) X2[j][c]), i < RI, j < RJ <= RJM: contraction over words / proposals
+// per channel pair out of registers.  M, M2 zero-padded LDS matrices: M(i, j) = M[i * ldm + j] (ldm % 4 == 0, whole padded rows read
+// as 16-byte vectors), or M[j * ldm + i] when TR.  X rows global; DUAL: the second product is present.
+template <int RJM, bool TR, bool DUAL>
 __device__ __forceinline__ void chanprod(const float* M, int ldm, const float* __restrict__ X, int64_t ldx, const float* M2,
                                          const float* __restrict__ X2, int64_t ldx2, int RI, int RJ, float alpha, float* __restrict__ Y,
                                          int64_t ldy, bool accum) {
     const int tid = threadIdx.x;
-    f32x2 x[RJM], x2[RJM];
+    f32x2 x[RJM], x2[DUAL ? RJM : 1];
 #pragma unroll
     for (int j = 0; j < RJM; ++j) {
         x[j] = j < RJ ? ld2(X + (int64_t)j * ldx + 2 * tid) : f32x2{0.f, 0.f};
-        x2[j] = (M2 && j < RJ) ? ld2(X2 + (int64_t)j * ldx2 + 2 * tid) : f32x2{0.f, 0.f};
+        if (DUAL) x2[j] = j < RJ ? ld2(X2 + (int64_t)j * ldx2 + 2 * tid) : f32x2{0.f, 0.f};
     }
     for (int i = 0; i < RI; ++i) {
-        f32x2 acc = {0.f, 0.f};
+        float m[RJM], m2[DUAL ? RJM : 1];
+        if (TR) {
 #pragma unroll
-        for (int j = 0; j < RJM; ++j)
-            if (j < RJ) {
-                const float m = TR ? M[j * ldm + i] : M[i * ldm + j];
-                acc.x += m * x[j].x; acc.y += m * x[j].y;
-                if (M2) {
-                    const float m2 = TR ? M2[j * ldm + i] : M2[i * ldm + j];
-                    acc.x += m2 * x2[j].x; acc.y += m2 * x2[j].y;
+            for (int j = 0; j < RJM; ++j) {
+                m[j] = M[j * ldm + i];
+                if (DUAL) m2[j] = M2[j * ldm + i];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RJM; j += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(M + i * ldm + j);
+                m[j] = v[0]; m[j + 1] = v[1]; m[j + 2] = v[2]; m[j + 3] = v[3];
+                if (DUAL) {
+                    const f32x4 v2 = *reinterpret_cast<const f32x4*>(M2 + i * ldm + j);
+                    m2[j] = v2[0]; m2[j + 1] = v2[1]; m2[j + 2] = v2[2]; m2[j + 3] = v2[3];
                 }
             }
+        }
+        f32x2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < RJM; ++j) {
+            acc.x += m[j] * x[j].x; acc.y += m[j] * x[j].y;
+            if (DUAL) { acc.x += m2[j] * x2[j].x; acc.y += m2[j] * x2[j].y; }
+        }
         float* y = Y + (int64_t)i * ldy + 2 * tid;
         f32x2 r = {alpha * acc.x, alpha * acc.y};
         if (accum) { const f32x2 o = ld2(y); r.x += o.x; r.y += o.y; }
@@ -483,9 +520,6 @@ bool cln_ok(const dlsg_cln_args* a) {
 }
 
 // ================================================================================================ masked self-attention core
-// LDS: w (and friends) as [L][LMAX+1] matrices.
-constexpr int LDW = LMAX + 1;
-
 __device__ __forceinline__ void sa_softmax_rows(float* S, const float* sm, int L) {
     // rows i < L of S (L x L, ld LDW): masked (sm[i] sm[j] <= 0 -> -9e15) softmax over j; one thread per row
     const int i = threadIdx.x;
@@ -509,27 +543,31 @@ __device__ __forceinline__ void sa_softmax_rows(float* S, const float* sm, int L
 }
 
 __global__ __launch_bounds__(NT) void sa_fwd_kernel(const dlsg_crit_sa_args a) {
-    __shared__ float S[LMAX * LDW], scratch[4 * LMAX * LMAX], sm[LMAX];
+    __shared__ __attribute__((aligned(16))) float S[LMAX * LDW], red[RED], sm[LMAX];
     const int i0 = blockIdx.x, L = a.L;
     const float* K = a.KQV + (int64_t)i0 * L * 3 * C;
+    zero_lds(S, LMAX * LDW);
     if (threadIdx.x < L) sm[threadIdx.x] = a.smask[(i0 % a.B) * L + threadIdx.x];
-    pairdot<LMAX>(K, 3 * C, L, K + C, 3 * C, L, a.scale, S, LDW, scratch);
+    __syncthreads();
+    pairdot(K, 3 * C, L, K + C, 3 * C, L, a.scale, S, LDW, red);
     sa_softmax_rows(S, sm, L);
     for (int k = threadIdx.x; k < L * L; k += NT) a.w[(int64_t)i0 * L * L + k] = S[(k / L) * LDW + (k % L)];
-    chanprod<LMAX, false>(S, LDW, K + 2 * C, 3 * C, nullptr, nullptr, 0, L, L, 1.f, a.ctx + (int64_t)i0 * L * C, C, false);
+    chanprod<LMAX, false, false>(S, LDW, K + 2 * C, 3 * C, nullptr, nullptr, 0, L, L, 1.f, a.ctx + (int64_t)i0 * L * C, C, false);
 }
 
 __global__ __launch_bounds__(NT) void sa_bwd_kernel(const dlsg_crit_sa_args a) {
-    __shared__ float W[LMAX * LDW], D[LMAX * LDW], scratch[4 * LMAX * LMAX], sm[LMAX];
+    __shared__ __attribute__((aligned(16))) float W[LMAX * LDW], D[LMAX * LDW], red[RED], sm[LMAX];
     const int i0 = blockIdx.x, L = a.L;
     const float* K = a.KQV + (int64_t)i0 * L * 3 * C;
     const float* dctx = a.dctx + (int64_t)i0 * L * C;
     float* dK = a.dKQV + (int64_t)i0 * L * 3 * C;
     const bool acc = i0 >= a.acc_lo && i0 < a.acc_hi;
+    zero_lds(W, LMAX * LDW); zero_lds(D, LMAX * LDW);
     if (threadIdx.x < L) sm[threadIdx.x] = a.smask[(i0 % a.B) * L + threadIdx.x];
+    __syncthreads();
     for (int k = threadIdx.x; k < L * L; k += NT) W[(k / L) * LDW + (k % L)] = a.w[(int64_t)i0 * L * L + k];
-    pairdot<LMAX>(dctx, C, L, K + 2 * C, 3 * C, L, 1.f, D, LDW, scratch);                 // dw = dctx V^T (ends with a barrier)
-    chanprod<LMAX, true>(W, LDW, dctx, C, nullptr, nullptr, 0, L, L, 1.f, dK + 2 * C, 3 * C, acc);   // dV = w^T dctx
+    pairdot(dctx, C, L, K + 2 * C, 3 * C, L, 1.f, D, LDW, red);                 // dw = dctx V^T (ends with a barrier)
+    chanprod<LMAX, true, false>(W, LDW, dctx, C, nullptr, nullptr, 0, L, L, 1.f, dK + 2 * C, 3 * C, acc);   // dV = w^T dctx
     if (threadIdx.x < L) {
         const int i = threadIdx.x;
         float r = 0.f;
@@ -537,24 +575,25 @@ __global__ __launch_bounds__(NT) void sa_bwd_kernel(const dlsg_crit_sa_args a) {
         for (int j = 0; j < L; ++j) D[i * LDW + j] = (sm[i] * sm[j] > 0.f) ? W[i * LDW + j] * (D[i * LDW + j] - r) : 0.f;
     }
     __syncthreads();
-    chanprod<LMAX, false>(D, LDW, K + C, 3 * C, nullptr, nullptr, 0, L, L, a.scale, dK, 3 * C, acc);          // dK = scale dlg Q
-    chanprod<LMAX, true>(D, LDW, K, 3 * C, nullptr, nullptr, 0, L, L, a.scale, dK + C, 3 * C, acc);          // dQ = scale dlg^T K
+    chanprod<LMAX, false, false>(D, LDW, K + C, 3 * C, nullptr, nullptr, 0, L, L, a.scale, dK, 3 * C, acc);          // dK = scale dlg Q
+    chanprod<LMAX, true, false>(D, LDW, K, 3 * C, nullptr, nullptr, 0, L, L, a.scale, dK + C, 3 * C, acc);          // dQ = scale dlg^T K
 }
 
 __global__ __launch_bounds__(NT) void sa_bwd2_kernel(const dlsg_crit_sa_args a) {
-    // w, wd (tangent of w), dlg, dlgd; S1 / S2 scratch matrices
-    __shared__ float W[LMAX * LDW], Wd[LMAX * LDW], D[LMAX * LDW], Dd[LMAX * LDW], scratch[4 * LMAX * LMAX], sm[LMAX];
+    // w, wd (tangent of w), dlg, dlgd
+    __shared__ __attribute__((aligned(16))) float W[LMAX * LDW], Wd[LMAX * LDW], D[LMAX * LDW], Dd[LMAX * LDW], red[RED], sm[LMAX];
     const int i0 = blockIdx.x, L = a.L;
     const float* K = a.KQV + (int64_t)i0 * L * 3 * C;
     const float* Ud = a.U + (int64_t)i0 * L * 3 * C;
     const float* dctx = a.dctx + (int64_t)i0 * L * C;
     float* g = a.gKQV + (int64_t)i0 * L * 3 * C;
+    zero_lds(W, LMAX * LDW); zero_lds(Wd, LMAX * LDW); zero_lds(D, LMAX * LDW); zero_lds(Dd, LMAX * LDW);
     if (threadIdx.x < L) sm[threadIdx.x] = a.smask[(i0 % a.B) * L + threadIdx.x];
-    // w = softmax(scale K Q^T) recomputed; Sd = scale (Kd Q^T + K Qd^T) on unmasked entries
-    pairdot<LMAX>(K, 3 * C, L, K + C, 3 * C, L, a.scale, W, LDW, scratch);
-    sa_softmax_rows(W, sm, L);
-    pairdot<LMAX>(Ud, 3 * C, L, K + C, 3 * C, L, a.scale, Wd, LDW, scratch);
-    pairdot<LMAX>(K, 3 * C, L, Ud + C, 3 * C, L, a.scale, D, LDW, scratch);
+    __syncthreads();
+    // w = softmax(scale K Q^T): the forward saved it (a.w) for these captions; Sd = scale (Kd Q^T + K Qd^T) on unmasked entries
+    for (int k = threadIdx.x; k < L * L; k += NT) W[(k / L) * LDW + (k % L)] = a.w[(int64_t)i0 * L * L + k];
+    pairdot(Ud, 3 * C, L, K + C, 3 * C, L, a.scale, Wd, LDW, red);
+    pairdot(K, 3 * C, L, Ud + C, 3 * C, L, a.scale, D, LDW, red);
     if (threadIdx.x < L) {
         const int i = threadIdx.x;
         float r = 0.f;
@@ -567,12 +606,12 @@ __global__ __launch_bounds__(NT) void sa_bwd2_kernel(const dlsg_crit_sa_args a) 
     }
     __syncthreads();
     // tangent of ctx = wd V + w Vd
-    chanprod<LMAX, false>(Wd, LDW, K + 2 * C, 3 * C, W, Ud + 2 * C, 3 * C, L, L, 1.f, a.Uctx + (int64_t)i0 * L * C, C, false);
+    chanprod<LMAX, false, true>(Wd, LDW, K + 2 * C, 3 * C, W, Ud + 2 * C, 3 * C, L, L, 1.f, a.Uctx + (int64_t)i0 * L * C, C, false);
     // derivative of dV = wd^T dctx
-    chanprod<LMAX, true>(Wd, LDW, dctx, C, nullptr, nullptr, 0, L, L, 1.f, g + 2 * C, 3 * C, false);
+    chanprod<LMAX, true, false>(Wd, LDW, dctx, C, nullptr, nullptr, 0, L, L, 1.f, g + 2 * C, 3 * C, false);
     // dw = dctx V^T, dwd = dctx Vd^T
-    pairdot<LMAX>(dctx, C, L, K + 2 * C, 3 * C, L, 1.f, D, LDW, scratch);
-    pairdot<LMAX>(dctx, C, L, Ud + 2 * C, 3 * C, L, 1.f, Dd, LDW, scratch);
+    pairdot(dctx, C, L, K + 2 * C, 3 * C, L, 1.f, D, LDW, red);
+    pairdot(dctx, C, L, Ud + 2 * C, 3 * C, L, 1.f, Dd, LDW, red);
     if (threadIdx.x < L) {
         const int i = threadIdx.x;
         float r = 0.f, rd = 0.f;
@@ -588,13 +627,11 @@ __global__ __launch_bounds__(NT) void sa_bwd2_kernel(const dlsg_crit_sa_args a) 
         }
     }
     __syncthreads();
-    chanprod<LMAX, false>(Dd, LDW, K + C, 3 * C, D, Ud + C, 3 * C, L, L, a.scale, g, 3 * C, false);           // d(dK) = scale (dlgd Q + dlg Qd)
-    chanprod<LMAX, true>(Dd, LDW, K, 3 * C, D, Ud, 3 * C, L, L, a.scale, g + C, 3 * C, false);                // d(dQ) = scale (dlgd^T K + dlg^T Kd)
+    chanprod<LMAX, false, true>(Dd, LDW, K + C, 3 * C, D, Ud + C, 3 * C, L, L, a.scale, g, 3 * C, false);           // d(dK) = scale (dlgd Q + dlg Qd)
+    chanprod<LMAX, true, true>(Dd, LDW, K, 3 * C, D, Ud, 3 * C, L, L, a.scale, g + C, 3 * C, false);                // d(dQ) = scale (dlgd^T K + dlg^T Kd)
 }
 
 // ================================================================================================ word -> proposal graph (PSLScore2)
-constexpr int LDT = TMAX + 1;
-
 // softmax over the words (rows l < L) per proposal column t < T of S (L x T, ld LDT), in place
 __device__ __forceinline__ void col_softmax(float* S, int L, int T) {
     const int t = threadIdx.x;
@@ -613,13 +650,43 @@ __device__ __forceinline__ void col_softmax(float* S, int L, int T) {
     __syncthreads();
 }
 
+// Y[l][c] (=|+=) sum_t (M1[l][t] G[t][c] + alpha2 M2[l][t] E[t][c]), l < L: two L x T matrices (LDS, zero-padded rows of TMAX)
+// against T proposal rows each (global), per channel pair
+__device__ __forceinline__ void words_from_proposals(const float* M1, const float* __restrict__ G, const float* M2, float alpha2,
+                                                     const float* __restrict__ E, int L, int T, float* __restrict__ Y, bool accum) {
+    const int tid = threadIdx.x;
+    f32x2 g2[TMAX], e2[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        g2[t] = t < T ? ld2(G + (int64_t)t * C + 2 * tid) : f32x2{0.f, 0.f};
+        e2[t] = t < T ? ld2(E + (int64_t)t * C + 2 * tid) : f32x2{0.f, 0.f};
+    }
+    for (int l = 0; l < L; ++l) {
+        float m1[TMAX], m2[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; t += 4) {
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(M1 + l * LDT + t), v2 = *reinterpret_cast<const f32x4*>(M2 + l * LDT + t);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { m1[t + q] = v1[q]; m2[t + q] = alpha2 * v2[q]; }
+        }
+        f32x2 r = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) { r.x += m1[t] * g2[t].x + m2[t] * e2[t].x; r.y += m1[t] * g2[t].y + m2[t] * e2[t].y; }
+        float* y = Y + (int64_t)l * C + 2 * tid;
+        if (accum) { const f32x2 o = ld2(y); r.x += o.x; r.y += o.y; }
+        st2(y, r);
+    }
+}
+
 __global__ __launch_bounds__(NT) void pattn_fwd_kernel(const dlsg_crit_pattn_args a) {
-    __shared__ float P[LMAX * LDT], adj[LMAX * LDT], scratch[4 * LMAX * TMAX], sm[LMAX];
+    __shared__ __attribute__((aligned(16))) float P[LMAX * LDT], adj[LMAX * LDT], red[RED], sm[LMAX];
     const int i0 = blockIdx.x, h = blockIdx.y, L = a.L, T = a.T;
     const float* av = a.a[h] + (int64_t)i0 * L * C;
     const float* ev = a.e[h] + (int64_t)(i0 % a.B) * T * C;
+    zero_lds(P, LMAX * LDT); zero_lds(adj, LMAX * LDT);
     if (threadIdx.x < L) sm[threadIdx.x] = a.smask[(i0 % a.B) * L + threadIdx.x];
-    pairdot<TMAX>(av, C, L, ev, C, T, a.scale, P, LDT, scratch);
+    __syncthreads();
+    pairdot(av, C, L, ev, C, T, a.scale, P, LDT, red);
     col_softmax(P, L, T);
     for (int k = threadIdx.x; k < L * T; k += NT) {
         const int l = k / T, t = k - l * T;
@@ -632,16 +699,17 @@ __global__ __launch_bounds__(NT) void pattn_fwd_kernel(const dlsg_crit_pattn_arg
         for (int l = 0; l < L; ++l) s += adj[l * LDT + threadIdx.x];
         a.wgt[h][(int64_t)i0 * T + threadIdx.x] = s;
     }
-    chanprod<LMAX, true>(adj, LDT, av, C, nullptr, nullptr, 0, T, L, 1.f, a.aggpre[h] + (int64_t)i0 * T * C, C, false);   // adj^T a
+    chanprod<LMAX, true, false>(adj, LDT, av, C, nullptr, nullptr, 0, T, L, 1.f, a.aggpre[h] + (int64_t)i0 * T * C, C, false);   // adj^T a
 }
 
 __global__ __launch_bounds__(NT) void pattn_bwd_kernel(const dlsg_crit_pattn_args a) {
-    __shared__ float P[LMAX * LDT], adj[LMAX * LDT], dS[LMAX * LDT], scratch[4 * LMAX * TMAX], sm[LMAX];
+    __shared__ __attribute__((aligned(16))) float P[LMAX * LDT], adj[LMAX * LDT], dS[LMAX * LDT], red[RED], sm[LMAX];
     const int i0 = blockIdx.x, h = blockIdx.y, L = a.L, T = a.T;
     const float* av = a.a[h] + (int64_t)i0 * L * C;
     const float* ev = a.e[h] + (int64_t)(i0 % a.B) * T * C;
     const float* dg = a.d_agg[h] + (int64_t)i0 * T * C;
     const bool acc = i0 >= a.acc_lo && i0 < a.acc_hi;
+    zero_lds(P, LMAX * LDT); zero_lds(adj, LMAX * LDT); zero_lds(dS, LMAX * LDT);
     if (threadIdx.x < L) sm[threadIdx.x] = a.smask[(i0 % a.B) * L + threadIdx.x];
     __syncthreads();
     for (int k = threadIdx.x; k < L * T; k += NT) {
@@ -650,7 +718,7 @@ __global__ __launch_bounds__(NT) void pattn_bwd_kernel(const dlsg_crit_pattn_arg
         P[l * LDT + t] = p;
         adj[l * LDT + t] = p * sm[l];
     }
-    pairdot<TMAX>(av, C, L, dg, C, T, 1.f, dS, LDT, scratch);                      // a . d_agg (ends with a barrier)
+    pairdot(av, C, L, dg, C, T, 1.f, dS, LDT, red);                                // a . d_agg (ends with a barrier)
     if (threadIdx.x < T) {
         const int t = threadIdx.x;
         const float dw = a.d_wgt[h][(int64_t)i0 * T + t];
@@ -663,46 +731,26 @@ __global__ __launch_bounds__(NT) void pattn_bwd_kernel(const dlsg_crit_pattn_arg
         for (int l = 0; l < L; ++l) dS[l * LDT + t] = P[l * LDT + t] * (dS[l * LDT + t] - rho);
     }
     __syncthreads();
-    // da = adj d_agg + scale dS e
-    {
-        const int tid = threadIdx.x;
-        f32x2 g2[TMAX], e2[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            g2[t] = t < T ? ld2(dg + (int64_t)t * C + 2 * tid) : f32x2{0.f, 0.f};
-            e2[t] = t < T ? ld2(ev + (int64_t)t * C + 2 * tid) : f32x2{0.f, 0.f};
-        }
-        float* da = a.da[h] + (int64_t)i0 * L * C;
-        for (int l = 0; l < L; ++l) {
-            f32x2 r = {0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-                    const float m1 = adj[l * LDT + t], m2 = a.scale * dS[l * LDT + t];
-                    r.x += m1 * g2[t].x + m2 * e2[t].x; r.y += m1 * g2[t].y + m2 * e2[t].y;
-                }
-            float* y = da + (int64_t)l * C + 2 * tid;
-            if (acc) { const f32x2 o = ld2(y); r.x += o.x; r.y += o.y; }
-            st2(y, r);
-        }
-    }
-    if (a.de[h]) chanprod<LMAX, true>(dS, LDT, av, C, nullptr, nullptr, 0, T, L, a.scale, a.de[h] + (int64_t)i0 * T * C, C, false);
+    words_from_proposals(adj, dg, dS, a.scale, ev, L, T, a.da[h] + (int64_t)i0 * L * C, acc);                       // da = adj d_agg + scale dS e
+    if (a.de[h]) chanprod<LMAX, true, false>(dS, LDT, av, C, nullptr, nullptr, 0, T, L, a.scale, a.de[h] + (int64_t)i0 * T * C, C, false);
 }
 
 __global__ __launch_bounds__(NT) void pattn_bwd2_kernel(const dlsg_crit_pattn_args a) {
-    __shared__ float P[LMAX * LDT], Pd[LMAX * LDT], dS[LMAX * LDT], dSd[LMAX * LDT], adj[LMAX * LDT], adjd[LMAX * LDT],
-        scratch[4 * LMAX * TMAX], sm[LMAX];
+    __shared__ __attribute__((aligned(16))) float P[LMAX * LDT], Pd[LMAX * LDT], dS[LMAX * LDT], dSd[LMAX * LDT], adj[LMAX * LDT],
+        adjd[LMAX * LDT], red[RED], sm[LMAX];
     const int i0 = blockIdx.x, h = blockIdx.y, L = a.L, T = a.T, tid = threadIdx.x;
     const float* av = a.a[h] + (int64_t)i0 * L * C;
     const float* ad = a.Ua[h] + (int64_t)i0 * L * C;
     const float* ev = a.e[h] + (int64_t)(i0 % a.B) * T * C;
     const float* dg = a.d_agg[h] + (int64_t)i0 * T * C;
+    zero_lds(P, LMAX * LDT); zero_lds(Pd, LMAX * LDT); zero_lds(dS, LMAX * LDT); zero_lds(dSd, LMAX * LDT);
+    zero_lds(adj, LMAX * LDT); zero_lds(adjd, LMAX * LDT);
     if (tid < L) sm[tid] = a.smask[(i0 % a.B) * L + tid];
-    pairdot<TMAX>(av, C, L, ev, C, T, a.scale, P, LDT, scratch);
-    col_softmax(P, L, T);
-    pairdot<TMAX>(ad, C, L, ev, C, T, a.scale, Pd, LDT, scratch);                  // Sd
-    pairdot<TMAX>(av, C, L, dg, C, T, 1.f, dS, LDT, scratch);                      // a . d_agg
-    pairdot<TMAX>(ad, C, L, dg, C, T, 1.f, dSd, LDT, scratch);                     // ad . d_agg
+    __syncthreads();
+    for (int k = tid; k < L * T; k += NT) P[(k / T) * LDT + (k % T)] = a.P[h][(int64_t)i0 * L * T + k];      // saved by the forward
+    pairdot(ad, C, L, ev, C, T, a.scale, Pd, LDT, red);                            // Sd
+    pairdot(av, C, L, dg, C, T, 1.f, dS, LDT, red);                                // a . d_agg
+    pairdot(ad, C, L, dg, C, T, 1.f, dSd, LDT, red);                               // ad . d_agg
     if (tid < T) {
         const int t = tid;
         const float dw = a.d_wgt[h][(int64_t)i0 * T + t];
@@ -729,29 +777,11 @@ __global__ __launch_bounds__(NT) void pattn_bwd2_kernel(const dlsg_crit_pattn_ar
     }
     __syncthreads();
     // tangent of aggpre = adjd^T a + adj^T ad
-    chanprod<LMAX, true>(adjd, LDT, av, C, adj, ad, C, T, L, 1.f, a.Uagg[h] + (int64_t)i0 * T * C, C, false);
+    chanprod<LMAX, true, true>(adjd, LDT, av, C, adj, ad, C, T, L, 1.f, a.Uagg[h] + (int64_t)i0 * T * C, C, false);
     // derivative of de = scale (dSd^T a + dS^T ad)
-    chanprod<LMAX, true>(dSd, LDT, av, C, dS, ad, C, T, L, a.scale, a.ge[h] + (int64_t)i0 * T * C, C, false);
+    chanprod<LMAX, true, true>(dSd, LDT, av, C, dS, ad, C, T, L, a.scale, a.ge[h] + (int64_t)i0 * T * C, C, false);
     // derivative of da = adjd d_agg + scale dSd e
-    {
-        f32x2 g2[TMAX], e2[TMAX];
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            g2[t] = t < T ? ld2(dg + (int64_t)t * C + 2 * tid) : f32x2{0.f, 0.f};
-            e2[t] = t < T ? ld2(ev + (int64_t)t * C + 2 * tid) : f32x2{0.f, 0.f};
-        }
-        float* ga = a.ga[h] + (int64_t)i0 * L * C;
-        for (int l = 0; l < L; ++l) {
-            f32x2 r = {0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < TMAX; ++t)
-                if (t < T) {
-                    const float m1 = adjd[l * LDT + t], m2 = a.scale * dSd[l * LDT + t];
-                    r.x += m1 * g2[t].x + m2 * e2[t].x; r.y += m1 * g2[t].y + m2 * e2[t].y;
-                }
-            st2(ga + (int64_t)l * C + 2 * tid, r);
-        }
-    }
+    words_from_proposals(adjd, dg, dSd, a.scale, ev, L, T, a.ga[h] + (int64_t)i0 * L * C, false);
 }
 
 // ================================================================================================ text summary + fusion weights
@@ -1326,7 +1356,7 @@ extern "C" int dlsg_crit_sa_bwd(const dlsg_crit_sa_args* a, void* stream) {
     return DLSG_OK;
 }
 extern "C" int dlsg_crit_sa_bwd2(const dlsg_crit_sa_args* a, void* stream) {
-    if (!sa_ok(a) || !a->dctx || !a->U || !a->Uctx || !a->gKQV || !al8(a->dctx) || !al8(a->U) || !al8(a->Uctx) || !al8(a->gKQV))
+    if (!sa_ok(a) || !a->w || !a->dctx || !a->U || !a->Uctx || !a->gKQV || !al8(a->dctx) || !al8(a->U) || !al8(a->Uctx) || !al8(a->gKQV))
         return DLSG_EINVAL;
     hipLaunchKernelGGL(sa_bwd2_kernel, dim3(a->n), dim3(NT), 0, ST(stream), *a);
     DLSG_CHECK_LAUNCH();
@@ -1358,7 +1388,7 @@ extern "C" int dlsg_crit_pattn_bwd(const dlsg_crit_pattn_args* a, void* stream) 
 extern "C" int dlsg_crit_pattn_bwd2(const dlsg_crit_pattn_args* a, void* stream) {
     if (!pattn_ok(a)) return DLSG_EINVAL;
     for (int h = 0; h < 2; ++h)
-        if (!a->d_agg[h] || !a->d_wgt[h] || !a->Ua[h] || !a->Uagg[h] || !a->Uwgt[h] || !a->ga[h] || !a->ge[h]) return DLSG_EINVAL;
+        if (!a->P[h] || !a->d_agg[h] || !a->d_wgt[h] || !a->Ua[h] || !a->Uagg[h] || !a->Uwgt[h] || !a->ga[h] || !a->ge[h]) return DLSG_EINVAL;
     hipLaunchKernelGGL(pattn_bwd2_kernel, dim3(a->n, 2), dim3(NT), 0, ST(stream), *a);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;

@@ -24,7 +24,7 @@ import math
 
 import torch
 
-from .hip import GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH
+from .hip import GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH, F_FORCE64, F_FORCE128
 
 C = 512              # DiscV2.dim and every internal width (models/model.py:113, layer.py:665-683)
 PW = 1024            # proposals enter through Linear(1024, 512) (layer.py:666)
@@ -181,12 +181,13 @@ class CriticEngine(object):
         ops.crit_relu_taps(h, h, p['bc'], 0.3, x1, taps)                       # ResBlock: in-place ReLU feeds the skip too
         ops.gemm(GEMM_NT, [(taps.view(R, 3 * C), p['Wc'], x1.view(R, C))], alpha=0.3, flags=F_ACCUM)
         xin = b['xin'][:nf]
-        ops.gemm(GEMM_NT, [(x1.view(R, C), p['W_ih'], xin.view(R, 4 * C))])
+        # (tiles: tools/critic_gemm_probe.py on an MI355X -- 4992 x 2048 x 512: 107 us on 64 x 64 tiles, 124 on the dispatcher's choice)
+        ops.gemm(GEMM_NT, [(x1.view(R, C), p['W_ih'], xin.view(R, 4 * C))], flags=F_FORCE64 if R >= 4096 else 0)
         ops.lstm_seq_fwd(xin, p['W_hh'], p['b_ih'], p['b_hh'], b['As'][:nf], b['Hs'][:nf], b['Cs'][:nf], b['Hprev'][:nf])
         y = b['y'][:nf]
         ops.cln_fwd([b['Hs'][:nf].view(R, C)], [p['ln_g']], [p['ln_b']], [y.view(R, C)], False, p_post=pd, site_post=SITE_LSTM, seed=seed)
         KQV = b['KQV'][:nf]
-        ops.gemm(GEMM_NT, [(y.view(R, C), p['Wkqv'], KQV.view(R, 3 * C))])
+        ops.gemm(GEMM_NT, [(y.view(R, C), p['Wkqv'], KQV.view(R, 3 * C))], flags=F_FORCE128 if R >= 4096 else 0)   # 79 us against 99
         ops.crit_sa_fwd(KQV, ws.smask, b['w'][:nf], b['ctx'][:nf], 1.0 / math.sqrt(D.att.attention_size))
         out, words = b['out'][:nf], b['words'][:nf]
         ops.gemm(GEMM_NT, [(b['ctx'][:nf].view(R, C), p['Wo'], out.view(R, C))])
@@ -306,7 +307,7 @@ class CriticEngine(object):
         ops.cln_bwd2([M('Hs').view(R, C)], [p['ln_g']], [[Tn('c_y').view(R, C)]], [Tn('Hs').view(R, C)], [M('c_hs').view(R, C)],
                      [Tn('y').view(R, C)], self._x2(ws, 'ln'), False, p_post=pd, site_post=SITE_LSTM, seed=seed, row0=row0)
         ops.gemm(GEMM_NT, [(Tn('y').view(R, C), p['Wkqv'], Tn('KQV').view(R, 3 * C))])
-        ops.crit_sa_bwd2(M('KQV'), ws.smask, Tn('c_ctx'), Tn('KQV'), Tn('ctx'), M('c_KQV'), 1.0 / math.sqrt(D.att.attention_size))
+        ops.crit_sa_bwd2(M('KQV'), ws.smask, M('w'), Tn('c_ctx'), Tn('KQV'), Tn('ctx'), M('c_KQV'), 1.0 / math.sqrt(D.att.attention_size))
         ops.gemm(GEMM_NT, [(Tn('ctx').view(R, C), p['Wo'], Tn('out').view(R, C))])
         cw = b['c_words']
         ops.cln_bwd2([M('out').view(R, C)], [p['an_g']], [[cw[k, t0:t1].view(R, C)] for k in range(3)], [Tn('out').view(R, C)],
@@ -316,7 +317,7 @@ class CriticEngine(object):
         ops.cln_bwd2([t.view(R, C) for t in M2('apre')], p['aa_g'], [[t.view(R, C) for t in T2('c_a')]], [t.view(R, C) for t in T2('apre')],
                      [t.view(R, C) for t in M2('c_apre')], [t.view(R, C) for t in T2('a')], self._x2(ws, 'aa'), True, row0=row0)
         e2 = [ws.esel[k].view(B, T, C) for k in range(2)]
-        ops.crit_pattn_bwd2(M2('a'), e2, ws.smask, T2('c_aggpre'), T2('c_wgt'), T2('a'), T2('aggpre'), T2('wgt'), M2('c_a'), T2('de'),
+        ops.crit_pattn_bwd2(M2('a'), e2, ws.smask, M2('P'), T2('c_aggpre'), T2('c_wgt'), T2('a'), T2('aggpre'), T2('wgt'), M2('c_a'), T2('de'),
                             1.0 / math.sqrt(C))
         ops.cln_bwd2([t.view(Rt, C) for t in M2('aggpre')], p['pn_g'], [[t.view(Rt, C) for t in T2('c_agg')]],
                      [t.view(Rt, C) for t in T2('aggpre')], [t.view(Rt, C) for t in M2('c_aggpre')], [t.view(Rt, C) for t in T2('agg')],
@@ -329,6 +330,28 @@ class CriticEngine(object):
         ops.crit_score_bwd2(v2, M2('s'), p['wc'], p['bcl'], M2('wgt'), M('fus'), M2('pair'), M2('score'), ws.ones_B, [uspre[0], uspre[1]], T2('wgt'), Tn('fus'),
                             M('c_fus'), M2('c_spre'), T2('c_vcap'), M2('c_wgt'), [ws.get('part_wc2', 2, B, C)[k] for k in range(2)],
                             ws.get('dbc2', 2))
+
+    def _tn(self, ws, key, items, alpha=1.0):
+        """out = alpha A^T B for every (A (K, M), B (K, N), out) of `items` (same shapes) in ONE launch.  A weight gradient of the
+        critic has few output tiles (512 x 512 .. 2048 x 512) and a deep contraction (K = every caption row): the K rows go to
+        `ns` groups of the launch, each writing its own slab, folded in a fixed order by slab_reduce (tools/critic_gemm_probe.py on
+        an MI355X: 512 x 512 x 6656: 147 us as one group, 50 us with 4; 512 x 1536 x 6656: 151 -> 108 us with 8)"""
+        ops = self.D.ops
+        A0, B0, _ = items[0]
+        K, M, N = A0.shape[0], A0.shape[1], B0.shape[1]
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        ns = 1 if K < 1024 else (2 if K < 4096 else (8 if tiles >= 128 else 4))
+        ns = max(1, min(ns, 16 // len(items)))
+        if ns == 1:
+            ops.gemm(GEMM_TN, items, alpha=alpha)
+            return
+        step = ((K + ns - 1) // ns + 31) // 32 * 32
+        bounds = [(k, min(K, k + step)) for k in range(0, K, step)]
+        slabs = ws.get('tn_' + key, len(items), len(bounds), M, N)
+        ops.gemm(GEMM_TN, [(A[k0:k1], Bm[k0:k1], slabs[j, i]) for j, (A, Bm, _) in enumerate(items) for i, (k0, k1) in enumerate(bounds)],
+                 alpha=alpha)
+        for j, (_, _, out) in enumerate(items):
+            ops.slab_reduce(slabs[j], out)
 
     # ------------------------------------------------------------------ parameter gradients after the last backward pass
     def _param_grads(self, ws, p, g, logits_tm, ids, eps):
@@ -343,12 +366,13 @@ class CriticEngine(object):
         Ra, Rp, Rta, Rtp = na * L, npr * L, na * T, npr * T
         f2 = lambda t, rows: t.reshape(rows, t.shape[-1])
         # ---- the caption trunk
-        ops.gemm(GEMM_TN, [(f2(b['c_x1'], Ra), f2(b['taps'], Ra), g['Wc'])], alpha=0.3)
-        ops.gemm(GEMM_TN, [(f2(b['DA'], Ra), f2(b['x1'], Ra), g['W_ih']), (f2(b['DA'], Ra), f2(b['Hprev'], Ra), g['W_hh'])])
-        ops.gemm(GEMM_TN, [(f2(b['c_KQV'], Ra), f2(b['y'], Ra), g['Wkqv'])])
-        ops.gemm(GEMM_TN, [(f2(b['c_out'], Ra), f2(b['ctx'], Ra), g['Wo'])])
-        ops.gemm(GEMM_TN, [(f2(b['c_apre'][k], Ra), f2(b['words'], Ra), g['Wa'][k]) for k in range(2)])
-        ops.gemm(GEMM_TN, [(f2(b['c_spre'][k], Rta), f2(b['agg'][k], Rta), g['Ws'][k]) for k in range(2)])
+        tn = self._tn
+        tn(ws, 'Wc', [(f2(b['c_x1'], Ra), f2(b['taps'], Ra), g['Wc'])], alpha=0.3)
+        tn(ws, 'Wl', [(f2(b['DA'], Ra), f2(b['x1'], Ra), g['W_ih']), (f2(b['DA'], Ra), f2(b['Hprev'], Ra), g['W_hh'])])
+        tn(ws, 'Wkqv', [(f2(b['c_KQV'], Ra), f2(b['y'], Ra), g['Wkqv'])])
+        tn(ws, 'Wsq', [(f2(b['c_out'], Ra), f2(b['ctx'], Ra), g['Wo'])] +
+           [(f2(b['c_apre'][k], Ra), f2(b['words'], Ra), g['Wa'][k]) for k in range(2)])
+        tn(ws, 'Ws', [(f2(b['c_spre'][k], Rta), f2(b['agg'][k], Rta), g['Ws'][k]) for k in range(2)])
         # ---- the proposal side: cotangents of e_sel and v summed over the caption slots
         c_vpre, c_esel = ws.get('c_vpre', 2, B * T, C), ws.get('c_esel', 2, B * T, C)
         for k in range(2):
@@ -368,10 +392,10 @@ class CriticEngine(object):
         # ---- vocabulary projection: fake logits (TN product); in an update also the real ids (scatter) and the penalty's Gram matrix
         dhr, dhf = (ws.get('dhr', B, L, C) if second else None), ws.get('dhf_tm', L, B, C)
         ops.crit_embed_mix_bwd(b['c_h'].view(min(S, 3), B, L, C), eps, dhr, dhf)
-        ops.gemm(GEMM_TN, [(dhf.view(L * B, C), logits_tm.reshape(L * B, V), g['Wvoc'])])
+        tn(ws, 'Wvoc', [(dhf.view(L * B, C), logits_tm.reshape(L * B, V), g['Wvoc'])])
         if second:
             Mg = ws.get('Mg', C, C)
-            ops.gemm(GEMM_TN, [(ws.get('gsc', B, L, C).view(B * L, C), ws.get('g', B, L, C).view(B * L, C), Mg)])
+            tn(ws, 'Mg', [(ws.get('gsc', B, L, C).view(B * L, C), ws.get('g', B, L, C).view(B * L, C), Mg)])
             ops.gemm(GEMM_NN, [(Mg, p['Wvoc'], g['Wvoc'])], alpha=2.0, flags=F_ACCUM)
             ops.crit_vocab_scatter(dhr, ids, g['Wvoc'])
         # ---- biases and the fused kernels' per-caption partials: ONE launch of column sums (a descriptor: sources, out, copy, scale)

@@ -385,8 +385,10 @@ class GanTrainer(object):
         return self._rank_mean(acc[0]), self._rank_mean(acc[4])
 
     # ------------------------------------------------------------------ the critic's term of the generator step (run_gun.py:214-231)
-    def _generator_term(self, logits_tm, obj, mot, smask, alpha, out, scale):
-        """loss_G = -D(tokens).mean() and out (L,B,V) = scale * d loss_G / d logits.  Returns the device scalar of loss_G."""
+    def _generator_term(self, logits_tm, obj, mot, smask, alpha, out):
+        """loss_G = -D(tokens).mean() (run_gun.py:214-217): enqueues the critic's forward and its backward down to the 512-wide
+        projection, returns finish(scale) -> device scalar of loss_G, which launches the last product:
+        out (L,B,V) = scale * d loss_G / d logits (gan_lambda is a host number that changes every step)."""
         D, eng = self.D, self.D.engine
         L, B, V = logits_tm.shape
         dev = logits_tm.device
@@ -394,9 +396,12 @@ class GanTrainer(object):
             ws = eng.prepare(dev, B, L, V, smask, 1)
             eng.proposals(ws, obj.contiguous(), mot.contiguous(), alpha, smask)
             score = eng.score(ws, logits_tm, eng.next_seed())
-            loss = -score.mean()
-            eng.score_backward(ws, logits_tm, ws.d_outG, eng.seed_last, out, scale=scale, params=False)
-            return loss
+            dhf = eng.score_backward(ws, logits_tm, ws.d_outG, eng.seed_last, None, params=False)
+
+            def finish(scale):
+                eng.dlogits(ws, dhf, out, scale)
+                return -score.mean()
+            return finish
         key = ('G', B, L, V, tuple(obj.shape), D.training)
         st = self._cg.get(key)
         if st is None:
@@ -423,9 +428,11 @@ class GanTrainer(object):
                     run()
             torch.cuda.current_stream().wait_stream(side)
         st['graph'].replay()
-        # the last product carries this step's gan_lambda (a host number that changes per step): launched outside the graph
-        eng.dlogits(st['ws'], st['dhf'], out, scale)
-        return -st['score'].mean()
+
+        def finish(scale):
+            eng.dlogits(st['ws'], st['dhf'], out, scale)
+            return -st['score'].mean()
+        return finish
 
     def iteration(self, frames, regions, captions, cap_lens, tf_ratio, epoch=0, i=1, max_len=26):
         model, D = self.model, self.D
@@ -449,14 +456,17 @@ class GanTrainer(object):
             s = sv['dec']
             obj_, mot_ = sv['dec_gsrc'][0].detach(), sv['dec_gsrc'][1].detach()
             alpha_ = s['ALPHA'].transpose(0, 1).detach()
+            g = dst if dst is not None else torch.empty_like(logits_tm)
+            # the critic's forward and backward do not depend on gan_lambda: they are enqueued BEFORE the caption loss is read back
+            # (a host synchronisation), so the device works through them while the host updates the weight
+            finish = self._generator_term(logits_tm.detach(), obj_, mot_, smask, alpha_, g)
             out['cap_loss_dev'] = sv['loss_dev']
             # the reference updates lambda from the caption loss of THIS step before using it (run_gun.py:210,224)
             # -- with several ranks the all-reduced mean, as the reference feeds it (run_gun.py:202-203,212)
             out['cap_loss_record'] = self._rank_mean(sv['loss_dev'])
             self.lambda_handler.update_gan_lambda(epoch, i, out['cap_loss_record'])
             out['gan_lambda'] = self.lambda_handler.get_current_lambda()
-            g = dst if dst is not None else torch.empty_like(logits_tm)
-            out['loss_G'] = self._generator_term(logits_tm.detach(), obj_, mot_, smask, alpha_, g, out['gan_lambda'])
+            out['loss_G'] = finish(out['gan_lambda'])
             return g
         gan_term.takes_dst = True
         cap_loss = self.trainer.step(frames, regions, captions, cap_lens, tf_ratio, max_len=max_len, extra_dlogits=gan_term)

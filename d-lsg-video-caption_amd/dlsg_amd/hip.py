@@ -1193,11 +1193,11 @@ class HipOps(object):
         a.w, a.dctx, a.dKQV = _p(w), _p(dctx), _p(dKQV)
         self._check(self.lib.dlsg_crit_sa_bwd(C.byref(a), self._stream()), 'crit_sa_bwd')
 
-    def crit_sa_bwd2(self, KQV, smask, dctx, U, Uctx, gKQV, scale):
+    def crit_sa_bwd2(self, KQV, smask, w, dctx, U, Uctx, gKQV, scale):
         a = self._sa_args(KQV, smask, scale)
-        for t in (dctx, U, Uctx, gKQV):
+        for t in (w, dctx, U, Uctx, gKQV):
             _chkc(t)
-        a.dctx, a.U, a.Uctx, a.gKQV = _p(dctx), _p(U), _p(Uctx), _p(gKQV)
+        a.w, a.dctx, a.U, a.Uctx, a.gKQV = _p(w), _p(dctx), _p(U), _p(Uctx), _p(gKQV)
         self._check(self.lib.dlsg_crit_sa_bwd2(C.byref(a), self._stream()), 'crit_sa_bwd2')
 
     @staticmethod
@@ -1229,9 +1229,9 @@ class HipOps(object):
         self._set2(a, P=P, d_agg=d_agg, d_wgt=d_wgt, da=da, de=de)
         self._check(self.lib.dlsg_crit_pattn_bwd(C.byref(a), self._stream()), 'crit_pattn_bwd')
 
-    def crit_pattn_bwd2(self, a_, e, smask, d_agg, d_wgt, Ua, Uagg, Uwgt, ga, ge, scale):
+    def crit_pattn_bwd2(self, a_, e, smask, P, d_agg, d_wgt, Ua, Uagg, Uwgt, ga, ge, scale):
         a = self._pattn_args(a_, e, smask, scale)
-        self._set2(a, d_agg=d_agg, d_wgt=d_wgt, Ua=Ua, Uagg=Uagg, Uwgt=Uwgt, ga=ga, ge=ge)
+        self._set2(a, P=P, d_agg=d_agg, d_wgt=d_wgt, Ua=Ua, Uagg=Uagg, Uwgt=Uwgt, ga=ga, ge=ge)
         self._check(self.lib.dlsg_crit_pattn_bwd2(C.byref(a), self._stream()), 'crit_pattn_bwd2')
 
     def _tsum_args(self, words, theta, gamma, beta, fusion, eps, p, site, seed, row0, acc=None):

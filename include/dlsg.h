@@ -479,7 +479,8 @@ int dlsg_cln_bwd2(const dlsg_cln_args* a, void* stream);
 /* Masked self-attention core of one caption on rows [K | Q | V] (n, L, 1536) (sublayer.py:66-78 with att_mask[b,i,j] =
  * smask[b,i] smask[b,j], run_gun.py:164-166; smask (B, L), caption i uses smask[i % B]):
  *   w = softmax_j(scale K_i . Q_j, masked entries -9e15), ctx = w V.     bwd: dctx -> dKQV.
- *   bwd2: U (n, L, 1536) tangent of [K | Q | V], dctx fixed -> Uctx (tangent of ctx), gKQV (derivative of dKQV; w varies with K, Q). */
+ *   bwd2: U (n, L, 1536) tangent of [K | Q | V], dctx fixed, w as the forward saved it -> Uctx (tangent of ctx), gKQV (derivative of
+ *         dKQV; w varies with K, Q). */
 typedef struct {
     const float* KQV; const float* smask; float* w; float* ctx;
     const float* dctx; float* dKQV;
@@ -496,7 +497,7 @@ int dlsg_crit_sa_bwd2(const dlsg_crit_sa_args* a, void* stream);
  *   P = softmax over the words of scale a e^T (n, L, T); adj = P * smask (mask AFTER the softmax, :703-704); wgt = sum_l adj (n, T);
  *   aggpre = adj^T a (n, T, 512).
  *   bwd : d_agg (n, T, 512), d_wgt (n, T) -> da (n, L, 512), de (n, T, 512) per caption (NULL: not wanted; the caller sums a clip's captions)
- *   bwd2: Ua = tangent of a -> Uagg, Uwgt (tangents), ga, ge (derivatives of da, de) */
+ *   bwd2: Ua = tangent of a, P as the forward saved it -> Uagg, Uwgt (tangents), ga, ge (derivatives of da, de) */
 typedef struct {
     const float* a[2]; const float* e[2]; const float* smask;
     float* P[2]; float* wgt[2]; float* aggpre[2];

@@ -300,7 +300,7 @@ class CriticEmul(object):
             d[acc[0]:acc[1]] += dKQV[acc[0]:acc[1]]
         dKQV.copy_(d)
 
-    def crit_sa_bwd2(self, KQV, smask, dctx, U, Uctx, gKQV, scale):
+    def crit_sa_bwd2(self, KQV, smask, w, dctx, U, Uctx, gKQV, scale):
         """Uctx = d/dU of the forward's ctx; gKQV = d/dU of the backward's dKQV at fixed dctx (w varies with K, Q)"""
         K, Q, V = [t.detach() for t in self._kqv(KQV)]
         UK, UQ, UV = [t.detach() for t in self._kqv(U)]
@@ -333,7 +333,7 @@ class CriticEmul(object):
             if de is not None:
                 de[h].copy_(dE)
 
-    def crit_pattn_bwd2(self, a, e, smask, d_agg, d_wgt, Ua, Uagg, Uwgt, ga, ge, scale):
+    def crit_pattn_bwd2(self, a, e, smask, P, d_agg, d_wgt, Ua, Uagg, Uwgt, ga, ge, scale):
         n = a[0].shape[0]
         sm = smask.repeat(n // smask.shape[0], 1).unsqueeze(2)
         for h in range(2):

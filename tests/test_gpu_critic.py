@@ -158,7 +158,7 @@ def test_self_attention_levels(n, B, L):
     dctx = rnd(n, L, C, seed=1)
     both('crit_sa_bwd', [KQV, sm, w, dctx, torch.zeros(n, L, 3 * C), sc], tol=5e-4)
     both('crit_sa_bwd', [KQV, sm, w, dctx, rnd(n, L, 3 * C, seed=2), sc], dict(acc=(B, 2 * B)), tol=5e-4)
-    both('crit_sa_bwd2', [KQV, sm, dctx, rnd(n, L, 3 * C, seed=3), torch.zeros(n, L, C), torch.zeros(n, L, 3 * C), sc], tol=1e-3, atol=1e-4)
+    both('crit_sa_bwd2', [KQV, sm, w, dctx, rnd(n, L, 3 * C, seed=3), torch.zeros(n, L, C), torch.zeros(n, L, 3 * C), sc], tol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize('n,B,L,T', [(6, 3, 9, 3), (8, 4, 26, 5), (4, 4, 26, 8)])
@@ -175,7 +175,7 @@ def test_proposal_graph_levels(n, B, L, T):
     both('crit_pattn_bwd', [a, e, sm, P, d_agg, d_wgt, z(n, L, C), z(n, T, C), sc], tol=5e-4)
     both('crit_pattn_bwd', [a, e, sm, P, d_agg, d_wgt, [rnd(n, L, C, seed=11 + h) for h in range(2)], None, sc], dict(acc=(B, n)), tol=5e-4)
     Ua = [rnd(n, L, C, seed=13 + h) for h in range(2)]
-    both('crit_pattn_bwd2', [a, e, sm, d_agg, d_wgt, Ua, z(n, T, C), z(n, T), z(n, L, C), z(n, T, C), sc], tol=1e-3, atol=1e-4)
+    both('crit_pattn_bwd2', [a, e, sm, P, d_agg, d_wgt, Ua, z(n, T, C), z(n, T), z(n, L, C), z(n, T, C), sc], tol=1e-3, atol=1e-4)
 
 
 @pytest.mark.parametrize('n,L,drop', [(5, 9, 0.0), (6, 26, 0.3)])

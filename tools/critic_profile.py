@@ -26,12 +26,13 @@ frames, regions, caps, lens = [t.cuda() for t in synth_batch(args, V, B, 1)]
 it = dlsg_amd.GanTrainer(G, D, num_D=num_D, total_step=100)
 with torch.no_grad():
     f_caption, obj, mot, alpha = G(frames, regions, caps, 26, 1.0)
-mask = gan.attention_mask(caps)
+logits_tm = f_caption.transpose(0, 1).contiguous()
+smask = (caps > 0).float()
 import time
 for i in range(calls + 2):
     if i == 2:
         torch.cuda.synchronize()
         t0 = time.time()
-    it.train_disc(caps, f_caption, obj, mot, mask, alpha)
+    it.train_disc(caps, logits_tm, obj, mot, smask, alpha)
 torch.cuda.synchronize()
 print('ms per critic update: %.2f' % ((time.time() - t0) / calls / num_D * 1e3))
