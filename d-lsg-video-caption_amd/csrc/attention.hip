@@ -821,6 +821,7 @@ extern "C" int dlsg_struct_size(int which) {
         case 26: return (int)sizeof(dlsg_crit_tsum_args);
         case 27: return (int)sizeof(dlsg_crit_score_args);
         case 28: return (int)sizeof(dlsg_crit_colsum_desc);
+        case 29: return (int)sizeof(dlsg_crit_reduce_desc);
         default: return -1;
     }
 }

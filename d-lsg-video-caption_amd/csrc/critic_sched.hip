@@ -1253,6 +1253,21 @@ __global__ __launch_bounds__(1024) void crit_colsum_kernel(const ColsumPack pk) 
     }
 }
 
+// `count` sums of slabs in one launch: out[i] = scale * sum_k src[k * stride + i], i < n (n % 4 == 0, 16-byte aligned): the K-split
+// partial weight gradients of a critic update (critic.py _tn), folded in slab order.  A block owns 1024 consecutive elements of one
+// descriptor; first[d] = the first block of descriptor d.
+struct ReducePack { dlsg_crit_reduce_desc d[DLSG_CRIT_REDUCE_MAX]; int first[DLSG_CRIT_REDUCE_MAX + 1]; int count; };
+__global__ __launch_bounds__(256) void crit_reduce_kernel(const ReducePack pk) {
+    int di = 0;
+    while (di + 1 < pk.count && (int)blockIdx.x >= pk.first[di + 1]) ++di;
+    const dlsg_crit_reduce_desc& d = pk.d[di];
+    const int64_t i = ((int64_t)(blockIdx.x - pk.first[di]) * 256 + threadIdx.x) * 4;
+    if (i >= d.n) return;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(d.src + i);
+    for (int k = 1; k < d.nslab; ++k) acc += *reinterpret_cast<const f32x4*>(d.src + (int64_t)k * d.stride + i);
+    *reinterpret_cast<f32x4*>(d.out + i) = d.scale * acc;
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 
@@ -1471,6 +1486,24 @@ extern "C" int dlsg_crit_unselect(const float* src, const int64_t* idx, float* d
     const int groups = rows_dst / per;
     if (rows_src % groups) return DLSG_EINVAL;
     hipLaunchKernelGGL(unselect_kernel, dim3(rows_dst), dim3(128), 0, ST(stream), src, idx, dst, rows_src / groups, per, n);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+extern "C" int dlsg_crit_reduce(const dlsg_crit_reduce_desc* d, int count, void* stream) {
+    if (!d || count < 1 || count > DLSG_CRIT_REDUCE_MAX) return DLSG_EINVAL;
+    ReducePack pk;
+    int blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!d[i].src || !d[i].out || d[i].nslab < 1 || d[i].n < 4 || (d[i].n & 3) || (d[i].stride & 3) || !al16(d[i].src) || !al16(d[i].out))
+            return DLSG_EINVAL;
+        pk.d[i] = d[i];
+        pk.first[i] = blocks;
+        blocks += (int)((d[i].n / 4 + 255) / 256);
+    }
+    pk.first[count] = blocks;
+    pk.count = count;
+    hipLaunchKernelGGL(crit_reduce_kernel, dim3(blocks), dim3(256), 0, ST(stream), pk);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

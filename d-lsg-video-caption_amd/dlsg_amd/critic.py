@@ -331,6 +331,23 @@ class CriticEngine(object):
                             M('c_fus'), M2('c_spre'), T2('c_vcap'), M2('c_wgt'), [ws.get('part_wc2', 2, B, C)[k] for k in range(2)],
                             ws.get('dbc2', 2))
 
+    def _colsums(self, ws, cs):
+        """column sums (sources, out, copy, scale) in two launches: tall sources (the 4 992-row bias gradients) go out as chunks of
+        <= 1280 rows into partial rows first -- a descriptor's columns are summed by ONE workgroup per 64 columns"""
+        ops = self.D.ops
+        first, second = [], []
+        for idx, (srcs, out, out_b, scale) in enumerate(cs):
+            if max(t.shape[0] for t in srcs) <= 1536:
+                first.append((srcs, out, out_b, scale))
+                continue
+            parts = [t[r0:r0 + 1280] for t in srcs for r0 in range(0, t.shape[0], 1280)]
+            scr = ws.get('cs_part_%d' % idx, len(parts), srcs[0].shape[1])
+            first += [([pt], scr[j], None, 1.0) for j, pt in enumerate(parts)]
+            second.append(([scr], out, out_b, scale))
+        ops.crit_colsum(first)
+        if second:
+            ops.crit_colsum(second)
+
     def _tn(self, ws, key, items, alpha=1.0):
         """out = alpha A^T B for every (A (K, M), B (K, N), out) of `items` (same shapes) in ONE launch.  A weight gradient of the
         critic has few output tiles (512 x 512 .. 2048 x 512) and a deep contraction (K = every caption row): the K rows go to
@@ -350,8 +367,7 @@ class CriticEngine(object):
         slabs = ws.get('tn_' + key, len(items), len(bounds), M, N)
         ops.gemm(GEMM_TN, [(A[k0:k1], Bm[k0:k1], slabs[j, i]) for j, (A, Bm, _) in enumerate(items) for i, (k0, k1) in enumerate(bounds)],
                  alpha=alpha)
-        for j, (_, _, out) in enumerate(items):
-            ops.slab_reduce(slabs[j], out)
+        ws.reduces += [(slabs[j], out) for j, (_, _, out) in enumerate(items)]
 
     # ------------------------------------------------------------------ parameter gradients after the last backward pass
     def _param_grads(self, ws, p, g, logits_tm, ids, eps):
@@ -365,14 +381,17 @@ class CriticEngine(object):
         na, npr = S * B, min(S, 3) * B                       # captions in the products / captions that carry the loss
         Ra, Rp, Rta, Rtp = na * L, npr * L, na * T, npr * T
         f2 = lambda t, rows: t.reshape(rows, t.shape[-1])
-        # ---- the caption trunk
+        # ---- the caption trunk (the K-split products leave slabs: folded by ONE launch below)
         tn = self._tn
+        ws.reduces = []
         tn(ws, 'Wc', [(f2(b['c_x1'], Ra), f2(b['taps'], Ra), g['Wc'])], alpha=0.3)
         tn(ws, 'Wl', [(f2(b['DA'], Ra), f2(b['x1'], Ra), g['W_ih']), (f2(b['DA'], Ra), f2(b['Hprev'], Ra), g['W_hh'])])
         tn(ws, 'Wkqv', [(f2(b['c_KQV'], Ra), f2(b['y'], Ra), g['Wkqv'])])
         tn(ws, 'Wsq', [(f2(b['c_out'], Ra), f2(b['ctx'], Ra), g['Wo'])] +
            [(f2(b['c_apre'][k], Ra), f2(b['words'], Ra), g['Wa'][k]) for k in range(2)])
         tn(ws, 'Ws', [(f2(b['c_spre'][k], Rta), f2(b['agg'][k], Rta), g['Ws'][k]) for k in range(2)])
+        ops.crit_reduce(ws.reduces)
+        ws.reduces = []
         # ---- the proposal side: cotangents of e_sel and v summed over the caption slots
         c_vpre, c_esel = ws.get('c_vpre', 2, B * T, C), ws.get('c_esel', 2, B * T, C)
         for k in range(2):
@@ -396,6 +415,9 @@ class CriticEngine(object):
         if second:
             Mg = ws.get('Mg', C, C)
             tn(ws, 'Mg', [(ws.get('gsc', B, L, C).view(B * L, C), ws.get('g', B, L, C).view(B * L, C), Mg)])
+        if ws.reduces:
+            ops.crit_reduce(ws.reduces)
+        if second:
             ops.gemm(GEMM_NN, [(Mg, p['Wvoc'], g['Wvoc'])], alpha=2.0, flags=F_ACCUM)
             ops.crit_vocab_scatter(dhr, ids, g['Wvoc'])
         # ---- biases and the fused kernels' per-caption partials: ONE launch of column sums (a descriptor: sources, out, copy, scale)
@@ -420,7 +442,7 @@ class CriticEngine(object):
         for k in range(2):
             cs.append(([pw[k, :npr]] + ([pw2[k]] if second else []), g['wc'][k].view(-1), None, 1.0))
             cs.append(([dbc[k:k + 1].view(1, 1)] + ([dbc2[k:k + 1].view(1, 1)] if second else []), g['bcl'][k].view(-1), None, 1.0))
-        ops.crit_colsum(cs)
+        self._colsums(ws, cs)
 
     # ------------------------------------------------------------------ one critic update (run_gun.py:343-381)
     @torch.no_grad()

@@ -147,6 +147,10 @@ class CritScoreArgs(C.Structure):
                 ('n', i32), ('B', i32), ('T', i32), ('ng', i32), ('acc_lo', i32), ('acc_hi', i32)]
 
 
+class CritReduceDesc(C.Structure):
+    _fields_ = [('src', c_f32p), ('stride', i64), ('n', i64), ('nslab', i32), ('scale', f32), ('out', c_f32p)]
+
+
 class CritColsumDesc(C.Structure):
     _fields_ = [('part', c_f32p), ('ld', i64), ('rows', i32), ('n', i32), ('part_b', c_f32p), ('ld_b', i64), ('rows_b', i32), ('pad_', i32),
                 ('out', c_f32p), ('out_b', c_f32p), ('scale', f32), ('pad2_', f32)]
@@ -231,7 +235,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_cln_ws_floats', 'dlsg_cln_fwd', 'dlsg_cln_bwd', 'dlsg_cln_bwd2', 'dlsg_crit_sa_fwd', 'dlsg_crit_sa_bwd', 'dlsg_crit_sa_bwd2',
            'dlsg_crit_pattn_fwd', 'dlsg_crit_pattn_bwd', 'dlsg_crit_pattn_bwd2', 'dlsg_crit_tsum_fwd', 'dlsg_crit_tsum_bwd',
            'dlsg_crit_tsum_bwd2', 'dlsg_crit_score_fwd', 'dlsg_crit_score_bwd', 'dlsg_crit_score_bwd2', 'dlsg_crit_gp', 'dlsg_crit_topk',
-           'dlsg_crit_unselect', 'dlsg_crit_colsum',
+           'dlsg_crit_unselect', 'dlsg_crit_colsum', 'dlsg_crit_reduce',
            'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd', 'dlsg_bilstm_bwd_x_floats', 'dlsg_bilstm_bwd',
            'dlsg_lstm_seq_supported', 'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_lstm_seq',
            'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
@@ -325,6 +329,7 @@ def load_library(path=LIB_PATH):
         'dlsg_crit_topk': [vp, i64, i64, i32, vp, vp, i32, i32, i32, i32, vp],
         'dlsg_crit_unselect': [vp, vp, vp, i32, i32, i32, i32, vp],
         'dlsg_crit_colsum': [P(CritColsumDesc), i32, vp],
+        'dlsg_crit_reduce': [P(CritReduceDesc), i32, vp],
         'dlsg_comm_init': [P(vp), vp, i32, i32],
         'dlsg_comm_destroy': [vp],
         'dlsg_comm_info': [vp, P(i32), P(i32), P(i32)],
@@ -345,7 +350,7 @@ STRUCTS = [GemmArgs, RowLnArgs, RowLnBwdArgs, O2VArgs, DecAttArgs, DecAttBwdArgs
            DecTailArgs, DecMidBwdArgs, DecattCacheGradsArgs, O2VBwdArgs, LatentPslArgs,
            SaCoreArgs, BeamSelectArgs, GatherMultiArgs, SaCoreBwdArgs,
            LatentPslBwdArgs, BilstmArgs, BilstmBwdArgs, ColsumDesc, LstmSeqArgs, ClnArgs, CritSaArgs, CritPattnArgs, CritTsumArgs,
-           CritScoreArgs, CritColsumDesc]
+           CritScoreArgs, CritColsumDesc, CritReduceDesc]
 
 
 def _p(t):
@@ -1324,11 +1329,22 @@ class HipOps(object):
         self._check(self.lib.dlsg_crit_unselect(_p(src), _p(idx), _p(dst), src.shape[0], dst.shape[0], per, dst.shape[1], self._stream()),
                     'crit_unselect')
 
+    def crit_reduce(self, descs):
+        """descs: list of (slabs (S, ...) contiguous, out): out = sum over the S slabs, in slab order; one launch per 16"""
+        for lo in range(0, len(descs), 16):
+            chunk = descs[lo:lo + 16]
+            arr = (CritReduceDesc * len(chunk))()
+            for d, (slabs, out) in zip(arr, chunk):
+                _chkc(slabs); _chkc(out)
+                assert out.numel() * slabs.shape[0] == slabs.numel() and out.numel() % 4 == 0
+                d.src, d.stride, d.n, d.nslab, d.scale, d.out = _p(slabs), out.numel(), out.numel(), slabs.shape[0], 1.0, _p(out)
+            self._check(self.lib.dlsg_crit_reduce(arr, len(chunk), self._stream()), 'crit_reduce')
+
     def crit_colsum(self, descs):
         """descs: list of (sources, out, out_b, scale): out = scale * sum over the rows of the one or two 2-d sources (unit column
-        stride); out_b (or None) receives a copy.  One launch per 32 descriptors, fixed order of additions."""
-        for lo in range(0, len(descs), 32):
-            chunk = descs[lo:lo + 32]
+        stride); out_b (or None) receives a copy.  One launch per 48 descriptors, fixed order of additions."""
+        for lo in range(0, len(descs), 48):
+            chunk = descs[lo:lo + 48]
             arr = (CritColsumDesc * len(chunk))()
             for d, (srcs, out, out_b, scale) in zip(arr, chunk):
                 a = srcs[0]

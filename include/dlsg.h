@@ -563,9 +563,18 @@ int dlsg_crit_topk(const float* alpha, int64_t sa, int64_t lda, int na, const fl
                    void* stream);
 int dlsg_crit_unselect(const float* src, const int64_t* idx, float* dst, int rows_src, int rows_dst, int per, int n, void* stream);
 
-/* `count` <= 32 column sums in one launch: out[j] = scale * (sum_r part[r, j] + sum_r part_b[r, j]) (part_b optional), also written
+/* `count` <= DLSG_CRIT_REDUCE_MAX sums of slabs in one launch: out[i] = scale * sum_{k < nslab} src[k * stride + i], i < n (n, stride
+ * multiples of 4, 16-byte aligned): the K-split partial weight gradients of a critic update, folded in slab order. */
+#define DLSG_CRIT_REDUCE_MAX 16
+typedef struct {
+    const float* src; int64_t stride; int64_t n; int32_t nslab; float scale;
+    float* out;
+} dlsg_crit_reduce_desc;
+int dlsg_crit_reduce(const dlsg_crit_reduce_desc* d, int count, void* stream);
+
+/* `count` <= DLSG_CRIT_COLSUM_MAX column sums in one launch: out[j] = scale * (sum_r part[r, j] + sum_r part_b[r, j]) (part_b optional), also written
  * to out_b when set (bias_ih / bias_hh of an LSTM receive the same gradient).  Fixed order of additions.  n <= 2048. */
-#define DLSG_CRIT_COLSUM_MAX 32
+#define DLSG_CRIT_COLSUM_MAX 48
 typedef struct {
     const float* part; int64_t ld; int32_t rows, n;
     const float* part_b; int64_t ld_b; int32_t rows_b, pad_;

@@ -444,6 +444,10 @@ class CriticEmul(object):
             top = a[:, :, sl].sum(1).topk(T, dim=-1).indices                       # (B,T)
             idx[h].copy_((h * B + torch.arange(B).unsqueeze(1)) * P + top)
 
+    def crit_reduce(self, descs):
+        for slabs, out in descs:
+            out.copy_(slabs.sum(0).reshape(out.shape))
+
     def crit_colsum(self, descs):
         for srcs, out, out_b, scale in descs:
             r = srcs[0].sum(0)

@@ -290,3 +290,8 @@ def test_critic_update_on_the_gpu_matches_the_emulated_schedule(B, L, V, topk, P
     sg2, gg2, _ = run_update(Dg, data, 0xABCDEF)
     for k in gg:
         assert torch.equal(gg[k], gg2[k]), k
+
+
+def test_slab_reduce_multi():
+    a, b2 = rnd(8, 512, 1536, seed=1), rnd(4, 512, 37, seed=2)
+    both('crit_reduce', [[(a, torch.zeros(512, 1536)), (b2, torch.zeros(512, 37)), (rnd(2, 512, 512, seed=3), torch.zeros(512, 512))]], tol=1e-5)
