@@ -240,10 +240,11 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs p) { gemm_body<BM,
 template <int BM, int BN, bool AT, bool BT, int BK>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void gemm_kernel_w3(const KArgs p) { gemm_body<BM, BN, AT, BT, BK>(p); }
 
-// ------------------------------------------------------------------------------------------------ skinny GEMM (M <= 64)
-// The recurrent products of the path (BiLSTM / LSTMCell gates and their input gradients) have M = batch <= 64 rows:
-// every weight element is used once per launch, so they are weight-streaming and latency-bound, not MFMA-bound.
-// Block = 4 waves on one 64 x 32 output tile, walking K in 128-wide super-chunks:
+// ------------------------------------------------------------------------------------------------ skinny GEMM (M <= 128)
+// The recurrent products of the path (BiLSTM / LSTMCell gates and their input gradients) have M = batch rows: every weight
+// element is used once per launch, so they are weight-streaming and latency-bound, not MFMA-bound.
+// Block = 4 waves on one (32 MI) x 32 output tile (MI = 2: batches up to 64 rows; MI = 4: up to 128 -- the weight stream of a
+// launch is the same, twice the rows ride on it), walking K in 128-wide super-chunks:
 //   * the activation chunk (64 x 128) and, for k-contiguous weights (NT), the weight chunk (32 x 128) are staged through
 //     LDS with fully coalesced loads (32 lanes x 16 B = one 512-B row segment); a lane-per-row gather straight into MFMA
 //     fragments was measured first: 64 cache lines per load instruction, address-coalescer bound (34 us vs 20 us);
@@ -254,11 +255,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void
 constexpr int SK = 128;            // super-chunk depth
 constexpr int SLD = SK + 4;        // LDS row stride (floats): 16-B slot stride 33 = 1 mod 16
 
-template <bool BT>
+constexpr int skinny_lds_bytes(int MI) { return (32 * MI + 32) * SLD * 4; }      // 50,688 B (MI = 2) / 84,480 B (MI = 4)
+
+template <bool BT, int MI>
 __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds[(64 + 32) * SLD];     // 50,688 B; reused for the final reduction
+    extern __shared__ __attribute__((aligned(16))) float lds[];             // (32 MI + 32) x SLD floats; reused for the final reduction
     float* ldsA = lds;
-    float* ldsB = lds + 64 * SLD;
+    float* ldsB = lds + 32 * MI * SLD;
     if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
     const int z = blockIdx.y;
     const int gi = z % p.ngroups, bi = z / p.ngroups;
@@ -275,13 +278,13 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
     const bool vecB = ((reinterpret_cast<uintptr_t>(B) & 15) == 0) && ((grp.ldb & 3) == 0);
     const int col = n0 + r;
 
-    f32x16 acc[2];
+    f32x16 acc[MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
-    f32x4 ra[8], rb[4];          // staged operands of the next super-chunk
+    f32x4 ra[4 * MI], rb[4];     // staged operands of the next super-chunk
     float bdir[16];              // NN: this lane's 16 weight values of the next super-chunk
 
     auto ld4s = [&](const float* ptr, int nvalid) {      // guarded (edge) load
@@ -296,14 +299,14 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
         const bool fullk = k0 + SK <= K;                  // wave-uniform: branch-free loads on interior super-chunks
         if (fullk && vecA) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4 * MI; ++j) {
                 const int f = threadIdx.x + NT * j;
                 const int row = min(f >> 5, M - 1);       // rows >= M feed output rows that are never stored
                 ra[j] = *reinterpret_cast<const f32x4*>(A + (int64_t)row * grp.lda + k0 + 4 * (f & 31));
             }
         } else if (vecA && (K & 3) == 0 && K >= 4) {       // aligned tail: whole float4s, clamped address + select
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4 * MI; ++j) {
                 const int f = threadIdx.x + NT * j;
                 const int row = min(f >> 5, M - 1), k = k0 + 4 * (f & 31);
                 const f32x4 v = *reinterpret_cast<const f32x4*>(A + (int64_t)row * grp.lda + min(k, K - 4));
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4 * MI; ++j) {
                 const int f = threadIdx.x + NT * j;
                 const int row = f >> 5, k = k0 + 4 * (f & 31);
                 ra[j] = ld4s(A + (int64_t)row * grp.lda + k, row < M ? min(max(K - k, 0), 4) : 0);
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
     };
     auto store_super = [&]() {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4 * MI; ++j) {
             const int f = threadIdx.x + NT * j;
             *reinterpret_cast<f32x4*>(ldsA + (f >> 5) * SLD + 4 * (f & 31)) = ra[j];
         }
@@ -385,9 +388,9 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
         __syncthreads();
         if (sc + 1 < nsup) load_super((sc + 1) * SK);
         // fragments of this wave's 32-deep slice: lane half h owns k = 32w + 16h + s
-        float fa[2][16];
+        float fa[MI][16];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             const float* ap = ldsA + (r + 32 * mi) * SLD + 32 * w + 16 * h;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -404,18 +407,17 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
             }
         }
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s2], bcur[s2], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][s2], bcur[s2], acc[1], 0, 0, 0);
-        }
+        for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][s2], bcur[s2], acc[mi], 0, 0, 0);
         __syncthreads();
     }
     // ---- sum the 4 waves' partial tiles through LDS (staging buffers are free now); wave w finalises e in [4w, 4w+4)
-    float* red = lds;               // [4][2][16][64] floats = 32 KB
+    float* red = lds;               // [4][MI][16][64] floats = MI x 16 KB
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) red[((w * 2 + mi) * 16 + e) * 64 + lane] = acc[mi][e];
+        for (int e = 0; e < 16; ++e) red[((w * MI + mi) * 16 + e) * 64 + lane] = acc[mi][e];
     __syncthreads();
     const float* biasp = grp.bias ? grp.bias : p.bias;
     const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && biasp != nullptr;
@@ -423,7 +425,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
     if (col < N) {
         const float bv = use_bias ? biasp[col] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee) {
                 const int e = 4 * w + ee;
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
                 if (row >= M) continue;
                 float v = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) v += red[((ww * 2 + mi) * 16 + e) * 64 + lane];
+                for (int ww = 0; ww < 4; ++ww) v += red[((ww * MI + mi) * 16 + e) * 64 + lane];
                 v = p.alpha * v + bv;
                 float* cp = C + (int64_t)row * (grp.ldc ? grp.ldc : (int64_t)p.ldc) + col;
                 if (accum) v += *cp;
@@ -442,7 +444,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------ skinny GEMM, NT, generation 2
-// Same decomposition as skinny_kernel<false> (64 x 32 output tile per workgroup, the 4 waves split K, K-split groups from the
+// Same decomposition as skinny_kernel<false> ((32 MI) x 32 output tile per workgroup, the 4 waves split K, K-split groups from the
 // caller), different pipeline: the first kernel staged global -> registers -> LDS with two barriers per 128-deep super-chunk
 // and one chunk of prefetch; at two workgroups per CU that left the matrix pipe ~40 % busy on the recurrent products
 // (23 us per launch against a ~11 us pipe floor).  Here every wave streams ITS OWN k-slices and nobody else's:
@@ -464,9 +466,9 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
 // same time, then all in their MFMA phase, and the per-tile 4-way partial sums add barriers that one wave per SIMD cannot hide.
 constexpr int S2_STAGE = 16;                 // k per wave and stage
 constexpr int S2_DEPTH = 3;                  // ring slots per wave
-constexpr int S2_A_BYTES = 64 * 64, S2_B_BYTES = 32 * 64, S2_SLOT = S2_A_BYTES + S2_B_BYTES;     // 6144
-constexpr int S2_LDS = 4 * S2_DEPTH * S2_SLOT;                                                    // 73,728 B (NJ = 1)
-constexpr int S2_LDS2 = 4 * S2_DEPTH * (S2_A_BYTES + 2 * S2_B_BYTES);                             // 98,304 B (NJ = 2)
+constexpr int S2_B_BYTES = 32 * 64;          // one 32-row block of a stage (A or B): 32 rows x 64 B
+constexpr int s2_lds_bytes(int MI, int NJ) { return 4 * S2_DEPTH * (MI + NJ) * S2_B_BYTES; }
+// MI = 2: 73,728 B (NJ = 1) / 98,304 B (NJ = 2);  MI = 4 (batches of 65..128 rows): 122,880 B / 147,456 B
 
 template <int VB>
 __device__ __forceinline__ void s2_glds(const char* src, char* dst) {
@@ -485,8 +487,9 @@ __device__ __forceinline__ void s2_glds(const char* src, char* dst) {
 // contiguous k range, so that its consecutive stages are the two halves of the same 128-B lines: 22.3 / 28.9 / 16.4; nor did
 // issuing the next stage's pieces one by one between the MFMA groups instead of together: 22.0 / 29.6 / 17.4.  The launch is
 // as long as its bytes take through the CUs' load paths, whatever the schedule around them.)
-template <int NJ>
+template <int MI, int NJ>
 __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
+    constexpr int S2_A_BYTES = MI * S2_B_BYTES;
     constexpr int SLOT = S2_A_BYTES + NJ * S2_B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char s2_lds[];
     if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
@@ -505,10 +508,10 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
 
     // ---- per-lane source rows of the pieces of a stage (row and swizzle never change; only k0 does)
     const int rho = lane >> 2, sig = lane & 3;
-    const float* srcA[4];
+    const float* srcA[2 * MI];
     const float* srcB[2 * NJ];
 #pragma unroll
-    for (int pc = 0; pc < 4; ++pc) {
+    for (int pc = 0; pc < 2 * MI; ++pc) {
         const int R = 16 * pc + rho;
         srcA[pc] = A + (int64_t)min(R, M - 1) * grp.lda + 4 * (sig ^ ((R >> 2) & 3));
     }
@@ -525,27 +528,27 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
         // a partial last stage is fetched from K - 16 (every 16-B read stays inside the row) and masked after the read
         const int koff = (k0 + S2_STAGE <= K) ? k0 : (K - S2_STAGE);
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) s2_glds<16>(reinterpret_cast<const char*>(srcA[pc] + koff), slot + pc * 1024);
+        for (int pc = 0; pc < 2 * MI; ++pc) s2_glds<16>(reinterpret_cast<const char*>(srcA[pc] + koff), slot + pc * 1024);
 #pragma unroll
         for (int pc = 0; pc < 2 * NJ; ++pc)
             s2_glds<16>(reinterpret_cast<const char*>(srcB[pc] + koff), slot + S2_A_BYTES + pc * 1024);
     };
 
-    f32x16 acc[2][NJ];
+    f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][nj][e] = 0.f;
 
     // fragment addresses inside a slot (bytes): row R, k-segment ks -> (R >> 4) * 1024 + (R & 15) * 64 + (ks ^ ((R >> 2) & 3)) * 16
-    int offA[2][2], offB[NJ][2];
+    int offA[MI][2], offB[NJ][2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int ks = 2 * q + h;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             const int R = 32 * mi + r;
             offA[mi][q] = (R >> 4) * 1024 + (R & 15) * 64 + ((ks ^ ((R >> 2) & 3)) * 16);
         }
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
             offB[nj][q] = S2_A_BYTES + (R >> 4) * 1024 + (R & 15) * 64 + ((ks ^ ((R >> 2) & 3)) * 16);
         }
     }
-    constexpr int PCS = 4 + 2 * NJ;                              // DMA pieces per stage
+    constexpr int PCS = 2 * MI + 2 * NJ;                         // DMA pieces per stage
 
     if (mine > 0) issue(0);
     if (mine > 1) issue(1);
@@ -572,11 +575,11 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
         const int k0 = (4 * i + w) * S2_STAGE;
         const bool part = k0 + S2_STAGE > K;                     // wave-uniform
         const int kbase = part ? K - S2_STAGE : k0;              // where the DMA really read
-        f32x4 fa[2][2], fb[NJ][2];
+        f32x4 fa[MI][2], fb[NJ][2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            fa[0][q] = *reinterpret_cast<const f32x4*>(slot + offA[0][q]);
-            fa[1][q] = *reinterpret_cast<const f32x4*>(slot + offA[1][q]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa[mi][q] = *reinterpret_cast<const f32x4*>(slot + offA[mi][q]);
 #pragma unroll
             for (int nj = 0; nj < NJ; ++nj) fb[nj][q] = *reinterpret_cast<const f32x4*>(slot + offB[nj][q]);
         }
@@ -588,8 +591,8 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
                 for (int j = 0; j < 4; ++j) {
                     const int k = kbase + 4 * (2 * q + h) + j;
                     const bool keep = k >= k0 && k < K;
-                    fa[0][q][j] = keep ? fa[0][q][j] : 0.f;
-                    fa[1][q][j] = keep ? fa[1][q][j] : 0.f;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) fa[mi][q][j] = keep ? fa[mi][q][j] : 0.f;
 #pragma unroll
                     for (int nj = 0; nj < NJ; ++nj) fb[nj][q][j] = keep ? fb[nj][q][j] : 0.f;
                 }
@@ -599,20 +602,20 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int nj = 0; nj < NJ; ++nj) {
-                    acc[0][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][q][j], fb[nj][q][j], acc[0][nj], 0, 0, 0);
-                    acc[1][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[1][q][j], fb[nj][q][j], acc[1][nj], 0, 0, 0);
-                }
+                for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][q][j], fb[nj][q][j], acc[mi][nj], 0, 0, 0);
     }
     // ---- sum the 4 waves' partial tiles through LDS (the rings are free now); wave w finalises e in [4w, 4w+4)
     __syncthreads();
-    float* red = reinterpret_cast<float*>(s2_lds);               // [4][2][NJ][16][64] floats = NJ x 32 KB
+    float* red = reinterpret_cast<float*>(s2_lds);               // [4][MI][NJ][16][64] floats = MI x NJ x 16 KB
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) red[(((w * 2 + mi) * NJ + nj) * 16 + e) * 64 + lane] = acc[mi][nj][e];
+            for (int e = 0; e < 16; ++e) red[(((w * MI + mi) * NJ + nj) * 16 + e) * 64 + lane] = acc[mi][nj][e];
     __syncthreads();
     const float* biasp = grp.bias ? grp.bias : p.bias;
     const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && biasp != nullptr;
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
         if (col >= N) continue;
         const float bv = use_bias ? biasp[col] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int ee = 0; ee < 4; ++ee) {
                 const int e = 4 * w + ee;
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
                 if (row >= M) continue;
                 float v = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < 4; ++ww) v += red[(((ww * 2 + mi) * NJ + nj) * 16 + e) * 64 + lane];
+                for (int ww = 0; ww < 4; ++ww) v += red[(((ww * MI + mi) * NJ + nj) * 16 + e) * 64 + lane];
                 v = p.alpha * v + bv;
                 float* cp = C + (int64_t)row * (grp.ldc ? grp.ldc : (int64_t)p.ldc) + col;
                 if (accum) v += *cp;
@@ -641,149 +644,45 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ skinny GEMM, NT, generation 3
-// Register-direct: no LDS staging at all.  With both operands k-contiguous (x W^T) a lane's MFMA fragment of four consecutive k
-// IS 16 contiguous bytes in memory: lane (r, kg) of a v_mfma_f32_16x16x4_f32 loads A[row 16 i + r][k0 + 4 kg .. + 3] for the four
-// 16-row blocks i and B[col 16 cb + r][k0 + 4 kg .. + 3] for the two 16-column blocks with one `global_load_dwordx4` each -- six
-// loads feed 32 MFMAs.  A wave keeps up to 48 such loads (48 KB per wave, 192 KB per CU at two workgroups) in flight, double
-// buffered by 4-block chunks, against 18 KB per wave in the LDS-DMA ring of generation 2; the persistent BiLSTM kernel
-// (bilstm.hip) showed the same structure streaming 256 KB per CU under 7.8 us of MFMAs.  The four waves split K, their partials
-// are summed through 24 KB of LDS (wave w ends with row block w).  256 registers per wave -> two workgroups per CU, so one
-// workgroup's load prologue sits under the other's MFMA phase.
-// MEASURED AND NOT USED (tools/recurrent_gemm_bench.py; env DLSG_SKINNY_GEN3=1 selects it): query gates 28.1 us against 22.3 for
-// generation 2, language gates 39.0 against 28.1, BiLSTM step 23.5 against 17.2.  A timing probe with the same bytes addressed as
-// fully coalesced runs (DLSG_SKINNY_GEN3=2: activations as if k-quad-major, weights as if packed in fragment order) changes nothing
-// (32.1 / 42.9 / 24.2): neither the staging mechanism nor the 64-byte row segments bound these launches -- the 196 MB a 64 x 32
-// tiling moves from L2 into the CUs per language-gate launch (two thirds of it re-fetched activations) do, at the ~7-10 TB/s the
-// chip sustains on that path; the LDS-DMA ring simply costs fewer issue slots for the same bytes.
-constexpr int S3_CH = 4;                     // 16-deep blocks per chunk (two chunks in flight)
-
-// Loads are unconditional (clamped addresses, the value zeroed afterwards): a load under a branch or an exec mask makes the
-// compiler's wait insertion give up counting and emit vmcnt(0), which would drain the chunk that was just issued.
-__device__ __forceinline__ void s3_load(f32x4 (&a)[S3_CH][4], f32x4 (&b)[S3_CH][2], const float* A, const float* B, int64_t lda,
-                                        int64_t ldb, int M, int Ncols, int K, int n0, int blk0, int nblk, int r, int kg) {
-#pragma unroll
-    for (int j = 0; j < S3_CH; ++j) {
-        const int k = 16 * (blk0 + j) + 4 * kg;
-        const int kc = min(k, K - 4);
-        if (lda < 0) {
-            // TIMING PROBE ONLY (DLSG_SKINNY_GEN3=2, wrong values): the same bytes addressed as if the activations were stored
-            // k-quad-major [k/4][64 rows][4] and the weights packed in fragment order [col block][k block][kg][col][4] -- every
-            // load instruction then reads four 256-byte runs (A) or one 1-KB run (B) instead of 64 scattered 64-byte segments
-            const int blk = min(blk0 + j, (K - 4) / 16);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[j][i] = *reinterpret_cast<const f32x4*>(A + ((int64_t)(kc / 4) * 64 + 16 * i + r) * 4);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                b[j][cb] = *reinterpret_cast<const f32x4*>(B + (((int64_t)(min(n0, Ncols - 32) / 16 + cb) * (K / 16) + blk) * 64 + kg * 16 + r) * 4);
-            continue;
+template <int MI>
+int launch_skinny_mi(const dlsg_gemm_args* a, const KArgs& k, hipStream_t st) {
+    dim3 grid((a->N + 31) / 32, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<MI, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  s2_lds_bytes(MI, 1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<MI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  s2_lds_bytes(MI, 2));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<false, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  skinny_lds_bytes(MI));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<true, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  skinny_lds_bytes(MI));
+    });
+    if (a->mode == 0) {
+        // generation 2 (LDS-DMA rings, no barrier in the K loop) when every operand is 16-B aligned with 4-float strides
+        bool ok = a->nbatch == 1;
+        for (int i = 0; i < a->ngroups && ok; ++i) {
+            const dlsg_gemm_group& g = a->g[i];
+            ok = (g.K % 4 == 0) && g.K >= S2_STAGE && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
+                 ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = min(16 * i + r, M - 1);
-            a[j][i] = *reinterpret_cast<const f32x4*>(A + (int64_t)row * lda + kc);
+        if (ok) {
+            // 64-column workgroups (one per CU) when they still put >= ~one workgroup on every CU
+            const int wg64 = ((a->N + 63) / 64) * a->ngroups * a->nbatch;
+            if (wg64 >= 224) {
+                dim3 grid2((a->N + 63) / 64, a->ngroups * a->nbatch, 1);
+                hipLaunchKernelGGL((skinny2_nt_kernel<MI, 2>), grid2, block, s2_lds_bytes(MI, 2), st, k);
+            } else {
+                hipLaunchKernelGGL((skinny2_nt_kernel<MI, 1>), grid, block, s2_lds_bytes(MI, 1), st, k);
+            }
+        } else {
+            hipLaunchKernelGGL((skinny_kernel<false, MI>), grid, block, skinny_lds_bytes(MI), st, k);
         }
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int col = min(n0 + 16 * cb + r, Ncols - 1);
-            b[j][cb] = *reinterpret_cast<const f32x4*>(B + (int64_t)col * ldb + kc);
-        }
+    } else {
+        hipLaunchKernelGGL((skinny_kernel<true, MI>), grid, block, skinny_lds_bytes(MI), st, k);
     }
-}
-// zero what lies beyond the contraction (rows / columns beyond M / N only produce outputs that are never stored)
-__device__ __forceinline__ void s3_mask(f32x4 (&a)[S3_CH][4], int K, int blk0, int nblk, int kg) {
-#pragma unroll
-    for (int j = 0; j < S3_CH; ++j) {
-        const bool kin = (blk0 + j) < nblk && 16 * (blk0 + j) + 4 * kg < K;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[j][i] = kin ? a[j][i] : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-}
-
-__global__ __launch_bounds__(NT, 2) void skinny3_nt_kernel(const KArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 3 * 8 * 64];
-    if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
-    const int z = blockIdx.y;
-    const int gi = z % p.ngroups, bi = z / p.ngroups;
-    const dlsg_gemm_group grp = p.g[gi];
-    const float* A = grp.A + (int64_t)bi * p.bsa;
-    const float* B = grp.B + (int64_t)bi * p.bsb;
-    float* C = grp.C + (int64_t)bi * p.bsc;
-    const int K = grp.K, M = p.M, N = grp.N > 0 ? grp.N : p.N;
-    const int n0 = blockIdx.x * 32;
-    if (n0 >= N) return;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 15, kg = lane >> 4;
-    // this wave's 16-deep blocks of the contraction
-    const int nb = (K + 15) / 16, nbw = (nb + 3) / 4;
-    const int b_lo = w * nbw, b_hi = min(nb, b_lo + nbw);
-
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
-    f32x4 a0[S3_CH][4], b0[S3_CH][2], a1[S3_CH][4], b1[S3_CH][2];
-    auto mma = [&](const f32x4 (&a)[S3_CH][4], const f32x4 (&b)[S3_CH][2]) {
-#pragma unroll
-        for (int j = 0; j < S3_CH; ++j)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i][s], b[j][0][s], acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i][s], b[j][1][s], acc[i][1], 0, 0, 0);
-                }
-    };
-    s3_load(a0, b0, A, B, grp.lda, grp.ldb, M, N, K, n0, b_lo, b_hi, r, kg);
-    for (int blk = b_lo; blk < b_hi; blk += 2 * S3_CH) {
-        s3_load(a1, b1, A, B, grp.lda, grp.ldb, M, N, K, n0, blk + S3_CH, b_hi, r, kg);
-        __builtin_amdgcn_sched_barrier(0);
-        s3_mask(a0, K, blk, b_hi, kg);
-        mma(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        s3_load(a0, b0, A, B, grp.lda, grp.ldb, M, N, K, n0, blk + 2 * S3_CH, b_hi, r, kg);
-        __builtin_amdgcn_sched_barrier(0);
-        s3_mask(a1, K, blk + S3_CH, b_hi, kg);
-        mma(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- the four K-partials: wave `dst` ends with row block `dst` (rows 16 dst + 4 q + reg of the C layout)
-#pragma unroll
-    for (int dst = 0; dst < 4; ++dst)
-        if (dst != w) {
-            float* q = red + ((dst * 3 + (w - (w > dst))) * 8) * 64 + lane;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { q[e * 64] = acc[dst][0][e]; q[(4 + e) * 64] = acc[dst][1][e]; }
-        }
-    __syncthreads();
-    f32x4 own[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i == w) { own[0] = acc[i][0]; own[1] = acc[i][1]; }
-#pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-        const float* q = red + ((w * 3 + s3) * 8) * 64 + lane;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { own[0][e] += q[e * 64]; own[1][e] += q[(4 + e) * 64]; }
-    }
-    const bool accum = p.flags & DLSG_GEMM_ACCUM, do_tanh = p.flags & DLSG_GEMM_TANH;
-    const float* bias = (p.flags & DLSG_GEMM_BIAS) ? (grp.bias ? grp.bias : p.bias) : nullptr;
-    const int64_t ldc = grp.ldc ? grp.ldc : (int64_t)p.ldc;
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int col = n0 + 16 * cb + r;
-        if (col >= N) continue;
-        const float bv = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = 16 * w + 4 * kg + e;
-            if (row >= M) continue;
-            float v = p.alpha * own[cb][e] + bv;
-            float* cp = C + (int64_t)row * ldc + col;
-            if (accum) v += *cp;
-            if (do_tanh) v = tanhf(v);
-            *cp = v;
-        }
-    }
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
 }
 
 int launch_skinny(const dlsg_gemm_args* a, hipStream_t st) {
@@ -791,47 +690,7 @@ int launch_skinny(const dlsg_gemm_args* a, hipStream_t st) {
     k.M = a->M; k.N = a->N; k.ldc = a->ldc; k.ngroups = a->ngroups; k.flags = a->flags;
     k.bsa = a->bsa; k.bsb = a->bsb; k.bsc = a->bsc; k.alpha = a->alpha; k.bias = a->bias; k.skip_if = a->skip_if;
     for (int i = 0; i < a->ngroups; ++i) k.g[i] = a->g[i];
-    dim3 grid((a->N + 31) / 32, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
-    if (a->mode == 0) {
-        // generation 2 (LDS-DMA rings, no barrier in the K loop) when every operand is 16-B aligned with 4-float strides
-        static const bool gen1 = getenv("DLSG_SKINNY_GEN1") != nullptr;        // A/B switch for tools/skinny_nt_nn_probe.py
-        bool ok = !gen1 && a->nbatch == 1;
-        for (int i = 0; i < a->ngroups && ok; ++i) {
-            const dlsg_gemm_group& g = a->g[i];
-            ok = (g.K % 4 == 0) && g.K >= S2_STAGE && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
-                 ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
-        }
-        static const int gen3 = getenv("DLSG_SKINNY_GEN3") ? atoi(getenv("DLSG_SKINNY_GEN3")) : 0;   // A/B switch: the register-direct kernel
-        if (ok && gen3) {
-            if (gen3 == 2)                       // timing probe of a coalesced operand layout (values are wrong): see s3_load
-                for (int i = 0; i < a->ngroups; ++i) k.g[i].lda = -1;
-            hipLaunchKernelGGL(skinny3_nt_kernel, grid, block, 0, st, k);
-        } else if (ok) {
-            static std::once_flag once;
-            std::call_once(once, [] {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<1>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS2);
-            });
-            // 64-column workgroups (one per CU, 96 KB of LDS) when they still put >= ~one workgroup on every CU
-            static const int force_nj = getenv("DLSG_SKINNY_NJ") ? atoi(getenv("DLSG_SKINNY_NJ")) : 0;
-            const int wg64 = ((a->N + 63) / 64) * a->ngroups * a->nbatch;
-            const bool wide = force_nj ? force_nj == 2 : wg64 >= 224;
-            if (wide) {
-                dim3 grid2((a->N + 63) / 64, a->ngroups * a->nbatch, 1);
-                hipLaunchKernelGGL(skinny2_nt_kernel<2>, grid2, block, S2_LDS2, st, k);
-            } else {
-                hipLaunchKernelGGL(skinny2_nt_kernel<1>, grid, block, S2_LDS, st, k);
-            }
-        } else {
-            hipLaunchKernelGGL((skinny_kernel<false>), grid, block, 0, st, k);
-        }
-    } else {
-        hipLaunchKernelGGL((skinny_kernel<true>), grid, block, 0, st, k);
-    }
-    DLSG_CHECK_LAUNCH();
-    return DLSG_OK;
+    return a->M <= 64 ? launch_skinny_mi<2>(a, k, st) : launch_skinny_mi<4>(a, k, st);
 }
 
 template <int BM, int BN, int BK>
@@ -897,8 +756,8 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
         return launch<128, 64, 64>(a, st);        // both bits: the 128 x 64 tile
     if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64, 64>(a, st);
     if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128, 32>(a, st);
-    // M <= 64, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernel
-    if (a->M <= 64 && a->mode != 2 && a->N >= 64) return launch_skinny(a, st);
+    // M <= 128, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernels (64- or 128-row tiles)
+    if (a->M <= 128 && a->mode != 2 && a->N >= 64) return launch_skinny(a, st);
     // measured on MI355X (tools/gemm_bench.py): the 128x128 tile only wins once it fills the chip several times over
     // (Wave quantisation is not what these launches lose: giving the 128-tile kernel whole 768-slot rounds only and the remaining
     // row panels to the 64-tile kernel was measured 1-3 % SLOWER on the region projection (4.33 rounds) and on the deep weight

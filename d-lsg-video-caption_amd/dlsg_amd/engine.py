@@ -49,16 +49,20 @@ def _ksplit_bounds(K, nsplit, align=32):
     return out
 
 
+SKINNY_M = 128          # batch rows the weight-streaming (skinny) GEMM kernels take: 64- or 128-row tiles (csrc/gemm.hip)
+
+
 def _bwd_bounds(K, M, nsplit):
-    """K-split of an input-gradient product dy (M, K) @ W (K, N).  For the skinny kernel (M <= 64) 1024-deep chunks measured
+    """K-split of an input-gradient product dy (M, K) @ W (K, N).  For the skinny kernels (M <= 128) 1024-deep chunks measured
     best on the batch-64 step (4 x 1024 for K = 4096: +0.6 % step throughput over 6 x 768 / 8 x 512; 5 x 896 is 2.7 % worse)."""
-    if M <= 64 and K >= 2048:
+    if M <= SKINNY_M and K >= 2048:
         return [(k, min(K, k + 1024)) for k in range(0, K, 1024)]
-    return _ksplit_bounds(K, nsplit, 128 if M <= 64 else 32)
+    return _ksplit_bounds(K, nsplit, 128 if M <= SKINNY_M else 32)
 
 
 def _nsplit_for(M, N, nseg, target=384, cap=16):
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    # (a skinny launch has ONE row tile whatever the batch: its workgroups are column tiles x groups)
+    tiles = (1 if M <= SKINNY_M else (M + 63) // 64) * ((N + 63) // 64)
     n = max(1, target // max(1, tiles * nseg))
     return max(1, min(n, cap // max(1, nseg)))
 
@@ -66,11 +70,11 @@ def _nsplit_for(M, N, nseg, target=384, cap=16):
 def seg_gemm_nt(ops, segs, M, N, ref):
     """sum_i  x_i @ W_i^T  as ONE grouped launch writing K-split slabs.  segs: list of (x (M,K_i), W (N,K_i)).
     Returns slabs (S, M, N); the consumer kernel (lstm_pw / slab_reduce) sums them."""
-    # M <= 64 (skinny kernel): one group per input segment -- whole 1024-deep segments measured better than 512-deep halves
-    ns = 1 if M <= 64 else _nsplit_for(M, N, len(segs))
+    # M <= 128 (skinny kernels): one group per input segment -- whole 1024-deep segments measured better than 512-deep halves
+    ns = 1 if M <= SKINNY_M else _nsplit_for(M, N, len(segs))
     groups = []
     for x, W in segs:
-        for k0, k1 in _ksplit_bounds(x.shape[1], ns, 128 if M <= 64 else 32):
+        for k0, k1 in _ksplit_bounds(x.shape[1], ns, 128 if M <= SKINNY_M else 32):
             groups.append((x[:, k0:k1], W[:, k0:k1]))
     slabs = _empty(ref, len(groups), M, N)
     ops.gemm(GEMM_NT, [(a, b, slabs[i]) for i, (a, b) in enumerate(groups)])
@@ -82,7 +86,7 @@ def gemm_nn_split(ops, dy, W, out, ref, accum=False):
     M, Nn = dy.shape
     Kin = W.shape[1]
     ns = _nsplit_for(M, Kin, 1)
-    bounds = _ksplit_bounds(Nn, ns, 128 if M <= 64 else 32)
+    bounds = _ksplit_bounds(Nn, ns, 128 if M <= SKINNY_M else 32)
     if len(bounds) == 1:
         ops.gemm(GEMM_NN, [(dy, W, out)], flags=F_ACCUM if accum else 0)
         return
@@ -546,7 +550,7 @@ BILSTM_ROWS = 64        # batch rows of one persistent BiLSTM launch (csrc/bilst
 def _bilstm_steps_fwd(ops, xg, Whh, bih, bhh, out, hprev, cst, gates, B, T, H, ref):
     """the BiLSTM recurrence step by step: per step one grouped K-split skinny GEMM (both directions) + one pointwise launch"""
     ns = _nsplit_for(B, 4 * H, 2)
-    bounds = _ksplit_bounds(H, ns, 128 if B <= 64 else 32)
+    bounds = _ksplit_bounds(H, ns, 128 if B <= SKINNY_M else 32)
     for step in range(T):
         tt = [step, T - 1 - step]
         tp = [step - 1, T - step]                                # previous time index per direction

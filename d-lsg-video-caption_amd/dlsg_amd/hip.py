@@ -485,8 +485,8 @@ class HipOps(object):
             # same dispatch rule as dlsg_gemm (csrc/gemm.hip, csrc/gemm_bf16x3.hip)
             x3 = bool(a.flags & F_BF16X3)
             tiles_l = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups)
-            if M <= 64 and mode != GEMM_TN and N >= 64:
-                variant = 'skinny_64x32'
+            if M <= 128 and mode != GEMM_TN and N >= 64:
+                variant = 'skinny_64x32' if M <= 64 else 'skinny_128x32'
             elif tiles_l >= 1000:
                 variant = '128x128'
             elif not x3 and ((M + 127) // 128 * 128 - M) * 10 <= M and tiles_l >= 200:

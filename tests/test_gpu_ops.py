@@ -191,7 +191,8 @@ def test_gemm_strided_views_flags_groups(hip):
 
 @pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN])
 @pytest.mark.parametrize('x3', [0, F_BF16X3])
-@pytest.mark.parametrize('shape', [(64, 4096, 2348), (37, 100, 77), (64, 96, 1024), (5, 3072, 333), (64, 1024, 4096)])
+@pytest.mark.parametrize('shape', [(64, 4096, 2348), (37, 100, 77), (64, 96, 1024), (5, 3072, 333), (64, 1024, 4096),
+                                   (128, 4096, 2348), (100, 96, 1024), (65, 3072, 333), (128, 1024, 4096), (97, 100, 77)])
 def test_gemm_skinny(hip, mode, shape, x3):
     M, N, K = shape
 
