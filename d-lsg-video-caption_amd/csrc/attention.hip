@@ -1,8 +1,7 @@
-// Graph-attention kernels of the D-LSG hot path (gfx950):
-//   * o2v_partial / o2v_combine : fused object->frame conditional graph (reference models/layer.py:184-192).
-//     One pass over the projected objects: obj_norm LayerNorm in registers while staging, scores and the
-//     aggregation on the f32 matrix cores, online softmax over the object axis, flash-decoding style split
-//     over object chunks so that B clips fill 256 CUs.
+// Graph-attention entry points of the D-LSG hot path (gfx950):
+//   * dlsg_o2v_* : the fused object->frame conditional graph (reference models/layer.py:184-192) -- the tile kernels live in
+//     o2v16.hip / o2v16_bwd.hip; here: argument checks, the flash-decoding style combine over object chunks (so that B clips
+//     fill 256 CUs) and the struct-size table of the ABI;
 //   * decatt fwd / bwd : the per-word attention over the cached, pre-projected proposals
 //     (reference models/sublayer.py:28-43 with K/V (and the Q / output projections) hoisted out of the word loop).
 #include <cstdlib>
@@ -15,228 +14,7 @@ using namespace dlsg;
 
 namespace {
 
-// ================================================================================================ o2v forward
-// Workgroup = 8 waves (512 threads), one (clip, object-chunk).  Tile = 32 objects x H in LDS.
-//   S-product  : wave w contracts its H/8 slice: D[obj][frame] += O[obj][k] * V[frame][k]; V lives in registers as
-//                ready-made B operands; partial S tiles are summed across the 8 waves through LDS.
-//   softmax    : every wave holds the full 32x32 S tile in the MFMA C layout (lane = frame, regs = objects) and
-//                updates the running max / sum redundantly (no broadcast needed).
-//   agg-product: D[frame][hcol] += P[obj][frame] * O[obj][hcol]; the P registers ARE the A operand (k order =
-//                C-layout row order), O comes from LDS with lanes on consecutive columns.
-constexpr int O2V_THREADS = 512;
-constexpr int O2V_TILE = 32;
-
-template <int H>
-struct O2VGeom {
-    static constexpr int LDO = H + 4;                 // LDS row stride (floats): 16-B slots advance by 1 per row
-    static constexpr int HS = H / 8;                  // k slice per wave in the S product
-    static constexpr int KH = HS / 2;                 // k values per lane half
-    static constexpr int EPL = H / 64;                // elements per lane when a wave holds one row
-    static constexpr int VEC = (EPL % 4 == 0) ? 4 : 1;
-    static constexpr int NCH = EPL / VEC;
-    static constexpr int NCB = H / 32;                // 32-column blocks of the aggregation output
-    static constexpr int CBW = (NCB + 7) / 8;         // column blocks per wave
-    static constexpr int LDS_FLOATS = O2V_TILE * LDO + 4 * 16 * 64 + 2 * H;   // tile + reduction scratch + obj_norm gamma | beta
-};
-
-__device__ __forceinline__ int crow(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
-
-template <int H>
-__global__ __launch_bounds__(O2V_THREADS) void o2v_partial_kernel(const dlsg_o2v_args a, int tiles_per_split) {
-    using G = O2VGeom<H>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* o_lds = smem;
-    float* red = smem + O2V_TILE * G::LDO;            // [4][16][64]
-    // obj_norm gamma / beta are read by every row of every tile: from LDS, not through 32 global loads per lane and tile
-    float* gam_l = red + 4 * 16 * 64;
-    float* bet_l = gam_l + H;
-    for (int j = threadIdx.x; j < H; j += O2V_THREADS) { gam_l[j] = a.g_obj[j]; bet_l[j] = a.b_obj[j]; }
-    __syncthreads();
-
-    const int b = blockIdx.x, sp = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int T = a.T, NO = a.NO;
-    const int n_begin = sp * tiles_per_split * O2V_TILE;
-    const int n_end = min(NO, n_begin + tiles_per_split * O2V_TILE);
-
-    // ---- V fragments (B operand of the S product): element s <-> k = w*HS + h*KH + s of frame r
-    float vreg[G::KH];
-    {
-        const float* vp = a.v + ((int64_t)b * T + r) * H + w * G::HS + h * G::KH;
-#pragma unroll
-        for (int s = 0; s < G::KH; ++s) vreg[s] = (r < T) ? vp[s] : 0.f;
-    }
-
-    f32x16 acc_o[G::CBW];
-#pragma unroll
-    for (int c = 0; c < G::CBW; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc_o[c][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // rows of the tile being staged (4 per wave): all four rows' loads are issued before the first reduction, so a tile
-    // costs one memory round trip.  (Issuing them one tile ahead, under the aggregation MFMAs, was measured: the 64
-    // extra live registers spill and it is slower, 1.76 vs 1.90 TB/s.)
-    float x[4][G::EPL];
-    auto issue_loads = [&](int n0) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int n = n0 + 4 * w + rr;
-            if (n < n_end) {
-                const float* yp = a.y + ((int64_t)b * NO + n) * H;
-#pragma unroll
-                for (int c = 0; c < G::NCH; ++c) {
-                    if (G::VEC == 4) {
-                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(yp + c * 256 + 4 * lane);
-                        x[rr][4 * c] = t4[0]; x[rr][4 * c + 1] = t4[1]; x[rr][4 * c + 2] = t4[2]; x[rr][4 * c + 3] = t4[3];
-                    } else {
-                        x[rr][c] = yp[c * 64 + lane];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < G::EPL; ++i) x[rr][i] = 0.f;
-            }
-        }
-    };
-    for (int n0 = n_begin; n0 < n_end; n0 += O2V_TILE) {
-        // ---- stage: global -> registers -> LayerNorm -> LDS
-        issue_loads(n0);
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = 4 * w + rr;
-            const int n = n0 + row;
-            const bool valid = n < n_end;
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < G::EPL; ++i) s += x[rr][i];
-            const float mean = wave_sum(s) / H;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < G::EPL; ++i) { const float d = x[rr][i] - mean; q += d * d; }
-            const float rstd = rsqrtf(wave_sum(q) / H + a.eps);
-            if (valid && a.ostats && lane == 0) {
-                a.ostats[2 * ((int64_t)b * NO + n)] = mean;
-                a.ostats[2 * ((int64_t)b * NO + n) + 1] = rstd;
-            }
-#pragma unroll
-            for (int c = 0; c < G::NCH; ++c) {
-                if (G::VEC == 4) {
-                    const int col = c * 256 + 4 * lane;
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gam_l + col);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bet_l + col);
-                    f32x4 o4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o4[i] = valid ? (x[rr][4 * c + i] - mean) * rstd * g4[i] + b4[i] : 0.f;
-                    *reinterpret_cast<f32x4*>(o_lds + row * G::LDO + col) = o4;
-                } else {
-                    const int col = c * 64 + lane;
-                    o_lds[row * G::LDO + col] = valid ? (x[rr][c] - mean) * rstd * gam_l[col] + bet_l[col] : 0.f;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- partial S over this wave's k slice
-        f32x16 sacc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-        {
-            const float* ap = o_lds + r * G::LDO + w * G::HS + h * G::KH;
-#pragma unroll
-            for (int s4 = 0; s4 < G::KH / 4; ++s4) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 4 * s4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], vreg[4 * s4 + i], sacc, 0, 0, 0);
-            }
-        }
-        // ---- sum the 8 partial tiles: 4..7 -> LDS, 0..3 add and republish, everyone sums 4 slots
-        if (w >= 4) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) red[((w - 4) * 16 + e) * 64 + lane] = sacc[e];
-        }
-        __syncthreads();
-        if (w < 4) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float t = sacc[e] + red[(w * 16 + e) * 64 + lane];
-                red[(w * 16 + e) * 64 + lane] = t;
-            }
-        }
-        __syncthreads();
-        float p[16];
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float sv = red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane] + red[(2 * 16 + e) * 64 + lane] +
-                       red[(3 * 16 + e) * 64 + lane];
-            sv *= a.scale;
-            const int n = n0 + crow(e, h);
-            const bool valid = n < n_end;
-            if (w == 0 && valid && r < T && a.S) a.S[((int64_t)b * NO + n) * T + r] = sv;
-            sv = valid ? sv : -INFINITY;
-            p[e] = sv;
-            tmax = fmaxf(tmax, sv);
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);      // m_run = -inf on the first tile -> 0
-        float psum = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            p[e] = __expf(p[e] - m_new);                // invalid rows: exp(-inf) = 0
-            psum += p[e];
-        }
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-
-        // ---- aggregation: acc_o[frame][hcol] = alpha_frame * acc_o + sum_n P[n][frame] * O[n][hcol]
-        {
-            float arow[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) arow[e] = __shfl(alpha, crow(e, h), 64);
-#pragma unroll
-            for (int c = 0; c < G::CBW; ++c)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc_o[c][e] *= arow[e];
-        }
-#pragma unroll
-        for (int c = 0; c < G::CBW; ++c) {
-            const int cb = w * G::CBW + c;
-            if (cb < G::NCB) {
-                const float* bp = o_lds + cb * 32 + r;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float bv = bp[crow(e, h) * G::LDO];
-                    acc_o[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[e], bv, acc_o[c], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();   // tile and `red` are free for the next iteration
-    }
-
-    // ---- partial results: ws[(b*nsplit+sp)] = { agg[T][H], m[32], l[32] }
-    float* wsp = a.ws + ((int64_t)b * a.nsplit + sp) * ((int64_t)T * H + 64);
-#pragma unroll
-    for (int c = 0; c < G::CBW; ++c) {
-        const int cb = w * G::CBW + c;
-        if (cb < G::NCB) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int t = crow(e, h);
-                if (t < T) wsp[(int64_t)t * H + cb * 32 + r] = acc_o[c][e];
-            }
-        }
-    }
-    if (w == 0 && h == 0 && r < T) {
-        wsp[(int64_t)T * H + r] = m_run;
-        wsp[(int64_t)T * H + 32 + r] = l_run;
-    }
-}
-
+// ================================================================================================ o2v: combine of the object chunks
 // z[b,t,:] = sum_s exp(m_s - M) agg_s[t,:] / L + v[b,t,:]
 __global__ __launch_bounds__(256) void o2v_combine_kernel(const dlsg_o2v_args a);
 __device__ __forceinline__ void o2v_combine_body(const dlsg_o2v_args& a) {
@@ -292,347 +70,7 @@ struct O2VCombinePack {
 __device__ __forceinline__ void o2v_combine_body(const dlsg_o2v_args& a);
 __global__ __launch_bounds__(256) void o2v_combine_multi_kernel(const O2VCombinePack pk) { o2v_combine_body(pk.s[blockIdx.z]); }
 
-template <int H>
-int o2v_launch(const dlsg_o2v_args* a, hipStream_t st) {
-    using G = O2VGeom<H>;
-    static std::once_flag once;
-    constexpr int lds_bytes = G::LDS_FLOATS * 4;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v_partial_kernel<H>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    });
-    const int tiles = (a->NO + O2V_TILE - 1) / O2V_TILE;
-    const int tps = (tiles + a->nsplit - 1) / a->nsplit;
-    hipLaunchKernelGGL((o2v_partial_kernel<H>), dim3(a->B, a->nsplit), dim3(O2V_THREADS), lds_bytes, st, *a, tps);
-    hipLaunchKernelGGL(o2v_combine_kernel, dim3(a->B, a->T), dim3(256), 0, st, *a);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? DLSG_OK : DLSG_ELAUNCH;
-}
 
-// ================================================================================================ o2v backward
-// Backward of the fused graph (z = softmax_n(scale * o v^T)^T o + v,  o = obj_norm(y)) in two passes over y instead of
-// the unfused chain (recompute o, softmax, 4 batched GEMMs, softmax backward, LayerNorm backward: ~10 launches and six
-// (B*NO x H) round trips per stream):
-//
-//   scores pass (o2v_bwd_scores_kernel, same tiling as the forward): dP = o dz^T on the matrix cores, then per object
-//     row n and frame t
-//        P  = exp(S - M_t) / L_t                       (S, M, L saved by the forward)
-//        dS = P * (dP - c_t),  c_t = sum_n P dP = (z_t - v_t) . dz_t      (no pass over the objects needed)
-//     and, because do = P dz + scale dS v is linear in dz and v, the two row means the LayerNorm backward needs follow
-//     from per-frame dot products without ever forming do:
-//        m1_n = mean_h(do * gamma)      = (sum_t P a_t + sum_t dS' b_t) / H,          a_t = dz_t . gamma, b_t = v_t . gamma
-//        m2_n = mean_h(do * gamma * xh) = (sum_t P (dP - e_t) + sum_t dS' (S/scale - f_t)) / H,  e_t = beta . dz_t, f_t = beta . v_t
-//     (dS' = scale * dS).  Output: pd (B, NO, 64) = [P (32 frame slots) | dS' (32 slots)] and m12 (B, NO, 2).
-//
-//   apply pass (o2v_bwd_apply_kernel, one workgroup per (clip, 64-column slice), all objects of the clip): do = pd . [dz ; v]
-//     (K = 64) on the matrix cores, LayerNorm + tanh backward as the epilogue (dy written once), dv += dS'^T o and the
-//     per-clip dgamma / dbeta partials accumulated in registers.  No cross-workgroup reduction anywhere.
-template <int H>
-__global__ __launch_bounds__(O2V_THREADS) void o2v_bwd_scores_kernel(const dlsg_o2v_bwd_args a, int tiles_per_split) {
-    using G = O2VGeom<H>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float fs[5][32];
-    float* o_lds = smem;
-    float* red = smem + O2V_TILE * G::LDO;            // [4][16][64]
-    float* gam_l = red + 4 * 16 * 64;
-    float* bet_l = gam_l + H;
-    for (int j = threadIdx.x; j < H; j += O2V_THREADS) { gam_l[j] = a.g_obj[j]; bet_l[j] = a.b_obj[j]; }
-    __syncthreads();
-
-    const int b = blockIdx.x, sp = blockIdx.y;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int T = a.T, NO = a.NO;
-    const int n_begin = sp * tiles_per_split * O2V_TILE;
-    const int n_end = min(NO, n_begin + tiles_per_split * O2V_TILE);
-
-    // ---- per-frame scalars c, a, b, e, f (wave w: frames w, w+8, ...)
-    for (int t = w; t < 32; t += 8) {
-        float c5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-        if (t < T) {
-            const float* dzp = a.dz + ((int64_t)b * T + t) * H;
-            const float* vp = a.v + ((int64_t)b * T + t) * H;
-            const float* zp = a.z + ((int64_t)b * T + t) * H;
-            for (int j = lane; j < H; j += 64) {
-                const float dzv = dzp[j], vv = vp[j], gg = a.g_obj[j], bb = a.b_obj[j];
-                c5[0] += (zp[j] - vv) * dzv; c5[1] += dzv * gg; c5[2] += vv * gg; c5[3] += bb * dzv; c5[4] += bb * vv;
-            }
-#pragma unroll
-            for (int i = 0; i < 5; ++i) c5[i] = wave_sum(c5[i]);
-        }
-        if (lane == 0)
-#pragma unroll
-            for (int i = 0; i < 5; ++i) fs[i][t] = c5[i];
-    }
-    // ---- dz fragments (B operand of the dP product): element s <-> k = w*HS + h*KH + s of frame r
-    float dzreg[G::KH];
-    {
-        const float* dp = a.dz + ((int64_t)b * T + r) * H + w * G::HS + h * G::KH;
-#pragma unroll
-        for (int s = 0; s < G::KH; ++s) dzreg[s] = (r < T) ? dp[s] : 0.f;
-    }
-    const float Mr = (r < T) ? a.ml[2 * ((int64_t)b * T + r)] : 0.f;
-    const float Lr = (r < T) ? a.ml[2 * ((int64_t)b * T + r) + 1] : 1.f;
-    const float inv_scale = 1.f / a.scale, inv_h = 1.f / H;
-    __syncthreads();
-    const float c_t = fs[0][r], a_t = fs[1][r], b_t = fs[2][r], e_t = fs[3][r], f_t = fs[4][r];
-
-    float x[4][G::EPL];
-    for (int n0 = n_begin; n0 < n_end; n0 += O2V_TILE) {
-        // ---- stage: y -> obj_norm with the saved statistics -> LDS
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int n = n0 + 4 * w + rr;
-            if (n < n_end) {
-                const float* yp = a.y + ((int64_t)b * NO + n) * H;
-#pragma unroll
-                for (int c = 0; c < G::NCH; ++c) {
-                    if (G::VEC == 4) {
-                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(yp + c * 256 + 4 * lane);
-                        x[rr][4 * c] = t4[0]; x[rr][4 * c + 1] = t4[1]; x[rr][4 * c + 2] = t4[2]; x[rr][4 * c + 3] = t4[3];
-                    } else {
-                        x[rr][c] = yp[c * 64 + lane];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < G::EPL; ++i) x[rr][i] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int row = 4 * w + rr;
-            const int n = n0 + row;
-            const bool valid = n < n_end;
-            const float mean = valid ? a.ostats[2 * ((int64_t)b * NO + n)] : 0.f;
-            const float rstd = valid ? a.ostats[2 * ((int64_t)b * NO + n) + 1] : 0.f;
-#pragma unroll
-            for (int c = 0; c < G::NCH; ++c) {
-                if (G::VEC == 4) {
-                    const int col = c * 256 + 4 * lane;
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gam_l + col);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bet_l + col);
-                    f32x4 o4;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o4[i] = valid ? (x[rr][4 * c + i] - mean) * rstd * g4[i] + b4[i] : 0.f;
-                    *reinterpret_cast<f32x4*>(o_lds + row * G::LDO + col) = o4;
-                } else {
-                    const int col = c * 64 + lane;
-                    o_lds[row * G::LDO + col] = valid ? (x[rr][c] - mean) * rstd * gam_l[col] + bet_l[col] : 0.f;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- partial dP over this wave's k slice, summed across the 8 waves through LDS (as the forward's S product)
-        f32x16 sacc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
-        {
-            const float* ap = o_lds + r * G::LDO + w * G::HS + h * G::KH;
-#pragma unroll
-            for (int s4 = 0; s4 < G::KH / 4; ++s4) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 4 * s4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], dzreg[4 * s4 + i], sacc, 0, 0, 0);
-            }
-        }
-        if (w >= 4) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) red[((w - 4) * 16 + e) * 64 + lane] = sacc[e];
-        }
-        __syncthreads();
-        if (w < 4) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float t = sacc[e] + red[(w * 16 + e) * 64 + lane];
-                red[(w * 16 + e) * 64 + lane] = t;
-            }
-        }
-        __syncthreads();
-        // ---- wave w finishes C-layout registers 2w, 2w+1: 4 object rows (2 per lane half) x 32 frames
-#pragma unroll
-        for (int ee = 0; ee < 2; ++ee) {
-            const int e = 2 * w + ee;
-            const float dp = red[(0 * 16 + e) * 64 + lane] + red[(1 * 16 + e) * 64 + lane] + red[(2 * 16 + e) * 64 + lane] +
-                             red[(3 * 16 + e) * 64 + lane];
-            const int n = n0 + crow(e, h);
-            const bool rowv = n < n_end;
-            const bool valid = rowv && r < T;
-            const float sval = valid ? a.S[((int64_t)b * NO + n) * T + r] : 0.f;
-            const float P = valid ? __expf(sval - Mr) / Lr : 0.f;
-            const float dSs = P * (dp - c_t) * a.scale;
-            float u1 = P * a_t + dSs * b_t;
-            float u2 = P * (dp - e_t) + dSs * (sval * inv_scale - f_t);
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) { u1 += __shfl_xor(u1, o, 64); u2 += __shfl_xor(u2, o, 64); }
-            if (rowv) {
-                float* pdp = a.pd + ((int64_t)b * NO + n) * 64;
-                pdp[r] = P;
-                pdp[32 + r] = dSs;
-                if (r == 0) {
-                    a.m12[2 * ((int64_t)b * NO + n)] = u1 * inv_h;
-                    a.m12[2 * ((int64_t)b * NO + n) + 1] = u2 * inv_h;
-                }
-            }
-        }
-        __syncthreads();   // tile and `red` are free for the next iteration
-    }
-}
-
-constexpr int AP_THREADS = 256;
-constexpr int AP_LD = 68;            // LDS row stride (floats) of the 64-wide tiles
-__global__ __launch_bounds__(AP_THREADS) void o2v_bwd_apply_kernel(const dlsg_o2v_bwd_args a) {
-    __shared__ __attribute__((aligned(16))) float yl[64 * AP_LD];     // y tile: 64 objects x 64 columns
-    __shared__ __attribute__((aligned(16))) float dzv[64 * AP_LD];    // rows 0..31: dz[t] slice, 32..63: v[t] slice
-    __shared__ __attribute__((aligned(16))) float pdl[64 * AP_LD];    // pd tile: 64 objects x [P | dS']
-    __shared__ float sm[64 * 4];                                      // mean, rstd, m1, m2 per object of the tile
-    __shared__ float xch[2][18][64];                                  // pair exchange between waves w and w^2
-    const int b = blockIdx.x, h0 = blockIdx.y * 64;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int T = a.T, NO = a.NO, H = a.H;
-    for (int f = threadIdx.x; f < 64 * 16; f += AP_THREADS) {
-        const int row = f >> 4, c4 = f & 15, t = row & 31;
-        const float* src = (row < 32 ? a.dz : a.v) + ((int64_t)b * T + t) * H + h0 + 4 * c4;
-        f32x4 val = {0.f, 0.f, 0.f, 0.f};
-        if (t < T) val = *reinterpret_cast<const f32x4*>(src);
-        *reinterpret_cast<f32x4*>(dzv + row * AP_LD + 4 * c4) = val;
-    }
-    const int mb = w >> 1, cb = w & 1;          // do product: 32-object block, 32-column block; dv product: object half = mb
-    const int col = h0 + cb * 32 + r;
-    const float gam = a.g_obj[col], bet = a.b_obj[col];
-    float gsum = 0.f, bsum = 0.f;
-    f32x16 accv;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) accv[e] = 0.f;
-
-    // next tile's y / pd rows travel in registers while the current tile is on the matrix cores
-    f32x4 yq[4], pq[4];
-    auto fetch = [&](int n0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = threadIdx.x + AP_THREADS * j;
-            const int row = f >> 4, c4 = f & 15, n = n0 + row;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            yq[j] = zero; pq[j] = zero;
-            if (n < NO) {
-                yq[j] = *reinterpret_cast<const f32x4*>(a.y + ((int64_t)b * NO + n) * H + h0 + 4 * c4);
-                pq[j] = *reinterpret_cast<const f32x4*>(a.pd + ((int64_t)b * NO + n) * 64 + 4 * c4);
-            }
-        }
-    };
-    float st4[4] = {0.f, 0.f, 0.f, 0.f};
-    auto fetch_stats = [&](int n0) {
-        if (threadIdx.x < 64) {
-            const int n = n0 + threadIdx.x;
-            const bool v = n < NO;
-            st4[0] = v ? a.ostats[2 * ((int64_t)b * NO + n)] : 0.f;
-            st4[1] = v ? a.ostats[2 * ((int64_t)b * NO + n) + 1] : 0.f;
-            st4[2] = v ? a.m12[2 * ((int64_t)b * NO + n)] : 0.f;
-            st4[3] = v ? a.m12[2 * ((int64_t)b * NO + n) + 1] : 0.f;
-        }
-    };
-    fetch(0);
-    fetch_stats(0);
-    for (int n0 = 0; n0 < NO; n0 += 64) {
-        __syncthreads();                        // previous tile fully consumed (also orders the dzv fill on the first pass)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int f = threadIdx.x + AP_THREADS * j;
-            const int row = f >> 4, c4 = f & 15;
-            *reinterpret_cast<f32x4*>(yl + row * AP_LD + 4 * c4) = yq[j];
-            *reinterpret_cast<f32x4*>(pdl + row * AP_LD + 4 * c4) = pq[j];
-        }
-        if (threadIdx.x < 64) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sm[threadIdx.x * 4 + i] = st4[i];
-        }
-        __syncthreads();
-        if (n0 + 64 < NO) { fetch(n0 + 64); fetch_stats(n0 + 64); }
-        // ---- do[n][col] = sum_k pd[n][k] * dzv[k][col]   (lane half h owns k in [32h, 32h+32))
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        {
-            const float* ap = pdl + (mb * 32 + r) * AP_LD + 32 * h;
-            const float* bp = dzv + (32 * h) * AP_LD + cb * 32 + r;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 4 * q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], bp[(4 * q + i) * AP_LD], acc, 0, 0, 0);
-            }
-        }
-        // ---- epilogue: obj_norm LayerNorm backward + tanh backward, dgamma / dbeta partials
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = mb * 32 + crow(e, h);
-            const int n = n0 + row;
-            if (n < NO) {
-                const float yv = yl[row * AP_LD + cb * 32 + r];
-                const float mean = sm[row * 4], rstd = sm[row * 4 + 1], m1 = sm[row * 4 + 2], m2 = sm[row * 4 + 3];
-                const float xh = (yv - mean) * rstd;
-                const float d = acc[e];
-                gsum += d * xh;
-                bsum += d;
-                a.dy[((int64_t)b * NO + n) * H + col] = rstd * (d * gam - m1 - xh * m2) * (1.f - yv * yv);
-            }
-        }
-        // ---- dv[t][col] += sum_n dS'[n][t] * o[n][col] over this wave's object half (lane half h: 16 objects)
-        {
-            const int nb = 32 * mb + 16 * h;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int nl = nb + s;
-                const float av = pdl[nl * AP_LD + 32 + r];
-                const float ov = (yl[nl * AP_LD + cb * 32 + r] - sm[nl * 4]) * sm[nl * 4 + 1] * gam + bet;
-                accv = __builtin_amdgcn_mfma_f32_32x32x2f32(av, ov, accv, 0, 0, 0);
-            }
-        }
-    }
-    // ---- combine the wave pairs (w, w^2): same columns, other object block
-    gsum += __shfl_xor(gsum, 32, 64);
-    bsum += __shfl_xor(bsum, 32, 64);
-    __syncthreads();
-    if (mb == 1) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) xch[cb][e][lane] = accv[e];
-        xch[cb][16][lane] = gsum;
-        xch[cb][17][lane] = bsum;
-    }
-    __syncthreads();
-    if (mb == 0) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int t = crow(e, h);
-            if (t < T)
-                a.dv[((int64_t)b * T + t) * H + col] = accv[e] + xch[cb][e][lane] + dzv[t * AP_LD + cb * 32 + r];
-        }
-        if (h == 0) {
-            a.part[(int64_t)b * 2 * H + col] = gsum + xch[cb][16][lane];
-            a.part[(int64_t)b * 2 * H + H + col] = bsum + xch[cb][17][lane];
-        }
-    }
-}
-
-template <int H>
-int o2v_bwd_launch(const dlsg_o2v_bwd_args* a, hipStream_t st) {
-    using G = O2VGeom<H>;
-    static std::once_flag once;
-    constexpr int lds_bytes = G::LDS_FLOATS * 4;
-    std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v_bwd_scores_kernel<H>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    });
-    const int tiles = (a->NO + O2V_TILE - 1) / O2V_TILE;
-    const int tps = (tiles + a->nsplit - 1) / a->nsplit;
-    hipLaunchKernelGGL((o2v_bwd_scores_kernel<H>), dim3(a->B, a->nsplit), dim3(O2V_THREADS), lds_bytes, st, *a, tps);
-    hipLaunchKernelGGL(o2v_bwd_apply_kernel, dim3(a->B, a->H / 64), dim3(AP_THREADS), 0, st, *a);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? DLSG_OK : DLSG_ELAUNCH;
-}
 
 // ================================================================================================ decoder attention
 // One workgroup per clip: 2 x 256 threads, each half owns one attention stream (proposal set).  K' (P x Q) and
@@ -842,30 +280,17 @@ extern "C" int dlsg_o2v_fwd_multi(const dlsg_o2v_args* a, int count, void* strea
     }
     if (a->B == 0) return DLSG_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static const bool gen1 = getenv("DLSG_O2V_GEN1") != nullptr;    // A/B switch of tools/o2v_bench.py: the first-generation kernel
-    if (!gen1 && (a->H == 1024 || a->H == 512 || a->H == 64)) {
-        const int rc = dlsg_o2v16_partial(a, count, st);
-        if (rc != DLSG_OK) return rc;
-        if (a->nsplit > 1) {
-            // (merging inside o2v16 by the chunk that arrives last -- arrival tickets, agent-scope release / acquire -- was built
-            // and measured: 150 us instead of 78 us per 64-clip launch; one workgroup reading the other chunks' partials
-            // in accumulator layout is far slower than this B x T-workgroup launch, and the fences are not free)
-            O2VCombinePack pk;
-            for (int i = 0; i < count; ++i) pk.s[i] = a[i];
-            hipLaunchKernelGGL(o2v_combine_multi_kernel, dim3(a->B, a->T, count), dim3(256), 0, st, pk);
-            DLSG_CHECK_LAUNCH();
-        }
-        return DLSG_OK;
-    }
-    for (int i = 0; i < count; ++i) {
-        int rc;
-        switch (a->H) {
-            case 1024: rc = o2v_launch<1024>(a + i, st); break;
-            case 512: rc = o2v_launch<512>(a + i, st); break;
-            case 64: rc = o2v_launch<64>(a + i, st); break;
-            default: return DLSG_EINVAL;   // caller falls back to the unfused GEMM + softmax path
-        }
-        if (rc != DLSG_OK) return rc;
+    if (a->H != 1024 && a->H != 512 && a->H != 64) return DLSG_EINVAL;   // caller falls back to the unfused GEMM + softmax path
+    const int rc = dlsg_o2v16_partial(a, count, st);
+    if (rc != DLSG_OK) return rc;
+    if (a->nsplit > 1) {
+        // (merging inside o2v16 by the chunk that arrives last -- arrival tickets, agent-scope release / acquire -- was built
+        // and measured: 150 us instead of 78 us per 64-clip launch; one workgroup reading the other chunks' partials
+        // in accumulator layout is far slower than this B x T-workgroup launch, and the fences are not free)
+        O2VCombinePack pk;
+        for (int i = 0; i < count; ++i) pk.s[i] = a[i];
+        hipLaunchKernelGGL(o2v_combine_multi_kernel, dim3(a->B, a->T, count), dim3(256), 0, st, pk);
+        DLSG_CHECK_LAUNCH();
     }
     return DLSG_OK;
 }
@@ -883,21 +308,6 @@ extern "C" int dlsg_o2v_bwd_multi(const dlsg_o2v_bwd_args* a, int count, void* s
     }
     if (a->B == 0) return DLSG_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static const bool gen1 = getenv("DLSG_O2V_BWD_GEN1") != nullptr;    // A/B switch: the first-generation two-pass kernels
-    if (gen1) {
-        // the first generation writes one dgamma | dbeta partial per clip: rows [0, B) of `part`; the caller zero-fills the rest
-        for (int i = 0; i < count; ++i) {
-            int rc;
-            switch (a->H) {
-                case 1024: rc = o2v_bwd_launch<1024>(a + i, st); break;
-                case 512: rc = o2v_bwd_launch<512>(a + i, st); break;
-                case 64: rc = o2v_bwd_launch<64>(a + i, st); break;
-                default: return DLSG_EINVAL;
-            }
-            if (rc != DLSG_OK) return rc;
-        }
-        return DLSG_OK;
-    }
     if (a->H != 1024 && a->H != 512 && a->H != 64) return DLSG_EINVAL;
     const int rc = dlsg_o2v16_bwd(a, count, st);
     if (rc != DLSG_OK) return rc;
@@ -916,7 +326,6 @@ extern "C" int dlsg_o2v_bwd_multi(const dlsg_o2v_bwd_args* a, int count, void* s
     return DLSG_OK;
 }
 extern "C" int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream) { return dlsg_o2v_bwd_multi(a, 1, stream); }
-extern "C" int dlsg_o2v_bwd_gen1(void) { return getenv("DLSG_O2V_BWD_GEN1") != nullptr; }
 
 extern "C" int dlsg_decatt_fwd(const dlsg_decatt_args* a, void* stream) {
     if (!a || a->P < 1 || a->P > DA_MAXP || a->nstream < 1 || a->nstream > 2) return DLSG_EINVAL;

@@ -34,8 +34,9 @@ using namespace o16;
 
 namespace {
 
-// STAMP: diagnostic build (tools/o2v_stamps.py, env DLSG_O2V_STAMPS): lane 0 of every wave of workgroup (0,0) records
-// s_memtime at the phase boundaries of each tile into a.ws (unused when nsplit == 1); the product build has no stamp code.
+// STAMP: diagnostic build only (make PROBES=1, i.e. -DDLSG_PROBES, then env DLSG_O2V_STAMPS; tools/o2v_stamps.py): lane 0 of every
+// wave of workgroup (0,0) records s_memtime at the phase boundaries of each tile into a.ws (unused when nsplit == 1).  The product
+// library neither reads the environment nor contains the stamped instantiation.
 // Several graphs of one shape per launch (the object and the motion stream of CapGnnEncoder: 2 x 64 clips fill the chip
 // with two object chunks per clip instead of four): blockIdx.z picks the argument block.
 struct O16Pack {
@@ -390,19 +391,24 @@ int o2v16_launch_t(const dlsg_o2v_args* a, int count, hipStream_t st) {
     std::call_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v16_kernel<H, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   lds_bytes);
+#ifdef DLSG_PROBES
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&o2v16_kernel<H, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   lds_bytes);
+#endif
     });
     const int tiles = (a->NO + O16_TILE - 1) / O16_TILE;
     const int tps = (tiles + a->nsplit - 1) / a->nsplit;
     O16Pack pk;
     for (int i = 0; i < count; ++i) pk.s[i] = a[i];
-    static const bool stamps = getenv("DLSG_O2V_STAMPS") != nullptr;
     const dim3 grid(a->B, a->nsplit, count);
-    if (stamps && a->nsplit == 1)
+#ifdef DLSG_PROBES
+    static const bool stamps = getenv("DLSG_O2V_STAMPS") != nullptr;
+    if (stamps && a->nsplit == 1) {
         hipLaunchKernelGGL((o2v16_kernel<H, true>), grid, dim3(O16_THREADS), lds_bytes, st, pk, tps);
-    else
-        hipLaunchKernelGGL((o2v16_kernel<H, false>), grid, dim3(O16_THREADS), lds_bytes, st, pk, tps);
+        return hipGetLastError() == hipSuccess ? DLSG_OK : DLSG_ELAUNCH;
+    }
+#endif
+    hipLaunchKernelGGL((o2v16_kernel<H, false>), grid, dim3(O16_THREADS), lds_bytes, st, pk, tps);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DLSG_OK : DLSG_ELAUNCH;
 }

@@ -234,32 +234,6 @@ def ln_grads(ops, part, G, prefix, n):
 
 
 # ================================================================================================ TUN encoder
-GEMM_SLOTS = 768        # workgroup slots of the 128 x 128 fp32 tile kernel: 3 per CU x 256 CUs (csrc/gemm.hip, waves_per_eu(3,3))
-TAIL_SPLIT = False      # measured (tools/gemm_rounds_probe.py): 1.78 vs 1.75 ms -- the partial last round costs nothing; kept for the probe
-
-
-def _tail_plan(rows, ncols, nstreams, slots=GEMM_SLOTS):
-    """Row split of a tall NT product into a part whose 128 x 128 tiles fill whole rounds of the chip's workgroup slots and
-    a tail whose tiles are split along K so that the last round is full too.  Returns (main_rows, ksplit) or None.
-    26624 rows x 1024 columns x 2 streams = 3328 tiles = 4.33 rounds of 768: the last third-full round ran one workgroup per
-    CU (a lone workgroup keeps only ~60 % of its matrix pipe busy).  With 24576 rows in the main launch (exactly 4 rounds) and
-    the last 2048 rows as 3 K-thirds (768 workgroups writing slabs, folded with the bias + tanh epilogue) no round is partial."""
-    tn = (ncols + 127) // 128
-    panels = (rows + 127) // 128
-    per_round = slots // (tn * nstreams)               # row panels of all streams that fill one round
-    if per_round < 1 or rows % 128:
-        return None
-    full = panels // per_round
-    tail_panels = panels - full * per_round
-    if full < 2 or tail_panels == 0:
-        return None
-    tail_tiles = tail_panels * tn * nstreams
-    best = min((1, 2, 3, 4), key=lambda ks: (-(-tail_tiles * ks // slots)) / ks)
-    if best == 1:
-        return None
-    return full * per_round * 128, best
-
-
 def region_projections(ops, mods, regions):
     """y_i = tanh(obj_embed_i(regions)) for every stream in ONE grouped launch (layer.py:184 runs once per stream on the
     same regions): the two 1664-tile grids of the batch-64 step pack into the chip's 768 workgroup slots in 5 rounds
@@ -268,20 +242,9 @@ def region_projections(ops, mods, regions):
     rows = B * T * O
     r2 = regions.view(rows, R)
     ys = [_empty(regions, rows, m.obj_embed.weight.shape[0]) for m in mods]
-    Hout = mods[0].obj_embed.weight.shape[0]
-    plan = _tail_plan(rows, Hout, len(mods)) if (TAIL_SPLIT and not (ops.extra_flags & F_BF16X3)) else None
-    if plan is None:
-        ops.gemm(GEMM_NT, [(r2, m.obj_embed.weight, y, m.obj_embed.bias) for m, y in zip(mods, ys)], flags=F_TANH)
-        return ys
-    main, ks = plan
-    ops.gemm(GEMM_NT, [(r2[:main], m.obj_embed.weight, y[:main], m.obj_embed.bias) for m, y in zip(mods, ys)], flags=F_TANH)
-    bounds = _ksplit_bounds(R, ks, 32)
-    trows = rows - main
-    slabs = [_empty(regions, len(bounds), trows, Hout) for _ in mods]
-    ops.gemm(GEMM_NT, [(r2[main:, k0:k1], m.obj_embed.weight[:, k0:k1], sl[i]) for m, sl in zip(mods, slabs)
-                       for i, (k0, k1) in enumerate(bounds)], flags=F_FORCE128)
-    for m, y, sl in zip(mods, ys, slabs):
-        ops.slab_reduce(sl, y[main:], bias=m.obj_embed.bias, flags=F_TANH)
+    # (wave quantisation is not what this launch loses: main rows in whole 768-slot rounds + the tail split along K measured
+    #  1.78 ms against 1.75 ms for the one launch, round 3)
+    ops.gemm(GEMM_NT, [(r2, m.obj_embed.weight, y, m.obj_embed.bias) for m, y in zip(mods, ys)], flags=F_TANH)
     return ys
 
 

@@ -228,7 +228,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduc
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
            'dlsg_argmax', 'dlsg_select_embed', 'dlsg_copy2d', 'dlsg_dropout', 'dlsg_fill', 'dlsg_ce_ragged', 'dlsg_log_softmax',
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
-           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd', 'dlsg_o2v_bwd_multi', 'dlsg_o2v_bwd_gen1',
+           'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd', 'dlsg_o2v_bwd_multi',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
            'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd',
            'dlsg_crit_embed_mix', 'dlsg_crit_embed_mix_bwd', 'dlsg_crit_vocab_scatter', 'dlsg_crit_relu_taps', 'dlsg_crit_relu_taps_bwd',
@@ -294,7 +294,6 @@ def load_library(path=LIB_PATH):
         'dlsg_decatt_cache_grads': [P(DecattCacheGradsArgs), vp],
         'dlsg_o2v_bwd': [P(O2VBwdArgs), vp],
         'dlsg_o2v_bwd_multi': [P(O2VBwdArgs), i32, vp],
-        'dlsg_o2v_bwd_gen1': [],
         'dlsg_latent_psl_fwd': [P(LatentPslArgs), vp],
         'dlsg_sa_core_fwd': [P(SaCoreArgs), vp],
         'dlsg_beam_select': [P(BeamSelectArgs), vp],
@@ -651,7 +650,6 @@ class HipOps(object):
         dev = items[0]['y'].device
         arr = (O2VBwdArgs * n)()
         wsb = int(self.lib.dlsg_o2v_workspace_bytes(B, T, H, nsplit))
-        gen1 = bool(self.lib.dlsg_o2v_bwd_gen1())
         keep, parts = [], []
         for a, it in zip(arr, items):
             for k in ('y', 'ostats', 'v', 'z', 'dz', 'S', 'ml', 'dy', 'dv'):
@@ -660,7 +658,7 @@ class HipOps(object):
             pd = torch.empty(B, NO, 64, dtype=torch.float32, device=dev)
             m12 = torch.empty(B, NO, 2, dtype=torch.float32, device=dev)
             ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
-            part = (torch.zeros if gen1 else torch.empty)(B * nsplit, 2, H, dtype=torch.float32, device=dev)
+            part = torch.empty(B * nsplit, 2, H, dtype=torch.float32, device=dev)
             keep += [pd, m12, ws]
             parts.append(part)
             for k in ('y', 'ostats', 'g_obj', 'b_obj', 'v', 'z', 'dz', 'S', 'ml', 'dy', 'dv'):

@@ -266,7 +266,7 @@ class CapGnnModel(_HipModel):
         ops.fill(self._gflat, 0.0)
         if self.merge_weight_grads and self._defer_ok:
             sv['tn_defer'] = []             # mid-size weight gradients of every module: launched together at the end
-        collect = hasattr(ops, 'colsum_flush') and not os.environ.get('DLSG_NO_COLSUM_MULTI')      # (env: A/B measurements)
+        collect = hasattr(ops, 'colsum_flush')
         if collect:
             ops.colsum_defer = []           # short column sums (LayerNorm / bias gradients): grouped launches (hip.py)
         frames, regions = sv['frames'], sv['regions']
@@ -586,13 +586,6 @@ class Trainer(object):
         self._rccl = None
         self._comm_stream = None
         self._comm_pending = False
-        # overlap_adam: Adam of a bucket on the side stream as soon as the bucket's gradients are complete (and, with several
-        # ranks, reduced) instead of one launch at the end of the step.  Measured and left off: the update streams 28 bytes per
-        # parameter (1.4 GB at 5 TB/s) through the Infinity Cache that the concurrent tile GEMMs re-read their panels from
-        # (their fabric traffic is 2-3x algorithmic, MALL-absorbed): 14.87 ms per step with the overlap against 14.47 without
-        self.overlap_adam = False
-        self._adam_ctx = None           # (step, hyper) while a step that may update is being scheduled
-        self._adam_done = []
         self.model = model
         self.lr, self.betas, self.eps = lr, betas, eps
         self.t = 0
@@ -673,22 +666,6 @@ class Trainer(object):
             ops.adam(model._flat[lo:hi], model._gflat[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
                      self.betas[1], self.eps, step, 1.0 / self.world_size, hyper=hyper)
 
-    def _adam_rest(self, step, hyper=None):
-        """Adam on every trainable range that no bucket hand-off has updated in this step"""
-        rest = []
-        for lo, hi in self._train_ranges:
-            cur = lo
-            for a, b in sorted(self._adam_done):
-                if b <= cur or a >= hi:
-                    continue
-                if a > cur:
-                    rest.append((cur, a))
-                cur = max(cur, b)
-            if cur < hi:
-                rest.append((cur, hi))
-        self._adam(step, hyper, rest)
-        self._adam_done = []
-
     # ------------------------------------------------------------------ checkpoint compatibility (run_gun.py:302-310)
     def optimizer_state_dict(self):
         """The Adam state in the layout of `torch.optim.Adam(model.parameters(), ...).state_dict()` -- what the reference
@@ -760,8 +737,9 @@ class Trainer(object):
         return self._comm_stream
 
     def _allreduce(self, key):
-        """key: a bucket name or a tuple of bucket names whose gradients are complete: hand them to the reduction and, where
-        the update may overlap the rest of the backward, to Adam."""
+        """key: a bucket name or a tuple of bucket names whose gradients are complete: hand them to the reduction.  (Adam per
+        bucket on the side stream right behind its all-reduce was measured and removed: 14.87 ms per step against 14.47 -- the
+        update's 1.4 GB stream evicts the Infinity-Cache-resident operands of the backward that is still running.)"""
         mode = self._comm_mode()
         ranges = [r for k in (key if isinstance(key, tuple) else (key,)) for r in self._minus_frozen(*self._ranges[k])]
         views = [self.model._gflat[lo:hi] for lo, hi in ranges]
@@ -770,22 +748,16 @@ class Trainer(object):
             for v in views:
                 self._works.append(dist.all_reduce(v, group=self.pg, async_op=True))
             return
-        early_adam = self.overlap_adam and self._adam_ctx is not None and self.model._flat.is_cuda
-        if mode == 'none' and not early_adam:
+        if mode == 'none':
             return
-        comm = self._rccl_comm() if mode == 'rccl' else None
+        comm = self._rccl_comm()
         side = self._side_stream()
         # fork: the side stream waits for everything enqueued so far (the bucket's gradients), the main stream goes on
         # with the rest of the backward; under stream capture both become edges of the step's graph
         ev = torch.cuda.Event()
         ev.record()
         side.wait_event(ev)
-        if comm is not None:
-            comm.allreduce(views, side)
-        if early_adam:
-            with torch.cuda.stream(side):
-                self._adam(self._adam_ctx[0], self._adam_ctx[1], ranges)
-            self._adam_done += ranges
+        comm.allreduce(views, side)
         self._comm_pending = True
 
     def _join_comm(self):
@@ -832,8 +804,7 @@ class Trainer(object):
         sv = {}
         training = model.training
         # a bucket handed to a reduction (or closing a graph segment) must be complete: deferred weight gradients go out there
-        model._flush_at_buckets = self._comm_mode() != 'none' or self.force_graph_cuts or \
-            (self.overlap_adam and self._adam_ctx is not None and model._flat.is_cuda)
+        model._flush_at_buckets = self._comm_mode() != 'none' or self.force_graph_cuts
         model._engine_forward(frames, regions, captions, L, coins, training, seed, sv, dev_coins, outputs=False)
         s = sv['dec']
         Bn = captions.shape[0]
@@ -883,13 +854,11 @@ class Trainer(object):
         if self.device_coins:
             dev_coins = torch.tensor([int(c) for c in coins], dtype=torch.int32).to(captions.device)
         self._works = []
-        self._adam_ctx, self._adam_done = (self.t, None), []
         loss = self._schedule(frames, regions, captions, cap_lens, coins, seed, dev_coins, self._allreduce, extra_dlogits)
-        self._adam_ctx = None
         for w in self._works:
             w.wait()
         self._join_comm()
-        self._adam_rest(self.t)
+        self._adam(self.t)
         return loss
 
     # ------------------------------------------------------------------ hipGraph path
@@ -912,8 +881,7 @@ class Trainer(object):
         with torch.cuda.stream(side):
             # eager warm-up on the capture stream (allocator warm, one-time kernel attribute calls)
             # (with RCCL the warm-up also runs the collectives once: channel buffers are set up before the capture;
-            #  _adam_ctx is None: the warm-up must not update anything)
-            self._adam_ctx = None
+            #  nothing is updated: Adam is not part of the schedule)
             self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'],
                            self._allreduce if mode == 'rccl' else None)
             self._join_comm()
@@ -951,16 +919,13 @@ class Trainer(object):
                     self._hook_sv = (logits, sv)
                     return st['extra']
 
-                self._adam_ctx, self._adam_done = ((1, st['hyper']) if mode != 'torch' else None), []
                 loss = self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'], cut,
                                       placeholder if hook else None)
-                self._adam_ctx = None
                 if mode != 'torch':
-                    # no host-issued collective between backward and update: Adam is part of the graph -- bucket by bucket on
-                    # the side stream behind the bucket's RCCL launch, the rest here behind the join; with host-issued
-                    # collectives it follows their waits
+                    # no host-issued collective between backward and update: Adam is part of the graph, behind the join of the
+                    # side stream's collectives; with host-issued collectives it follows their waits
                     self._join_comm()
-                    self._adam_rest(1, hyper=st['hyper'])
+                    self._adam(1, hyper=st['hyper'])
                 cur[0].capture_end()
                 graphs.append((cur[0], None))
             except BaseException:
@@ -973,7 +938,6 @@ class Trainer(object):
                 graphs.clear()
                 self._graphs = None
                 self._comm_pending = False
-                self._adam_ctx, self._adam_done = None, []
                 raise
         torch.cuda.current_stream().wait_stream(side)
         self._graphs, self._loss = graphs, loss
@@ -1069,7 +1033,6 @@ class Trainer(object):
                 w.wait()
             # same arithmetic as the captured Adam launch (bias corrections read from the device word the host just wrote),
             # so a segmented step is bit-identical to the single-graph step
-            self._adam_done = []
-            self._adam_rest(self.t, hyper=st['hyper'])
+            self._adam(self.t, hyper=st['hyper'])
         # the loss lives in the graphs' static memory: hand out a copy, so losses kept across steps do not alias
         return self._loss.clone()

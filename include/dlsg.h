@@ -174,8 +174,7 @@ int dlsg_o2v_fwd_multi(const dlsg_o2v_args* a, int count, void* stream);
  * graphs of one shape in one launch per pass (the object and the motion stream of CapGnnEncoder).
  * Same support as the forward (T <= 32, H in {64,512,1024}); otherwise the caller runs the unfused chain
  * (dlsg_softmax_fwd/bwd on S + batched dlsg_gemm + dlsg_rowln_bwd; engine.py tun_bwd).
- * dlsg_o2v_bwd_gen1() != 0: the environment selects the first-generation kernels (A/B measurements), which write only rows
- * [0, B) of `part` -- the caller zero-fills it. */
+ */
 typedef struct {
     const float* y; const float* ostats; const float* g_obj; const float* b_obj;
     const float* v; const float* z; const float* dz; const float* S; const float* ml;
@@ -186,7 +185,6 @@ typedef struct {
     float scale;
 } dlsg_o2v_bwd_args;
 int dlsg_o2v_bwd_multi(const dlsg_o2v_bwd_args* a, int count, void* stream);
-int dlsg_o2v_bwd_gen1(void);
 int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream);
 
 /* ---------------------------------------------------------------- LatentPSL forward (sublayer.py:189-198), one launch

@@ -1,6 +1,6 @@
 """The recurrent (M = batch = 64) gate products of one word step / BiLSTM step as the engine launches them, timed in
 isolation: grouped NT launches writing K-split slabs (forward) and grouped NN launches (input gradients).
-    python tools/recurrent_gemm_bench.py            (DLSG_SKINNY_GEN1=1 -> first-generation NT kernel)"""
+    python tools/recurrent_gemm_bench.py"""
 import os
 import sys
 
@@ -52,7 +52,7 @@ def nt_case(name, N, segs):
     print('%-34s NT  %6.1f us  %6.1f TFLOP/s  (%.2f GFLOP, weights %.0f MB)' % (name, us, gf / us, gf, N * sum(segs) * 4 / 1e6))
     ref = sum(x @ W[:, c:c + k].t() for x, k, c in zip(xs, segs, [sum(segs[:i]) for i in range(len(segs))]))
     err = (slabs.sum(0) - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 1e-5 or os.environ.get('DLSG_SKINNY_GEN3') == '2', err      # (=2: timing probe with a remapped layout)
+    assert err < 1e-5, err
 
 
 def nn_case(name, Kc, widths, chunk=1024):
