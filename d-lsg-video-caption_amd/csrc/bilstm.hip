@@ -437,6 +437,8 @@ static int device_cus() {
 }
 extern "C" int dlsg_bilstm_supported(int B, int T, int H) {
     if (!(B >= 1 && B <= BL_ROWS && T >= 1 && T <= 4096 && (H == 64 || H == 512 || H == 1024))) return 0;
+    // buffer sizes and byte offsets are 32-bit: the backward's exchange buffers are the largest (2 T x 4H x 64 rows x 4 bytes)
+    if ((int64_t)2 * T * 4 * H * BL_ROWS * 4 >= (int64_t)1 << 31) return 0;
     return device_cus() >= 2 * (H / 8) ? 1 : 0;
 }
 extern "C" int64_t dlsg_bilstm_hx_floats(int T, int H) { return (int64_t)2 * T * H * BL_ROWS; }

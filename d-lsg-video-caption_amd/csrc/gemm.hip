@@ -764,8 +764,8 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     // gradient (2.67 rounds), tools/gemm_split_probe.py -- workgroups of a partly filled last round simply run faster.)
     if (tilesL >= 1000) return launch<128, 128, 32>(a, st);
     // Mid-size launches (tools/gemm_tile_probe.py; M = 1664 = 26 frames x 64 clips and the weight gradients over them), when
-    // the 128-row panels waste < 10 % of their rows: from ~700 tiles the 128 x 128 tile is already ahead (2048 x 2048 x 1664 x 3
-    // TN: 402 us against 445), between 200 and 700 a 128 x 64 tile (21 flop per staged byte instead of 16, twice the
+    // the 128-row panels waste < 10 % of their rows: the TN form takes the 128 x 128 tile from 500 tiles (2048 x 2048 x 1664 x 3
+    // TN: 402 us against 445; NT / NN only from 1000), between 200 tiles and that a 128 x 64 tile (21 flop per staged byte instead of 16, twice the
     // workgroups of the square tile) wins 3-8 % over the 64 x 64 one; below that only the small tile fills the chip.
     const int padM = (a->M + 127) / 128 * 128;
     if ((padM - a->M) * 10 <= a->M) {

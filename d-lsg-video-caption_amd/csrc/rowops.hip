@@ -871,7 +871,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 // scalar head and tail (a trainable range may start at any parameter boundary)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2s, float gscale, const float* __restrict__ hyper) {
+                                                   float bc1, float bc2s, float gscale, const float* __restrict__ hyper,
+                                                   const int32_t* __restrict__ guard) {
+    if (guard && *guard != 0) return;      // a persistent kernel reported a time-out in this step: its gradients are invalid
     if (hyper) { lr = hyper[0]; bc1 = 1.f; bc2s = hyper[1]; }
     const float lr_bc1 = lr / bc1;
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (int64_t)gridDim.x * blockDim.x;
@@ -1169,12 +1171,12 @@ extern "C" int dlsg_gather_rows_multi(const dlsg_gather_multi_args* a, void* str
     return DLSG_OK;
 }
 extern "C" int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                         int step, float grad_scale, const float* hyper, void* stream) {
+                         int step, float grad_scale, const float* hyper, const int32_t* guard, void* stream) {
     if (n == 0) return DLSG_OK;
     const float bc1 = 1.f - powf(b1, (float)step);
     const float bc2s = sqrtf(1.f - powf(b2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256, 8192)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, b1, b2, eps, bc1,
-                       bc2s, grad_scale, hyper);
+                       bc2s, grad_scale, hyper, guard);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -109,7 +109,10 @@ def beam_device(model, visual_feats, region_feats, early_exit=True):
 def beam_finish(model, preds, backs, lps, ended, done, B, k, R, L, extras):
     """Host side of the search: where the reference would have stopped (allennlp_beamsearch.py:168), the back-trace
     (:272-292) and the choice of the best beam (layer.py:456-460)."""
-    cnt = ended[:done].tolist()
+    cnt = ended[:done].tolist()                                   # host synchronisation
+    chk = getattr(model.ops, 'check_persistent', None)
+    if chk is not None:
+        chk()                                                     # the encoder's persistent BiLSTM: time-out word is final here
     n_steps = done
     hit = [i for i, c in enumerate(cnt[:L - 1]) if c == R]
     if hit:

@@ -13,23 +13,43 @@ import torch
 from .hip import load_library
 
 
+def _agree_min(value, process_group=None, negate=False):
+    """the minimum (negate: the maximum) of an int over the ranks of a torch.distributed group, on the device its backend moves"""
+    import torch.distributed as dist
+    dev = 'cuda' if dist.get_backend(process_group) == 'nccl' else 'cpu'
+    t = torch.tensor([-value if negate else value], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=process_group)
+    return -int(t.item()) if negate else int(t.item())
+
+
 class RcclComm(object):
     def __init__(self, world, rank, process_group=None, lib=None):
         self.lib = lib or load_library()
         self.world, self.rank = int(world), int(rank)
         self._h = C.c_void_p()
         uid = (C.c_char * 128)()
+        rc = 0
         if self.rank == 0:
-            rc = self.lib.dlsg_comm_unique_id(uid)
-            if rc != 0:
-                raise RuntimeError('dlsg_comm_unique_id failed with code %d (librccl not loadable?)' % rc)
+            rc = int(self.lib.dlsg_comm_unique_id(uid))
         if self.world > 1:
             import torch.distributed as dist
-            box = [bytes(uid)]
+            # rank 0 ships its STATUS with the id: a rank 0 whose librccl did not load must not leave its peers waiting in this
+            # broadcast -- they receive the code and raise with it (the group's own timeout bounds a rank 0 that died earlier)
+            box = [(rc, bytes(uid))]
             dist.broadcast_object_list(box, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                                        group=process_group)
-            uid = (C.c_char * 128).from_buffer_copy(box[0])
-        rc = self.lib.dlsg_comm_init(C.byref(self._h), uid, self.world, self.rank)
+            rc, raw = box[0]
+            uid = (C.c_char * 128).from_buffer_copy(raw)
+        if rc != 0:
+            raise RuntimeError('dlsg_comm_unique_id failed on rank 0 with code %d (librccl not loadable?)' % rc)
+        rc = int(self.lib.dlsg_comm_init(C.byref(self._h), uid, self.world, self.rank))
+        if self.world > 1:
+            # every rank learns whether EVERY rank has a communicator: one rank raising alone would leave the others in the first
+            # all-reduce of the step
+            worst = _agree_min(0 if rc == 0 else 1, process_group, negate=True)
+            if worst != 0 and rc == 0:
+                self.close()
+                raise RuntimeError('dlsg_comm_init failed on another rank')
         if rc != 0:
             raise RuntimeError('dlsg_comm_init(world=%d, rank=%d) failed with code %d' % (self.world, self.rank, rc))
         v = C.c_int32()

@@ -285,7 +285,7 @@ def load_library(path=LIB_PATH):
         'dlsg_fill': [vp, i64, f32, vp],
         'dlsg_ce_ragged': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         'dlsg_log_softmax': [vp, vp, i32, i32, vp],
-        'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp],
+        'dlsg_adam': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp, vp, vp],
         'dlsg_permute_tb': [vp, vp, i32, i32, i32, vp],
         'dlsg_gather_rows': [vp, i64, vp, vp, i64, i32, i32, vp],
         'dlsg_dec_mid_fwd': [P(DecMidArgs), vp],
@@ -864,18 +864,30 @@ class HipOps(object):
         self._check(self.lib.dlsg_decatt_cache_grads(C.byref(a), self._stream()), 'dlsg_decatt_cache_grads')
 
     # ------------------------------------------------------------------ persistent kernels: time-out word
+    def _persist_word(self, dev):
+        """the int32 device word every persistent recurrent launch of this process reports a hand-off time-out into
+        (csrc/bilstm.hip, csrc/critic_lstm.hip) and dlsg_adam reads as its guard"""
+        w = getattr(self, '_persist_err', None)
+        if w is None or w.device != dev:
+            w = self._persist_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        return w
+
     def check_persistent(self):
-        """Read the error words of the persistent recurrent kernels (csrc/bilstm.hip, csrc/critic_lstm.hip): a workgroup that
-        waited ~1 s for another one's flag (the launch was not fully co-resident) sets it and the results since then are
-        invalid.  A host synchronisation: the trainers call it where they read a loss back anyway."""
-        for name in ('_bilstm_err', '_lstm_seq_err'):
-            w = getattr(self, name, None)
-            if w is not None:
-                code = int(w.item())
-                if code:
-                    w.zero_()
-                    raise RuntimeError('persistent kernel hand-off timed out (%s = %d): the launch was not co-resident on this '
-                                       'device; set ops.persistent_bilstm / ops.persistent_lstm_seq = False' % (name[1:], code))
+        """Read the persistent kernels' time-out word: a workgroup that waited ~1 s for another one's flag (the launch was not
+        fully co-resident: the device is shared with another process, or another stream held the compute units) sets it; results
+        since then are invalid and every Adam launch since then was a no-op (dlsg_adam's guard).  Raises, after switching the
+        BiLSTM to its step-by-step schedule for later launches.  A host synchronisation: called where a loss or token ids are read
+        back anyway (Trainer.step every `check_every` steps, GanTrainer.iteration, beam.beam_finish, scoring.gather_results)."""
+        w = getattr(self, '_persist_err', None)
+        if w is None:
+            return
+        code = int(w.item())
+        if code:
+            w.zero_()
+            self.persistent_bilstm = False
+            raise RuntimeError('persistent kernel hand-off timed out (code %d): the launch was not co-resident on this device.  '
+                               'No parameter was updated by the steps since; the BiLSTM now runs step by step '
+                               '(ops.persistent_bilstm = False).  Is the GPU shared with another process?' % code)
 
     # ------------------------------------------------------------------ persistent BiLSTM recurrence
     persistent_bilstm = True      # False: the per-step schedule (grouped skinny GEMM + pointwise launch per step)
@@ -893,8 +905,7 @@ class HipOps(object):
         dev = out.device
         hx = torch.empty(int(self.lib.dlsg_bilstm_hx_floats(T, H)), dtype=torch.float32, device=dev)
         flags = torch.empty(int(self.lib.dlsg_bilstm_flag_words(T, H)), dtype=torch.int32, device=dev)
-        if getattr(self, '_bilstm_err', None) is None or self._bilstm_err.device != dev:
-            self._bilstm_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._bilstm_err = self._persist_word(dev)
         for d in range(2):
             for t in (xg[d], w_hh[d], hprev[d], c[d], gates[d]):
                 _chkc(t) if t is not xg[d] else _chk2(t)
@@ -918,8 +929,7 @@ class HipOps(object):
         gx = torch.empty(nx, dtype=torch.float32, device=dev)
         px = torch.empty(nx, dtype=torch.float32, device=dev)
         flags = torch.empty(2 * int(self.lib.dlsg_bilstm_flag_words(T, H)), dtype=torch.int32, device=dev)
-        if getattr(self, '_bilstm_err', None) is None or self._bilstm_err.device != dev:
-            self._bilstm_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._bilstm_err = self._persist_word(dev)
         _chkc(dout)
         for d in range(2):
             for t in (gates[d], c[d], w_hh[d], dgates[d]):
@@ -944,8 +954,7 @@ class HipOps(object):
         if not self.lib.dlsg_lstm_seq_supported(L, min(n, 256), H):
             raise RuntimeError('dlsg_lstm_seq does not take L = %d, H = %d on this device (H in {64, 512}, >= 4 * H / 8 compute units)'
                                % (L, H))
-        if getattr(self, '_lstm_seq_err', None) is None or self._lstm_seq_err.device != dev:
-            self._lstm_seq_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._lstm_seq_err = self._persist_word(dev)
         _chkc(W)
         for name, v in t.items():
             if v is not None:
@@ -1381,6 +1390,8 @@ class HipOps(object):
         self._check(self.lib.dlsg_log_softmax(_p(logits), _p(out), rows, V, self._stream()), 'log_softmax')
 
     def adam(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, hyper=None):
-        """hyper: optional device tensor {lr/(1-b1^step), sqrt(1-b2^step)} read at run time (graph replay)."""
+        """hyper: optional device tensor {lr/(1-b1^step), sqrt(1-b2^step)} read at run time (graph replay).  The launch is guarded
+        by the persistent kernels' time-out word of this device: a step whose recurrent hand-off timed out (gradients invalid)
+        updates nothing; `check_persistent()` then reports it."""
         self._check(self.lib.dlsg_adam(_p(p), _p(g), _p(m), _p(v), i64(p.numel()), f32(lr), f32(b1), f32(b2), f32(eps),
-                                       int(step), f32(grad_scale), _p(hyper), self._stream()), 'adam')
+                                       int(step), f32(grad_scale), _p(hyper), _p(self._persist_word(p.device)), self._stream()), 'adam')

@@ -573,7 +573,7 @@ class Trainer(object):
     memory: inputs (static buffers), the dropout seed, the scheduled-sampling coins, the Adam bias corrections."""
 
     def __init__(self, model, lr=1.6e-4, betas=(0.5, 0.9), eps=1e-8, process_group=None, world_size=1, use_graphs=False,
-                 device_coins=None, graph_fallback=False, comm='auto'):
+                 device_coins=None, graph_fallback=False, comm='auto', check_every=100):
         """comm: how the gradient buckets are summed over ranks.
           'rccl'  -- librccl through the C ABI (dlsg_allreduce_bucket) on a side stream forked by an event: the collectives
                      are part of the captured step, so one iteration is ONE hipGraph replay and a bucket's all-reduce runs
@@ -583,6 +583,9 @@ class Trainer(object):
           'auto'  -- 'rccl' when the model lives on a GPU, else 'torch'."""
         assert comm in ('auto', 'rccl', 'torch'), comm
         self.comm = comm
+        # every `check_every` steps the persistent kernels' time-out word is read back (one host synchronisation): a launch that
+        # was not co-resident (GPU shared with another process) raises here; meanwhile dlsg_adam's guard kept the weights intact
+        self.check_every = check_every
         self._rccl = None
         self._comm_stream = None
         self._comm_pending = False
@@ -842,9 +845,13 @@ class Trainer(object):
         self.t += 1
         hook = extra_dlogits is not None
         if self.use_graphs and (self._graphs is None or self._hook_mode == hook):
-            return self._step_graphs(frames, regions, captions, cap_lens, coins, seed, extra_dlogits)
-        # (a trainer's graphs are captured for one of the two forms of the step; the other form runs kernel by kernel)
-        return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True, extra_dlogits=extra_dlogits)
+            loss = self._step_graphs(frames, regions, captions, cap_lens, coins, seed, extra_dlogits)
+        else:
+            # (a trainer's graphs are captured for one of the two forms of the step; the other form runs kernel by kernel)
+            loss = self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True, extra_dlogits=extra_dlogits)
+        if self.check_every and self.t % self.check_every == 0:
+            self.check()
+        return loss
 
     def _eager_step(self, frames, regions, captions, cap_lens, coins, seed, counted=False, extra_dlogits=None):
         model, ops = self.model, self.model.ops
@@ -943,6 +950,22 @@ class Trainer(object):
         self._graphs, self._loss = graphs, loss
         self._adam_in_graph = mode != 'torch'
 
+    def _capture_agreed(self, frames, regions, captions, cap_lens, hook):
+        """`_capture`, and with several ranks the agreement on its outcome: returns None when EVERY rank captured, else the error
+        (this rank's own, or a stand-in when only another rank failed) after dropping this rank's graphs -- so that all ranks take
+        the same fallback together"""
+        err = None
+        try:
+            self._capture(frames, regions, captions, cap_lens, hook)
+        except RuntimeError as e:
+            err = e
+        if self.world_size > 1:
+            from .comm import _agree_min
+            if _agree_min(0 if err is not None else 1, self.pg) == 0 and err is None:
+                err = RuntimeError('hipGraph capture failed on another rank')
+                self._graphs = None
+        return err
+
     @torch.no_grad()
     def forward_only(self, frames, regions, captions, tf_ratio, max_len=26, time_major=False):
         """The no-grad generator forward of the GAN iteration (run_gun.py:167) from the captured step's FIRST graph (forward +
@@ -985,29 +1008,26 @@ class Trainer(object):
         model, ops = self.model, self.model.ops
         hook = extra_dlogits is not None
         if self._graphs is None:
-            if not self.graph_fallback:
-                self._capture(frames, regions, captions, cap_lens, hook)
-            else:
-                try:
-                    try:
-                        self._capture(frames, regions, captions, cap_lens, hook)
-                    except RuntimeError as e1:
-                        if self._comm_mode() != 'rccl' or self.world_size <= 1:
-                            raise
-                        # the in-graph RCCL capture was refused: before giving up on graphs altogether, the segmented form
-                        # (torch.distributed collectives issued by the host between graph segments)
-                        import warnings
-                        warnings.warn('capture with in-graph RCCL collectives failed (%s: %s); retrying with host-issued '
-                                      'torch.distributed collectives between graph segments' % (type(e1).__name__, e1))
-                        torch.cuda.synchronize()
-                        self.comm = 'torch'
-                        self._capture(frames, regions, captions, cap_lens, hook)
-                except RuntimeError as e:   # opted in: keep the run alive on kernel-by-kernel launches
-                    import warnings
-                    warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(e).__name__, e))
-                    torch.cuda.synchronize()
-                    self.use_graphs, self._graphs = False, None
-                    return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True, extra_dlogits=extra_dlogits)
+            err = self._capture_agreed(frames, regions, captions, cap_lens, hook)
+            if err is not None and self.graph_fallback and self._comm_mode() == 'rccl' and self.world_size > 1:
+                # the in-graph RCCL capture was refused somewhere: EVERY rank retries the segmented form (torch.distributed
+                # collectives issued by the host between graph segments) -- a rank replaying graphs that hold private-communicator
+                # collectives next to ranks issuing host collectives would hang the job
+                import warnings
+                warnings.warn('capture with in-graph RCCL collectives failed (%s: %s); all ranks retry with host-issued '
+                              'torch.distributed collectives between graph segments' % (type(err).__name__, err))
+                torch.cuda.synchronize()
+                self.comm = 'torch'
+                err = self._capture_agreed(frames, regions, captions, cap_lens, hook)
+            if err is not None:
+                if not self.graph_fallback:
+                    raise err
+                # opted in: keep the run alive on kernel-by-kernel launches -- on every rank
+                import warnings
+                warnings.warn('hipGraph capture failed (%s: %s); continuing with eager launches' % (type(err).__name__, err))
+                torch.cuda.synchronize()
+                self.use_graphs, self._graphs = False, None
+                return self._eager_step(frames, regions, captions, cap_lens, coins, seed, counted=True, extra_dlogits=extra_dlogits)
         st = self._static
         if (frames.shape, regions.shape, captions.shape) != (st['frames'].shape, st['regions'].shape, st['captions'].shape):
             # a batch of another shape (the short last batch of an epoch): the captured graphs are for one shape only

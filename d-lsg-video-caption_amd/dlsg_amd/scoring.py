@@ -182,7 +182,11 @@ def gather_results(net, eval_loader):
     with torch.no_grad():
         for frames, regions, spatials, video_ids in eval_loader:
             outputs = net(frames, regions, None)[0]
-            for tokens, vid in zip(outputs.cpu(), video_ids):
+            ids = outputs.cpu()                                    # host synchronisation: the time-out word is final too
+            chk = getattr(getattr(net.module if hasattr(net, 'module') else net, 'ops', None), 'check_persistent', None)
+            if chk is not None:
+                chk()                                              # a timed-out persistent launch must not pass as captions
+            for tokens, vid in zip(ids, video_ids):
                 result[vid] = dec.decode_tokens(tokens)
     return result
 

@@ -610,9 +610,10 @@ typedef struct {
 int dlsg_gather_rows_multi(const dlsg_gather_multi_args* a, void* stream);
 /* torch.optim.Adam semantics (no weight decay, no amsgrad); step = 1-based step count; grad_scale folds 1/world */
 int dlsg_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step,
-              float grad_scale, const float* hyper, void* stream);
+              float grad_scale, const float* hyper, const int32_t* guard, void* stream);
 /* hyper (optional, device): {lr / (1 - b1^step), sqrt(1 - b2^step)} -- overrides lr/step so a captured graph can be
- * replayed with a new step count. */
+ * replayed with a new step count.  guard (optional, device): the launch updates nothing when *guard != 0 -- the `err` word of the
+ * persistent recurrent kernels (dlsg_bilstm_*, dlsg_lstm_seq): a step whose hand-off timed out has invalid gradients. */
 
 
 /* ---------------------------------------------------------------- persistent BiLSTM recurrence (csrc/bilstm.hip)

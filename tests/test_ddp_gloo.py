@@ -221,3 +221,65 @@ def test_two_rank_evaluation_merges_the_ranks_caption_dicts(tmp_path):
     assert sorted(k for k, _ in r0['merged']) == list(range(100, 111))
     assert set(r0['mine']) != set(r1['mine']) and set(r0['mine']) | set(r1['mine']) == set(range(100, 111))
     assert all(v == 'caption of clip %d' % k for k, v in r0['merged'])
+
+
+def _worker_fail(rank, world, port, out_dir):
+    for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'd-lsg-video-caption_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import datetime
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    import time
+    from dlsg_amd import comm
+    from dlsg_amd.hip import load_library
+    t0 = time.time()
+    msgs = []
+    # (1) rank 0 cannot produce the RCCL id (no device / no librccl in this container): its peers must get the code with the
+    #     broadcast and raise too, instead of waiting for an id that never comes
+    class NoRccl(object):                      # the library as it behaves where librccl cannot be loaded (DLSG_ENOCOMM = -4)
+        def __init__(self, lib):
+            self._lib = lib
+
+        def __getattr__(self, name):
+            return getattr(self._lib, name)
+
+        def dlsg_comm_unique_id(self, uid):
+            return -4
+    try:
+        comm.RcclComm(world, rank, None, lib=NoRccl(load_library()))
+        msgs.append('no error')
+    except RuntimeError as e:
+        msgs.append(str(e))
+    # (2) a hipGraph capture that fails on ONE rank: every rank learns it and takes the fallback together
+    import dlsg_amd
+    net, frames, regions, caps, lens = _build()
+    tr = dlsg_amd.Trainer(net, world_size=world)
+
+    def capture(*a, **k):
+        if rank == 1:
+            raise RuntimeError('capture refused on rank 1')
+        tr._graphs = ['captured on rank 0']
+    tr._capture = capture
+    err = tr._capture_agreed(frames, regions, caps, lens, False)
+    msgs.append('none' if err is None else str(err))
+    msgs.append(repr(tr._graphs))
+    with open(os.path.join(out_dir, 'fail%d.txt' % rank), 'w') as f:
+        f.write('\n'.join(msgs) + '\n%.1f\n' % (time.time() - t0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(240)
+def test_failures_on_one_rank_reach_every_rank(tmp_path):
+    """N > 1 failure modes: (1) rank 0 fails to create the RCCL id -> rank 1 raises with rank 0's code instead of blocking in the
+    id broadcast; (2) a capture failing on one rank -> `Trainer._capture_agreed` returns an error on every rank and no rank keeps
+    graphs (run_gun.py:63-64 / train_debug.py:20: a job in which one rank silently changed its collective schedule hangs)."""
+    port = _free_port()
+    mp.spawn(_worker_fail, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out = [open(tmp_path / ('fail%d.txt' % r)).read().split('\n') for r in range(2)]
+    for r in range(2):
+        assert 'dlsg_comm_unique_id failed on rank 0 with code -4' in out[r][0], out[r]
+        assert float(out[r][3]) < 60.0
+    assert out[0][1] == 'hipGraph capture failed on another rank' and out[1][1] == 'capture refused on rank 1'
+    assert out[0][2] == 'None'

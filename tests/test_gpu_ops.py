@@ -1053,3 +1053,27 @@ def _gp_like(hs_of, xin, W, r1, r2):
     pen = ((g.reshape(g.shape[0], g.shape[1], -1).norm(dim=-1) - 1.0) ** 2).mean()
     return pen * 10.0 + (hs * r2).sum() * 0.01
 
+
+
+def test_adam_is_guarded_by_the_persistent_time_out_word(hip):
+    """a persistent recurrent launch whose hand-off timed out leaves invalid gradients: dlsg_adam reads the same device word and
+    updates nothing; check_persistent() raises, clears the word and switches the BiLSTM to its step-by-step schedule"""
+    p = torch.ones(1000, device='cuda')
+    g = torch.full((1000,), 0.5, device='cuda')
+    m, v = torch.zeros(1000, device='cuda'), torch.zeros(1000, device='cuda')
+    word = hip._persist_word(p.device)
+    try:
+        word.fill_(7)
+        hip.adam(p, g, m, v, 1e-2, 0.5, 0.9, 1e-8, 1)
+        torch.cuda.synchronize()
+        assert torch.equal(p, torch.ones_like(p)) and float(m.abs().max()) == 0.0
+        with pytest.raises(RuntimeError):
+            hip.check_persistent()
+        assert int(word.item()) == 0 and hip.persistent_bilstm is False
+        hip.check_persistent()
+        hip.adam(p, g, m, v, 1e-2, 0.5, 0.9, 1e-8, 1)
+        torch.cuda.synchronize()
+        assert float((p - 1).abs().max()) > 5e-3
+    finally:
+        word.zero_()
+        hip.persistent_bilstm = True
