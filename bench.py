@@ -157,7 +157,7 @@ def gpu_eager_baseline(dev, batch, steps=4, warmup=2):
                     'tf eps %.3f' % (torch.__version__, batch, eps)}
 
 
-def gan_iteration_leg(dev, batch, with_eager=True, iters=6):
+def gan_iteration_leg(dev, batch, with_eager=True, iters=10, product=True):
     """SURVEY.md 8(f) rank 1, what train_debug.py really trains: one RunGAN iteration (run_gun.py:147-234 -- no-grad generator
     forward, 5 critic updates with gradient penalty, generator step with the GAN term) at the bench shape.  The generator and the
     DiscV2 critic run on the HIP kernels as hand-written launch schedules replayed from hipGraphs (dlsg_amd/gan.py, critic.py); the comparator is
@@ -176,21 +176,28 @@ def gan_iteration_leg(dev, batch, with_eager=True, iters=6):
     frames, regions, caps, lens = synth_batch(args, V, batch, 1)
     frames, regions, caps = frames.to(dev), regions.to(dev), caps.to(dev)
     eps = dlsg_amd.ss_epsilon(0)
-    net, critic = net.to(dev).train(), critic.to(dev).train()
-    it = dlsg_amd.GanTrainer(net, critic, num_D=num_D, total_step=100)
-    random.seed(12)
-    for i in range(3):
-        it.iteration(frames, regions, caps, lens, eps, 0, i + 1)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(iters):
-        it.iteration(frames, regions, caps, lens, eps, 0, i + 4)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / iters * 1e3
-    out = {'what': 'RunGAN iteration: no-grad generator forward + %d critic updates (WGAN-GP) + generator step with the GAN term; '
-                   'MSVD-shaped, batch %d, fp32' % (num_D, batch), 'ms_per_iteration': round(ms, 2),
-           'clips_per_s': round(batch / ms * 1e3, 1), 'iterations': iters}
-    del it, net, critic
+    out = {}
+    if product:
+        net, critic = net.to(dev).train(), critic.to(dev).train()
+        it = dlsg_amd.GanTrainer(net, critic, num_D=num_D, total_step=100)
+        random.seed(12)
+        for i in range(3):
+            it.iteration(frames, regions, caps, lens, eps, 0, i + 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(iters):
+            it.iteration(frames, regions, caps, lens, eps, 0, i + 4)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / iters * 1e3
+        launches0 = net.ops.launches
+        it.iteration(frames, regions, caps, lens, eps, 0, iters + 4)
+        out = {'what': 'RunGAN iteration: no-grad generator forward + %d critic updates (WGAN-GP: forward, input backward, the '
+                       'derivative of both along the penalty direction, loss backward -- hand-written schedules, no autograd, no '
+                       'vendor GEMM) + generator step with the GAN term; MSVD-shaped, batch %d, fp32' % (num_D, batch),
+               'ms_per_iteration': round(ms, 2), 'clips_per_s': round(batch / ms * 1e3, 1), 'iterations': iters,
+               'host_issued_kernel_launches_per_iteration': net.ops.launches - launches0}
+        del it
+    del net, critic
     torch.cuda.empty_cache()
     if with_eager:
         from oracle import torch_ref as R
@@ -213,8 +220,7 @@ def gan_iteration_leg(dev, batch, with_eager=True, iters=6):
                 gan_ref.gan_iteration(eager, Dref, opt_G, opt_D, frames, regions, caps, lens, eps, 0.01, num_D, eps_gp)
             torch.cuda.synchronize()
         ems = (time.perf_counter() - t0) / 3 * 1e3
-        out['vs_pytorch_rocm_eager'] = {'ms_per_iteration': round(ems, 1), 'clips_per_s': round(batch / ems * 1e3, 1),
-                                        'speedup': round(ems / ms, 2), 'kind': 'port',
+        out['vs_pytorch_rocm_eager'] = {'ms_per_iteration': round(ems, 1), 'clips_per_s': round(batch / ems * 1e3, 1), 'kind': 'port',
                                         'what': 'oracle/torch_ref.py + oracle/gan_ref.py modules on cuda:0, torch %s eager' % torch.__version__}
         del eager, Dref, opt_G, opt_D
         torch.cuda.empty_cache()
@@ -382,6 +388,60 @@ def inference_leg(dev, a):
     return out
 
 
+def bucket_timeline(tr, batch, eps, dev, world):
+    """Where an N > 1 step spends its exchange: ONE extra kernel-by-kernel step with HIP events at every gradient-bucket hand-off
+    (main stream: `ready_us`, since the start of the step), behind its all-reduce on the side stream (`reduced_us`) and around the
+    join in front of Adam (`join_wait_us` = what the backward did not hide).  Every rank runs it (it has collectives); the maximum
+    over ranks of each figure is reported.  Replayed graphs run the same schedule ~0.85x as long (no launch gaps)."""
+    import torch.distributed as dist
+    model = tr.model
+    marks = []
+
+    def ev(name, stream=None):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream) if stream is not None else e.record()
+        marks.append((name, e))
+    orig_allreduce, orig_join = tr._allreduce, tr._join_comm
+
+    def allreduce(key):
+        label = key if isinstance(key, str) else ' + '.join(key)
+        ev('ready: ' + label)
+        orig_allreduce(key)
+        if tr._comm_stream is not None and tr._comm_pending:
+            ev('reduced: ' + label, tr._comm_stream)
+
+    def join():
+        ev('join')
+        orig_join()
+        ev('joined')
+    tr._allreduce, tr._join_comm = allreduce, join
+    try:
+        captions = batch[2].contiguous()
+        lens = torch.as_tensor(batch[3]).to(device=dev, dtype=torch.int64)
+        coins = model._draw_coins(captions.shape[1], False, eps)
+        torch.cuda.synchronize()
+        ev('start')
+        tr._eager_step(batch[0], batch[1], captions, lens, coins, model.next_seed())
+        ev('end')
+        torch.cuda.synchronize()
+    finally:
+        tr._allreduce, tr._join_comm = orig_allreduce, orig_join
+    t0 = marks[0][1]
+    rows = [(n, t0.elapsed_time(e) * 1e3) for n, e in marks[1:]]
+    names = [n for n, _ in rows]
+    vals = torch.tensor([t for _, t in rows], dtype=torch.float64, device=dev)
+    dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+    at = dict(zip(names, [round(float(x), 1) for x in vals]))
+    buckets = []
+    for n in names:
+        if n.startswith('ready: '):
+            k = n[7:]
+            buckets.append({'bucket': k, 'ready_us': at[n], 'reduced_us': at.get('reduced: ' + k)})
+    return {'what': 'one kernel-by-kernel step, HIP events, max over ranks', 'step_us': at.get('end'), 'buckets': buckets,
+            'join_wait_us': round(at['joined'] - at['join'], 1) if 'joined' in at and 'join' in at else None,
+            'buckets_MB': tr.collectives_info().get('buckets_MB')}
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (the parent makes no GPU call,
     before or after -- counting devices does not initialise the runtime on this image), one per device, RCCL rendezvous on
@@ -403,14 +463,42 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0', DLSG_BENCH_SPAWNED='1')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    # poll every rank: the first one that fails (device init, out of memory, an assertion) takes the others down -- they would sit
+    # in a collective waiting for it -- and its exit code is the job's; an overall time-out does the same
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get('DLSG_BENCH_TIMEOUT_S', '2400'))
+    bad = None
+    while bad is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            c = p.poll()
+            if c is not None and c != 0:
+                bad = (r, c)
+                break
+        if bad is None and time.time() > deadline:
+            bad = (-1, 124)
+        time.sleep(0.2)
+    if bad is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+    reader.join(timeout=10)
+    sys.stdout.write(b''.join(c for c in chunks if c).decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
-    if bad:
-        sys.stderr.write('bench.py: rank(s) failed: %s\n' % bad)
-        return bad[0][1] if bad[0][1] > 0 else 1
+    rcs = [p.poll() for p in procs]
+    if bad is None:
+        fails = [(r, c) for r, c in enumerate(rcs) if c != 0]
+        bad = fails[0] if fails else None
+    if bad is not None:
+        sys.stderr.write('bench.py: %s; exit codes %s\n' % ('timed out' if bad[0] < 0 else 'rank %d failed with code %s' % bad, rcs))
+        return bad[1] if isinstance(bad[1], int) and bad[1] > 0 else 1
     return 0
 
 
@@ -431,7 +519,7 @@ def main():
     ap.add_argument('--no-batch128', action='store_true', help='skip the extra N = 1 measurement at 128 clips per GPU')
     ap.add_argument('--no-graphs', action='store_true', help='launch every kernel from Python instead of replaying hipGraphs')
     ap.add_argument('--no-gan', action='store_true', help='skip the GAN-iteration leg (SURVEY.md 8f rank 1)')
-    ap.add_argument('--leg', default=None, choices=['gan_iteration'],
+    ap.add_argument('--leg', default=None, choices=['gan_eager'],
                     help='(internal) run only this side leg and print its JSON: the parent bench starts it as a child process')
     ap.add_argument('--no-inference', action='store_true', help='skip the inference leg (BASELINE configs[4])')
     ap.add_argument('--no-msrvtt', action='store_true', help='skip the MSR-VTT-shaped batch-64 leg (BASELINE configs[2] per GPU)')
@@ -445,8 +533,8 @@ def main():
     # dmabuf IPC between the ranks' processes (the host driver supports nothing else): must be in the environment before the
     # first HIP call of this process, i.e. before torch.cuda.set_device below
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    if a.leg == 'gan_iteration':
-        print(json.dumps(gan_iteration_leg(torch.device('cuda', 0), a.batch, with_eager=not a.no_eager_baseline)))
+    if a.leg == 'gan_eager':
+        print(json.dumps(gan_iteration_leg(torch.device('cuda', 0), a.batch, with_eager=True, product=False)))
         return
     if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
         sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
@@ -469,7 +557,6 @@ def main():
         # per-step schedule
         from dlsg_amd.hip import HipOps
         HipOps.persistent_bilstm = False
-        HipOps.persistent_lstm_seq = False
     backend = os.environ.get('DLSG_BENCH_BACKEND', 'nccl')
     if not rehearsal and torch.cuda.device_count() <= local:
         sys.stderr.write('bench.py: rank %d has no device %d (%d visible)\n' % (rank, local, torch.cuda.device_count()))
@@ -481,10 +568,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get('DLSG_BENCH_PG_TIMEOUT_S', '600')))
+        # a rank that never arrives (or dies inside a collective) must end the job, not hang it: rendezvous and collectives time out
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
         if dist.get_world_size() != a.gpus:
             sys.stderr.write('bench.py: process group has %d ranks, --gpus %d\n' % (dist.get_world_size(), a.gpus))
             sys.exit(2)
@@ -609,10 +699,29 @@ def main():
       except Exception as e:                 # noqa: BLE001
         b128 = {'error': '%s: %s' % (type(e).__name__, e)}
         torch.cuda.synchronize()
-    tr.check()                             # persistent kernels: no hand-off timed out anywhere above
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    # persistent kernels: no hand-off timed out anywhere above -- checked on EVERY rank before the next collective, and the
+    # verdict is shared: one rank raising alone would leave the others in the all-reduce below
+    failed = 0
+    try:
+        tr.check()
+    except RuntimeError as e:
+        sys.stderr.write('bench.py: rank %d: %s\n' % (rank, e))
+        failed = 1
+    per_rank_ms = [round(1e3 * dt / a.steps, 3)]
+    timeline = None
     if world > 1:
         import torch.distributed as dist
+        flag = torch.tensor([failed], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = int(flag.item())
+    if failed:
+        sys.exit(4)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, per_rank_ms[0])
+        per_rank_ms = every
+        timeline = bucket_timeline(tr, (frames, regions, caps, lens), eps, dev, world)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -632,6 +741,9 @@ def main():
                        'gemm_arithmetic': a.gemm, 'final_loss': round(loss_v, 5)},
             'rccl_ranks': comm_info.get('rccl_ranks', 1), 'collectives': comm_info,
         }
+        if world > 1:
+            out['per_rank_ms_per_step'] = per_rank_ms
+            out['bucket_timeline'] = timeline
         out['kernel_time_ms_per_step'] = {k: round(v['ms_total'] / nprof, 3) for k, v in prof.items()}
         rl = gemm_roofline(prof, nprof)
         if rl:
@@ -704,10 +816,17 @@ def main():
         if world == 1 and not a.no_eager_baseline and a.shape == 'msvd':
             leg('vs_pytorch_rocm_eager', eager_leg)
         if world == 1 and not a.no_gan and a.shape == 'msvd' and a.gemm == 'fp32' and not a.no_graphs:
-            # in a child process: this leg is PyTorch autograd + rocBLAS + captured graphs around this repo's kernels; whatever
-            # happens in there (an abort inside a vendor library included) must not cost the line
-            leg('gan_iteration', lambda: child_leg('gan_iteration', ['--batch', str(a.batch)] +
-                                                   (['--no-eager-baseline'] if a.no_eager_baseline else []), 900))
+            # the product's GAN iteration runs here, in this process (every launch one of this repo's kernels); only the COMPARATOR
+            # -- the oracle stepped by PyTorch-ROCm eager: autograd's double backward over rocBLAS / MIOpen -- runs in a child
+            def gan_leg():
+                g = gan_iteration_leg(dev, a.batch, with_eager=False)
+                if not a.no_eager_baseline:
+                    e = child_leg('gan_eager', ['--batch', str(a.batch)], 900)
+                    g['vs_pytorch_rocm_eager'] = e.get('vs_pytorch_rocm_eager', e)
+                    if 'ms_per_iteration' in g['vs_pytorch_rocm_eager']:
+                        g['vs_pytorch_rocm_eager']['speedup'] = round(g['vs_pytorch_rocm_eager']['ms_per_iteration'] / g['ms_per_iteration'], 2)
+                return g
+            leg('gan_iteration', gan_leg)
         if world == 1 and not a.no_cpu_baseline:
             leg('cpu_baseline', cpu_baseline)
         out['dtype_note'] = {'fp32': 'all products on fp32-input MFMA (exact fp32)',
