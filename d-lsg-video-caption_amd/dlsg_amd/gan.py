@@ -308,19 +308,29 @@ class GanTrainer(object):
             dist.all_reduce(self.D._gflat, group=self.pg)
 
     # ------------------------------------------------------------------ critic updates (run_gun.py:339-381)
-    def _critic_static(self, captions, logits_tm, obj, mot, smask, alpha):
-        """static buffers + captured graphs of one batch shape: graph A = update_gradients, graph B = Adam (the gradient
-        all-reduce of a multi-GPU run sits between them)"""
+    @staticmethod
+    def _sig(ts):
+        return tuple((t.data_ptr(), tuple(t.shape), tuple(t.stride())) for t in ts)
+
+    def _critic_static(self, captions, logits_tm, obj, mot, smask, alpha, alias):
+        """static buffers + captured graphs of one batch shape: graph P = proposals, graph A = update_gradients, graph B = Adam (the
+        gradient all-reduce of a multi-GPU run sits between A and B).  alias: the generator's outputs (logits, proposals, attention
+        weights) ARE static buffers of the generator's own captured step (Trainer.forward_only): the critic's graphs read them in
+        place -- no staging copies (6.6 MB of logits per iteration at batch 64) -- and are keyed by their addresses."""
         D, eng = self.D, self.D.engine
         L, B, V = logits_tm.shape
-        key = ('D', B, L, V, tuple(obj.shape), D.training, self.lr_D)
+        big = (logits_tm, obj, mot, alpha)
+        key = ('D', B, L, V, tuple(obj.shape), D.training, self.lr_D, self._sig(big) if alias else None)
         st = self._cg.get(key)
         if st is not None:
             return st
         dev = logits_tm.device
-        st = dict(captions=captions.clone(), logits=logits_tm.clone(), obj=obj.clone(), mot=mot.clone(), smask=smask.clone(),
-                  alpha=alpha.contiguous().clone(), eps=torch.zeros(B, device=dev), seed=torch.zeros(1, dtype=torch.int64, device=dev),
-                  hyper=torch.zeros(2, device=dev), graphs=None)
+        st = dict(captions=captions.clone(), smask=smask.clone(), eps=torch.zeros(B, device=dev),
+                  seed=torch.zeros(1, dtype=torch.int64, device=dev), hyper=torch.zeros(2, device=dev), graphs=None, alias=alias)
+        if alias:
+            st.update(logits=logits_tm, obj=obj, mot=mot, alpha=alpha)
+        else:
+            st.update(logits=logits_tm.clone(), obj=obj.clone(), mot=mot.clone(), alpha=alpha.contiguous().clone())
         st['ws'] = eng.prepare(dev, B, L, V, st['smask'], 4)
         self._cg[key] = st
         return st
@@ -344,17 +354,18 @@ class GanTrainer(object):
         torch.cuda.current_stream().wait_stream(side)
         st['graphs'] = (gP, gA, gB)
 
-    def train_disc(self, captions, logits_tm, obj, mot, smask, alpha):
+    def train_disc(self, captions, logits_tm, obj, mot, smask, alpha, alias=False):
         """run_gun.py:339-381: num_D critic updates.  logits_tm (L,B,V): the generator's logits, time-major as its decoder writes
-        them.  Returns (mean loss_D, mean Wasserstein estimate) as floats."""
+        them.  alias: see _critic_static.  Returns (mean loss_D, mean Wasserstein estimate) as floats."""
         D, eng = self.D, self.D.engine
         self._bind_D()
         L, B, V = logits_tm.shape
         dev = logits_tm.device
         acc = torch.zeros(8, device=dev)
         if self.use_graphs:
-            st = self._critic_static(captions, logits_tm, obj, mot, smask, alpha)
-            for k_, src in (('captions', captions), ('logits', logits_tm), ('obj', obj), ('mot', mot), ('smask', smask), ('alpha', alpha)):
+            st = self._critic_static(captions, logits_tm, obj, mot, smask, alpha, alias)
+            for k_, src in (('captions', captions), ('smask', smask)) + \
+                    (() if alias else (('logits', logits_tm), ('obj', obj), ('mot', mot), ('alpha', alpha))):
                 st[k_].copy_(src, non_blocking=True)
             if st['graphs'] is None:
                 self._capture_critic(st)
@@ -402,15 +413,15 @@ class GanTrainer(object):
                 eng.dlogits(ws, dhf, out, scale)
                 return -score.mean()
             return finish
-        key = ('G', B, L, V, tuple(obj.shape), D.training)
+        # (inside Trainer.step's cut graphs the logits, proposals and attention weights are static buffers: read in place)
+        key = ('G', B, L, V, tuple(obj.shape), D.training, self._sig((logits_tm, obj, mot, alpha)))
         st = self._cg.get(key)
         if st is None:
-            st = dict(logits=logits_tm.clone(), obj=obj.clone(), mot=mot.clone(), smask=smask.clone(), alpha=alpha.contiguous().clone(),
+            st = dict(logits=logits_tm, obj=obj, mot=mot, smask=smask.clone(), alpha=alpha,
                       seed=torch.zeros(1, dtype=torch.int64, device=dev), graph=None)
             st['ws'] = eng.prepare(dev, B, L, V, st['smask'], 1)
             self._cg[key] = st
-        for k_, src in (('logits', logits_tm), ('obj', obj), ('mot', mot), ('smask', smask), ('alpha', alpha)):
-            st[k_].copy_(src, non_blocking=True)
+        st['smask'].copy_(smask, non_blocking=True)
         st['seed'].copy_(torch.tensor([eng.next_seed()], dtype=torch.int64), non_blocking=True)
         if st['graph'] is None:
             side = torch.cuda.Stream(device=dev)
@@ -447,7 +458,7 @@ class GanTrainer(object):
             D.ops.permute_tb(f_caption.contiguous(), logits_tm)                           # (B,L,V) -> (L,B,V)
         else:
             logits_tm, obj, mot, alpha = fwd
-        loss_D, wass = self.train_disc(captions, logits_tm, obj, mot, smask, alpha)
+        loss_D, wass = self.train_disc(captions, logits_tm, obj, mot, smask, alpha, alias=fwd is not None)
         # ---- Train the captioning model (run_gun.py:180-234)
         out = {}
 
