@@ -13,7 +13,6 @@
 //     panel: the panel stays in that XCD's L2 instead of being fetched by all eight.
 #include <cstdlib>
 #include <mutex>
-#include <type_traits>
 
 #include "common.hpp"
 #include "dlsg.h"
@@ -645,255 +644,6 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ skinny GEMM, generation 4
-// (32 MI) x 128 output tile per workgroup, NT and NN, loader waves + MFMA waves.
-// What generations 1-2 leave on the table is the CU's intake: a 32-column tile re-fetches the 64-row activation slice for every
-// 32 weight columns (two thirds of the bytes through the CU), a wave-private 16-deep stage reads 64-B row segments (half of every
-// 128-B line the L1 pulls), and a wave that both issues the loads and runs the MFMAs stalls AT THE ISSUE once the CU's miss
-// queue is full (a shared 4- or 6-slot ring filled by the MFMA waves themselves: 1.66 us per 32-deep stage = 1.0 us of loads +
-// 0.7 us of MFMAs, one after the other, whatever the ring depth -- tools/skinny4_probe.py).  Here:
-//   * 8 waves: waves 0-3 own the four 32-column blocks of the tile and ALL walk the group's whole K range (no partial sums
-//     through LDS; the K split over workgroups stays the caller's: groups writing slabs); waves 4-7 only load;
-//   * stage = 32 k: activations (32 MI rows x 128 B) once per WORKGROUP + weights (NT: 128 rows x 128 B; NN: 32 k-rows x 512 B),
-//     every row segment a whole cache line, by LDS-DMA (`global_load_lds_dwordx4`; 1-KB pieces, MI + 4 per loader wave and stage);
-//   * ring of stages in LDS; per slot a FULL word per loader wave (the number of times it filled the slot, written behind a
-//     counted vmcnt that leaves the next stages in flight) and a FREE word per MFMA wave (written once its fragments are in
-//     registers, before the MFMAs); nobody meets at a barrier;
-//   * k-contiguous images are lane-linear per piece (8 rows x 8 segments of 16 B), swizzled on the SOURCE address: slot (row, s)
-//     holds k-segment s ^ ((row >> 1) & 7) -- b128 fragment reads (lane = row) are conflict-free in the hardware's 16-lane groups;
-//     the n-contiguous weight image is [k][128] and read by b32, lanes on consecutive banks.
-// Needs 16-B aligned operands with 4-float strides, K >= 32, K % 4 == 0 and widths that are multiples of 128.
-#ifndef R4_EXP
-#define R4_EXP 0
-#endif
-constexpr int R4_STAGE = 32;
-constexpr int R4_THREADS = 512;
-constexpr int R4_B_BYTES = 128 * 128;
-constexpr int r4_depth(int MI) { return MI == 2 ? 6 : 4; }     // ring slots
-#ifndef R4_AH
-#define R4_AH 3
-#endif
-constexpr int r4_ahead(int MI) { return MI == 2 ? R4_AH : 2; }     // stages a loader keeps in flight
-constexpr int r4_lds_bytes(int MI) { return r4_depth(MI) * (32 * MI * 128 + R4_B_BYTES); }     // + 192 B of flags (static)
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// the wave polls four LDS words (lane l reads word l & 3) until each is >= gen
-__device__ __forceinline__ void r4_wait4(int* w4, int gen, int lane) {
-    for (;;) {
-        const int v = __atomic_load_n(w4 + (lane & 3), __ATOMIC_RELAXED);
-        if (__all(v >= gen)) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-template <bool BT, int MI>
-__global__ __launch_bounds__(R4_THREADS) void skinny4_kernel(const KArgs p) {
-    constexpr int A_BYTES = 32 * MI * 128;
-    constexpr int SLOT = A_BYTES + R4_B_BYTES;
-    constexpr int PCS = MI + 4;                                   // DMA pieces per loader wave and stage
-    constexpr int S = r4_depth(MI), AH = r4_ahead(MI);
-    extern __shared__ __attribute__((aligned(16))) char r4_lds[];
-    __shared__ int r4_flags[2 * S * 4];
-    int* full = r4_flags;                                                         // [S][4]
-    int* fre = r4_flags + S * 4;                                                  // [S][4]
-    if (p.skip_if && *p.skip_if) return;     // block-uniform: the whole launch is a no-op on this replay
-    const int z = blockIdx.y;
-    const int gi = z % p.ngroups, bi = z / p.ngroups;
-    const dlsg_gemm_group grp = p.g[gi];
-    const float* A = grp.A + (int64_t)bi * p.bsa;
-    const float* B = grp.B + (int64_t)bi * p.bsb;
-    float* C = grp.C + (int64_t)bi * p.bsc;
-    const int K = grp.K, M = p.M, N = grp.N > 0 ? grp.N : p.N;
-    const int n0 = blockIdx.x * 128;
-    if (n0 >= N) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x < 2 * S * 4) full[threadIdx.x] = 0;
-    __syncthreads();
-    const int nst = (K + R4_STAGE - 1) / R4_STAGE;
-
-    if (wv >= 4) {
-        // ================================================================ loader wave
-        const int w = wv - 4;
-        const float* srcA[MI];
-        const float* srcB[4];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int R = 8 * (w * MI + i) + (lane >> 3);
-            srcA[i] = A + (int64_t)min(R, M - 1) * grp.lda + 4 * ((lane & 7) ^ ((R >> 1) & 7));
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (!BT) {
-                const int R = 8 * (4 * w + i) + (lane >> 3);           // weight row (= output column) inside the tile
-                srcB[i] = B + (int64_t)(n0 + R) * grp.ldb + 4 * ((lane & 7) ^ ((R >> 1) & 7));
-            } else {
-                const int kr = 2 * (4 * w + i) + (lane >> 5);          // k-row inside the stage
-                srcB[i] = B + (int64_t)kr * grp.ldb + n0 + 4 * (lane & 31);
-            }
-        }
-        auto publish = [&](int s) {                                    // stage s of this wave has landed
-            if (lane == 0) __atomic_store_n(full + (s % S) * 4 + w, s / S + 1, __ATOMIC_RELAXED);
-        };
-        for (int s = 0; s < nst; ++s) {
-            const int slot_i = s % S;
-            if (s >= S) r4_wait4(fre + slot_i * 4, s / S, lane);       // every MFMA wave has read stage s - S out of the slot
-            const int k0 = s * R4_STAGE;
-            // a partial last stage is fetched from K - 32 (every read stays inside the operand) and masked after the read
-            const int koff = (k0 + R4_STAGE <= K) ? k0 : (K - R4_STAGE);
-            char* slot = r4_lds + slot_i * SLOT;
-#if R4_EXP != 2
-#pragma unroll
-            for (int j = 0; j < MI; ++j) s2_glds<16>(reinterpret_cast<const char*>(srcA[j] + koff), slot + (w * MI + j) * 1024);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                s2_glds<16>(reinterpret_cast<const char*>(BT ? srcB[j] + (int64_t)koff * grp.ldb : srcB[j] + koff),
-                            slot + A_BYTES + (4 * w + j) * 1024);
-#else
-            (void)koff; (void)slot;
-#endif
-            if (s >= AH) {
-                wait_vmcnt<AH * PCS>();
-                publish(s - AH);
-            }
-        }
-        // drain: the last min(AH, nst) stages
-        if (AH >= 3 && nst >= 3) { wait_vmcnt<2 * PCS>(); publish(nst - 3); }
-        if (AH >= 2 && nst >= 2) { wait_vmcnt<PCS>(); publish(nst - 2); }
-        wait_vmcnt<0>();
-        publish(nst - 1);
-        return;
-    }
-
-    // ==================================================================== MFMA wave: column block w of the tile
-    const int w = wv;
-    const int r = lane & 31, h = lane >> 5;
-    f32x16 acc[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    int offA[MI][4], offB[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ks = (2 * q + h) ^ ((r >> 1) & 7);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) offA[mi][q] = (32 * mi + r) * 128 + ks * 16;
-        offB[q] = BT ? A_BYTES + (4 * (2 * q + h)) * 512 + (32 * w + r) * 4 : A_BYTES + (32 * w + r) * 128 + ks * 16;
-    }
-    // fragments of a stage: double-buffered, the next stage's LDS reads ride in the gaps between this stage's MFMAs
-    f32x4 fa[2][MI][4], fb[2][4];
-    auto read_q = [&](int buf, const char* slot, int q) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) fa[buf][mi][q] = *reinterpret_cast<const f32x4*>(slot + offA[mi][q]);
-        if (!BT) fb[buf][q] = *reinterpret_cast<const f32x4*>(slot + offB[q]);
-        else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[buf][q][j] = *reinterpret_cast<const float*>(slot + offB[q] + j * 512);
-        }
-    };
-    auto mask_part = [&](int buf, int i) {                          // partial last stage: fetched from K - 32, keep k >= k0 only
-        const int k0 = i * R4_STAGE, kbase = K - R4_STAGE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool keep = kbase + 4 * (2 * q + h) + j >= k0;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) fa[buf][mi][q][j] = keep ? fa[buf][mi][q][j] : 0.f;
-                fb[buf][q][j] = keep ? fb[buf][q][j] : 0.f;
-            }
-    };
-    auto mfma_q = [&](int buf, int q) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-#if R4_EXP == 1
-                if (j == 0 && q == 0) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][mi][q][j] + fa[buf][mi][1][1] + fa[buf][mi][2][2] + fa[buf][mi][3][3], fb[buf][q][j] + fb[buf][1][1] + fb[buf][2][2] + fb[buf][3][3], acc[mi], 0, 0, 0);
-#else
-                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf][mi][q][j], fb[buf][q][j], acc[mi], 0, 0, 0);
-#endif
-            }
-    };
-    auto release = [&](int i) {                                     // the fragments of stage i are in registers
-        __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0), visible to the compiler's own wait-count pass
-        if (lane == 0) __atomic_store_n(fre + (i % S) * 4 + w, i / S + 1, __ATOMIC_RELAXED);
-    };
-#if R4_EXP
-    const long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    if (nst > 0) {
-        r4_wait4(full, 1, lane);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) read_q(0, r4_lds, q);
-        release(0);
-        if (R4_STAGE > K) mask_part(0, 0);
-    }
-    // stage i: its 32 MFMAs pace the wave (one issue per 64 cycles); the poll of stage i + 1's FULL words is issued before
-    // the first group and looked at after it, the 12 fragment reads of stage i + 1 are issued before the second group and
-    // waited for after the last -- the matrix pipe never waits for the LDS
-    auto stage = [&](int i, auto cur, auto nxt) {
-        constexpr int CUR = decltype(cur)::value, NXT = decltype(nxt)::value;
-        const bool more = i + 1 < nst;                              // block-uniform
-        const char* nslot = r4_lds + ((i + 1) % S) * SLOT;
-        int* nfull = full + ((i + 1) % S) * 4;
-        const int ngen = (i + 1) / S + 1;
-        int seen = 0;
-        seen = __atomic_load_n(nfull + (lane & 3), __ATOMIC_RELAXED);   // (unconditional: a join in front of the MFMAs costs a full wait)
-        __builtin_amdgcn_sched_barrier(0);                          // (the compare below must not be hoisted over the MFMAs)
-        mfma_q(CUR, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(seen));                              // the poll's value is first LOOKED AT here
-        if (more) {
-            if (!__all(seen >= ngen)) r4_wait4(nfull, ngen, lane);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) read_q(NXT, nslot, q);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_q(CUR, 1);
-        mfma_q(CUR, 2);
-        mfma_q(CUR, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            release(i + 1);
-            if ((i + 2) * R4_STAGE > K) mask_part(NXT, i + 1);
-        }
-    };
-    for (int i = 0; i < nst; i += 2) {
-        stage(i, std::integral_constant<int, 0>(), std::integral_constant<int, 1>());
-        if (i + 1 < nst) stage(i + 1, std::integral_constant<int, 1>(), std::integral_constant<int, 0>());
-    }
-#if R4_EXP
-    const long long st_c1 = __builtin_amdgcn_s_memtime(), st_r1 = __builtin_amdgcn_s_memrealtime();
-#endif
-    const float* biasp = grp.bias ? grp.bias : p.bias;
-    const bool accum = p.flags & DLSG_GEMM_ACCUM, use_bias = (p.flags & DLSG_GEMM_BIAS) && biasp != nullptr;
-    const bool do_tanh = p.flags & DLSG_GEMM_TANH;
-    const int col = n0 + 32 * w + r;
-    const float bv = use_bias ? biasp[col] : 0.f;
-    const int64_t ldc = grp.ldc ? grp.ldc : (int64_t)p.ldc;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = 32 * mi + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (row >= M) continue;
-            float v = p.alpha * acc[mi][e] + bv;
-            float* cp = C + (int64_t)row * ldc + col;
-            if (accum) v += *cp;
-            if (do_tanh) v = tanhf(v);
-            *cp = v;
-        }
-#if R4_EXP
-    // diagnostic build: the loop's cycles and 100-MHz ticks of workgroup (1, 0), wave 0, over the output's first two elements
-    if (blockIdx.x == 1 && blockIdx.y == 0 && w == 0) {
-        __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) { C[0] = (float)(st_c1 - st_c0); C[1] = (float)(st_r1 - st_r0); }
-    }
-#endif
-}
-
 template <int MI>
 int launch_skinny_mi(const dlsg_gemm_args* a, const KArgs& k, hipStream_t st) {
     dim3 grid((a->N + 31) / 32, a->ngroups * a->nbatch, 1), block(NT, 1, 1);
@@ -907,27 +657,7 @@ int launch_skinny_mi(const dlsg_gemm_args* a, const KArgs& k, hipStream_t st) {
                                   skinny_lds_bytes(MI));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<true, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   skinny_lds_bytes(MI));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny4_kernel<false, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  r4_lds_bytes(MI));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny4_kernel<true, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  r4_lds_bytes(MI));
     });
-    if (a->flags & DLSG_GEMM_RING128) {
-        bool ok = a->nbatch == 1;
-        for (int i = 0; i < a->ngroups && ok; ++i) {
-            const dlsg_gemm_group& g = a->g[i];
-            const int gn = g.N > 0 ? g.N : a->N;
-            ok = (g.K % 4 == 0) && g.K >= R4_STAGE && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (gn % 128 == 0) &&
-                 ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
-        }
-        if (!ok) return DLSG_EINVAL;
-        dim3 grid4((a->N + 127) / 128, a->ngroups, 1);
-        const dim3 block4(R4_THREADS, 1, 1);
-        if (a->mode == 0) hipLaunchKernelGGL((skinny4_kernel<false, MI>), grid4, block4, r4_lds_bytes(MI), st, k);
-        else hipLaunchKernelGGL((skinny4_kernel<true, MI>), grid4, block4, r4_lds_bytes(MI), st, k);
-        DLSG_CHECK_LAUNCH();
-        return DLSG_OK;
-    }
     if (a->mode == 0) {
         // generation 2 (LDS-DMA rings, no barrier in the K loop) when every operand is 16-B aligned with 4-float strides
         bool ok = a->nbatch == 1;

@@ -54,7 +54,6 @@ int dlsg_struct_size(int which);
 #define DLSG_GEMM_TANH 4  /* tanh(.)     */
 #define DLSG_GEMM_FORCE64 256  /* tuning: force the 64x64 block tile  */
 #define DLSG_GEMM_FORCE128 512 /* tuning: force the 128x128 block tile (both FORCE bits: the 128x64 tile) */
-#define DLSG_GEMM_RING128 2048 /* tuning (M <= 128): the (32 MI) x 128 shared-ring kernel, csrc/gemm.hip generation 4 */
 #define DLSG_GEMM_BF16X3 1024  /* split-bf16 matrix path: x = hi + lo, 3 bf16 MFMAs per product, fp32 accumulate
                                   (~1e-5 relative error per product instead of 6e-8; see csrc/gemm_bf16x3.hip) */
 typedef struct {
