@@ -741,6 +741,8 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, i
 }  // namespace
 
 int dlsg_gemm_bf16x3_dispatch(const dlsg_gemm_args* a, hipStream_t st);   // gemm_bf16x3.hip
+int dlsg_gemm_big_ok(const dlsg_gemm_args* a);                             // gemm_big.hip
+int dlsg_gemm_big_dispatch(const dlsg_gemm_args* a, hipStream_t st, int bn);
 
 extern "C" int dlsg_abi_version(void) { return DLSG_ABI_VERSION; }
 
@@ -752,6 +754,7 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     const int64_t z = (int64_t)a->ngroups * a->nbatch;
     const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
     if (a->flags & DLSG_GEMM_BF16X3) return dlsg_gemm_bf16x3_dispatch(a, st);
+    if (a->flags & DLSG_GEMM_TILE256) return dlsg_gemm_big_dispatch(a, st, (a->flags & DLSG_GEMM_FORCE128) ? 128 : 256);
     if ((a->flags & (DLSG_GEMM_FORCE64 | DLSG_GEMM_FORCE128)) == (DLSG_GEMM_FORCE64 | DLSG_GEMM_FORCE128))
         return launch<128, 64, 64>(a, st);        // both bits: the 128 x 64 tile
     if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64, 64>(a, st);
@@ -762,7 +765,39 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     // (Wave quantisation is not what these launches lose: giving the 128-tile kernel whole 768-slot rounds only and the remaining
     // row panels to the 64-tile kernel was measured 1-3 % SLOWER on the region projection (4.33 rounds) and on the deep weight
     // gradient (2.67 rounds), tools/gemm_split_probe.py -- workgroups of a partly filled last round simply run faster.)
-    if (tilesL >= 1000) return launch<128, 128, 32>(a, st);
+    if (tilesL >= 1000) {
+        // 256 x 256 tiles (gemm_big.hip: one workgroup per CU, 64 flop per staged byte) for as many row panels as come in whole
+        // rounds of the 256 CUs -- a launch that leaves its last round mostly empty loses more than the tile gains (region
+        // projection as one launch of 832 tiles = 3.25 rounds: 108 TFLOP/s against 122 on the 128 x 128 tile, 135-142 per full
+        // round) -- and the remaining rows through the dispatch below.  tools/gemm_vs_rocblas.py, tools/gemm_census.py.
+        bool plain = dlsg_gemm_big_ok(a) != 0;
+        for (int i = 0; i < a->ngroups && plain; ++i) plain = a->g[i].N == 0 || a->g[i].N == a->N;
+        const int64_t pad_n = (a->N + 255) / 256 * 256;
+        if (plain && pad_n * 10 <= (int64_t)a->N * 11) {
+            const int64_t panel = (pad_n / 256) * z;                   // tiles per 256-row panel
+            int64_t g = panel, b = 256;
+            while (b) { const int64_t t = g % b; g = b; b = t; }       // gcd(panel, 256)
+            const int64_t need = 256 / g;                              // row panels per whole number of rounds
+            const int64_t main_rt = (a->M / 256) / need * need;
+            const int64_t m1 = main_rt * 256;
+            if (m1 == a->M || (a->M - m1) * 4 <= a->M) {               // whole rounds cover (nearly) everything
+                if (m1 == a->M) return dlsg_gemm_big_dispatch(a, st, 256);
+                if (m1 > 0) {
+                    dlsg_gemm_args head = *a, tail = *a;
+                    head.M = (int)m1;
+                    tail.M = a->M - (int)m1;
+                    for (int i = 0; i < a->ngroups; ++i) {
+                        const int64_t ldc = a->g[i].ldc ? a->g[i].ldc : (int64_t)a->ldc;
+                        tail.g[i].A = a->g[i].A + (a->mode == 2 ? m1 : m1 * a->g[i].lda);
+                        tail.g[i].C = a->g[i].C + m1 * ldc;
+                    }
+                    const int rc = dlsg_gemm_big_dispatch(&head, st, 256);
+                    return rc != DLSG_OK ? rc : dlsg_gemm(&tail, stream);
+                }
+            }
+        }
+        return launch<128, 128, 32>(a, st);
+    }
     // Mid-size launches (tools/gemm_tile_probe.py; M = 1664 = 26 frames x 64 clips and the weight gradients over them), when
     // the 128-row panels waste < 10 % of their rows: the TN form takes the 128 x 128 tile from 500 tiles (2048 x 2048 x 1664 x 3
     // TN: 402 us against 445; NT / NN only from 1000), between 200 tiles and that a 128 x 64 tile (21 flop per staged byte instead of 16, twice the

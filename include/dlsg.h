@@ -54,6 +54,8 @@ int dlsg_struct_size(int which);
 #define DLSG_GEMM_TANH 4  /* tanh(.)     */
 #define DLSG_GEMM_FORCE64 256  /* tuning: force the 64x64 block tile  */
 #define DLSG_GEMM_FORCE128 512 /* tuning: force the 128x128 block tile (both FORCE bits: the 128x64 tile) */
+#define DLSG_GEMM_TILE256 2048  /* tuning: force the 256x256 block tile of csrc/gemm_big.hip (with FORCE128: 256x128); EINVAL when
+                                   the operands do not meet its alignment conditions */
 #define DLSG_GEMM_BF16X3 1024  /* split-bf16 matrix path: x = hi + lo, 3 bf16 MFMAs per product, fp32 accumulate
                                   (~1e-5 relative error per product instead of 6e-8; see csrc/gemm_bf16x3.hip) */
 typedef struct {

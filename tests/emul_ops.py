@@ -14,7 +14,7 @@ from emul_critic import CriticEmul
 
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
-F_FORCE64, F_FORCE128, F_BF16X3 = 256, 512, 1024     # tile / precision selectors: no effect on the emulation
+F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256 = 256, 512, 1024, 2048     # tile / precision selectors: no effect on the emulation
 
 _M32 = np.uint64(0xFFFFFFFF)
 
@@ -83,21 +83,6 @@ class EmulOps(CriticEmul):
             if flags & F_TANH:
                 r = torch.tanh(r)
             C.copy_(r)
-
-    def gemm_narrow_kind(self, mode, M, N, K, nbatch=1):
-        """csrc/gemm_narrow.hip: dlsg_gemm_narrow_kind"""
-        if mode == GEMM_TN and M <= 4 and nbatch == 1 and K > 32:
-            return 3
-        if mode in (GEMM_NN, GEMM_TN) and K <= 32:
-            return 1
-        if mode == GEMM_NT and N <= 32:
-            return 2
-        return 0
-
-    def gemm_narrow(self, mode, A, B, C, alpha=1.0, bias=None):
-        self._count('gemm_narrow')
-        r = A @ B.transpose(-1, -2) if mode == GEMM_NT else (A @ B if mode == GEMM_NN else A.transpose(-1, -2) @ B)
-        C.copy_(alpha * r if bias is None else alpha * r + bias)
 
     def slab_reduce(self, slabs, out, bias=None, flags=0):
         self._count('slab_reduce')

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from emul_ops import EmulOps, GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH, F_BF16X3, F_FORCE64, F_FORCE128
+from emul_ops import EmulOps, GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH, F_BF16X3, F_FORCE64, F_FORCE128, F_TILE256
 
 pytestmark = pytest.mark.gpu
 
@@ -94,6 +94,65 @@ def test_gemm_128x64_tile(hip, mode, shape):
         ops.gemm(mode, [(A, B, t['C'][:, :N], t['bias']), (A, B2, t['C2'][:, :N2], t['bias'][:N2])], alpha=0.5,
                  flags=F_ACCUM | F_FORCE64 | F_FORCE128)
     both(hip, build, run, ['C', 'C2'], tol=1e-5 * max(1.0, math.sqrt(K)), name='gemm 128x64 %d %s' % (mode, shape))
+
+
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
+@pytest.mark.parametrize('tile', [F_TILE256, F_TILE256 | F_FORCE128])
+@pytest.mark.parametrize('shape', [(256, 256, 32), (600, 520, 100), (260, 132, 36), (512, 1000, 96)])
+def test_gemm_256_tiles(hip, mode, tile, shape):
+    """csrc/gemm_big.hip (256 x 256 and 256 x 128 tiles, LDS-DMA stages): ragged edges, a partial last K stage, strided views,
+    bias + accumulate, two groups of different width"""
+    M, N, K = shape
+
+    def build(g):
+        if mode == GEMM_NT:
+            A, B = rnd(g, M, K + 4), rnd(g, N, K + 4)
+        elif mode == GEMM_NN:
+            A, B = rnd(g, M, K + 4), rnd(g, K, N + 4)
+        else:
+            A, B = rnd(g, K, M + 4), rnd(g, K, N + 4)
+        return dict(A=A, B=B, C=rnd(g, M, N + 5), C2=rnd(g, M, N + 5), bias=rnd(g, N))
+
+    def run(ops, t):
+        N2 = max(4, N // 2 // 4 * 4)
+        if mode == GEMM_NT:
+            A, B, B2 = t['A'][:, :K], t['B'][:, :K], t['B'][:N2, :K]
+        elif mode == GEMM_NN:
+            A, B, B2 = t['A'][:, :K], t['B'][:, :N], t['B'][:, :N2]
+        else:
+            A, B, B2 = t['A'][:, :M], t['B'][:, :N], t['B'][:, :N2]
+        ops.gemm(mode, [(A, B, t['C'][:, :N], t['bias']), (A, B2, t['C2'][:, :N2], t['bias'][:N2])], alpha=0.5, flags=F_ACCUM | tile)
+    both(hip, build, run, ['C', 'C2'], tol=1e-5 * max(1.0, math.sqrt(K)), name='gemm 256 tile %d %s' % (mode, shape))
+
+
+def test_gemm_256_tiles_refuse_unaligned_operands(hip):
+    A, B, C = torch.randn(256, 30, device='cuda'), torch.randn(256, 30, device='cuda'), torch.zeros(256, 256, device='cuda')
+    with pytest.raises(RuntimeError):
+        hip.gemm(GEMM_NT, [(A, B, C)], flags=F_TILE256)          # K = 30: not a multiple of 4, shorter than a stage
+
+
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
+def test_gemm_whole_rounds_on_256_tiles_and_the_rest(hip, mode):
+    """a launch of >= 1000 tiles whose row panels do not come in whole rounds of the 256 CUs: the dispatcher multiplies the
+    first 8192 rows on 256 x 256 tiles and the remaining 300 through the smaller tiles (csrc/gemm.hip, dlsg_gemm)"""
+    M, N, K, G = 8492, 1024, 64, 2
+
+    def build(g):
+        d = {}
+        for i in range(G):
+            if mode == GEMM_NT:
+                d['A%d' % i], d['B%d' % i] = rnd(g, M, K), rnd(g, N, K)
+            elif mode == GEMM_NN:
+                d['A%d' % i], d['B%d' % i] = rnd(g, M, K), rnd(g, K, N)
+            else:
+                d['A%d' % i], d['B%d' % i] = rnd(g, K, M), rnd(g, K, N)
+            d['C%d' % i] = rnd(g, M, N)
+        d['bias'] = rnd(g, N)
+        return d
+
+    def run(ops, t):
+        ops.gemm(mode, [(t['A%d' % i], t['B%d' % i], t['C%d' % i]) for i in range(G)], bias=t['bias'], flags=F_ACCUM | F_TANH)
+    both(hip, build, run, ['C%d' % i for i in range(G)], tol=2e-5, name='head/tail gemm %d' % mode)
 
 
 @pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])

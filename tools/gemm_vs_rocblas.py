@@ -1,0 +1,62 @@
+"""The step's largest products on this repo's fp32 GEMM against PyTorch-ROCm's library call (rocBLAS / hipBLASLt, TF32 off) on the
+same operands: a ceiling check, not a product path.  usage: python3 tools/gemm_vs_rocblas.py"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
+import torch  # noqa: E402
+from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_TILE256, F_FORCE128  # noqa: E402
+
+torch.backends.cuda.matmul.allow_tf32 = False
+ops = HipOps()
+
+
+def timeit(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    st = torch.cuda.Stream()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        with torch.cuda.graph(gr, stream=st):
+            for _ in range(reps):
+                fn()
+    gr.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        gr.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3
+
+
+out = {}
+for name, mode, M, N, K in (('NT region projection 26624 x 1024 x 2048', GEMM_NT, 26624, 1024, 2048),
+                            ('NN input gradient 26624 x 2048 x 1024', GEMM_NN, 26624, 2048, 1024),
+                            ('TN weight gradient 1024 x 2048 x 26624', GEMM_TN, 1024, 2048, 26624),
+                            ('NT 8192^3', GEMM_NT, 8192, 8192, 8192),
+                            ('NT 1664 x 4096 x 1024', GEMM_NT, 1664, 4096, 1024)):
+    if mode == GEMM_NT:
+        A, B = torch.randn(M, K, device='cuda'), torch.randn(N, K, device='cuda')
+        lib = lambda: torch.mm(A, B.t(), out=C2)
+    elif mode == GEMM_NN:
+        A, B = torch.randn(M, K, device='cuda'), torch.randn(K, N, device='cuda')
+        lib = lambda: torch.mm(A, B, out=C2)
+    else:
+        A, B = torch.randn(K, M, device='cuda'), torch.randn(K, N, device='cuda')
+        lib = lambda: torch.mm(A.t(), B, out=C2)
+    C1, C2 = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    us_lib = timeit(lib)
+    gf = 2.0 * M * N * K / 1e9
+    row = {'library_us': round(us_lib, 1), 'library_TFLOPs': round(gf / us_lib * 1e3, 1)}
+    for tag, fl in (('dispatcher', 0), ('tile 256x256', F_TILE256), ('tile 256x128', F_TILE256 | F_FORCE128)):
+        C1.zero_()
+        us_own = timeit(lambda: ops.gemm(mode, [(A, B, C1)], flags=fl))
+        err = ((C1 - C2).abs().max() / C2.abs().max()).item()
+        assert err < 2e-5, (name, tag, err)
+        row[tag] = {'us': round(us_own, 1), 'TFLOPs': round(gf / us_own * 1e3, 1), 'max_rel_diff_vs_library': err}
+    out[name] = row
+print(json.dumps(out, indent=1))
