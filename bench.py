@@ -262,6 +262,12 @@ def gemm_roofline(prof, nsteps, root=ROOT):
     tmpl = {'nt': 'false, false', 'nn': 'false, true', 'tn': 'true, true'}.get(mode, '')
     if tile == '128x128':
         sym = '%s_w3<128, 128, %s, 32>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
+    elif tile.startswith('256x'):
+        # csrc/gemm_big.hip; '256x256+rest': the row panels that come in whole rounds of the CUs on this tile, the rest of the
+        # rows on the smaller tiles, both inside the one timed call
+        sym = 'gemm_big_kernel<256, %s, %s>' % (tile[4:7], tmpl) + (' + the smaller-tile kernel of the remaining rows' if '+' in tile else '')
+    elif tile == '128x64':
+        sym = '%s_w3<128, 64, %s, 64>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
     elif tile == '64x64':
         sym = '%s<64, 64, %s, 64>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
     else:

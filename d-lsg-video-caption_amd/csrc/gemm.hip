@@ -746,30 +746,27 @@ int dlsg_gemm_big_dispatch(const dlsg_gemm_args* a, hipStream_t st, int bn);
 
 extern "C" int dlsg_abi_version(void) { return DLSG_ABI_VERSION; }
 
-extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
-    if (!a || a->ngroups < 1 || a->ngroups > DLSG_GEMM_MAXG || a->nbatch < 1 || a->M < 0 || a->N < 0) return DLSG_EINVAL;
-    if (a->M == 0 || a->N == 0) return DLSG_OK;
-    if ((int64_t)a->ngroups * a->nbatch > 65535) return DLSG_EINVAL;
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+// Which kernel family a call runs on (fp32 path): the ONE place that decides, shared by dlsg_gemm and dlsg_gemm_variant.
+// *m1: rows of the head that DLSG_GEMM_V_256_HEAD multiplies on 256 x 256 tiles (the rest goes through the choice again).
+static int gemm_plan(const dlsg_gemm_args* a, int64_t* m1_out) {
     const int64_t z = (int64_t)a->ngroups * a->nbatch;
     const int64_t tilesL = (int64_t)((a->M + 127) / 128) * ((a->N + 127) / 128) * z;
-    if (a->flags & DLSG_GEMM_BF16X3) return dlsg_gemm_bf16x3_dispatch(a, st);
-    if (a->flags & DLSG_GEMM_TILE256) return dlsg_gemm_big_dispatch(a, st, (a->flags & DLSG_GEMM_FORCE128) ? 128 : 256);
+    if (a->flags & DLSG_GEMM_TILE256) return (a->flags & DLSG_GEMM_FORCE128) ? DLSG_GEMM_V_256x128 : DLSG_GEMM_V_256;
     if ((a->flags & (DLSG_GEMM_FORCE64 | DLSG_GEMM_FORCE128)) == (DLSG_GEMM_FORCE64 | DLSG_GEMM_FORCE128))
-        return launch<128, 64, 64>(a, st);        // both bits: the 128 x 64 tile
-    if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64, 64>(a, st);
-    if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128, 32>(a, st);
+        return DLSG_GEMM_V_128x64;                 // both bits: the 128 x 64 tile
+    if (a->flags & DLSG_GEMM_FORCE64) return DLSG_GEMM_V_64;
+    if (a->flags & DLSG_GEMM_FORCE128) return DLSG_GEMM_V_128;
     // M <= 128, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernels (64- or 128-row tiles)
-    if (a->M <= 128 && a->mode != 2 && a->N >= 64) return launch_skinny(a, st);
+    if (a->M <= 128 && a->mode != 2 && a->N >= 64) return DLSG_GEMM_V_SKINNY;
     // measured on MI355X (tools/gemm_bench.py): the 128x128 tile only wins once it fills the chip several times over
-    // (Wave quantisation is not what these launches lose: giving the 128-tile kernel whole 768-slot rounds only and the remaining
+    // (Wave quantisation is not what the 128-tile launches lose: giving that kernel whole 768-slot rounds only and the remaining
     // row panels to the 64-tile kernel was measured 1-3 % SLOWER on the region projection (4.33 rounds) and on the deep weight
     // gradient (2.67 rounds), tools/gemm_split_probe.py -- workgroups of a partly filled last round simply run faster.)
     if (tilesL >= 1000) {
         // 256 x 256 tiles (gemm_big.hip: one workgroup per CU, 64 flop per staged byte) for as many row panels as come in whole
         // rounds of the 256 CUs -- a launch that leaves its last round mostly empty loses more than the tile gains (region
         // projection as one launch of 832 tiles = 3.25 rounds: 108 TFLOP/s against 122 on the 128 x 128 tile, 135-142 per full
-        // round) -- and the remaining rows through the dispatch below.  tools/gemm_vs_rocblas.py, tools/gemm_census.py.
+        // round) -- and the remaining rows through this choice again.  tools/gemm_vs_rocblas.py, tools/gemm_census.py.
         bool plain = dlsg_gemm_big_ok(a) != 0;
         for (int i = 0; i < a->ngroups && plain; ++i) plain = a->g[i].N == 0 || a->g[i].N == a->N;
         const int64_t pad_n = (a->N + 255) / 256 * 256;
@@ -778,25 +775,14 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
             int64_t g = panel, b = 256;
             while (b) { const int64_t t = g % b; g = b; b = t; }       // gcd(panel, 256)
             const int64_t need = 256 / g;                              // row panels per whole number of rounds
-            const int64_t main_rt = (a->M / 256) / need * need;
-            const int64_t m1 = main_rt * 256;
-            if (m1 == a->M || (a->M - m1) * 4 <= a->M) {               // whole rounds cover (nearly) everything
-                if (m1 == a->M) return dlsg_gemm_big_dispatch(a, st, 256);
-                if (m1 > 0) {
-                    dlsg_gemm_args head = *a, tail = *a;
-                    head.M = (int)m1;
-                    tail.M = a->M - (int)m1;
-                    for (int i = 0; i < a->ngroups; ++i) {
-                        const int64_t ldc = a->g[i].ldc ? a->g[i].ldc : (int64_t)a->ldc;
-                        tail.g[i].A = a->g[i].A + (a->mode == 2 ? m1 : m1 * a->g[i].lda);
-                        tail.g[i].C = a->g[i].C + m1 * ldc;
-                    }
-                    const int rc = dlsg_gemm_big_dispatch(&head, st, 256);
-                    return rc != DLSG_OK ? rc : dlsg_gemm(&tail, stream);
-                }
+            const int64_t m1 = (a->M / 256) / need * need * 256;
+            if (m1 == a->M) return DLSG_GEMM_V_256;
+            if (m1 > 0 && (a->M - m1) * 4 <= a->M) {                   // whole rounds cover nearly everything
+                if (m1_out) *m1_out = m1;
+                return DLSG_GEMM_V_256_HEAD;
             }
         }
-        return launch<128, 128, 32>(a, st);
+        return DLSG_GEMM_V_128;
     }
     // Mid-size launches (tools/gemm_tile_probe.py; M = 1664 = 26 frames x 64 clips and the weight gradients over them), when
     // the 128-row panels waste < 10 % of their rows: the TN form takes the 128 x 128 tile from 500 tiles (2048 x 2048 x 1664 x 3
@@ -806,10 +792,49 @@ extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
     if ((padM - a->M) * 10 <= a->M) {
         // (500-999 tiles: only the TN form gains from the square tile -- 2048 x 2048 x 1664 x 3: 343 us against 354; the BiLSTM's
         // input projection NT 1664 x 4096 x 1024 x 2 runs 264 us on 128 x 64 against 284, tools/gemm_mid_probe.py)
-        if (tilesL >= 500 && a->mode == 2) return launch<128, 128, 32>(a, st);       // (1024 x 1024 x 512 x 8 groups: 82 us against 100)
-        if (tilesL >= 200) return launch<128, 64, 64>(a, st);
+        if (tilesL >= 500 && a->mode == 2) return DLSG_GEMM_V_128;       // (1024 x 1024 x 512 x 8 groups: 82 us against 100)
+        if (tilesL >= 200) return DLSG_GEMM_V_128x64;
     }
-    return launch<64, 64, 64>(a, st);
+    return DLSG_GEMM_V_64;
+}
+
+static bool gemm_args_ok(const dlsg_gemm_args* a) {
+    return a && a->ngroups >= 1 && a->ngroups <= DLSG_GEMM_MAXG && a->nbatch >= 1 && a->M >= 0 && a->N >= 0 &&
+           (int64_t)a->ngroups * a->nbatch <= 65535;
+}
+
+extern "C" int dlsg_gemm_variant(const dlsg_gemm_args* a) {
+    if (!gemm_args_ok(a)) return DLSG_EINVAL;
+    if (a->flags & DLSG_GEMM_BF16X3) return DLSG_EINVAL;       // (the split-bf16 path has its own tile rule, gemm_bf16x3.hip)
+    return gemm_plan(a, nullptr);
+}
+
+extern "C" int dlsg_gemm(const dlsg_gemm_args* a, void* stream) {
+    if (!gemm_args_ok(a)) return DLSG_EINVAL;
+    if (a->M == 0 || a->N == 0) return DLSG_OK;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (a->flags & DLSG_GEMM_BF16X3) return dlsg_gemm_bf16x3_dispatch(a, st);
+    int64_t m1 = 0;
+    switch (gemm_plan(a, &m1)) {
+        case DLSG_GEMM_V_256: return dlsg_gemm_big_dispatch(a, st, 256);
+        case DLSG_GEMM_V_256x128: return dlsg_gemm_big_dispatch(a, st, 128);
+        case DLSG_GEMM_V_256_HEAD: {
+            dlsg_gemm_args head = *a, tail = *a;
+            head.M = (int)m1;
+            tail.M = a->M - (int)m1;
+            for (int i = 0; i < a->ngroups; ++i) {
+                const int64_t ldc = a->g[i].ldc ? a->g[i].ldc : (int64_t)a->ldc;
+                tail.g[i].A = a->g[i].A + (a->mode == 2 ? m1 : m1 * a->g[i].lda);
+                tail.g[i].C = a->g[i].C + m1 * ldc;
+            }
+            const int rc = dlsg_gemm_big_dispatch(&head, st, 256);
+            return rc != DLSG_OK ? rc : dlsg_gemm(&tail, stream);
+        }
+        case DLSG_GEMM_V_SKINNY: return launch_skinny(a, st);
+        case DLSG_GEMM_V_128: return launch<128, 128, 32>(a, st);
+        case DLSG_GEMM_V_128x64: return launch<128, 64, 64>(a, st);
+        default: return launch<64, 64, 64>(a, st);
+    }
 }
 
 extern "C" int dlsg_slab_reduce(const float* slabs, int nslab, int64_t slab_stride, const float* bias, float* out,

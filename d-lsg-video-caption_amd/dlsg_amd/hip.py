@@ -222,7 +222,7 @@ class DecattCacheGradsArgs(C.Structure):
 
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
-SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
+SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_gemm_variant', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
            'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_colsum_ws_floats', 'dlsg_colsum_multi', 'dlsg_colsum_multi_ok', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
@@ -254,6 +254,7 @@ def load_library(path=LIB_PATH):
         'dlsg_abi_version': [],
         'dlsg_struct_size': [i32],
         'dlsg_gemm': [P(GemmArgs), vp],
+        'dlsg_gemm_variant': [P(GemmArgs)],
         'dlsg_slab_reduce': [vp, i32, i64, vp, vp, i64, i32, i32, i32, vp],
         'dlsg_rowln_fwd': [P(RowLnArgs), vp],
         'dlsg_rowln_bwd': [P(RowLnBwdArgs), vp],
@@ -481,17 +482,20 @@ class HipOps(object):
                 e0 = self._prof_begin()
         self._check(self.lib.dlsg_gemm(C.byref(a), self._stream()), 'dlsg_gemm')
         if e0 is not None:
-            # same dispatch rule as dlsg_gemm (csrc/gemm.hip, csrc/gemm_bf16x3.hip)
             x3 = bool(a.flags & F_BF16X3)
-            tiles_l = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups)
-            if M <= 128 and mode != GEMM_TN and N >= 64:
-                variant = 'skinny_64x32' if M <= 64 else 'skinny_128x32'
-            elif tiles_l >= 1000:
-                variant = '128x128'
-            elif not x3 and ((M + 127) // 128 * 128 - M) * 10 <= M and tiles_l >= 200:
-                variant = '128x128' if (tiles_l >= 500 and mode == GEMM_TN) else '128x64'
+            if x3:
+                # the split-bf16 dispatch rule (csrc/gemm_bf16x3.hip)
+                tiles_l = ((M + 127) // 128) * ((N + 127) // 128) * nb * len(groups)
+                if a.flags & (F_FORCE64 | F_FORCE128):
+                    variant = '64x64' if a.flags & F_FORCE64 else '128x128'
+                elif M <= 64 and mode != GEMM_TN and N >= 64:
+                    variant = 'skinny_64x32'
+                else:
+                    variant = '128x128' if tiles_l >= 1000 else '64x64'
             else:
-                variant = '64x64'
+                v = self.lib.dlsg_gemm_variant(C.byref(a))         # the library's own answer (csrc/gemm.hip, gemm_plan)
+                variant = {0: '64x64', 1: '128x64', 2: '128x128', 3: 'skinny_64x32' if M <= 64 else 'skinny_128x32', 4: '256x256',
+                           5: '256x128', 6: '256x256+rest'}[v]
             # one key per kernel symbol (arithmetic, tile, operand layout), as rocprofv3 --stats lists them
             ks = sorted(set(a.g[i].K for i in range(len(groups))))
             shape = '%s M=%d N=%d K=%s groups=%d batch=%d' % (('NT', 'NN', 'TN')[mode], M, N, '/'.join(map(str, ks)), len(groups), nb)

@@ -82,6 +82,17 @@ typedef struct {
     dlsg_gemm_group g[DLSG_GEMM_MAXG];
 } dlsg_gemm_args;
 int dlsg_gemm(const dlsg_gemm_args* args, void* stream);
+/* The kernel family dlsg_gemm runs this call on (fp32 arithmetic; EINVAL with DLSG_GEMM_BF16X3): what a profiler's kernel
+ * symbol will be, without repeating the dispatch rule on the caller's side. */
+#define DLSG_GEMM_V_64 0        /* gemm_kernel<64, 64, ...> */
+#define DLSG_GEMM_V_128x64 1    /* gemm_kernel_w3<128, 64, ...> */
+#define DLSG_GEMM_V_128 2       /* gemm_kernel_w3<128, 128, ...> */
+#define DLSG_GEMM_V_SKINNY 3    /* skinny_kernel / skinny2_nt_kernel (M <= 128) */
+#define DLSG_GEMM_V_256 4       /* gemm_big_kernel<256, 256, ...> */
+#define DLSG_GEMM_V_256x128 5   /* gemm_big_kernel<256, 128, ...> */
+#define DLSG_GEMM_V_256_HEAD 6  /* gemm_big_kernel<256, 256, ...> on the row panels that come in whole rounds of the CUs, the
+                                   remaining rows through the choice again */
+int dlsg_gemm_variant(const dlsg_gemm_args* args);
 
 /* out[r, :] = sum_s slabs[s][r, :] (+ bias) (tanh); slabs are nslab consecutive (rows x n) arrays. */
 int dlsg_slab_reduce(const float* slabs, int nslab, int64_t slab_stride, const float* bias, float* out,

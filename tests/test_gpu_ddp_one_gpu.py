@@ -65,7 +65,9 @@ def test_two_ranks_on_one_gpu_match_mean_of_shard_gradients(tmp_path, use_graphs
     f0, f1 = np.load(tmp_path / 'flat0.npy'), np.load(tmp_path / 'flat1.npy')
     assert np.array_equal(f0, f1)                           # replicas stay bit-identical
     if use_graphs:
-        assert np.load(tmp_path / 'meta0.npy')[1] == 4      # capture was cut at the three bucket boundaries
+        # the capture is cut at every bucket hand-off: decoder, the two pre-encoders' bucket, the graph modules without their
+        # obj_embed weights, then each of those two weights behind its own product (model.py, _engine_backward) + the closing segment
+        assert np.load(tmp_path / 'meta0.npy')[1] == 6
     # single process: two steps, each = Adam on the mean of the two shards' gradients
     import dlsg_amd
     net, frames, regions, caps, lens = _build()

@@ -8,13 +8,18 @@ import csv
 import json
 import sys
 
-SYMS = {   # prof key -> (kernel symbols of one launch group, in dispatch order; '?' = optional follower)
-    'gemm_f32_mfma_128x128_tn': ['gemm_kernel_w3<128, 128, true, true, 32>'],
-    'gemm_f32_mfma_128x128_nt': ['gemm_kernel_w3<128, 128, false, false, 32>'],
-    'gemm_f32_mfma_128x128_nn': ['gemm_kernel_w3<128, 128, false, true, 32>'],
+SYMS = {   # prof key -> (kernel symbols of one launch group, in dispatch order; '?' = optional follower, '1?' = at most one,
+           # and only as the very next dispatch)
     'o2v_graph_fwd': ['o2v16_kernel<', '?o2v_combine_multi_kernel'],
     'o2v_graph_bwd': ['o2v16_bwd_scores_kernel<', 'o2v16_bwd_apply_kernel<', '?o2v_combine_multi_kernel'],
 }
+for _mode, _t in (('nt', 'false, false'), ('nn', 'false, true'), ('tn', 'true, true')):
+    SYMS['gemm_f32_mfma_64x64_' + _mode] = ['gemm_kernel<64, 64, %s, 64>' % _t]
+    SYMS['gemm_f32_mfma_128x64_' + _mode] = ['gemm_kernel_w3<128, 64, %s, 64>' % _t]
+    SYMS['gemm_f32_mfma_128x128_' + _mode] = ['gemm_kernel_w3<128, 128, %s, 32>' % _t]
+    SYMS['gemm_f32_mfma_256x256_' + _mode] = ['gemm_big_kernel<256, 256, %s>' % _t]
+    # whole rounds on the 256 tile + the remaining rows on a smaller tile, one timed call (csrc/gemm.hip, gemm_plan)
+    SYMS['gemm_f32_mfma_256x256+rest_' + _mode] = ['gemm_big_kernel<256, 256, %s>' % _t, '1?gemm_kernel']
 
 
 def last_step(path):
@@ -34,17 +39,25 @@ for key, syms in SYMS.items():
     per = []
     for rows, cname in ((fetch, 'FETCH_SIZE'), (write, 'WRITE_SIZE')):
         # walk the step: every dispatch of syms[0] opens a launch group, followers join it
-        groups, cur = [], None
+        groups, cur, prev_head = [], None, False
         for r in rows:
             n = r['Kernel_Name']
             if syms[0] in n:
                 cur = [float(r['Counter_Value'])]
                 groups.append(cur)
-            elif cur is not None and any(s.lstrip('?') in n for s in syms[1:]):
+                prev_head = True
+                continue
+            if cur is not None and any(s.startswith('1?') and s[2:] in n for s in syms[1:]):
+                if prev_head:
+                    cur.append(float(r['Counter_Value']))
+                cur = None                  # only the dispatch right behind the head belongs to the call
+            elif cur is not None and any(not s.startswith('1?') and s.lstrip('?') in n for s in syms[1:]):
                 cur.append(float(r['Counter_Value']))
-            elif cur is not None and not any(s.lstrip('?') in n for s in syms):
-                if key.startswith('o2v'):
-                    cur = None          # a foreign kernel ends the group
+            elif cur is not None and key.startswith('o2v'):
+                cur = None                  # a foreign kernel ends the group
+            elif cur is not None and any(s.startswith('1?') for s in syms[1:]):
+                cur = None
+            prev_head = False
         per.append([sum(g) for g in groups])
     if len(per[0]) != len(mine) or len(per[1]) != len(mine):
         print('skip %s: %d logged launches, %d / %d dispatch groups' % (key, len(mine), len(per[0]), len(per[1])), file=sys.stderr)
