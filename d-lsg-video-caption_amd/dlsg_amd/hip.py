@@ -389,6 +389,7 @@ class HipOps(object):
                                % (self.lib.dlsg_abi_version(), ABI_VERSION))
         self.prof = None          # set to {} by bench.py: key -> list of (start event, end event, algorithmic work)
         self.extra_flags = 0      # OR-ed into every dlsg_gemm call (precision policy: F_BF16X3), set by the model
+        self.prof_min_flops = 2e9  # dlsg_gemm calls below this are not bracketed by profile events (tools/pmc_step_target.py: 0)
 
     # ------------------------------------------------------------------ live per-kernel timing (bench.py roofline)
     def _prof_begin(self):
@@ -478,7 +479,7 @@ class HipOps(object):
         e0 = None
         if self.prof is not None:
             flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))
-            if flops >= 2e9:     # only the heavy launches are timed, so the events do not perturb the step
+            if flops >= self.prof_min_flops:     # only the heavy launches are timed, so the events do not perturb the step
                 e0 = self._prof_begin()
         self._check(self.lib.dlsg_gemm(C.byref(a), self._stream()), 'dlsg_gemm')
         if e0 is not None:

@@ -32,6 +32,7 @@ for it in range(3):
     if it == 2:
         ops = net.ops
         ops.prof = {}
+        ops.prof_min_flops = 0.0          # log EVERY dlsg_gemm call: the counters are attributed by position in the step
         orig = ops._prof_end
 
         def log(key, e0, work, shape='', *rest, _orig=orig):

@@ -31,6 +31,8 @@ def last_step(path):
 
 
 fetch, write, calls = last_step(sys.argv[1]), last_step(sys.argv[2]), json.load(open(sys.argv[3]))
+# heads of the calls that ran as 'whole rounds on the 256 tile + the rest on a smaller tile'
+rest_heads = [SYMS[c['key']][0] for c in calls if c['key'] in SYMS and '+rest' in c['key']]
 out = collections.OrderedDict()
 for key, syms in SYMS.items():
     mine = [c for c in calls if c['key'] == key]
@@ -39,9 +41,12 @@ for key, syms in SYMS.items():
     per = []
     for rows, cname in ((fetch, 'FETCH_SIZE'), (write, 'WRITE_SIZE')):
         # walk the step: every dispatch of syms[0] opens a launch group, followers join it
-        groups, cur, prev_head = [], None, False
+        groups, cur, prev_head, prev_name = [], None, False, ''
         for r in rows:
             n = r['Kernel_Name']
+            was, prev_name = prev_name, n
+            if '256' not in key and any(h in was for h in rest_heads):
+                continue                    # the smaller-tile launch right behind a '+rest' head belongs to THAT call
             if syms[0] in n:
                 cur = [float(r['Counter_Value'])]
                 groups.append(cur)
