@@ -32,8 +32,9 @@ int dlsg_abi_version(void);
 /* sizeof() of the i-th argument struct below (0 gemm_args, 1 rowln_args, 2 rowln_bwd_args, 3 o2v_args, 4 decatt_args,
  * 5 decatt_bwd_args, 6 lstm_pw_args, 7 lstm_pw_bwd_args, 8 dec_mid_args, 9 dec_tail_args, 10 dec_mid_bwd_args, 11 decatt_cache_grads_args,
  * 12 o2v_bwd_args, 13 latent_psl_args, 14 sa_core_args, 15 beam_select_args,
- * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args, 19 bilstm_args, 20 bilstm_bwd_args, 21 colsum_desc): lets a binding verify its
- * struct layout without a GPU. */
+ * 16 gather_multi_args, 17 sa_core_bwd_args, 18 latent_psl_bwd_args, 19 bilstm_args, 20 bilstm_bwd_args, 21 colsum_desc,
+ * 22 lstm_seq_args, 23 cln_args, 24 crit_sa_args, 25 crit_pattn_args, 26 crit_tsum_args, 27 crit_score_args, 28 crit_colsum_desc,
+ * 29 crit_reduce_desc): lets a binding verify its struct layout without a GPU. */
 int dlsg_struct_size(int which);
 
 /* ---------------------------------------------------------------- GEMM (fp32-in / fp32-acc MFMA 32x32x2)
