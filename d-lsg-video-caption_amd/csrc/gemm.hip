@@ -219,15 +219,24 @@ __device__ __forceinline__ void gemm_body(const KArgs& p) {
             const int col = n0 + wn * WN + j * 32 + r;
             if (col >= Ng) continue;
             const float bv = use_bias ? biasp[col] : 0.f;
+            const int64_t ldc = grp.ldc ? grp.ldc : (int64_t)p.ldc;
+            const int rbase = m0 + wm * WM + i * 32 + 4 * h;
+            float* cp = C + (int64_t)rbase * ldc + col;
+            // C += : the tile's 16 old values are loaded together BEFORE the first store (a store may alias the next load as far
+            // as the compiler knows: 16 dependent round trips per tile otherwise)
+            float oldv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float* cp = C + (int64_t)row * (grp.ldc ? grp.ldc : (int64_t)p.ldc) + col;
-                float v = p.alpha * acc[i][j][e] + bv;
-                if (accum) v += *cp;
+                const int ro = (e & 3) + 8 * (e >> 2);
+                oldv[e] = (accum && rbase + ro < p.M) ? cp[(int64_t)ro * ldc] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ro = (e & 3) + 8 * (e >> 2);
+                if (rbase + ro >= p.M) continue;
+                float v = p.alpha * acc[i][j][e] + bv + oldv[e];
                 if (do_tanh) v = tanhf(v);
-                *cp = v;
+                cp[(int64_t)ro * ldc] = v;
             }
         }
 }
@@ -767,6 +776,8 @@ static int gemm_plan(const dlsg_gemm_args* a, int64_t* m1_out) {
         // rounds of the 256 CUs -- a launch that leaves its last round mostly empty loses more than the tile gains (region
         // projection as one launch of 832 tiles = 3.25 rounds: 108 TFLOP/s against 122 on the 128 x 128 tile, 135-142 per full
         // round) -- and the remaining rows through this choice again.  tools/gemm_vs_rocblas.py, tools/gemm_census.py.
+        // (groups of different widths -- the decoder's weight-gradient blocks 4096 x {1024 x 10, 300} -- stay on the 128 tile: eight
+        // of the full-width groups as two rounds of 256 tiles and the rest behind them measured 1 313 us against 1 305)
         bool plain = dlsg_gemm_big_ok(a) != 0;
         for (int i = 0; i < a->ngroups && plain; ++i) plain = a->g[i].N == 0 || a->g[i].N == a->N;
         const int64_t pad_n = (a->N + 255) / 256 * 256;

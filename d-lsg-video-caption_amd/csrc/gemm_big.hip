@@ -191,15 +191,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const int col = n0 + wn * WN + j * 32 + r;
             if (col >= Ng) continue;
             const float bv = use_bias ? biasp[col] : 0.f;
+            float* cp = C + (int64_t)(m0 + wm * WM + i * 32 + 4 * h) * ldc + col;
+            const int rbase = m0 + wm * WM + i * 32 + 4 * h;
+            // C += : the 16 old values of the tile are loaded together BEFORE the first store (the compiler cannot prove that a
+            // store does not alias the next load and would otherwise wait for 16 dependent round trips per tile)
+            float oldv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * WM + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                float* cp = C + (int64_t)row * ldc + col;
-                float v = p.alpha * acc[i][j][e] + bv;
-                if (accum) v += *cp;
+                const int ro = (e & 3) + 8 * (e >> 2);
+                oldv[e] = (accum && rbase + ro < p.M) ? cp[(int64_t)ro * ldc] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ro = (e & 3) + 8 * (e >> 2);
+                if (rbase + ro >= p.M) continue;
+                float v = p.alpha * acc[i][j][e] + bv + oldv[e];
                 if (do_tanh) v = tanhf(v);
-                *cp = v;
+                cp[(int64_t)ro * ldc] = v;
             }
         }
 }

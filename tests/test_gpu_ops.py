@@ -156,6 +156,34 @@ def test_gemm_whole_rounds_on_256_tiles_and_the_rest(hip, mode):
 
 
 @pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
+def test_gemm_whole_rounds_of_groups_on_256_tiles_and_the_rest(hip, mode):
+    """a grouped launch whose groups differ in width (the decoder's weight-gradient blocks): eight of the nine full-width groups
+    make one round of 256 tiles, the ninth and the narrow one go through the smaller tiles (csrc/gemm.hip, DLSG_GEMM_V_256_GROUPS)"""
+    M, N, K = 2048, 1024, 64
+    widths = [1024, 1024, 300, 1024, 1024, 1024, 1024, 1024, 1024, 1024]
+
+    def build(g):
+        d = {}
+        for i, wd in enumerate(widths):
+            if mode == GEMM_NT:
+                d['A%d' % i], d['B%d' % i] = rnd(g, M, K), rnd(g, wd, K)
+            elif mode == GEMM_NN:
+                d['A%d' % i], d['B%d' % i] = rnd(g, M, K), rnd(g, K, wd + (4 - wd % 4) % 4)
+            else:
+                d['A%d' % i], d['B%d' % i] = rnd(g, K, M), rnd(g, K, wd + (4 - wd % 4) % 4)
+            d['C%d' % i] = rnd(g, M, wd)
+        return d
+
+    def run(ops, t):
+        groups = []
+        for i, wd in enumerate(widths):
+            B = t['B%d' % i] if mode == GEMM_NT else t['B%d' % i][:, :wd]
+            groups.append((t['A%d' % i], B, t['C%d' % i]))
+        ops.gemm(mode, groups, alpha=0.5, flags=F_ACCUM)
+    both(hip, build, run, ['C%d' % i for i in range(len(widths))], tol=2e-5, name='group head/tail gemm %d' % mode)
+
+
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
 @pytest.mark.parametrize('shape', [(1664, 2048, 40, 3), (1000, 2048, 64, 2), (1664, 2048, 24, 4)])
 def test_gemm_mid_size_tile_choice(hip, mode, shape):
     """launches whose tile the dispatcher picks itself: 624 / 256 (128x64) and 832 (128x128) 128-square tiles"""
