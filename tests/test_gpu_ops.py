@@ -156,9 +156,8 @@ def test_gemm_whole_rounds_on_256_tiles_and_the_rest(hip, mode):
 
 
 @pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
-def test_gemm_whole_rounds_of_groups_on_256_tiles_and_the_rest(hip, mode):
-    """a grouped launch whose groups differ in width (the decoder's weight-gradient blocks): eight of the nine full-width groups
-    make one round of 256 tiles, the ninth and the narrow one go through the smaller tiles (csrc/gemm.hip, DLSG_GEMM_V_256_GROUPS)"""
+def test_gemm_many_groups_of_different_width(hip, mode):
+    """a grouped launch of >= 1000 tiles whose groups differ in width (the decoder's weight-gradient blocks), with C += and alpha"""
     M, N, K = 2048, 1024, 64
     widths = [1024, 1024, 300, 1024, 1024, 1024, 1024, 1024, 1024, 1024]
 
