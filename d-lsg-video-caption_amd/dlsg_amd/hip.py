@@ -434,8 +434,9 @@ class HipOps(object):
             raise RuntimeError('%s failed with code %d' % (what, rc))
 
     # ------------------------------------------------------------------ GEMM
-    def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None, skip_if=None):
-        """groups: list of (A, B, C[, bias]) views (2-d, or 3-d batched with identical batch strides across groups)."""
+    def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None, skip_if=None, plan_only=False):
+        """groups: list of (A, B, C[, bias]) views (2-d, or 3-d batched with identical batch strides across groups).
+        plan_only: nothing is launched; returns the tile family the library would run the call on (dlsg_gemm_variant)."""
         a = GemmArgs()
         A0, B0, C0 = groups[0][:3]
         batched = A0.dim() == 3
@@ -476,6 +477,8 @@ class HipOps(object):
             g.lda, g.ldb, g.K, g.N = A.stride(-2), B.stride(-2), K, (Ng if Ng != N else 0)
             g.bias = _p(grp_[3]) if len(grp_) > 3 else None
             g.ldc = Cc.stride(-2) if Cc.stride(-2) != a.ldc else 0
+        if plan_only:
+            return int(self.lib.dlsg_gemm_variant(C.byref(a)))
         e0 = None
         if self.prof is not None:
             flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))

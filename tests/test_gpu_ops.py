@@ -125,6 +125,30 @@ def test_gemm_256_tiles(hip, mode, tile, shape):
     both(hip, build, run, ['C', 'C2'], tol=1e-5 * max(1.0, math.sqrt(K)), name='gemm 256 tile %d %s' % (mode, shape))
 
 
+def test_gemm_variant_names_the_tile_family(hip):
+    """dlsg_gemm_variant == the choice dlsg_gemm makes (include/dlsg.h DLSG_GEMM_V_*), on the shapes DESIGN.md quotes"""
+    def plan(mode, M, N, K, G=1, flags=0):
+        dev = 'cuda'
+        if mode == GEMM_NT:
+            A, B = torch.empty(M, K, device=dev), torch.empty(N, K, device=dev)
+        elif mode == GEMM_NN:
+            A, B = torch.empty(M, K, device=dev), torch.empty(K, N, device=dev)
+        else:
+            A, B = torch.empty(K, M, device=dev), torch.empty(K, N, device=dev)
+        Cc = torch.empty(M, N, device=dev)
+        return hip.gemm(mode, [(A, B, Cc)] * G, flags=flags, plan_only=True)
+    assert plan(GEMM_NT, 64, 4096, 1024, 4) == 3                 # recurrent product: skinny kernels
+    assert plan(GEMM_NT, 128, 4096, 1024, 4) == 3
+    assert plan(GEMM_TN, 64, 4096, 1024) != 3                    # (row-contiguous A: not a skinny shape)
+    assert plan(GEMM_NT, 200, 130, 37) == 0                      # 64 x 64
+    assert plan(GEMM_NT, 1664, 2048, 2048, 3) == 1               # 128 x 64
+    assert plan(GEMM_TN, 2048, 2048, 1664, 3) == 2               # 128 x 128
+    assert plan(GEMM_TN, 1024, 2048, 3328, 16) == 4              # whole launch on 256 x 256: 512 tiles = two rounds of the CUs
+    assert plan(GEMM_NT, 26624, 1024, 2048, 2) == 6              # 96 row panels in three rounds on 256 x 256, 8 panels on smaller tiles
+    assert plan(GEMM_NT, 26624, 1024, 2046, 2) == 2              # K % 4 != 0: the LDS-DMA tiles do not take it
+    assert plan(GEMM_NT, 512, 512, 64, flags=F_TILE256) == 4 and plan(GEMM_NT, 512, 512, 64, flags=F_TILE256 | F_FORCE128) == 5
+
+
 def test_gemm_256_tiles_refuse_unaligned_operands(hip):
     A, B, C = torch.randn(256, 30, device='cuda'), torch.randn(256, 30, device='cuda'), torch.zeros(256, 256, device='cuda')
     with pytest.raises(RuntimeError):
