@@ -34,11 +34,23 @@ def timeit(fn, reps=10):
 
 
 out = {}
-for name, mode, M, N, K in (('NT region projection 26624 x 1024 x 2048', GEMM_NT, 26624, 1024, 2048),
-                            ('NN input gradient 26624 x 2048 x 1024', GEMM_NN, 26624, 2048, 1024),
-                            ('TN weight gradient 1024 x 2048 x 26624', GEMM_TN, 1024, 2048, 26624),
-                            ('NT 8192^3', GEMM_NT, 8192, 8192, 8192),
-                            ('NT 1664 x 4096 x 1024', GEMM_NT, 1664, 4096, 1024)):
+CASES = (('NT region projection 26624 x 1024 x 2048', GEMM_NT, 26624, 1024, 2048),
+         ('NN input gradient 26624 x 2048 x 1024', GEMM_NN, 26624, 2048, 1024),
+         ('TN weight gradient 1024 x 2048 x 26624', GEMM_TN, 1024, 2048, 26624),
+         ('NT 8192^3', GEMM_NT, 8192, 8192, 8192),
+         ('NT 1664 x 4096 x 1024', GEMM_NT, 1664, 4096, 1024),
+         # mid-size products of the step (one group of the grouped launches)
+         ('NT 1664 x 2048 x 2048', GEMM_NT, 1664, 2048, 2048), ('NN 1664 x 2048 x 2048', GEMM_NN, 1664, 2048, 2048),
+         ('TN 2048 x 2048 x 1664', GEMM_TN, 2048, 2048, 1664), ('NN 1664 x 1024 x 4096', GEMM_NN, 1664, 1024, 4096),
+         ('NT 1664 x 1024 x 6144', GEMM_NT, 1664, 1024, 6144), ('TN 1024 x 6144 x 1664', GEMM_TN, 1024, 6144, 1664),
+         ('TN 4096 x 1024 x 1664', GEMM_TN, 4096, 1024, 1664), ('NT 1664 x 1000 x 1024', GEMM_NT, 1664, 1000, 1024),
+         # recurrent products (one launch of the word loop as ONE product over the concatenated K)
+         ('NT 64 x 4096 x 4096 (language gates)', GEMM_NT, 64, 4096, 4096), ('NT 64 x 4096 x 2348 (query gates)', GEMM_NT, 64, 4096, 2348),
+         ('NN 64 x 4096 x 4096 (d language-cell inputs)', GEMM_NN, 64, 4096, 4096), ('NT 128 x 4096 x 4096', GEMM_NT, 128, 4096, 4096),
+         # critic
+         ('NT 4992 x 2048 x 512', GEMM_NT, 4992, 2048, 512), ('NT 1664 x 512 x 512', GEMM_NT, 1664, 512, 512),
+         ('TN 512 x 1536 x 6656', GEMM_TN, 512, 1536, 6656), ('NN 4992 x 512 x 1536', GEMM_NN, 4992, 512, 1536))
+for name, mode, M, N, K in CASES:
     if mode == GEMM_NT:
         A, B = torch.randn(M, K, device='cuda'), torch.randn(N, K, device='cuda')
         lib = lambda: torch.mm(A, B.t(), out=C2)
@@ -52,7 +64,7 @@ for name, mode, M, N, K in (('NT region projection 26624 x 1024 x 2048', GEMM_NT
     us_lib = timeit(lib)
     gf = 2.0 * M * N * K / 1e9
     row = {'library_us': round(us_lib, 1), 'library_TFLOPs': round(gf / us_lib * 1e3, 1)}
-    for tag, fl in (('dispatcher', 0), ('tile 256x256', F_TILE256), ('tile 256x128', F_TILE256 | F_FORCE128)):
+    for tag, fl in (('dispatcher', 0),) + ((('tile 256x256', F_TILE256), ('tile 256x128', F_TILE256 | F_FORCE128)) if (K % 4 == 0 and M >= 1024) else ()):
         C1.zero_()
         us_own = timeit(lambda: ops.gemm(mode, [(A, B, C1)], flags=fl))
         err = ((C1 - C2).abs().max() / C2.abs().max()).item()
