@@ -201,6 +201,7 @@ class GanTrainer(object):
 
     def __init__(self, model, D, lr=1.6e-4, betas=(0.5, 0.9), num_D=5, gan_lambda=0.01, total_step=1, cap_list=None,
                  process_group=None, world_size=1, use_graphs=None, eps=1e-8):
+        self._loss_host = None            # pinned word the generator step's caption loss is copied into (iteration)
         from .model import Trainer
         self.model, self.D = model, D
         on_gpu = next(D.parameters()).is_cuda
@@ -354,9 +355,11 @@ class GanTrainer(object):
         torch.cuda.current_stream().wait_stream(side)
         st['graphs'] = (gP, gA, gB)
 
-    def train_disc(self, captions, logits_tm, obj, mot, smask, alpha, alias=False):
+    def train_disc(self, captions, logits_tm, obj, mot, smask, alpha, alias=False, as_tensor=False):
         """run_gun.py:339-381: num_D critic updates.  logits_tm (L,B,V): the generator's logits, time-major as its decoder writes
-        them.  alias: see _critic_static.  Returns (mean loss_D, mean Wasserstein estimate) as floats."""
+        them.  alias: see _critic_static.  Returns (mean loss_D, mean Wasserstein estimate) as floats -- or, as_tensor, as a
+        2-element device tensor (means over ranks included) WITHOUT a host synchronisation: `iteration` reads it back together
+        with the generator's losses, so the device does not drain between the critic updates and the generator step."""
         D, eng = self.D, self.D.engine
         self._bind_D()
         L, B, V = logits_tm.shape
@@ -393,6 +396,13 @@ class GanTrainer(object):
                 self._adam_D(hyper=torch.tensor(self._hyper_D(), dtype=torch.float32).to(dev))
                 acc += stats
         acc /= self.num_D
+        if as_tensor:
+            t = torch.stack([acc[0], acc[4]])
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.all_reduce(t, group=self.pg)
+                t /= self.world_size
+            return t
         return self._rank_mean(acc[0]), self._rank_mean(acc[4])
 
     # ------------------------------------------------------------------ the critic's term of the generator step (run_gun.py:214-231)
@@ -458,7 +468,7 @@ class GanTrainer(object):
             D.ops.permute_tb(f_caption.contiguous(), logits_tm)                           # (B,L,V) -> (L,B,V)
         else:
             logits_tm, obj, mot, alpha = fwd
-        loss_D, wass = self.train_disc(captions, logits_tm, obj, mot, smask, alpha, alias=fwd is not None)
+        d_stats = self.train_disc(captions, logits_tm, obj, mot, smask, alpha, alias=fwd is not None, as_tensor=True)
         # ---- Train the captioning model (run_gun.py:180-234)
         out = {}
 
@@ -470,11 +480,24 @@ class GanTrainer(object):
             g = dst if dst is not None else torch.empty_like(logits_tm)
             # the critic's forward and backward do not depend on gan_lambda: they are enqueued BEFORE the caption loss is read back
             # (a host synchronisation), so the device works through them while the host updates the weight
+            # the caption loss goes to the host through a copy + event issued BEFORE the critic's launches: the host has it (and
+            # with it gan_lambda) while the device is still working through them, and enqueues the rest of the step without a gap
+            pending = None
+            if self.world_size <= 1 and sv['loss_dev'].is_cuda:
+                if self._loss_host is None:
+                    self._loss_host = torch.empty(1, dtype=torch.float32).pin_memory()
+                self._loss_host.copy_(sv['loss_dev'].detach().reshape(1), non_blocking=True)
+                pending = torch.cuda.Event()
+                pending.record()
             finish = self._generator_term(logits_tm.detach(), obj_, mot_, smask, alpha_, g)
             out['cap_loss_dev'] = sv['loss_dev']
             # the reference updates lambda from the caption loss of THIS step before using it (run_gun.py:210,224)
             # -- with several ranks the all-reduced mean, as the reference feeds it (run_gun.py:202-203,212)
-            out['cap_loss_record'] = self._rank_mean(sv['loss_dev'])
+            if pending is not None:
+                pending.synchronize()
+                out['cap_loss_record'] = float(self._loss_host[0])
+            else:
+                out['cap_loss_record'] = self._rank_mean(sv['loss_dev'])
             self.lambda_handler.update_gan_lambda(epoch, i, out['cap_loss_record'])
             out['gan_lambda'] = self.lambda_handler.get_current_lambda()
             out['loss_G'] = finish(out['gan_lambda'])
@@ -482,13 +505,21 @@ class GanTrainer(object):
         gan_term.takes_dst = True
         cap_loss = self.trainer.step(frames, regions, captions, cap_lens, tf_ratio, max_len=max_len, extra_dlogits=gan_term)
         # cap_loss / loss_G: this rank's values (what its backward used); *_record: the means over ranks the reference logs
-        out.update(cap_loss=float(cap_loss), loss_G_record=self._rank_mean(out['loss_G']), loss_G=float(out['loss_G']),
-                   loss_D=loss_D, wasserstein=wass)
+        # ONE read-back for the iteration's remaining scalars (the caption loss was read once already, for gan_lambda)
+        loss_G_record = self._rank_mean(out['loss_G']) if self.world_size > 1 else None
+        word = getattr(model.ops, 'persist_word_or_none', lambda: None)()         # the persistent kernels' time-out word rides along
+        vals = torch.cat([cap_loss.detach().reshape(1).float(), out['loss_G'].detach().reshape(1).float(), d_stats.float()] +
+                         ([word.float()] if word is not None else [])).tolist()
+        out.update(cap_loss=vals[0], loss_G_record=vals[1] if loss_G_record is None else loss_G_record, loss_G=vals[1],
+                   loss_D=vals[2], wasserstein=vals[3])
         out['total_loss'] = out['cap_loss'] + out['loss_G'] * out['gan_lambda']
         out.pop('cap_loss_dev')
         check = getattr(model.ops, 'check_persistent', None)
         if check is not None:
-            check()                        # the losses above were read back: the device is idle, the time-out words are final
+            if word is not None:
+                check(code=int(vals[4]))   # read back with the losses: the device was idle, the time-out word is final
+            else:
+                check()
         return out
 
 

@@ -880,7 +880,12 @@ class HipOps(object):
             w = self._persist_err = torch.zeros(1, dtype=torch.int32, device=dev)
         return w
 
-    def check_persistent(self):
+    def persist_word_or_none(self):
+        """the time-out word (int32 device tensor) if a persistent kernel ran in this process: a caller that reads scalars back
+        anyway appends it to that read and hands the value to `check_persistent(code=...)` -- one host synchronisation, not two"""
+        return getattr(self, '_persist_err', None)
+
+    def check_persistent(self, code=None):
         """Read the persistent kernels' time-out word: a workgroup that waited ~1 s for another one's flag (the launch was not
         fully co-resident: the device is shared with another process, or another stream held the compute units) sets it; results
         since then are invalid and every Adam launch since then was a no-op (dlsg_adam's guard).  Raises, after switching the
@@ -889,7 +894,8 @@ class HipOps(object):
         w = getattr(self, '_persist_err', None)
         if w is None:
             return
-        code = int(w.item())
+        if code is None:
+            code = int(w.item())
         if code:
             w.zero_()
             self.persistent_bilstm = False
