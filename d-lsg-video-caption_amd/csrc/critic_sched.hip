@@ -107,7 +107,15 @@ __device__ __forceinline__ void chanprod(const float* M, int ldm, const float* _
         x[j] = j < RJ ? ld2(X + (int64_t)j * ldx + 2 * tid) : f32x2{0.f, 0.f};
         if (DUAL) x2[j] = j < RJ ? ld2(X2 + (int64_t)j * ldx2 + 2 * tid) : f32x2{0.f, 0.f};
     }
+    constexpr int IC = 8;               // rows of Y whose old values (accum) are fetched together, ahead of their use
+    f32x2 yo[IC];
     for (int i = 0; i < RI; ++i) {
+        if (accum && (i % IC) == 0) {
+            // Y += : a load -> add -> store per row is a memory round trip per row (26 of them in a row of words); the old values
+            // of the next IC rows are requested at once
+#pragma unroll
+            for (int u = 0; u < IC; ++u) yo[u] = (i + u < RI) ? ld2(Y + (int64_t)(i + u) * ldy + 2 * tid) : f32x2{0.f, 0.f};
+        }
         float m[RJM], m2[DUAL ? RJM : 1];
         if (TR) {
 #pragma unroll
@@ -134,7 +142,12 @@ __device__ __forceinline__ void chanprod(const float* M, int ldm, const float* _
         }
         float* y = Y + (int64_t)i * ldy + 2 * tid;
         f32x2 r = {alpha * acc.x, alpha * acc.y};
-        if (accum) { const f32x2 o = ld2(y); r.x += o.x; r.y += o.y; }
+        if (accum) {
+            f32x2 o = yo[0];
+#pragma unroll
+            for (int u = 1; u < IC; ++u) o = (i % IC) == u ? yo[u] : o;
+            r.x += o.x; r.y += o.y;
+        }
         st2(y, r);
     }
 }
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(256) void cln_bwd_kernel(const dlsg_cln_args a) {
     const int N = a.N, E = N / 64;
     const float* x = a.x[g]; const float* gamma = a.gamma[g];
     float* dx = a.dx[g];
-    const bool want = a.dgamma[g] != nullptr;
+    const bool want = a.dgamma[g] != nullptr || a.defer;
     float* part = a.ws + (int64_t)g * 2 * gridDim.x * N;                    // [group][dgamma | dbeta][workgroup][N]
     const uint64_t seed = seed_of(a.seed, a.seed_ptr);
     float t[EMAX], mp[EMAX], gam[EMAX], pg[EMAX], pb[EMAX];
@@ -661,7 +674,13 @@ __device__ __forceinline__ void words_from_proposals(const float* M1, const floa
         g2[t] = t < T ? ld2(G + (int64_t)t * C + 2 * tid) : f32x2{0.f, 0.f};
         e2[t] = t < T ? ld2(E + (int64_t)t * C + 2 * tid) : f32x2{0.f, 0.f};
     }
+    constexpr int IC = 8;               // (Y += : the old values of IC rows are requested together, see chanprod)
+    f32x2 yo[IC];
     for (int l = 0; l < L; ++l) {
+        if (accum && (l % IC) == 0) {
+#pragma unroll
+            for (int u = 0; u < IC; ++u) yo[u] = (l + u < L) ? ld2(Y + (int64_t)(l + u) * C + 2 * tid) : f32x2{0.f, 0.f};
+        }
         float m1[TMAX], m2[TMAX];
 #pragma unroll
         for (int t = 0; t < TMAX; t += 4) {
@@ -673,7 +692,12 @@ __device__ __forceinline__ void words_from_proposals(const float* M1, const floa
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) { r.x += m1[t] * g2[t].x + m2[t] * e2[t].x; r.y += m1[t] * g2[t].y + m2[t] * e2[t].y; }
         float* y = Y + (int64_t)l * C + 2 * tid;
-        if (accum) { const f32x2 o = ld2(y); r.x += o.x; r.y += o.y; }
+        if (accum) {
+            f32x2 o = yo[0];
+#pragma unroll
+            for (int u = 1; u < IC; ++u) o = (l % IC) == u ? yo[u] : o;
+            r.x += o.x; r.y += o.y;
+        }
         st2(y, r);
     }
 }
@@ -867,12 +891,22 @@ __global__ __launch_bounds__(NT) void tsum_bwd_kernel(const dlsg_crit_tsum_args 
     const f32x2 th = ld2(a.theta + 2 * tid);
     f32x2 dth = {0.f, 0.f};
     float* dw = a.dwords + (int64_t)i0 * L * C;
+    constexpr int IC = 8;               // rows whose loads (the words; with acc the old dwords) are requested together
+    f32x2 yo[IC], wv8[IC];
     for (int l = 0; l < L; ++l) {
-        f32x2 r = {adj_s[l] * du.x + dlg_s[l] * th.x, adj_s[l] * du.y + dlg_s[l] * th.y};
-        float* y = dw + (int64_t)l * C + 2 * tid;
-        if (acc) { const f32x2 o = ld2(y); r.x += o.x; r.y += o.y; }
-        st2(y, r);
-        const f32x2 wv = ld2(words + (int64_t)l * C + 2 * tid);
+        if ((l % IC) == 0) {
+#pragma unroll
+            for (int u = 0; u < IC; ++u) {
+                const bool in = l + u < L;
+                wv8[u] = in ? ld2(words + (int64_t)(l + u) * C + 2 * tid) : f32x2{0.f, 0.f};
+                yo[u] = (in && acc) ? ld2(dw + (int64_t)(l + u) * C + 2 * tid) : f32x2{0.f, 0.f};
+            }
+        }
+        f32x2 o = yo[0], wv = wv8[0];
+#pragma unroll
+        for (int u = 1; u < IC; ++u) { o = (l % IC) == u ? yo[u] : o; wv = (l % IC) == u ? wv8[u] : wv; }
+        const f32x2 r = {adj_s[l] * du.x + dlg_s[l] * th.x + o.x, adj_s[l] * du.y + dlg_s[l] * th.y + o.y};
+        st2(dw + (int64_t)l * C + 2 * tid, r);
         dth.x += dlg_s[l] * wv.x; dth.y += dlg_s[l] * wv.y;
     }
     if (a.part) {
@@ -1332,25 +1366,26 @@ extern "C" int dlsg_cln_bwd(const dlsg_cln_args* a, void* stream) {
         if ((a->dgamma[g] == nullptr) != (a->dbeta[g] == nullptr)) return DLSG_EINVAL;
         want = want || a->dgamma[g];
     }
-    if (want && !a->ws) return DLSG_EINVAL;
+    if ((want || a->defer) && !a->ws) return DLSG_EINVAL;
     const int nb = ln_blocks(a->rows);
     const dim3 grid(nb, a->groups), block(256);
     CLN_DISPATCH(cln_bwd_kernel);
-    if (want) hipLaunchKernelGGL(cln_colsum_kernel, dim3(a->N / 64, 2, a->groups), block, 0, ST(stream), *a, nb, 2, 0);
+    // defer: the per-workgroup partials stay in ws for the caller's own column sums (dlsg_crit_colsum)
+    if (want && !a->defer) hipLaunchKernelGGL(cln_colsum_kernel, dim3(a->N / 64, 2, a->groups), block, 0, ST(stream), *a, nb, 2, 0);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
 extern "C" int dlsg_cln_bwd2(const dlsg_cln_args* a, void* stream) {
     if (!cln_ok(a) || a->ndy < 1 || a->ndy > 3 || !a->ws) return DLSG_EINVAL;
     for (int g = 0; g < a->groups; ++g) {
-        if (!a->x[g] || !a->gamma[g] || !a->U[g] || !a->gx[g] || !a->gdy[g] || !a->gpart[g]) return DLSG_EINVAL;
+        if (!a->x[g] || !a->gamma[g] || !a->U[g] || !a->gx[g] || !a->gdy[g] || (!a->gpart[g] && !a->defer)) return DLSG_EINVAL;
         for (int k = 0; k < a->ndy; ++k)
             if (!a->dy[k][g]) return DLSG_EINVAL;
     }
     const int nb = ln_blocks(a->rows);
     const dim3 grid(nb, a->groups), block(256);
     CLN_DISPATCH(cln_bwd2_kernel);
-    hipLaunchKernelGGL(cln_colsum_kernel, dim3(a->N / 64, 2, a->groups), block, 0, ST(stream), *a, nb, 2, 1);
+    if (!a->defer) hipLaunchKernelGGL(cln_colsum_kernel, dim3(a->N / 64, 2, a->groups), block, 0, ST(stream), *a, nb, 2, 1);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

@@ -245,27 +245,24 @@ class CriticEngine(object):
         ops.crit_tsum_bwd(A('words'), p['theta'], p['ts_g'], p['ts_b'], p['fusion'], A('adj'), A('u'), A('sent'), A('fus'), Cc('c_fus'),
                           cw[0, c0:c1], ts_part, p=pd, site=SITE_TSUM, seed=seed, row0=a0, acc=acc)
         ops.gemm(GEMM_NN, [(b['c_spre'][k, c0:c1].view(Rt, C), p['Ws'][k], b['c_agg'][k, c0:c1].view(Rt, C)) for k in range(2)])
-        x2 = self._x2(ws, 'pn') if want else None
         ops.cln_bwd([t.view(Rt, C) for t in A2('aggpre')], p['pn_g'], [[t.view(Rt, C) for t in C2('c_agg')]],
-                    [t.view(Rt, C) for t in C2('c_aggpre')], params and params['pn_g'], params and params['pn_b'], True,
-                    p_post=pd, site_post=SITE_PSL, seed=seed, row0=row0t, acc=self._rows(acc, T), extra=x2)
+                    [t.view(Rt, C) for t in C2('c_aggpre')], None, None, True,
+                    p_post=pd, site_post=SITE_PSL, seed=seed, row0=row0t, acc=self._rows(acc, T),
+                    defer_ws=self._lnws(ws, 'pn', 0, Rt) if want else None)
         ops.crit_pattn_bwd(A2('a'), e2, ws.smask, A2('P'), C2('c_aggpre'), C2('c_wgt'), C2('c_a'), C2('de') if want else None, sc_a, acc=acc)
-        x2 = self._x2(ws, 'aa') if want else None
         ops.cln_bwd([t.view(R, C) for t in A2('apre')], p['aa_g'], [[t.view(R, C) for t in C2('c_a')]],
-                    [t.view(R, C) for t in C2('c_apre')], params and params['aa_g'], params and params['aa_b'], True, row0=row0,
-                    acc=self._rows(acc, L), extra=x2)
+                    [t.view(R, C) for t in C2('c_apre')], None, None, True, row0=row0,
+                    acc=self._rows(acc, L), defer_ws=self._lnws(ws, 'aa', 0, R) if want else None)
         ops.gemm(GEMM_NN, [(b['c_apre'][k, c0:c1].view(R, C), p['Wa'][k], cw[1 + k, c0:c1].view(R, C)) for k in range(2)])
-        x2 = self._x2(ws, 'an') if want else None
         ops.cln_bwd([A('out').view(R, C)], [p['an_g']], [[cw[k, c0:c1].view(R, C)] for k in range(3)], [Cc('c_out').view(R, C)],
-                    params and [params['an_g']], params and [params['an_b']], True, p_pre=self._sa_drop(), site_pre=SITE_SA, seed=seed,
-                    row0=row0, acc=self._rows(acc, L), extra=x2)
+                    None, None, True, p_pre=self._sa_drop(), site_pre=SITE_SA, seed=seed,
+                    row0=row0, acc=self._rows(acc, L), defer_ws=self._lnws(ws, 'an', 0, R) if want else None)
         ops.gemm(GEMM_NN, [(Cc('c_out').view(R, C), p['Wo'], Cc('c_ctx').view(R, C))])
         ops.crit_sa_bwd(A('KQV'), ws.smask, A('w'), Cc('c_ctx'), Cc('c_KQV'), 1.0 / math.sqrt(D.att.attention_size), acc=acc)
         ops.gemm(GEMM_NN, [(Cc('c_KQV').view(R, 3 * C), p['Wkqv'], Cc('c_y').view(R, C))])
-        x2 = self._x2(ws, 'ln') if want else None
         ops.cln_bwd([A('Hs').view(R, C)], [p['ln_g']], [[Cc('c_y').view(R, C)]], [Cc('c_hs').view(R, C)],
-                    params and [params['ln_g']], params and [params['ln_b']], False, p_post=pd, site_post=SITE_LSTM, seed=seed, row0=row0,
-                    acc=self._rows(acc, L), extra=x2)
+                    None, None, False, p_post=pd, site_post=SITE_LSTM, seed=seed, row0=row0,
+                    acc=self._rows(acc, L), defer_ws=self._lnws(ws, 'ln', 0, R) if want else None)
         inj = acc is not None
         ops.lstm_seq_bwd(A('As'), A('Cs'), p['W_hh'], Cc('c_hs'), ws.get('dAs_inj', 3 * B, L, 4 * C, zero=True)[:nb] if inj else None,
                          ws.get('dCs_inj', 3 * B, L, C, zero=True)[:nb] if inj else None, Cc('DA'), Cc('DH'), Cc('DC'))
@@ -279,11 +276,14 @@ class CriticEngine(object):
     def _rows(acc, k):
         return None if acc is None else (acc[0] * k, acc[1] * k)
 
-    def _x2(self, ws, key):
-        """second-order (dgamma, dbeta) of a LayerNorm, written by the T pass: a list of (2, C) arrays per block"""
+    def _lnws(self, ws, key, level, rows):
+        """where a LayerNorm's backward (level 0: the last backward pass over `rows` rows; level 1: the T pass) leaves the
+        per-workgroup partial sums of (dgamma, dbeta): (G, 2, partial rows, C).  `_param_grads` sums the rows of both levels in the
+        one column-sum launch that also folds the biases -- instead of one small reduction launch behind every LayerNorm kernel"""
         G = 2 if key in ('pn', 'aa') else 1
-        t = ws.get('x2_' + key, G, 2, C, zero=True)
-        return [t[g] for g in range(G)]
+        t = ws.get('lnws%d_%s' % (level, key), G, 2, self.D.ops.cln_ws_rows(rows, C), C)
+        ws.__dict__.setdefault('_lnws_seen', {})[(key, level)] = t
+        return t
 
     # ------------------------------------------------------------------ T: derivative of F and B1 along v, mixed captions
     def _second(self, ws, p, vseed, seed):
@@ -305,23 +305,25 @@ class CriticEngine(object):
         dAs, dCs = ws.get('dAs_inj', 3 * B, L, 4 * C, zero=True)[m0:m1], ws.get('dCs_inj', 3 * B, L, C, zero=True)[m0:m1]
         ops.lstm_seq_bwd2(M('As'), M('Cs'), p['W_hh'], Tn('DH'), Tn('DC'), ubar, dAs, dCs, Tn('Hs'), Tn('Hprev'), ws.get('gDC', B, L, C))
         ops.cln_bwd2([M('Hs').view(R, C)], [p['ln_g']], [[Tn('c_y').view(R, C)]], [Tn('Hs').view(R, C)], [M('c_hs').view(R, C)],
-                     [Tn('y').view(R, C)], self._x2(ws, 'ln'), False, p_post=pd, site_post=SITE_LSTM, seed=seed, row0=row0)
+                     [Tn('y').view(R, C)], None, False, p_post=pd, site_post=SITE_LSTM, seed=seed, row0=row0,
+                     defer_ws=self._lnws(ws, 'ln', 1, R))
         ops.gemm(GEMM_NT, [(Tn('y').view(R, C), p['Wkqv'], Tn('KQV').view(R, 3 * C))])
         ops.crit_sa_bwd2(M('KQV'), ws.smask, M('w'), Tn('c_ctx'), Tn('KQV'), Tn('ctx'), M('c_KQV'), 1.0 / math.sqrt(D.att.attention_size))
         ops.gemm(GEMM_NT, [(Tn('ctx').view(R, C), p['Wo'], Tn('out').view(R, C))])
         cw = b['c_words']
         ops.cln_bwd2([M('out').view(R, C)], [p['an_g']], [[cw[k, t0:t1].view(R, C)] for k in range(3)], [Tn('out').view(R, C)],
-                     [M('c_out').view(R, C)], [Tn('words').view(R, C)], self._x2(ws, 'an'), True, p_pre=self._sa_drop(), site_pre=SITE_SA,
-                     seed=seed, row0=row0)
+                     [M('c_out').view(R, C)], [Tn('words').view(R, C)], None, True, p_pre=self._sa_drop(), site_pre=SITE_SA,
+                     seed=seed, row0=row0, defer_ws=self._lnws(ws, 'an', 1, R))
         ops.gemm(GEMM_NT, [(Tn('words').view(R, C), p['Wa'][k], b['apre'][k, t0:t1].view(R, C)) for k in range(2)])
         ops.cln_bwd2([t.view(R, C) for t in M2('apre')], p['aa_g'], [[t.view(R, C) for t in T2('c_a')]], [t.view(R, C) for t in T2('apre')],
-                     [t.view(R, C) for t in M2('c_apre')], [t.view(R, C) for t in T2('a')], self._x2(ws, 'aa'), True, row0=row0)
+                     [t.view(R, C) for t in M2('c_apre')], [t.view(R, C) for t in T2('a')], None, True, row0=row0,
+                     defer_ws=self._lnws(ws, 'aa', 1, R))
         e2 = [ws.esel[k].view(B, T, C) for k in range(2)]
         ops.crit_pattn_bwd2(M2('a'), e2, ws.smask, M2('P'), T2('c_aggpre'), T2('c_wgt'), T2('a'), T2('aggpre'), T2('wgt'), M2('c_a'), T2('de'),
                             1.0 / math.sqrt(C))
         ops.cln_bwd2([t.view(Rt, C) for t in M2('aggpre')], p['pn_g'], [[t.view(Rt, C) for t in T2('c_agg')]],
                      [t.view(Rt, C) for t in T2('aggpre')], [t.view(Rt, C) for t in M2('c_aggpre')], [t.view(Rt, C) for t in T2('agg')],
-                     self._x2(ws, 'pn'), True, p_post=pd, site_post=SITE_PSL, seed=seed, row0=row0t)
+                     None, True, p_post=pd, site_post=SITE_PSL, seed=seed, row0=row0t, defer_ws=self._lnws(ws, 'pn', 1, Rt))
         uspre = ws.get('uspre', 2, B, T, C)
         ops.gemm(GEMM_NT, [(b['agg'][k, t0:t1].view(Rt, C), p['Ws'][k], uspre[k].view(Rt, C)) for k in range(2)])
         ops.crit_tsum_bwd2(M('words'), p['theta'], p['ts_g'], p['ts_b'], p['fusion'], Tn('c_fus'), Tn('words'), Tn('fus'), cw[0, m0:m1],
@@ -394,9 +396,7 @@ class CriticEngine(object):
         ws.reduces = []
         # ---- the proposal side: cotangents of e_sel and v summed over the caption slots
         c_vpre, c_esel = ws.get('c_vpre', 2, B * T, C), ws.get('c_esel', 2, B * T, C)
-        for k in range(2):
-            ops.slab_reduce(b['c_vcap'][k].view(S, B * T, C), c_vpre[k])
-            ops.slab_reduce(b['de'][k].view(S, B * T, C), c_esel[k])
+        ops.crit_reduce([(b[name][k].view(S, B * T, C), dst[k]) for k in range(2) for name, dst in (('c_vcap', c_vpre), ('de', c_esel))])
         ops.gemm(GEMM_NN, [(c_vpre[k], p['Wv'][k], c_esel[k]) for k in range(2)], flags=F_ACCUM)
         ops.gemm(GEMM_TN, [(c_vpre[k], ws.esel[k], g['Wv'][k]) for k in range(2)])
         if ws.select:
@@ -442,6 +442,14 @@ class CriticEngine(object):
         for k in range(2):
             cs.append(([pw[k, :npr]] + ([pw2[k]] if second else []), g['wc'][k].view(-1), None, 1.0))
             cs.append(([dbc[k:k + 1].view(1, 1)] + ([dbc2[k:k + 1].view(1, 1)] if second else []), g['bcl'][k].view(-1), None, 1.0))
+        # the LayerNorms' (dgamma, dbeta): rows of the partials the backward kernels left (+ the T pass's second-order dgamma)
+        for key, dg, db in (('ln', [g['ln_g']], [g['ln_b']]), ('an', [g['an_g']], [g['an_b']]), ('aa', g['aa_g'], g['aa_b']),
+                            ('pn', g['pn_g'], g['pn_b'])):
+            w0 = ws._lnws_seen[(key, 0)]
+            w1 = ws._lnws_seen.get((key, 1)) if second else None
+            for gi in range(len(dg)):
+                cs.append(([w0[gi, 0]] + ([w1[gi, 0]] if w1 is not None else []), dg[gi].view(-1), None, 1.0))
+                cs.append(([w0[gi, 1]], db[gi].view(-1), None, 1.0))
         self._colsums(ws, cs)
 
     # ------------------------------------------------------------------ one critic update (run_gun.py:343-381)

@@ -117,7 +117,7 @@ _P2 = c_f32p * 2
 class ClnArgs(C.Structure):
     _fields_ = [('x', _P4), ('gamma', _P4), ('beta', _P4), ('y', _P4), ('dy', _P4 * 3), ('dx', _P4), ('dgamma', _P4), ('dbeta', _P4),
                 ('extra', _P4), ('U', _P4), ('gx', _P4), ('gdy', _P4), ('gpart', _P4), ('ws', c_f32p),
-                ('rows', i32), ('N', i32), ('groups', i32), ('pre_tanh', i32), ('ndy', i32), ('acc_lo', i32), ('acc_hi', i32), ('pad_', i32),
+                ('rows', i32), ('N', i32), ('groups', i32), ('pre_tanh', i32), ('ndy', i32), ('acc_lo', i32), ('acc_hi', i32), ('defer', i32),
                 ('eps', f32), ('p_pre', f32), ('p_post', f32), ('site_pre', u32), ('site_post', u32), ('pad2_', u32),
                 ('seed', u64), ('seed_ptr', C.c_void_p), ('row0', i64)]
 
@@ -1168,33 +1168,52 @@ class HipOps(object):
             a.beta[g], a.y[g] = _p(beta[g]), _p(y[g])
         self._check(self.lib.dlsg_cln_fwd(C.byref(a), self._stream()), 'cln_fwd')
 
+    def cln_ws_rows(self, rows, N):
+        """rows of the per-workgroup partial arrays cln_bwd / cln_bwd2 leave in a deferred workspace (G, 2, this, N)"""
+        return int(self.lib.dlsg_cln_ws_floats(rows, N)) // (2 * N)
+
     def cln_bwd(self, x, gamma, dys, dx, dgamma, dbeta, pre_tanh, eps=1e-5, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, seed=0,
-                row0=0, acc=None, extra=None):
+                row0=0, acc=None, extra=None, defer_ws=None):
+        """defer_ws (G, 2, cln_ws_rows, N): the per-workgroup partials of (dgamma, dbeta) are left there, unfolded (the caller sums the
+        rows); dgamma / dbeta / extra are then ignored"""
         a = self._cln_args(x, gamma, pre_tanh, eps, p_pre, site_pre, p_post, site_post, seed, row0)
         self._cln_dys(a, dys)
         for g in range(len(x)):
             _chkc(dx[g])
             a.dx[g] = _p(dx[g])
-            if dgamma:
+            if dgamma and defer_ws is None:
                 a.dgamma[g], a.dbeta[g] = _p(dgamma[g]), _p(dbeta[g])
                 if extra is not None:
                     _chkc(extra[g])
                     a.extra[g] = _p(extra[g])
         if acc is not None:
             a.acc_lo, a.acc_hi = acc
-        ws = self._cln_ws(a, x[0].device) if dgamma else None
+        if defer_ws is not None:
+            _chkc(defer_ws)
+            assert tuple(defer_ws.shape) == (len(x), 2, self.cln_ws_rows(a.rows, a.N), a.N), defer_ws.shape
+            ws, a.defer = defer_ws, 1
+        else:
+            ws = self._cln_ws(a, x[0].device) if dgamma else None
         a.ws = _p(ws)
         self._check(self.lib.dlsg_cln_bwd(C.byref(a), self._stream()), 'cln_bwd')
 
     def cln_bwd2(self, x, gamma, dys, U, gx, gdy, gpart, pre_tanh, eps=1e-5, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, seed=0,
-                 row0=0):
+                 row0=0, defer_ws=None):
         a = self._cln_args(x, gamma, pre_tanh, eps, p_pre, site_pre, p_post, site_post, seed, row0)
         self._cln_dys(a, dys)
         for g in range(len(x)):
-            for t in (U[g], gx[g], gdy[g], gpart[g]):
+            for t in (U[g], gx[g], gdy[g]):
                 _chkc(t)
-            a.U[g], a.gx[g], a.gdy[g], a.gpart[g] = _p(U[g]), _p(gx[g]), _p(gdy[g]), _p(gpart[g])
-        ws = self._cln_ws(a, x[0].device)
+            a.U[g], a.gx[g], a.gdy[g] = _p(U[g]), _p(gx[g]), _p(gdy[g])
+            if defer_ws is None:
+                _chkc(gpart[g])
+                a.gpart[g] = _p(gpart[g])
+        if defer_ws is not None:
+            _chkc(defer_ws)
+            assert tuple(defer_ws.shape) == (len(x), 2, self.cln_ws_rows(a.rows, a.N), a.N), defer_ws.shape
+            ws, a.defer = defer_ws, 1
+        else:
+            ws = self._cln_ws(a, x[0].device)
         a.ws = _p(ws)
         self._check(self.lib.dlsg_cln_bwd2(C.byref(a), self._stream()), 'cln_bwd2')
 

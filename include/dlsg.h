@@ -479,7 +479,10 @@ typedef struct {
     float* dgamma[DLSG_CLN_MAXG]; float* dbeta[DLSG_CLN_MAXG]; const float* extra[DLSG_CLN_MAXG];
     const float* U[DLSG_CLN_MAXG]; float* gx[DLSG_CLN_MAXG]; float* gdy[DLSG_CLN_MAXG]; float* gpart[DLSG_CLN_MAXG];
     float* ws;
-    int32_t rows, N, groups, pre_tanh, ndy, acc_lo, acc_hi, pad_;
+    int32_t rows, N, groups, pre_tanh, ndy, acc_lo, acc_hi;
+    int32_t defer; /* != 0: dlsg_cln_bwd / dlsg_cln_bwd2 leave the per-workgroup partial sums in ws -- [group][dgamma | dbeta]
+                    * [dlsg_cln_ws_floats(rows, N) / (2 N) rows][N], bwd2 fills the dgamma half only (its dbeta is zero) -- and do
+                    * not fold them: the caller sums the rows with the other column sums of its step (dlsg_crit_colsum) */
     float eps, p_pre, p_post; uint32_t site_pre, site_post, pad2_;
     uint64_t seed; const uint64_t* seed_ptr; int64_t row0;
 } dlsg_cln_args;

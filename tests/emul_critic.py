@@ -248,8 +248,12 @@ class CriticEmul(object):
             mpre, mpost = self._cln_masks(g, x[g].shape[0], x[g].shape[1], x[g], p_pre, site_pre, p_post, site_post, seed, row0)
             y[g].copy_(cln_f(x[g], gamma[g], beta[g], pre_tanh, eps, mpre, mpost))
 
+    def cln_ws_rows(self, rows, N):
+        """the emulation leaves ONE row of partials (the HIP kernels: one per workgroup)"""
+        return 1
+
     def cln_bwd(self, x, gamma, dys, dx, dgamma, dbeta, pre_tanh, eps=1e-5, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, seed=0,
-                row0=0, acc=None, extra=None):
+                row0=0, acc=None, extra=None, defer_ws=None):
         """dys: list (<= 3) of lists of G arrays, summed to dy; acc = (lo, hi): rows [lo, hi) of every block are added to dx instead
         of written; dgamma / dbeta: lists of G destinations or None; extra: optional list of G (2, N) arrays added to them"""
         for g in range(len(x)):
@@ -261,13 +265,15 @@ class CriticEmul(object):
             if acc is not None:
                 d[acc[0]:acc[1]] += dx[g][acc[0]:acc[1]]
             dx[g].copy_(d)
-            if dgamma is not None:
+            if defer_ws is not None:
+                defer_ws[g, 0, 0].copy_(dg); defer_ws[g, 1, 0].copy_(db)
+            elif dgamma is not None:
                 if extra is not None:
                     dg, db = dg + extra[g][0], db + extra[g][1]
                 dgamma[g].copy_(dg); dbeta[g].copy_(db)
 
     def cln_bwd2(self, x, gamma, dys, U, gx, gdy, gpart, pre_tanh, eps=1e-5, p_pre=0.0, site_pre=0, p_post=0.0, site_post=0, seed=0,
-                 row0=0):
+                 row0=0, defer_ws=None):
         """gx = d/dU of cln_b's dx, gdy = d/dU of cln_f (the tangent of y), gpart[g] (2, N) = d/dU of (dgamma, dbeta)"""
         for g in range(len(x)):
             dy = dys[0][g]
@@ -279,7 +285,10 @@ class CriticEmul(object):
             _, ty = jvp(lambda x_: cln_f(x_, ga, torch.zeros_like(ga), pre_tanh, eps, mpre, mpost), (x[g].detach(),), (U[g].detach(),))
             _, tb = jvp(lambda x_: cln_b(x_, ga, dy, pre_tanh, eps, mpre, mpost), (x[g].detach(),), (U[g].detach(),))
             gdy[g].copy_(ty); gx[g].copy_(tb[0])
-            gpart[g][0].copy_(tb[1]); gpart[g][1].copy_(tb[2])
+            if defer_ws is not None:
+                defer_ws[g, 0, 0].copy_(tb[1])              # (the dbeta half is zero by construction and is not read)
+            else:
+                gpart[g][0].copy_(tb[1]); gpart[g][1].copy_(tb[2])
 
     # ---- masked self-attention core on [K | Q | V] rows
     @staticmethod

@@ -147,6 +147,35 @@ def test_layernorm_levels(rows, N, G, drop, pre_tanh):
                       [torch.zeros(rows, N) for _ in range(G)], [torch.zeros(2, N) for _ in range(G)], pre_tanh], kw, tol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize('rows,N,G', [(50, 512, 2), (1664, 512, 1), (4992, 512, 2)])
+def test_layernorm_deferred_partials_sum_to_the_folded_gradients(rows, N, G):
+    """cln_bwd / cln_bwd2 with defer_ws leave per-workgroup partials (G, 2, ws rows, N): their row sums are the (dgamma, dbeta) /
+    the second-order dgamma the folding launch writes (critic.CriticEngine folds them with its other column sums)"""
+    ops = hip_ops()
+    x = dev([rnd(rows, N, seed=g) for g in range(G)])
+    gamma = dev([1 + 0.1 * rnd(N, seed=10 + g) for g in range(G)])
+    dys = dev([[rnd(rows, N, seed=30 + k + g) for g in range(G)] for k in range(2)])
+    U = dev([rnd(rows, N, seed=60 + g) for g in range(G)])
+    kw = dict(p_pre=0.3, site_pre=3, seed=0x1234567, row0=17)
+    z = lambda *s: torch.zeros(*s, device='cuda')
+    dx0, dx1 = [z(rows, N) for _ in range(G)], [z(rows, N) for _ in range(G)]
+    dg, db = [z(N) for _ in range(G)], [z(N) for _ in range(G)]
+    ops.cln_bwd(x, gamma, dys, dx0, dg, db, True, **kw)
+    wsb = torch.full((G, 2, ops.cln_ws_rows(rows, N), N), float('nan'), device='cuda')
+    ops.cln_bwd(x, gamma, dys, dx1, None, None, True, defer_ws=wsb, **kw)
+    gp = [z(2, N) for _ in range(G)]
+    gx0, gy0, gx1, gy1 = ([z(rows, N) for _ in range(G)] for _ in range(4))
+    ops.cln_bwd2(x, gamma, dys, U, gx0, gy0, gp, True, **kw)
+    wst = torch.full((G, 2, ops.cln_ws_rows(rows, N), N), float('nan'), device='cuda')
+    ops.cln_bwd2(x, gamma, dys, U, gx1, gy1, None, True, defer_ws=wst, **kw)
+    torch.cuda.synchronize()
+    for g in range(G):
+        assert torch.equal(dx0[g], dx1[g]) and torch.equal(gx0[g], gx1[g]) and torch.equal(gy0[g], gy1[g])
+        for got, want in ((wsb[g, 0].sum(0), dg[g]), (wsb[g, 1].sum(0), db[g]), (wst[g, 0].sum(0), gp[g][0])):
+            assert torch.isfinite(got).all()
+            assert (got - want).abs().max().item() <= 1e-4 + 1e-5 * want.abs().max().item()
+
+
 @pytest.mark.parametrize('n,B,L', [(6, 3, 9), (8, 4, 26)])
 def test_self_attention_levels(n, B, L):
     KQV = rnd(n, L, 3 * C, scale=0.7)
