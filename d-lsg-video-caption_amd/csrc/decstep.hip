@@ -280,8 +280,17 @@ __global__ __launch_bounds__(DT) void dec_mid_bwd_kernel(const dlsg_dec_mid_bwd_
         xq[i] = 0.f; rec[i] = 0.f;
         if (j < Q) {
             xq[i] = a.qh[(int64_t)b * Q + j];
-            if (a.rec_slabs)
-                for (int k = 0; k < a.rec_nslab; ++k) rec[i] += a.rec_slabs[k * a.rec_slab_stride + (int64_t)b * a.rec_ld + j];
+            if (a.rec_slabs) {
+                // four slabs per round trip (a load -> add per slab waits for each load in turn)
+                const float* rp = a.rec_slabs + (int64_t)b * a.rec_ld + j;
+                int k = 0;
+                for (; k + 4 <= a.rec_nslab; k += 4) {
+                    const float t0 = rp[(int64_t)k * a.rec_slab_stride], t1 = rp[(int64_t)(k + 1) * a.rec_slab_stride],
+                                t2 = rp[(int64_t)(k + 2) * a.rec_slab_stride], t3 = rp[(int64_t)(k + 3) * a.rec_slab_stride];
+                    rec[i] += t0; rec[i] += t1; rec[i] += t2; rec[i] += t3;
+                }
+                for (; k < a.rec_nslab; ++k) rec[i] += rp[(int64_t)k * a.rec_slab_stride];
+            }
         }
     }
     if (threadIdx.x < ns * P) {

@@ -738,7 +738,13 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, i
         const int64_t rrow = i / n;
         const int col = (int)(i - rrow * n);
         float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += slabs[k * stride + i];
+        int k = 0;
+        for (; k + 4 <= nslab; k += 4) {               // four slabs per round trip; same order of additions
+            const float t0 = slabs[k * stride + i], t1 = slabs[(k + 1) * stride + i], t2 = slabs[(k + 2) * stride + i],
+                        t3 = slabs[(k + 3) * stride + i];
+            s += t0; s += t1; s += t2; s += t3;
+        }
+        for (; k < nslab; ++k) s += slabs[k * stride + i];
         if ((flags & DLSG_GEMM_BIAS) && bias) s += bias[col];
         float* op = out + rrow * ldo + col;
         if (flags & DLSG_GEMM_ACCUM) s += *op;

@@ -411,7 +411,14 @@ __global__ __launch_bounds__(256) void lstm_pw_bwd_kernel(const PwBwdSet set) {
         if (a.dh3) d2 += a.dh3[(int64_t)b * a.lddh3 + j];
         if (a.dh4) {
             const int ns4 = a.dh4_nslab > 1 ? a.dh4_nslab : 1;
-            for (int k = 0; k < ns4; ++k) d2 += a.dh4[k * a.dh4_slab_stride + (int64_t)b * a.lddh4 + j];
+            const float* hp = a.dh4 + (int64_t)b * a.lddh4 + j;
+            int k = 0;
+            for (; k + 4 <= ns4; k += 4) {             // four slabs per round trip; same order of additions
+                const float t0 = hp[(int64_t)k * a.dh4_slab_stride], t1 = hp[(int64_t)(k + 1) * a.dh4_slab_stride],
+                            t2 = hp[(int64_t)(k + 2) * a.dh4_slab_stride], t3 = hp[(int64_t)(k + 3) * a.dh4_slab_stride];
+                d2 += t0; d2 += t1; d2 += t2; d2 += t3;
+            }
+            for (; k < ns4; ++k) d2 += hp[(int64_t)k * a.dh4_slab_stride];
         }
         if (a.p > 0.f) d2 *= drop_scale(a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull), a.site, (uint64_t)b * H + j, a.p);
         dh += d2;
