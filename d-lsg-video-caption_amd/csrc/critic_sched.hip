@@ -1298,7 +1298,15 @@ __global__ __launch_bounds__(256) void crit_reduce_kernel(const ReducePack pk) {
     const int64_t i = ((int64_t)(blockIdx.x - pk.first[di]) * 256 + threadIdx.x) * 4;
     if (i >= d.n) return;
     f32x4 acc = *reinterpret_cast<const f32x4*>(d.src + i);
-    for (int k = 1; k < d.nslab; ++k) acc += *reinterpret_cast<const f32x4*>(d.src + (int64_t)k * d.stride + i);
+    int k = 1;
+    for (; k + 4 <= d.nslab; k += 4) {                 // four slabs per round trip; same order of additions
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(d.src + (int64_t)k * d.stride + i),
+                    t1 = *reinterpret_cast<const f32x4*>(d.src + (int64_t)(k + 1) * d.stride + i),
+                    t2 = *reinterpret_cast<const f32x4*>(d.src + (int64_t)(k + 2) * d.stride + i),
+                    t3 = *reinterpret_cast<const f32x4*>(d.src + (int64_t)(k + 3) * d.stride + i);
+        acc += t0; acc += t1; acc += t2; acc += t3;
+    }
+    for (; k < d.nslab; ++k) acc += *reinterpret_cast<const f32x4*>(d.src + (int64_t)k * d.stride + i);
     *reinterpret_cast<f32x4*>(d.out + i) = d.scale * acc;
 }
 

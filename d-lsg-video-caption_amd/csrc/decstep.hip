@@ -65,10 +65,16 @@ __device__ __forceinline__ void cell_row(int b, int N, const float* slabs, int n
 #pragma unroll
                 for (int e = 0; e < V; ++e) acc[e] += t[u][e];
         }
-        for (; k < nslab; ++k) {
-            vload<V>(t[0], sp + k * slab_stride);
+        if (k < nslab) {                                   // the last 1-3 slabs: requested together as well (the query gates come in 3)
+            const int rem = nslab - k;
 #pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] += t[0][e];
+            for (int u = 0; u < 3; ++u)
+                if (u < rem) vload<V>(t[u], sp + (k + u) * slab_stride);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (u < rem)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += t[u][e];
         }
         if (addend) { vload<V>(t[0], addend + (int64_t)b * ldadd + col);
 #pragma unroll
@@ -313,10 +319,16 @@ __global__ __launch_bounds__(DT) void dec_mid_bwd_kernel(const dlsg_dec_mid_bwd_
 #pragma unroll
                 for (int e = 0; e < V; ++e) acc[e] += t[u][e];
         }
-        for (; k < a.nslab; ++k) {
-            vload<V>(t[0], sp + k * a.slab_stride);
+        if (k < a.nslab) {
+            const int rem = a.nslab - k;
 #pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] += t[0][e];
+            for (int u = 0; u < 3; ++u)
+                if (u < rem) vload<V>(t[u], sp + (k + u) * a.slab_stride);
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (u < rem)
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += t[u][e];
         }
         if (col < NX) vstore<V>(dxb + col, acc);
         else vstore<V>(a.dlh_rec + (int64_t)b * D + (col - NX), acc);
