@@ -51,6 +51,13 @@ template <int V>
 __device__ __forceinline__ void cell_row(int b, int N, const float* slabs, int nslab, int64_t slab_stride, const float* addend,
                                          int64_t ldadd, const float* b_ih, const float* b_hh, const float* c_prev, float* c_out,
                                          float* h_out, float* gates, float p, uint32_t site, uint64_t seed, float* gb, float* hb) {
+    // (c_prev is needed after the gates: requested with them, not a round trip later)
+    float cpv[MAXW / DT];
+#pragma unroll
+    for (int i = 0; i < MAXW / DT; ++i) {
+        const int j = threadIdx.x + i * DT;
+        cpv[i] = (c_prev && j < N) ? c_prev[(int64_t)b * N + j] : 0.f;
+    }
     for (int col = threadIdx.x * V; col < 4 * N; col += DT * V) {
         float acc[V], t[4][V];
 #pragma unroll
@@ -92,8 +99,11 @@ __device__ __forceinline__ void cell_row(int b, int N, const float* slabs, int n
         vstore<V>(gb + col, acc);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < N; j += DT) {
-        const float cp = c_prev ? c_prev[(int64_t)b * N + j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXW / DT; ++i) {
+        const int j = threadIdx.x + i * DT;
+        if (j >= N) break;
+        const float cp = cpv[i];
         const float c = gb[N + j] * cp + gb[j] * gb[2 * N + j];
         float h = gb[3 * N + j] * tanhf(c);
         c_out[(int64_t)b * N + j] = c;
@@ -227,13 +237,24 @@ __global__ __launch_bounds__(DT) void dec_tail_fwd_kernel(const dlsg_dec_tail_ar
     const int b = blockIdx.x;
     const int D = a.D;
     const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
+    constexpr int ND = MAXW / DT;
+    float lg[ND], lb[ND];                     // (requested with the gates, used after the statistics)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int j = threadIdx.x + i * DT;
+        lg[i] = j < D ? a.ln_g[j] : 0.f; lb[i] = j < D ? a.ln_b[j] : 0.f;
+    }
     cell_row<V>(b, D, a.slabs, a.nslab, a.slab_stride, nullptr, 0, a.b_ih, a.b_hh, a.c_prev, a.c, a.hd, a.gates, a.p, a.site,
                 seed, gb, hb);
     float mean, rstd;
     ln_stats(hb, D, a.eps, red, mean, rstd);
     if (threadIdx.x == 0) { a.st_l[2 * b] = mean; a.st_l[2 * b + 1] = rstd; }
-    for (int j = threadIdx.x; j < D; j += DT)
-        a.dout[(int64_t)b * D + j] = tanhf((hb[j] - mean) * rstd * a.ln_g[j] + a.ln_b[j]);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int j = threadIdx.x + i * DT;
+        if (j >= D) break;
+        a.dout[(int64_t)b * D + j] = tanhf((hb[j] - mean) * rstd * lg[i] + lb[i]);
+    }
 }
 
 
