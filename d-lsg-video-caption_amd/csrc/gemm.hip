@@ -496,7 +496,10 @@ __device__ __forceinline__ void s2_glds(const char* src, char* dst) {
 // contiguous k range, so that its consecutive stages are the two halves of the same 128-B lines: 22.3 / 28.9 / 16.4; nor did
 // issuing the next stage's pieces one by one between the MFMA groups instead of together: 22.0 / 29.6 / 17.4.  The launch is
 // as long as its bytes take through the CUs' load paths, whatever the schedule around them.)
-template <int MI, int NJ>
+// BT: the weights are (K x N) row-major (the NN form: input gradients): a stage's weight block is [16 k][32 columns], one 128-B
+// row per k, read by b32 with lanes on consecutive banks; the activation side is the same.  (Until round 4 the NN form ran on the
+// register-staged first kernel: 32.1 us against 26.5 for the same 64 x 4096 x 4096 product.)
+template <int MI, int NJ, bool BT = false>
 __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
     constexpr int S2_A_BYTES = MI * S2_B_BYTES;
     constexpr int SLOT = S2_A_BYTES + NJ * S2_B_BYTES;
@@ -526,8 +529,14 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
     }
 #pragma unroll
     for (int pc = 0; pc < 2 * NJ; ++pc) {
-        const int R = 16 * pc + rho;
-        srcB[pc] = B + (int64_t)min(n0 + R, N - 1) * grp.ldb + 4 * (sig ^ ((R >> 2) & 3));
+        if (!BT) {
+            const int R = 16 * pc + rho;
+            srcB[pc] = B + (int64_t)min(n0 + R, N - 1) * grp.ldb + 4 * (sig ^ ((R >> 2) & 3));
+        } else {
+            // piece pc = k-rows 8 (pc & 1) .. + 7 of column block pc >> 1; lane -> (k-row, 16-B segment = 4 columns)
+            const int kr = 8 * (pc & 1) + (lane >> 3), c = n0 + 32 * (pc >> 1) + 4 * (lane & 7);
+            srcB[pc] = B + (int64_t)kr * grp.ldb + min(c, N - 4);
+        }
     }
     const int nst = (K + S2_STAGE - 1) / S2_STAGE;            // stages of the whole K range
     const int mine = (nst - w + 3) / 4;                        // stages s = w, w + 4, ... of this wave
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
         for (int pc = 0; pc < 2 * MI; ++pc) s2_glds<16>(reinterpret_cast<const char*>(srcA[pc] + koff), slot + pc * 1024);
 #pragma unroll
         for (int pc = 0; pc < 2 * NJ; ++pc)
-            s2_glds<16>(reinterpret_cast<const char*>(srcB[pc] + koff), slot + S2_A_BYTES + pc * 1024);
+            s2_glds<16>(reinterpret_cast<const char*>(BT ? srcB[pc] + (int64_t)koff * grp.ldb : srcB[pc] + koff), slot + S2_A_BYTES + pc * 1024);
     };
 
     f32x16 acc[MI][NJ];
@@ -564,7 +573,8 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
 #pragma unroll
         for (int nj = 0; nj < NJ; ++nj) {
             const int R = 32 * nj + r;
-            offB[nj][q] = S2_A_BYTES + (R >> 4) * 1024 + (R & 15) * 64 + ((ks ^ ((R >> 2) & 3)) * 16);
+            offB[nj][q] = BT ? S2_A_BYTES + nj * 2048 + (4 * ks) * 128 + r * 4
+                             : S2_A_BYTES + (R >> 4) * 1024 + (R & 15) * 64 + ((ks ^ ((R >> 2) & 3)) * 16);
         }
     }
     constexpr int PCS = 2 * MI + 2 * NJ;                         // DMA pieces per stage
@@ -590,7 +600,13 @@ __global__ __launch_bounds__(NT) void skinny2_nt_kernel(const KArgs p) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fa[mi][q] = *reinterpret_cast<const f32x4*>(slot + offA[mi][q]);
 #pragma unroll
-            for (int nj = 0; nj < NJ; ++nj) fb[nj][q] = *reinterpret_cast<const f32x4*>(slot + offB[nj][q]);
+            for (int nj = 0; nj < NJ; ++nj) {
+                if (!BT) fb[nj][q] = *reinterpret_cast<const f32x4*>(slot + offB[nj][q]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[nj][q][j] = *reinterpret_cast<const float*>(slot + offB[nj][q] + j * 128);
+                }
+            }
         }
         if (part) {
             // the stage was fetched from kbase (< k0): keep only k in [k0, K), zero the rest (already counted by earlier stages)
@@ -662,6 +678,10 @@ int launch_skinny_mi(const dlsg_gemm_args* a, const KArgs& k, hipStream_t st) {
                                   s2_lds_bytes(MI, 1));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<MI, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   s2_lds_bytes(MI, 2));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<MI, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  s2_lds_bytes(MI, 1));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny2_nt_kernel<MI, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  s2_lds_bytes(MI, 2));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<false, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   skinny_lds_bytes(MI));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_kernel<true, MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -688,7 +708,30 @@ int launch_skinny_mi(const dlsg_gemm_args* a, const KArgs& k, hipStream_t st) {
             hipLaunchKernelGGL((skinny_kernel<false, MI>), grid, block, skinny_lds_bytes(MI), st, k);
         }
     } else {
-        hipLaunchKernelGGL((skinny_kernel<true, MI>), grid, block, skinny_lds_bytes(MI), st, k);
+        // NN form on the same LDS-DMA ring when the operands are 16-B aligned and the widths multiples of 4
+        bool ok = a->nbatch == 1;
+        for (int i = 0; i < a->ngroups && ok; ++i) {
+            const dlsg_gemm_group& g = a->g[i];
+            const int gn = g.N > 0 ? g.N : a->N;
+            ok = (g.K % 4 == 0) && g.K >= S2_STAGE && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (gn % 4 == 0) && gn >= 4 &&
+                 ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+        }
+        if (ok) {
+            // 64-column workgroups (one per CU) only when every group is as wide as the launch: groups of different widths leave
+            // empty workgroups in the grid, and at one workgroup per CU the real ones behind them wait for a second round
+            // (the language cell's [W_ih | W_hh] gradients: 49 us on 64-column workgroups, 32 on the first kernel)
+            bool same_n = true;
+            for (int i = 0; i < a->ngroups; ++i) same_n = same_n && (a->g[i].N == 0 || a->g[i].N == a->N);
+            const int wg64 = ((a->N + 63) / 64) * a->ngroups * a->nbatch;
+            if (wg64 >= 224 && same_n) {
+                dim3 grid2((a->N + 63) / 64, a->ngroups * a->nbatch, 1);
+                hipLaunchKernelGGL((skinny2_nt_kernel<MI, 2, true>), grid2, block, s2_lds_bytes(MI, 2), st, k);
+            } else {
+                hipLaunchKernelGGL((skinny2_nt_kernel<MI, 1, true>), grid, block, s2_lds_bytes(MI, 1), st, k);
+            }
+        } else {
+            hipLaunchKernelGGL((skinny_kernel<true, MI>), grid, block, skinny_lds_bytes(MI), st, k);
+        }
     }
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
