@@ -159,6 +159,14 @@ def gemm_nn_multi_slabs(ops, dy, Ws, width, ref):
     ns = _nsplit_for(M, tot, 1)
     ns = max(1, min(ns, 16 // len(Ws)))
     bounds = _bwd_bounds(Nn, M, ns)
+    if M <= SKINNY_M and len(set(widths)) > 1:
+        # recurrent products: a launch whose groups are all equally wide runs on 64-column workgroups, one per CU (csrc/gemm.hip,
+        # launch_skinny_mi) -- the wide weight is cut into column blocks as wide as the narrow one when that stays within 16 groups
+        # (the language cell's [W_ih 3072 | W_hh 1024] over four K chunks: 16 groups of 1024 columns)
+        wmin = min(widths)
+        if all(wd % wmin == 0 for wd in widths) and (tot // wmin) * len(bounds) <= 16:
+            Ws = [W[:, c:c + wmin] for W, wd in zip(Ws, widths) for c in range(0, wd, wmin)]
+            widths = [wmin] * len(Ws)
     slabs = _empty(ref, len(bounds), M, width)
     groups, c0 = [], 0
     for W, wd in zip(Ws, widths):
