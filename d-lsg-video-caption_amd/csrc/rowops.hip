@@ -16,15 +16,25 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_fwd_kernel(const dlsg_rowln_
     __shared__ float red[16];
     const int n = a.n;
     const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
+    // gamma / beta are the same for every row, the positional row is known up front: requested with the row itself, not a
+    // memory round trip after the two reductions
+    float gam[LN_MAXPT], bet[LN_MAXPT];
+#pragma unroll
+    for (int i = 0; i < LN_MAXPT; ++i) {
+        const int j = threadIdx.x + i * LN_THREADS;
+        gam[i] = j < n ? a.gamma[j] : 0.f; bet[i] = j < n ? a.beta[j] : 0.f;
+    }
     for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
         const float* x = a.x + (int64_t)row * a.ldx;
         const float* res = a.res ? a.res + (int64_t)row * a.ldres : nullptr;
-        float t[LN_MAXPT];
+        const float* pe = a.pe ? a.pe + (int64_t)(row % a.pe_rows) * n : nullptr;
+        float t[LN_MAXPT], pev[LN_MAXPT];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < LN_MAXPT; ++i) {
             const int j = threadIdx.x + i * LN_THREADS;
             float z = 0.f;
+            pev[i] = (pe && j < n) ? pe[j] : 0.f;
             if (j < n) {
                 z = x[j];
                 if (res) z += res[j];
@@ -43,17 +53,16 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_fwd_kernel(const dlsg_rowln_
         const float rstd = rsqrtf(block_sum(q, red) / n + a.eps);
         if (a.stats && threadIdx.x == 0) { a.stats[2 * (int64_t)row] = mean; a.stats[2 * (int64_t)row + 1] = rstd; }
         float* y = a.y + (int64_t)row * a.ldy;
-        const float* pe = a.pe ? a.pe + (int64_t)(row % a.pe_rows) * n : nullptr;
 #pragma unroll
         for (int i = 0; i < LN_MAXPT; ++i) {
             const int j = threadIdx.x + i * LN_THREADS;
             if (j < n) {
-                float v = (t[i] - mean) * rstd * a.gamma[j] + a.beta[j];
+                float v = (t[i] - mean) * rstd * gam[i] + bet[i];
                 if (a.post_tanh) v = tanhf(v);
                 const uint64_t idx = (uint64_t)row * n + j;
                 if (a.p1 > 0.f) v *= drop_scale(seed, a.site1, idx, a.p1);
                 if (pe) {
-                    v += pe[j];
+                    v += pev[i];
                     if (a.p2 > 0.f) v *= drop_scale(seed, a.site2, idx, a.p2);
                 }
                 y[j] = v;
@@ -76,8 +85,14 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_
         const float* x = a.x + (int64_t)row * a.ldx;
         const float* res = a.res ? a.res + (int64_t)row * a.ldres : nullptr;
         const float* dy = b.dy + (int64_t)row * b.lddy;
+        float* dx = b.dx + (int64_t)row * b.lddx;
         float mean, rstd;
-        float t[LN_MAXPT];
+        float t[LN_MAXPT], dxo[LN_MAXPT];
+#pragma unroll
+        for (int i = 0; i < LN_MAXPT; ++i) {       // dx += : the old values are requested with the row, not after the reductions
+            const int j = threadIdx.x + i * LN_THREADS;
+            dxo[i] = (b.accum_dx && j < n) ? dx[j] : 0.f;
+        }
         if (a.stats) {
             mean = a.stats[2 * (int64_t)row]; rstd = a.stats[2 * (int64_t)row + 1];
 #pragma unroll
@@ -131,7 +146,6 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_
         }
         const float m1 = block_sum(s1, red) / n;
         const float m2 = block_sum(s2, red) / n;
-        float* dx = b.dx + (int64_t)row * b.lddx;
 #pragma unroll
         for (int i = 0; i < LN_MAXPT; ++i) {
             const int j = threadIdx.x + i * LN_THREADS;
@@ -139,8 +153,7 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_
                 const float xh = (t[i] - mean) * rstd;
                 float d = rstd * (gx[i] - m1 - xh * m2);
                 if (a.pre_tanh) d *= (1.f - t[i] * t[i]);   // mode 1: t = tanh(x); mode 2: x is already a tanh output
-                if (b.accum_dx) d += dx[j];
-                dx[j] = d;
+                dx[j] = d + dxo[i];
             }
         }
     }
