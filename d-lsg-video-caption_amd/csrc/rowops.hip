@@ -577,10 +577,11 @@ __global__ __launch_bounds__(256) void select_embed_kernel(const float* __restri
                                                            const int32_t* __restrict__ coins, const float* __restrict__ E,
                                                            int64_t* __restrict__ ids_out, float* __restrict__ out,
                                                            int64_t ldo, int W, float p, uint64_t seed, uint32_t site,
-                                                           int64_t row0, const uint64_t* seed_ptr) {
+                                                           int64_t row0, const uint64_t* seed_ptr, int prefilled) {
     __shared__ float bv[4];
     __shared__ int bi[4];
     __shared__ int64_t chosen;
+    if (prefilled && coins[t] != 0) return;      // teacher-forced step whose word the caller embedded up front: nothing to do
     if (seed_ptr) seed += *seed_ptr;
     const int r = blockIdx.x;
     if (coins[t] != 0) {
@@ -1101,10 +1102,11 @@ extern "C" int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* id
 }
 extern "C" int dlsg_select_embed(const float* logits, int64_t ld, int V, const int64_t* captions, int L, int t,
                                  const int32_t* coins, const float* E, int64_t* ids_out, float* out, int64_t ldo, int rows, int W,
-                                 float p, uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream) {
+                                 float p, uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, int prefilled,
+                                 void* stream) {
     if (rows == 0) return DLSG_OK;
     hipLaunchKernelGGL(select_embed_kernel, dim3(rows), dim3(256), 0, ST(stream), logits, ld, V, captions, L, t, coins, E, ids_out,
-                       out, ldo, W, p, seed, site, row0, seed_ptr);
+                       out, ldo, W, p, seed, site, row0, seed_ptr, prefilled);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }

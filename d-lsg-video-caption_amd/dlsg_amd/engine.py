@@ -871,6 +871,13 @@ def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed, dev_coins=No
     s['pw'] = pw
     if dev_coins is not None:
         ops.embed_fwd(E, ids[0], s['WE'][0], p=pw, seed=seed, site=SITE_WORD, row0=0)
+        pre = captions is not None and L > 1
+        if pre:
+            # the teacher-forced choice of EVERY step in one launch (ids[t + 1] = captions[:, t], its embedding under the mask rows
+            # of slot t + 1): the per-step select_embed then only has work on sampled steps -- with the reference's schedule
+            # (utils ss epsilon 0.95 .. ) that is about one step in twenty
+            ids[1:L].copy_(captions[:, :L - 1].t())
+            ops.embed_fwd(E, ids[1:L].reshape(-1), s['WE'][1:L].view((L - 1) * B, -1), p=pw, seed=seed, site=SITE_WORD, row0=B)
         for t in range(L):
             dec_step(ops, dec, s, t, ref, training, seed, B)
             if t + 1 < L:
@@ -878,7 +885,7 @@ def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed, dev_coins=No
                 # (device coin set) the per-step vocab projection is a no-op and select_embed takes the caption word
                 dec_logits(ops, dec, s, t, t + 1, skip_if=dev_coins[t:t + 1])
                 ops.select_embed(s['LOGITS'][t], captions, t, dev_coins, E, ids[t + 1], s['WE'][t + 1], p=pw, seed=seed,
-                                 site=SITE_WORD, row0=(t + 1) * B)
+                                 site=SITE_WORD, row0=(t + 1) * B, prefilled=pre)
         dec_logits(ops, dec, s, 0, L)          # logits of all steps for the loss, one (L*B)-row product
         return s
     if captions is not None:

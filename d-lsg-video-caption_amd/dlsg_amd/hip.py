@@ -279,7 +279,7 @@ def load_library(path=LIB_PATH):
         'dlsg_mean_rows_bwd': [vp, i64, vp, i32, i32, i32, i32, vp],
         'dlsg_embed_fwd': [vp, vp, vp, i64, i32, i32, f32, u64, u32, i64, vp, vp],
         'dlsg_embed_bwd': [vp, i64, vp, vp, i32, i32, f32, u64, u32, i64, vp, vp],
-        'dlsg_select_embed': [vp, i64, i32, vp, i32, i32, vp, vp, vp, vp, i64, i32, i32, f32, u64, u32, i64, vp, vp],
+        'dlsg_select_embed': [vp, i64, i32, vp, i32, i32, vp, vp, vp, vp, i64, i32, i32, f32, u64, u32, i64, vp, i32, vp],
         'dlsg_argmax': [vp, i64, vp, i32, i32, vp],
         'dlsg_copy2d': [vp, i64, vp, i64, i32, i32, i32, vp],
         'dlsg_dropout': [vp, i64, vp, i64, i32, i32, f32, u64, u32, vp, vp],
@@ -1076,13 +1076,14 @@ class HipOps(object):
         self._check(self.lib.dlsg_embed_fwd(_p(E), _p(ids), _p(out), i64(out.stride(0)), rows, W, f32(p), u64(sd), u32(site),
                                             i64(row0), sp, self._stream()), 'embed_fwd')
 
-    def select_embed(self, logits, captions, t, coins, E, ids_out, out, p=0.0, seed=0, site=0, row0=0):
-        """ids_out[b] = coins[t] ? captions[b, t] : argmax(logits[b]); out[b] = drop(E[id])."""
+    def select_embed(self, logits, captions, t, coins, E, ids_out, out, p=0.0, seed=0, site=0, row0=0, prefilled=False):
+        """ids_out[b] = coins[t] ? captions[b, t] : argmax(logits[b]); out[b] = drop(E[id]).  prefilled: ids_out / out already
+        hold the teacher-forced choice (the caller embedded every caption word in one launch): a no-op when coins[t] is set."""
         rows, V = logits.shape
         sd, sp = _seed(seed)
         self._check(self.lib.dlsg_select_embed(_p(logits), i64(logits.stride(0)), V, _p(captions), captions.shape[1], int(t),
                                                _p(coins), _p(E), _p(ids_out), _p(out), i64(out.stride(0)), rows, out.shape[1],
-                                               f32(p), u64(sd), u32(site), i64(row0), sp, self._stream()), 'select_embed')
+                                               f32(p), u64(sd), u32(site), i64(row0), sp, int(bool(prefilled)), self._stream()), 'select_embed')
 
     def embed_bwd(self, dout, ids, dE, p=0.0, seed=0, site=0, row0=0):
         rows, W = dout.shape

@@ -410,10 +410,11 @@ int dlsg_embed_bwd(const float* dout, int64_t lddo, const int64_t* ids, float* d
                    uint64_t seed, uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream);
 /* scheduled sampling on device (layer.py:432-439): id[b] = coins[t] ? captions[b*L + t] : argmax(logits[b, :]);
  * ids_out[b] = id; out[b, :] = drop(E[id, :]).  coins is a device int32 array, so a captured graph is invariant to the
- * coin pattern. */
+ * coin pattern.  prefilled != 0: the caller wrote the teacher-forced choice of this step into ids_out / out up front (one
+ * dlsg_embed_fwd over all steps), so the launch is a no-op when coins[t] is set. */
 int dlsg_select_embed(const float* logits, int64_t ld, int V, const int64_t* captions, int L, int t, const int32_t* coins,
                       const float* E, int64_t* ids_out, float* out, int64_t ldo, int rows, int W, float p, uint64_t seed,
-                      uint32_t site, int64_t row0, const uint64_t* seed_ptr, void* stream);
+                      uint32_t site, int64_t row0, const uint64_t* seed_ptr, int prefilled, void* stream);
 /* argmax over logits rows (first max wins, like torch.max) */
 int dlsg_argmax(const float* logits, int64_t ld, int64_t* ids, int rows, int V, void* stream);
 /* strided 2-d copy / add: dst[r*ldd + j] (+)= src[r*lds + j] */

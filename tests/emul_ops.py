@@ -468,7 +468,9 @@ class EmulOps(CriticEmul):
             g = g * _mask(seed, site, dout.shape[0], dout.shape[1], p, row0)
         dE.index_add_(0, ids, g)
 
-    def select_embed(self, logits, captions, t, coins, E, ids_out, out, p=0.0, seed=0, site=0, row0=0):
+    def select_embed(self, logits, captions, t, coins, E, ids_out, out, p=0.0, seed=0, site=0, row0=0, prefilled=False):
+        if prefilled and int(coins[t]) != 0:
+            return
         ids = captions[:, t] if int(coins[t]) != 0 else logits.max(1)[1]
         ids_out.copy_(ids)
         self.embed_fwd(E, ids, out, p=p, seed=seed, site=site, row0=row0)
