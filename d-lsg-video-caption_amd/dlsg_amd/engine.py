@@ -552,7 +552,16 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
     ref = frames2d
     s = sv[pfx] = {}
     e = _empty(ref, B * T, H)
-    lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
+    Kf = frames2d.shape[1]
+    if B * T <= 2048 and Kf >= 4096 and Kf % 96 == 0:
+        # a 1 664 x 1 024 output is 416 tiles for a 6 144-deep contraction: three K thirds as groups writing slabs + one fold
+        # (210 us against 228, tools/_exp: K-split probe of the mid-size products)
+        k3 = Kf // 3
+        sl = _empty(ref, 3, B * T, H)
+        ops.gemm(GEMM_NT, [(frames2d[:, i * k3:(i + 1) * k3], m.linear_embed.weight[:, i * k3:(i + 1) * k3], sl[i]) for i in range(3)])
+        ops.slab_reduce(sl, e, bias=m.linear_embed.bias)
+    else:
+        lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
     lstm = m.lstm
     Wih = [lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]
     Whh = [lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]
@@ -719,10 +728,19 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     tn_grouped(ops, [(dG[d].view(B * T, 4 * H), src, G[name + '.lstm.' + wn + sfx[d]])
                      for d in range(2) for src, wn in ((e, 'weight_ih_l0'), (hprev[d].view(B * T, H), 'weight_hh_l0'))],
                sv.get('tn_defer'))
+    # de = sum_d dG_d W_ih_d: both directions in ONE launch, each contraction (4H deep for a 416-tile output) in two halves,
+    # four slabs folded once (two accumulating launches before: 2 x 161 us; a single product K-split four ways: 146 against 168)
+    dgs = [dG[d].view(B * T, 4 * H) for d in range(2)]
+    kh = (4 * H) // 2
+    if kh % 32 == 0:
+        sl = _empty(ref, 4, B * T, H)
+        ops.gemm(GEMM_NN, [(dgs[d][:, i * kh:(i + 1) * kh], Wih[d][i * kh:(i + 1) * kh, :], sl[2 * d + i]) for d in range(2) for i in range(2)])
+        ops.slab_reduce(sl, de)
+    else:
+        for d in range(2):
+            ops.gemm(GEMM_NN, [(dgs[d], Wih[d], de)], flags=F_ACCUM if d else 0)
     for d in range(2):
-        dg2 = dG[d].view(B * T, 4 * H)
-        ops.gemm(GEMM_NN, [(dg2, Wih[d], de)], flags=F_ACCUM if d else 0)
-        ops.colsum2(dg2, G[name + '.lstm.bias_ih_l0' + sfx[d]], G[name + '.lstm.bias_hh_l0' + sfx[d]], accum=True)
+        ops.colsum2(dgs[d], G[name + '.lstm.bias_ih_l0' + sfx[d]], G[name + '.lstm.bias_hh_l0' + sfx[d]], accum=True)
     ops.gemm(GEMM_TN, [(de, frames2d, G[name + '.linear_embed.weight'])], flags=F_ACCUM)
     ops.colsum(de, G[name + '.linear_embed.bias'], accum=True)
 
