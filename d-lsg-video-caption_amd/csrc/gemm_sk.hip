@@ -1,0 +1,616 @@
+// Persistent stream-K fp32 GEMM: ONE launch of (at most) one workgroup per CU for the products that fill the chip --
+// the region projections (layer.py:184), their weight gradients, the mid-size weight-gradient groups.  256 x 256 output
+// tile on v_mfma_f32_32x32x2_f32 (exact fp32; per output element the same k-ordered fmaf chain as gemm.hip / gemm_big.hip,
+// except on the tiles whose contraction is split between workgroups, where the partial chains are added in a fixed order).
+//
+// Schedule (host: sk_plan).  The launch has T tiles (all groups) and P workgroups, T = R * P + rem:
+//   * the last `rem` tiles are "split tiles": each is contracted by n = P / rem (+1) workgroups over disjoint k ranges --
+//     every workgroup starts with its share of one split tile, so all of them stay busy for the same time; the share is
+//     written to a workspace slot in accumulator order (16-B stores), published (release + counter), and finished at the END
+//     of the kernel: contributor c of n sums the n slots of every sub-block k = c (mod n) (16 sub-blocks of 32 x 32 per
+//     wave) in contributor order and runs the epilogue on them.  Between the partial store and the fix-up lie R full tiles,
+//     so nobody waits for anybody in practice; the wait is bounded and reports into an error word instead of hanging;
+//   * then R rounds of whole tiles, workgroup v (virtual id: the 32 workgroups an XCD receives are consecutive) takes tile
+//     j * P + v: the workgroups of one XCD walk one compact block of row panels x column tiles in lock step, so the XCD's
+//     L2 serves every staged A / B block to several of them.
+// Main loop (per 32-deep stage: 256 MFMAs per wave; LDS: two 64-KB stage buffers filled by LDS-DMA):
+//   q0 | q1 | q2 | wait + barrier | q3      (q = 8 k = 64 MFMAs)
+// the barrier sits BETWEEN q2 and q3: at it, this stage's buffer has been read out completely (q3's fragments are in
+// registers) and the next stage's buffer has landed; q3 then reads the next stage's first fragments under its own MFMAs and
+// the DMA of the stage after next starts into the buffer that just became free -- the matrix pipe never waits for an LDS
+// round trip, and a stage's bytes are requested 1.3 stages (~9 us) before they are used.  Fragment reads and DMA pieces are
+// pinned between groups of four MFMAs (sched_barrier): left to the scheduler they sit in a clump in front of each q block
+// behind an lgkmcnt(0) (gemm_big.hip: 5-10 % of the loop).  Tile changes happen inside the same stage stream: the next
+// tile's first stages are in flight while the finished tile is stored, and its stores drain under the next tile's MFMAs.
+#include <mutex>
+#include <type_traits>
+
+#include "common.hpp"
+#include "dlsg.h"
+
+namespace {
+
+constexpr int SK_THREADS = 256;
+constexpr int SK_BM = 256, SK_BN = 256, SK_BK = 32;
+constexpr int SK_ABYTES = SK_BM * 128, SK_BBYTES = SK_BN * 128, SK_STAGE = SK_ABYTES + SK_BBYTES;      // 64 KB per stage
+constexpr int SK_SLOT_BYTES = SK_BM * SK_BN * 4;
+constexpr int SK_CNT_BYTES = 16384;                // in front of the slots: counters (2 words per split tile) in the first 4 KB; the
+                                                   // rest is where a PROBES=1 build leaves its timestamps
+constexpr int SK_MAXSPLIT = 16;                    // contributors per split tile (= sub-blocks a wave can hand out)
+constexpr unsigned SK_SPIN_LIMIT = 1u << 22;       // x s_sleep(8): ~1-2 s
+
+struct SkGroup {
+    const float* A; const float* B; float* C; const float* bias;
+    int64_t lda, ldb, ldc;
+    int32_t nst, tiles_n, N, tile0;                // stages (K / 32), column tiles, output width, first linear tile id
+};
+struct SkArgs {
+    int32_t M, ngroups, flags, P;
+    int32_t T, rounds, rem, sk_wgs;                // T = rounds * P + rem; sk_wgs: workgroups that share the last rem tiles
+    int32_t sk_nst, pad_;                          // stages per tile of those tiles when they are split (0: one whole tile each)
+    float alpha; int32_t pad2_;
+    const int32_t* skip_if;
+    float* slots; uint32_t* cnt; int32_t* err;
+    SkGroup g[DLSG_GEMM_MAXG];
+};
+
+struct Item {                                      // one contiguous stage range of one tile; every field wave-uniform
+    int32_t gi, m0, n0, Ng;
+    int32_t s0, s1, kind, r;                       // kind: 1 whole tile, 2 share of split tile r (its slot: 2 v + item index)
+};
+
+typedef __attribute__((address_space(3))) void* sk_lp_t;
+typedef const __attribute__((address_space(1))) void* sk_gp_t;
+
+// One LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to LDS at `lds_addr` + 16 * lane.  Written as
+// inline assembly on purpose: as the builtin, the compiler orders every later ds_read behind it with an s_waitcnt vmcnt(0)
+// (it cannot tell the stage buffer being filled from the one being read) -- one in the first fragment reads of every stage,
+// 0.5 us after the pieces were issued.  Its own vmcnt bookkeeping does not see these requests; the waits it places for its
+// own loads can only become stricter by that (the counter is in-order), and the stage loop waits for the pieces itself.
+__device__ __forceinline__ void sk_glds16(const char* base, uint32_t voff, uint32_t lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
+#endif
+}
+__device__ __forceinline__ int sk_u(int x) { return __builtin_amdgcn_readfirstlane(x); }       // pin a uniform value to an SGPR
+__device__ __forceinline__ const char* sk_up(const void* q) {
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+
+#ifdef DLSG_PROBES
+// diagnostic build (make PROBES=1): workgroups v < 8 leave 100-MHz timestamps in the upper half of the counter area
+#define SK_STAMP(i) do { if (v < 8 && threadIdx.x == 0 && (i) < 32) reinterpret_cast<uint64_t*>(p.cnt + 1024)[v * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// ... and workgroup 0 one per stage (the first 1024 stages)
+#define SK_STAGE_STAMP(i) do { if (v == 0 && threadIdx.x == 0 && (i) < 1024) reinterpret_cast<uint64_t*>(p.cnt + 2048)[(i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SK_STAMP(i) do { } while (0)
+#define SK_STAGE_STAMP(i) do { } while (0)
+#endif
+
+// The split tiles' stages, U = rem * sk_nst of them, are dealt to the sk_wgs workgroups in equal consecutive runs: workgroup v
+// has [v U / sk_wgs, (v + 1) U / sk_wgs) -- a run is shorter than a tile, so it lies in one tile or ends one and begins the next.
+__device__ __forceinline__ int64_t sk_run0(const SkArgs& p, int v) { return (int64_t)v * p.rem * p.sk_nst / p.sk_wgs; }
+// items of the split phase of workgroup v: 0 (not taking part), 1 or 2
+__device__ __forceinline__ int sk_nsplit(const SkArgs& p, int v) {
+    if (v >= p.sk_wgs) return 0;
+    if (p.sk_nst == 0) return 1;
+    const int64_t u0 = sk_run0(p, v), u1 = sk_run0(p, v + 1);
+    return (u1 - 1) / p.sk_nst != u0 / p.sk_nst ? 2 : 1;
+}
+// contributors of split tile r: workgroups [lo, hi]
+__device__ __forceinline__ void sk_contributors(const SkArgs& p, int r, int& lo, int& hi) {
+    const int64_t U = (int64_t)p.rem * p.sk_nst, b = (int64_t)r * p.sk_nst, e = b + p.sk_nst;
+    lo = (int)(b * p.sk_wgs / U);
+    while (lo > 0 && sk_run0(p, lo) > b) --lo;
+    while (sk_run0(p, lo + 1) <= b) ++lo;
+    hi = (int)((e - 1) * p.sk_wgs / U);
+    while (hi + 1 < p.sk_wgs && sk_run0(p, hi + 1) < e) ++hi;
+    while (sk_run0(p, hi) >= e) --hi;
+}
+
+// item idx of virtual workgroup v (idx < its item count): its one or two shares of split tiles first, then one whole tile per round
+__device__ __forceinline__ Item sk_item(const SkArgs& p, int v, int idx) {
+    Item it;
+    it.r = 0; it.kind = 1;
+    const int ns = sk_nsplit(p, v);
+    int tile, s0 = 0, s1 = -1;
+    if (idx < ns) {
+        if (p.sk_nst == 0) it.r = v;
+        else {
+            const int64_t u0 = sk_run0(p, v), u1 = sk_run0(p, v + 1);
+            const int r0 = (int)(u0 / p.sk_nst);
+            it.r = r0 + idx;
+            s0 = idx == 0 ? (int)(u0 - (int64_t)r0 * p.sk_nst) : 0;
+            s1 = (idx == 0 && ns == 2) ? p.sk_nst : (int)(u1 - (int64_t)it.r * p.sk_nst);
+            it.kind = (s0 == 0 && s1 == p.sk_nst) ? 1 : 2;
+        }
+        tile = p.rounds * p.P + it.r;
+    } else {
+        tile = (idx - ns) * p.P + v;
+    }
+    int gi = 0;
+    for (int i = 1; i < p.ngroups; ++i) gi = (tile >= p.g[i].tile0) ? i : gi;
+    const SkGroup& g = p.g[gi];
+    const int local = tile - g.tile0;
+    const int tm = local / g.tiles_n, tn = local - tm * g.tiles_n;
+    it.gi = sk_u(gi); it.m0 = sk_u(tm * SK_BM); it.n0 = sk_u(tn * SK_BN); it.Ng = sk_u(g.N);
+    if (s1 < 0) { s0 = 0; s1 = g.nst; }
+    it.s0 = sk_u(s0); it.s1 = sk_u(s1); it.kind = sk_u(it.kind); it.r = sk_u(it.r);
+    return it;
+}
+
+// per-lane byte offsets of this wave's 8 DMA pieces of one operand, relative to (tile base + stage offset)
+//   T == false: element (row, k) at base[row * ld + k] -> image [row][32], 16-B segments swizzled: slot (row, s) holds
+//               k-segment s ^ ((row >> 1) & 7); piece = 8 rows
+//   T == true : element (row, k) at base[k * ld + row] -> image [k][256]; piece = one k row
+template <bool T>
+__device__ __forceinline__ void sk_voff(int (&voff)[8], int w, int lane, int row0, int rmax, int64_t ld) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pc = w * 8 + i;
+        if (!T) {
+            const int R = 8 * pc + (lane >> 3);
+            const int seg = (lane & 7) ^ ((R >> 1) & 7);
+            voff[i] = (int)((min(row0 + R, rmax - 1) - row0) * ld * 4) + 16 * seg;
+        } else {
+            voff[i] = (int)(pc * ld * 4) + (min(row0 + 4 * lane, rmax - 4) - row0) * 4;
+        }
+    }
+}
+
+constexpr int SK_BOUNCE = 32 * 32 * 4;           // bytes of a wave's bounce tile in LDS
+
+// tanh x = 1 - 2 / (1 + e^{2x}) on the hardware's exp2 / rcp (1 ulp each): absolute error ~1e-7, saturates to +-1 through
+// e^{2x} -> inf / 0.  tanhf (~60 instructions) cost 25 us per 256 x 256 tile, a third of the tile's epilogue.
+__device__ __forceinline__ float sk_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+}
+
+// Epilogue of one 32 x 32 sub-block (i, j) of a wave.  `val` is in the C/D layout of the 32x32 MFMA (col = lane & 31, row =
+// e' + 4 (2 e4 + (lane >> 5)) for element e = 4 e4 + e'): stored that way, a wave instruction writes 4 bytes per lane into two
+// rows -- 42 us per 256-KB tile with every CU storing at once, against 12 us for the same bytes in 16-B pieces.  So the
+// sub-block goes through the wave's own 4-KB bounce tile in LDS: a lane writes its four row quads as 16-B pieces (straight
+// from the accumulator file: four consecutive accumulators are one ds_write_b128; any arithmetic on them first makes the
+// register allocator copy all 256 accumulators out at the top of the block), tile layout [row quad G][column][row in quad];
+// lane (G, cs) = (lane >> 3, lane & 7) reads the 4 x 4 block of row quad G and columns 4 cs .. 4 cs + 3 back as 64 contiguous
+// bytes and stores its four rows as 16-B pieces: 8 rows x 128 B per store instruction.  One wave's DS operations execute in
+// order: no barrier.  bias4: the lane's bias values of its four columns, fetched by the caller before the tile's first store.
+template <class V>
+__device__ __forceinline__ void sk_store_block(const SkArgs& p, const SkGroup& g, const Item& it, const V& val, int i, int j,
+                                               int w, int lane, f32x4 bias4, float* bounce) {
+    const int r = lane & 31, h = lane >> 5, wm = w >> 1, wn = w & 1;
+    f32x4* bw = reinterpret_cast<f32x4*>(bounce) + h * 32 + r;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+        f32x4 t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = val[4 * e4 + e];
+        bw[e4 * 64] = t;
+    }
+    const int G = lane >> 3, cs = lane & 7;
+    const f32x4* br = reinterpret_cast<const f32x4*>(bounce) + G * 32 + 4 * cs;
+    f32x4 x[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) x[c] = br[c];
+    const int col = it.n0 + wn * 128 + j * 32 + 4 * cs;
+    const int row0 = it.m0 + wm * 128 + i * 32 + 4 * G;
+    const bool accum = p.flags & DLSG_GEMM_ACCUM, do_tanh = p.flags & DLSG_GEMM_TANH;
+    const bool col_ok = col < it.Ng;                          // (widths are multiples of 4: the whole piece is in or out)
+    float* cp = g.C + (int64_t)row0 * g.ldc + col;
+    // C += (rare: the engine accumulates only into gradients that already hold a contribution): every loaded value is consumed
+    // below whether or not its row is stored, so no request is left pending when the stage loop is entered again
+    f32x4 old[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        old[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (accum && col_ok && row0 + q < p.M) old[q] = *reinterpret_cast<const f32x4*>(cp + (int64_t)q * g.ldc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 y = f32x4{x[0][q], x[1][q], x[2][q], x[3][q]};
+        y = p.alpha * y + bias4 + old[q];
+        if (do_tanh) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) y[c] = sk_tanh(y[c]);
+        }
+        if (col_ok && row0 + q < p.M) *reinterpret_cast<f32x4*>(cp + (int64_t)q * g.ldc) = y;
+    }
+}
+
+// this lane's bias values for the four column blocks j of its wave (zeros without a bias or past the group's width)
+__device__ __forceinline__ void sk_bias(const SkArgs& p, const SkGroup& g, const Item& it, int w, int lane, f32x4 (&bias4)[4]) {
+    const bool use_bias = (p.flags & DLSG_GEMM_BIAS) && g.bias != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = it.n0 + (w & 1) * 128 + j * 32 + 4 * (lane & 7);
+        bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (use_bias && col < it.Ng) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + col);
+    }
+}
+
+template <bool AT, bool BT>
+__global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_sk_kernel(const SkArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char sk_lds[];           // 2 stage buffers
+    if (p.skip_if && *p.skip_if) return;                                    // block-uniform
+    const int lane = threadIdx.x & 63;
+    const int w = sk_u(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    // virtual id: the workgroups an XCD receives (blockIdx % 8) are consecutive -- speed only
+    const int bid = blockIdx.x;
+    const int v = sk_u((p.P & 7) ? bid : (bid & 7) * (p.P >> 3) + (bid >> 3));
+    const int n_items = sk_u(p.rounds + sk_nsplit(p, v));
+    if (n_items == 0) return;
+    SK_STAMP(0);
+    const uint32_t lds0 = sk_u((uint32_t)reinterpret_cast<uintptr_t>((sk_lp_t)sk_lds));      // LDS byte address of the stage buffers
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragment byte offsets of k-group q inside a stage buffer (lane (r, h) feeds k = 4 (2q + h) + j to MFMA j of group q)
+    int offA[4], offB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ks = (2 * q + h) ^ ((r >> 1) & 7);
+        offA[q] = AT ? ((4 * (2 * q + h)) * SK_BM + wm * 128 + r) * 4 : (wm * 128 + r) * 128 + ks * 16;
+        offB[q] = SK_ABYTES + (BT ? ((4 * (2 * q + h)) * SK_BN + wn * 128 + r) * 4 : (wn * 128 + r) * 128 + ks * 16);
+    }
+    f32x4 fa[2][4], fb[2][4];
+    auto read_frag = [&](int buf, const char* st, int q, int f) {          // f < 4: A fragment f, else B fragment f - 4
+        if (f < 4) {
+            if (!AT) fa[buf][f] = *reinterpret_cast<const f32x4*>(st + offA[q] + f * 32 * 128);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[buf][f][j] = *reinterpret_cast<const float*>(st + offA[q] + (j * SK_BM + f * 32) * 4);
+            }
+        } else {
+            const int g = f - 4;
+            if (!BT) fb[buf][g] = *reinterpret_cast<const f32x4*>(st + offB[q] + g * 32 * 128);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[buf][g][j] = *reinterpret_cast<const float*>(st + offB[q] + (j * SK_BN + g * 32) * 4);
+            }
+        }
+    };
+
+    // ---- load cursor: the stage whose DMA is issued next.  Past the last stage of the stream it stays on that stage: the
+    // pieces it keeps issuing land in buffers nobody reads any more (no branches in the stage body)
+    int li = 0, l_left = 0, lpar = 0;              // item index, stages of the item not yet issued, buffer parity
+    int voffA[8], voffB[8];
+    const char* lA = nullptr; const char* lB = nullptr;                     // stage bases
+    int64_t sA = 0, sB = 0;                                                  // bytes per stage
+    auto l_enter = [&](int idx) {
+        // (rare path: its inputs go through empty asm statements so that nothing computed from them is hoisted out of the stage
+        //  loop and kept in registers across it -- with 256 accumulators the loop has none to spare)
+        int lane_ = lane, w_ = w, v_ = v;
+        asm volatile("" : "+v"(lane_), "+s"(w_), "+s"(v_));
+        const Item it = sk_item(p, v_, idx);
+        const SkGroup& g = p.g[it.gi];
+        sk_voff<AT>(voffA, w_, lane_, it.m0, p.M, g.lda);
+        sk_voff<BT>(voffB, w_, lane_, it.n0, it.Ng, g.ldb);
+        const int64_t k0 = (int64_t)it.s0 * SK_BK;
+        lA = sk_up(AT ? g.A + it.m0 + k0 * g.lda : g.A + (int64_t)it.m0 * g.lda + k0);
+        lB = sk_up(BT ? g.B + it.n0 + k0 * g.ldb : g.B + (int64_t)it.n0 * g.ldb + k0);
+        sA = AT ? SK_BK * 4 * g.lda : SK_BK * 4;
+        sB = BT ? SK_BK * 4 * g.ldb : SK_BK * 4;
+        l_left = it.s1 - it.s0;
+    };
+    auto l_issue = [&](int pc) {                   // piece pc in [0, 16): A pieces 0..7, B pieces 8..15 of this wave
+        const uint32_t dst = lds0 + lpar * SK_STAGE + (pc < 8 ? 0 : SK_ABYTES) + (w * 8 + (pc & 7)) * 1024;
+        if (pc < 8) sk_glds16(lA, (uint32_t)voffA[pc], dst);
+        else sk_glds16(lB, (uint32_t)voffB[pc - 8], dst);
+    };
+    auto l_advance = [&]() {
+        lpar ^= 1;
+        if (--l_left > 0) { lA += sA; lB += sB; return; }
+        ++li;
+        if (li < n_items) l_enter(li);
+        else { sA = sB = 0; l_left = 1 << 30; }    // past the end of the stream: stay on the last stage
+    };
+    l_enter(0);
+
+    // ---- compute cursor
+    int ci = 0, c_left = l_left, cpar = 0;
+
+    // prologue: stage 0 whole, first half of stage 1
+#pragma unroll
+    for (int pc = 0; pc < 16; ++pc) l_issue(pc);
+    l_advance();
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) l_issue(pc);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int f = 0; f < 8; ++f) read_frag(0, sk_lds, 0, f);
+
+    int stage_no = 0;      // (used by the PROBES build only)
+    // one stage: q0 .. q3, 16 slots of four MFMAs each, one fragment read or DMA piece pinned behind each.  FAST: the load cursor
+    // stays inside its item (plain pointer increments); the other instantiation may enter the next item (rare code in the body)
+    auto stage = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const char* st = sk_lds + cpar * SK_STAGE;
+        const char* stn = sk_lds + (cpar ^ 1) * SK_STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int cur = q & 1, nxt = cur ^ 1;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int j = s >> 2, i = s & 3;
+#pragma unroll
+                for (int jn = 0; jn < 4; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j], acc[i][jn], 0, 0, 0);
+                if (s < 8) {
+                    if (q < 3) read_frag(nxt, st, q + 1, s);
+                    else read_frag(nxt, stn, 0, s);              // the next stage's first fragments (unused after the last stage)
+                } else if (q == 0) {
+                    l_issue(8 + (s - 8));                         // second half of the stage after this one
+                } else if (q == 3) {
+                    l_issue(s - 8);                               // first half of the stage after next
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q == 0) {
+                if (FAST) { lpar ^= 1; --l_left; lA += sA; lB += sB; }
+                else l_advance();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q == 2) {
+                // this stage's buffer is read out (q3's fragments requested: wait for them), the next stage has landed
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        cpar ^= 1;
+        SK_STAGE_STAMP(stage_no); ++stage_no;
+    };
+    using TagFast = std::true_type;
+    using TagSlow = std::false_type;
+
+    for (;;) {
+        // the run of stages in which neither cursor changes its item: a loop of nothing but the stage body
+        int n = sk_u(min(c_left - 1, l_left - 1));
+        c_left -= max(n, 0);
+        for (; n > 0; --n) stage(TagFast{});
+        stage(TagSlow{});
+        if (--c_left > 0) continue;
+        SK_STAMP(1 + 2 * ci);
+        // ---------------- the item is complete: store it (inputs made opaque: see l_enter)
+        int lane_ = lane, w_ = w, v_ = v;
+        asm volatile("" : "+v"(lane_), "+s"(w_), "+s"(v_));
+        const int lane = lane_, w = w_, v = v_;
+        const Item it = sk_item(p, v, ci);
+        const SkGroup& g = p.g[it.gi];
+        if (it.kind == 1) {
+            float* bounce = reinterpret_cast<float*>(sk_lds + 2 * SK_STAGE + w * SK_BOUNCE);
+            f32x4 bias4[4];
+            sk_bias(p, g, it, w, lane, bias4);                 // before the first store: a later load would wait behind the stores
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sk_store_block(p, g, it, acc[i][j], i, j, w, lane, bias4[j], bounce);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                    __builtin_amdgcn_sched_barrier(0);       // one sub-block's values in flight at a time
+                }
+        } else {
+            // share of a split tile: accumulator order, 16-B stores: slot[((w * 16 + i * 4 + j) * 4 + e4) * 64 + lane]
+            f32x4* slot = reinterpret_cast<f32x4*>(p.slots) + (int64_t)(2 * v + ci) * (SK_SLOT_BYTES / 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        f32x4 t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = acc[i][j][4 * e4 + e];
+                        slot[((w * 16 + i * 4 + j) * 4 + e4) * 64 + lane] = t;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            // publish: every wave drains its stores, the workgroup meets, one lane releases and counts
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(p.cnt + 2 * it.r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        SK_STAMP(2 + 2 * ci);
+        if (++ci >= n_items) break;
+        const Item nx = sk_item(p, v, ci);
+        c_left = nx.s1 - nx.s0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the pieces issued past the end of the stream
+    SK_STAMP(27);
+
+    // ---- fix-up of the split tiles this workgroup contributed to (its first one or two items)
+    const int ns = sk_nsplit(p, v);
+    float* fbounce = reinterpret_cast<float*>(sk_lds + 2 * SK_STAGE + w * SK_BOUNCE);
+    for (int si = 0; si < ns; ++si) {
+        const Item S = sk_item(p, v, si);
+        if (S.kind != 2) continue;
+        int lo, hi;
+        sk_contributors(p, S.r, lo, hi);
+        const int n = hi - lo + 1, c = v - lo;
+        uint32_t* cnt = p.cnt + 2 * S.r;
+        if (threadIdx.x == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)n) {
+                if (++spins > SK_SPIN_LIMIT) {
+                    if (p.err) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        SK_STAMP(28 + 2 * si);
+        const SkGroup& g = p.g[S.gi];
+        const bool f_bias = (p.flags & DLSG_GEMM_BIAS) && g.bias != nullptr;
+        for (int k = c; k < 16; k += n) {
+            f32x16 sum;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum[e] = 0.f;
+            for (int v2 = lo; v2 <= hi; ++v2) {
+                // contributor v2's share of this tile is its first item when its run begins inside the tile, else its second
+                const int sl = 2 * v2 + ((int)(sk_run0(p, v2) / p.sk_nst) == S.r ? 0 : 1);
+                const f32x4* slot = reinterpret_cast<const f32x4*>(p.slots) + (int64_t)sl * (SK_SLOT_BYTES / 16);
+                f32x4 t[4];
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) t[e4] = slot[((w * 16 + k) * 4 + e4) * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum[e] += t[e >> 2][e & 3];
+            }
+            const int bcol = S.n0 + (w & 1) * 128 + (k & 3) * 32 + 4 * (lane & 7);
+            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (f_bias && bcol < S.Ng) b4 = *reinterpret_cast<const f32x4*>(g.bias + bcol);
+            sk_store_block(p, g, S, sum, k >> 2, k & 3, w, lane, b4, fbounce);
+        }
+        // the contributor that finishes reading last leaves the tile's counters at zero for the next launch
+        __syncthreads();
+        SK_STAMP(29 + 2 * si);
+        if (threadIdx.x == 0) {
+            const uint32_t d = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d + 1 == (uint32_t)n) {
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+int sk_cus() {
+    static int cus = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    });
+    return cus;
+}
+
+template <bool AT, bool BT>
+int sk_launch(const SkArgs& k, hipStream_t st) {
+    constexpr int lds_bytes = 2 * SK_STAGE + 4 * SK_BOUNCE;  // two stage buffers + the epilogue's bounce tiles
+    static std::once_flag once;
+    std::call_once(once, [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    });
+    hipLaunchKernelGGL((gemm_sk_kernel<AT, BT>), dim3(k.P), dim3(SK_THREADS), lds_bytes, st, k);
+    DLSG_CHECK_LAUNCH();
+    return DLSG_OK;
+}
+
+}  // namespace
+
+// stages per tile of the first group that owns a tile at or behind linear tile id `from`
+static int max_nst_sk(const SkArgs& k, int from, int tiles_m) {
+    for (int i = 0; i < k.ngroups; ++i)
+        if (k.g[i].tile0 + tiles_m * k.g[i].tiles_n > from) return k.g[i].nst;
+    return 0;
+}
+
+// bytes of caller scratch a stream-K launch needs on this device (zero-filled once by the caller; the kernels leave the
+// counter area zeroed); 0 when the device cannot be queried
+extern "C" int64_t dlsg_gemm_ws_bytes(void) {
+    const int cus = sk_cus();
+    return cus > 0 ? (int64_t)SK_CNT_BYTES + (int64_t)2 * cus * SK_SLOT_BYTES : 0;
+}
+
+// 1: this call can run on the stream-K kernel (alignment, K a multiple of 32 in every group, one batch, a workspace)
+int dlsg_gemm_sk_ok(const dlsg_gemm_args* a) {
+    const bool at = a->mode == 2, bt = a->mode != 0;
+    if (a->nbatch != 1 || a->M < 4 || a->N < 4) return 0;
+    if (!a->ws || a->ws_bytes < dlsg_gemm_ws_bytes() || dlsg_gemm_ws_bytes() == 0) return 0;
+    if (at && (a->M % 4)) return 0;
+    for (int i = 0; i < a->ngroups; ++i) {
+        const dlsg_gemm_group& g = a->g[i];
+        const int gn = g.N > 0 ? g.N : a->N;
+        if (g.K < SK_BK || (g.K % SK_BK) || (g.lda % 4) || (g.ldb % 4) || gn < 4 || (gn % 4)) return 0;
+        if ((reinterpret_cast<uintptr_t>(g.A) & 15) || (reinterpret_cast<uintptr_t>(g.B) & 15)) return 0;
+        // 16-B pieces of the result rows (and of the bias)
+        const int64_t ldc = g.ldc ? g.ldc : (int64_t)a->ldc;
+        const float* bias = g.bias ? g.bias : a->bias;
+        if ((reinterpret_cast<uintptr_t>(g.C) & 15) || (ldc % 4)) return 0;
+        if ((a->flags & DLSG_GEMM_BIAS) && bias && (reinterpret_cast<uintptr_t>(bias) & 15)) return 0;
+        // 32-bit piece offsets inside a tile
+        if (!at && (int64_t)255 * g.lda * 4 >= (1LL << 31)) return 0;
+        if (at && (int64_t)31 * g.lda * 4 >= (1LL << 31)) return 0;
+        if (!bt && (int64_t)255 * g.ldb * 4 >= (1LL << 31)) return 0;
+        if (bt && (int64_t)31 * g.ldb * 4 >= (1LL << 31)) return 0;
+    }
+    return 1;
+}
+
+int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
+    if (!dlsg_gemm_sk_ok(a)) return DLSG_EINVAL;
+    SkArgs k;
+    k.M = a->M; k.ngroups = a->ngroups; k.flags = a->flags; k.alpha = a->alpha; k.skip_if = a->skip_if; k.pad_ = 0;
+    const int tiles_m = (a->M + SK_BM - 1) / SK_BM;
+    int T = 0;
+    for (int i = 0; i < a->ngroups; ++i) {
+        const dlsg_gemm_group& g = a->g[i];
+        SkGroup& s = k.g[i];
+        s.A = g.A; s.B = g.B; s.C = g.C;
+        s.bias = g.bias ? g.bias : a->bias;
+        s.lda = g.lda; s.ldb = g.ldb; s.ldc = g.ldc ? g.ldc : (int64_t)a->ldc;
+        s.N = g.N > 0 ? g.N : a->N;
+        s.nst = g.K / SK_BK;
+        s.tiles_n = (s.N + SK_BN - 1) / SK_BN;
+        s.tile0 = T;
+        T += tiles_m * s.tiles_n;
+    }
+    const int cus = sk_cus();
+    const int P = cus;
+    k.P = P; k.T = T;
+    k.rounds = T / P; k.rem = T % P;
+    k.sk_wgs = 0; k.sk_nst = 0; k.pad_ = 0; k.pad2_ = 0;
+    if (k.rem > 0) {
+        // the last rem tiles: split evenly over the workgroups when their tiles are equally deep (the common case; a run of
+        // stages then touches at most two tiles), else one whole tile per workgroup
+        bool uniform = true;
+        for (int i = 0; i < a->ngroups; ++i)
+            if (k.g[i].tile0 + tiles_m * k.g[i].tiles_n > k.rounds * P) uniform = uniform && k.g[i].nst == max_nst_sk(k, k.rounds * P, tiles_m);
+        if (uniform) {
+            const int nst = max_nst_sk(k, k.rounds * P, tiles_m);
+            const int64_t U = (int64_t)k.rem * nst;
+            // every workgroup takes part unless that would cut a tile into more than SK_MAXSPLIT - 1 runs (tiny launches)
+            int64_t wgs = P;
+            if (wgs > (int64_t)k.rem * (SK_MAXSPLIT - 2)) wgs = (int64_t)k.rem * (SK_MAXSPLIT - 2);
+            if (wgs > U) wgs = U;
+            k.sk_wgs = (int)wgs; k.sk_nst = nst;
+        } else {
+            k.sk_wgs = k.rem; k.sk_nst = 0;
+        }
+    }
+    char* ws = reinterpret_cast<char*>(a->ws);
+    k.cnt = reinterpret_cast<uint32_t*>(ws);
+    k.slots = reinterpret_cast<float*>(ws + SK_CNT_BYTES);
+    k.err = a->err;
+    if (2 * k.rem * (int)sizeof(uint32_t) > 4096) return DLSG_EINVAL;
+    switch (a->mode) {
+        case 0: return sk_launch<false, false>(k, st);
+        case 1: return sk_launch<false, true>(k, st);
+        case 2: return sk_launch<true, true>(k, st);
+        default: return DLSG_EINVAL;
+    }
+}

@@ -23,6 +23,8 @@ import torch
 
 from .hip import GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH, F_BF16X3, F_FORCE128
 
+V_SK = 7        # include/dlsg.h DLSG_GEMM_V_SK: the persistent stream-K kernel
+
 # dropout sites (stateless masks are keyed by (seed, site, element index))
 SITE_PSL_OBJ, SITE_PSL_MOT, SITE_LSTM, SITE_PE, SITE_SA, SITE_WORD, SITE_QUERY, SITE_ATT1, SITE_ATT2, SITE_LANG = range(1, 11)
 # per-step sites add STEP_SITE*(t+1)
@@ -98,6 +100,20 @@ def gemm_nn_split(ops, dy, W, out, ref, accum=False):
 DEEP_TN_CHUNKS = 8
 
 
+def _accum_flag(ops, gout):
+    """F_ACCUM unless this is the first product written into `gout` since the gradient arena was zero-filled (the backward sets
+    ops.grad_written = set() right after the fill): a first writer stores instead of adding, which spares the kernel's epilogue a
+    read of zeros in front of every store.  Without that bookkeeping (ops.grad_written is None) everything accumulates."""
+    seen = getattr(ops, 'grad_written', None)
+    if seen is None:
+        return F_ACCUM
+    key = (gout.data_ptr(), tuple(gout.shape), tuple(gout.stride()))
+    if key in seen:
+        return F_ACCUM
+    seen.add(key)
+    return 0
+
+
 def gemm_tn_deep(ops, items, ref):
     """gout_i (Nout, Kin) += dy_i^T x_i for very deep contractions (rows >= 8192: the 26624-row obj_embed weight gradients):
     the output has too few tiles to fill the chip, so the rows are split over groups writing slabs (measured 98 vs 86
@@ -107,7 +123,17 @@ def gemm_tn_deep(ops, items, ref):
     deep = [it for it in items if it[0].shape[0] >= 8192]
     for dy, x, gout in items:
         if dy.shape[0] < 8192:
-            ops.gemm(GEMM_TN, [(dy, x, gout)], flags=F_ACCUM)
+            ops.gemm(GEMM_TN, [(dy, x, gout)], flags=_accum_flag(ops, gout))
+    if deep and getattr(ops, 'stream_k', False) and all(ops.gemm(GEMM_TN, [it], flags=F_ACCUM, plan_only=True) == V_SK for it in deep):
+        # the persistent stream-K kernel cuts the contraction between the workgroups itself (csrc/gemm_sk.hip): one launch for
+        # all the products, no slabs, no fold
+        for fl in (0, F_ACCUM):
+            part = [it for it in deep if _accum_flag_peek(ops, it[2]) == fl]
+            for i0 in range(0, len(part), 16):
+                for it in part[i0:i0 + 16]:
+                    _accum_flag(ops, it[2])
+                ops.gemm(GEMM_TN, part[i0:i0 + 16], flags=fl)
+        return
     by_shape = {}
     for it in deep:
         by_shape.setdefault((it[0].shape, it[1].shape), []).append(it)
@@ -126,6 +152,13 @@ def gemm_tn_deep(ops, items, ref):
                                for i, (k0, k1) in enumerate(bounds)])
             for (_, _, gout), sl in zip(part, slabs):
                 ops.slab_reduce(sl, gout, flags=F_ACCUM)
+
+
+def _accum_flag_peek(ops, gout):
+    seen = getattr(ops, 'grad_written', None)
+    if seen is None or (gout.data_ptr(), tuple(gout.shape), tuple(gout.stride())) in seen:
+        return F_ACCUM
+    return 0
 
 
 def gemm_nn_multi(ops, dy, Ws, out, ref):
@@ -203,7 +236,15 @@ def tn_grouped(ops, items, defer=None):
             else:
                 waves.append([it]); seen.append({key})
         for w_ in waves:
-            ops.gemm(GEMM_TN, w_, flags=F_ACCUM)
+            # first writers store, the rest accumulate: two launches at most
+            first = [it for it in w_ if _accum_flag_peek(ops, it[2]) == 0]
+            rest = [it for it in w_ if _accum_flag_peek(ops, it[2]) != 0]
+            for it in first:
+                _accum_flag(ops, it[2])
+            if first:
+                ops.gemm(GEMM_TN, first, flags=0)
+            if rest:
+                ops.gemm(GEMM_TN, rest, flags=F_ACCUM)
 
 
 def gemm_bucketed(ops, mode, groups, flags=0):

@@ -15,10 +15,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 
-ABI_VERSION = 4            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
+ABI_VERSION = 5            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
-F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256 = 256, 512, 1024, 2048
+F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256, F_SK, F_NOSK = 256, 512, 1024, 2048, 4096, 8192
 MAXG = 16
 
 c_f32p = C.c_void_p
@@ -33,7 +33,7 @@ class GemmGroup(C.Structure):
 class GemmArgs(C.Structure):
     _fields_ = [('mode', i32), ('M', i32), ('N', i32), ('ldc', i32), ('ngroups', i32), ('nbatch', i32), ('flags', i32),
                 ('pad_', i32), ('bsa', i64), ('bsb', i64), ('bsc', i64), ('alpha', f32), ('pad2_', i32),
-                ('bias', c_f32p), ('skip_if', c_f32p), ('g', GemmGroup * MAXG)]
+                ('bias', c_f32p), ('skip_if', c_f32p), ('ws', c_f32p), ('ws_bytes', i64), ('err', c_f32p), ('g', GemmGroup * MAXG)]
 
 
 class RowLnArgs(C.Structure):
@@ -222,7 +222,7 @@ class DecattCacheGradsArgs(C.Structure):
 
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
-SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_gemm_variant', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
+SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_gemm_variant', 'dlsg_gemm_ws_bytes', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
            'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_colsum_ws_floats', 'dlsg_colsum_multi', 'dlsg_colsum_multi_ok', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
@@ -255,6 +255,7 @@ def load_library(path=LIB_PATH):
         'dlsg_struct_size': [i32],
         'dlsg_gemm': [P(GemmArgs), vp],
         'dlsg_gemm_variant': [P(GemmArgs)],
+        'dlsg_gemm_ws_bytes': [],
         'dlsg_slab_reduce': [vp, i32, i64, vp, vp, i64, i32, i32, i32, vp],
         'dlsg_rowln_fwd': [P(RowLnArgs), vp],
         'dlsg_rowln_bwd': [P(RowLnBwdArgs), vp],
@@ -340,7 +341,7 @@ def load_library(path=LIB_PATH):
     for name, args in sig.items():
         fn = getattr(lib, name)
         fn.argtypes = args
-        fn.restype = C.c_int64 if name in ('dlsg_o2v_workspace_bytes', 'dlsg_cln_ws_floats', 'dlsg_colsum_ws_floats',
+        fn.restype = C.c_int64 if name in ('dlsg_gemm_ws_bytes', 'dlsg_o2v_workspace_bytes', 'dlsg_cln_ws_floats', 'dlsg_colsum_ws_floats',
                                             'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_bwd_x_floats',
                                             'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words') else C.c_int
     return lib
@@ -434,6 +435,23 @@ class HipOps(object):
             raise RuntimeError('%s failed with code %d' % (what, rc))
 
     # ------------------------------------------------------------------ GEMM
+    stream_k = True           # False: dlsg_gemm gets no workspace, so every product runs on the tiled kernels
+
+    def _gemm_workspace(self, dev):
+        """the stream-K kernel's scratch (csrc/gemm_sk.hip): counters + one accumulator slot per CU, zero-filled once; one per
+        (device, stream), because two launches that may overlap must not share it"""
+        key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        d = self.__dict__.setdefault('_gemm_ws', {})
+        ws = d.get(key)
+        if ws is None:
+            n = int(self.lib.dlsg_gemm_ws_bytes())
+            if n <= 0:
+                raise RuntimeError('dlsg_gemm_ws_bytes() failed: no device?')
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the stream-K workspace of this stream must exist before a capture starts (run the step once eagerly)')
+            ws = d[key] = torch.zeros((n + 3) // 4, dtype=torch.float32, device=dev)
+        return ws
+
     def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None, skip_if=None, plan_only=False):
         """groups: list of (A, B, C[, bias]) views (2-d, or 3-d batched with identical batch strides across groups).
         plan_only: nothing is launched; returns the tile family the library would run the call on (dlsg_gemm_variant)."""
@@ -454,6 +472,10 @@ class HipOps(object):
         a.flags = flags | self.extra_flags | (F_BIAS if (bias is not None or gbias) else 0)
         a.bias = _p(bias)
         a.skip_if = _p(skip_if)          # 1-element int32 device tensor: launch is a no-op when it is non-zero
+        if (self.stream_k or (flags & F_SK)) and not (flags & F_NOSK):
+            ws = self._gemm_workspace(C0.device)
+            a.ws, a.ws_bytes = _p(ws), ws.numel() * 4
+            a.err = _p(self._persist_word(C0.device))
         assert len(groups) <= MAXG
         for i, grp_ in enumerate(groups):
             A, B, Cc = grp_[:3]
@@ -499,7 +521,7 @@ class HipOps(object):
             else:
                 v = self.lib.dlsg_gemm_variant(C.byref(a))         # the library's own answer (csrc/gemm.hip, gemm_plan)
                 variant = {0: '64x64', 1: '128x64', 2: '128x128', 3: 'skinny_64x32' if M <= 64 else 'skinny_128x32', 4: '256x256',
-                           5: '256x128', 6: '256x256+rest'}[v]
+                           5: '256x128', 6: '256x256+rest', 7: 'streamk_256x256'}[v]
             # one key per kernel symbol (arithmetic, tile, operand layout), as rocprofv3 --stats lists them
             ks = sorted(set(a.g[i].K for i in range(len(groups))))
             shape = '%s M=%d N=%d K=%s groups=%d batch=%d' % (('NT', 'NN', 'TN')[mode], M, N, '/'.join(map(str, ks)), len(groups), nb)

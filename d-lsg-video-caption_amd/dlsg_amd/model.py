@@ -264,6 +264,7 @@ class CapGnnModel(_HipModel):
         ops.extra_flags = self._gemm_flags(True)
         G = self._G
         ops.fill(self._gflat, 0.0)
+        ops.grad_written = set()            # engine._accum_flag: the first product into a gradient block stores, later ones add
         if self.merge_weight_grads and self._defer_ok:
             sv['tn_defer'] = []             # mid-size weight gradients of every module: launched together at the end
         collect = hasattr(ops, 'colsum_flush')

@@ -19,8 +19,9 @@ extern "C" {
  * workspace pointer before the stream; the RCCL communicator entry points and the persistent BiLSTM were added).  A binding
  * must refuse a library whose version differs from the header it was written against.  (4: the critic's per-op entry points --
  * dlsg_lstm_cell_*, dlsg_tanh_ln_*, dlsg_conv_taps, dlsg_softmax_bwd2, dlsg_gemm_narrow -- gave way to the blocks of its schedule,
- * dlsg_crit_* / dlsg_cln_*; dlsg_lstm_seq takes batch-major arrays.) */
-#define DLSG_ABI_VERSION 4
+ * dlsg_crit_* / dlsg_cln_*; dlsg_lstm_seq takes batch-major arrays.  5: dlsg_gemm_args carries a workspace and an error word for the
+ * stream-K kernel, dlsg_gemm_ws_bytes added; dlsg_adam takes `guard` before the stream and dlsg_select_embed `prefilled`.) */
+#define DLSG_ABI_VERSION 5
 int dlsg_abi_version(void);
 
 /* Return codes of every entry point that returns int: 0 or one of these. */
@@ -57,6 +58,9 @@ int dlsg_struct_size(int which);
 #define DLSG_GEMM_FORCE128 512 /* tuning: force the 128x128 block tile (both FORCE bits: the 128x64 tile) */
 #define DLSG_GEMM_TILE256 2048  /* tuning: force the 256x256 block tile of csrc/gemm_big.hip (with FORCE128: 256x128); EINVAL when
                                    the operands do not meet its alignment conditions */
+#define DLSG_GEMM_SK 4096      /* tuning: force the persistent stream-K kernel of csrc/gemm_sk.hip; EINVAL without a workspace
+                                  or when the operands do not meet its conditions (16-B alignment, K % 32 == 0, one batch) */
+#define DLSG_GEMM_NOSK 8192    /* tuning: never the stream-K kernel */
 #define DLSG_GEMM_BF16X3 1024  /* split-bf16 matrix path: x = hi + lo, 3 bf16 MFMAs per product, fp32 accumulate
                                   (~1e-5 relative error per product instead of 6e-8; see csrc/gemm_bf16x3.hip) */
 typedef struct {
@@ -80,9 +84,18 @@ typedef struct {
     const float* bias;
     const int32_t* skip_if; /* optional device flag: the launch does nothing when *skip_if != 0 (a hipGraph-replayed step whose
                                product is needed only on some replays, e.g. per-word logits under scheduled sampling) */
+    void* ws;               /* optional caller scratch of >= dlsg_gemm_ws_bytes() bytes, 16-B aligned, zero-filled ONCE by the
+                               caller and not shared by launches that may run concurrently (one per stream): with it the
+                               chip-filling products run on the persistent stream-K kernel (csrc/gemm_sk.hip), which leaves
+                               the counter area at the front of it zeroed again; NULL = the tiled kernels only */
+    int64_t ws_bytes;
+    int32_t* err;           /* optional device word: set to 3 when a stream-K workgroup gave up waiting for another one's
+                               share of a split tile (~1 s; the result of that launch is then invalid) */
     dlsg_gemm_group g[DLSG_GEMM_MAXG];
 } dlsg_gemm_args;
 int dlsg_gemm(const dlsg_gemm_args* args, void* stream);
+/* Scratch a stream-K launch needs on the current device: a 16-KB counter area + two 256-KB accumulator slots per CU. */
+int64_t dlsg_gemm_ws_bytes(void);
 /* The kernel family dlsg_gemm runs this call on (fp32 arithmetic; EINVAL with DLSG_GEMM_BF16X3): what a profiler's kernel
  * symbol will be, without repeating the dispatch rule on the caller's side. */
 #define DLSG_GEMM_V_64 0        /* gemm_kernel<64, 64, ...> */
@@ -93,6 +106,7 @@ int dlsg_gemm(const dlsg_gemm_args* args, void* stream);
 #define DLSG_GEMM_V_256x128 5   /* gemm_big_kernel<256, 128, ...> */
 #define DLSG_GEMM_V_256_HEAD 6  /* gemm_big_kernel<256, 256, ...> on the row panels that come in whole rounds of the CUs, the
                                    remaining rows through the choice again */
+#define DLSG_GEMM_V_SK 7        /* gemm_sk_kernel<...>: one persistent launch, 256 x 256 tiles, stream-K remainder */
 int dlsg_gemm_variant(const dlsg_gemm_args* args);
 
 /* out[r, :] = sum_s slabs[s][r, :] (+ bias) (tanh); slabs are nslab consecutive (rows x n) arrays. */

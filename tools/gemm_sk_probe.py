@@ -1,0 +1,149 @@
+"""Stream-K GEMM (csrc/gemm_sk.hip) against torch on the same operands: numerics on the shapes and edge cases the dispatcher may
+send to it, and its time beside the tiled kernels' and the vendor library's.  usage: python3 tools/gemm_sk_probe.py [quick]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
+import torch  # noqa: E402
+from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_TILE256, F_SK, F_NOSK, F_ACCUM, F_TANH  # noqa: E402
+
+torch.backends.cuda.matmul.allow_tf32 = False
+ops = HipOps()
+quick = len(sys.argv) > 1 and sys.argv[1] == 'quick'
+STREAM = torch.cuda.Stream()
+
+
+def timeit(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    st = STREAM
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(st):
+        ops._gemm_workspace(torch.device('cuda', 0))
+        fn()
+        with torch.cuda.graph(gr, stream=st):
+            for _ in range(reps):
+                fn()
+    gr.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        gr.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (3 * reps) * 1e3
+
+
+def operands(mode, M, N, K, g):
+    if mode == GEMM_NT:
+        return torch.randn(M, K, device='cuda', generator=g), torch.randn(N, K, device='cuda', generator=g)
+    if mode == GEMM_NN:
+        return torch.randn(M, K, device='cuda', generator=g), torch.randn(K, N, device='cuda', generator=g)
+    return torch.randn(K, M, device='cuda', generator=g), torch.randn(K, N, device='cuda', generator=g)
+
+
+def ref(mode, A, B):
+    A, B = A.double(), B.double()
+    if mode == GEMM_NT:
+        return A @ B.t()
+    if mode == GEMM_NN:
+        return A @ B
+    return A.t() @ B
+
+
+out = {'numerics': {}, 'timing': {}}
+g = torch.Generator(device='cuda')
+g.manual_seed(5)
+
+# ---------------------------------------------------------------- numerics: (name, mode, M, [(N, K)...], flags, bias)
+NUM = [('NT 512x512x4096 (4 tiles, 16-way split)', GEMM_NT, 512, [(512, 4096)], 0, False),
+       ('NT 1664x1000x1024 bias (ragged M, N)', GEMM_NT, 1664, [(1000, 1024)], 0, True),
+       ('NT 3000x768x2048 x2 groups bias tanh', GEMM_NT, 3000, [(768, 2048), (768, 2048)], F_TANH, True),
+       ('NN 1664x2048x2048', GEMM_NN, 1664, [(2048, 2048)], 0, False),
+       ('NN 1700x1028x1024 x3 groups of different K, N', GEMM_NN, 1700, [(1028, 1024), (512, 2048), (300, 512)], 0, False),
+       ('TN 1024x2048x6656 x2 accum', GEMM_TN, 1024, [(2048, 6656), (2048, 6656)], F_ACCUM, False),
+       ('TN 4096x{1024,300,1024}x1664 accum (decoder blocks)', GEMM_TN, 4096, [(1024, 1664), (300, 1664), (1024, 1664)], F_ACCUM, False),
+       ('TN 260x516x64 (K = 2 stages)', GEMM_TN, 260, [(516, 64)], 0, False),
+       ('NT 8192x8192x512', GEMM_NT, 8192, [(8192, 512)], 0, False)]
+for name, mode, M, nk, fl, use_bias in NUM:
+    groups, refs = [], []
+    for N, K in nk:
+        A, B = operands(mode, M, N, K, g)
+        Cc = torch.randn(M, N, device='cuda', generator=g) if (fl & F_ACCUM) else torch.full((M, N), float('nan'), device='cuda')
+        bias = torch.randn(N, device='cuda', generator=g) if use_bias else None
+        r = ref(mode, A, B)
+        if use_bias:
+            r = r + bias.double()
+        if fl & F_ACCUM:
+            r = r + Cc.double()
+        if fl & F_TANH:
+            r = torch.tanh(r)
+        groups.append((A, B, Cc, bias))
+        refs.append(r)
+    worst = 0.0
+    for rep in range(3):                        # the counters must be back at zero after every launch
+        if rep and (fl & F_ACCUM):
+            break
+        ops.gemm(mode, groups, flags=fl | F_SK)
+        torch.cuda.synchronize()
+        for (A, B, Cc, _), r in zip(groups, refs):
+            err = ((Cc.double() - r).abs().max() / r.abs().max().clamp_min(1e-30)).item()
+            worst = max(worst, err if err == err else float('inf'))
+    ws = ops._gemm_workspace(torch.device('cuda', 0))
+    cnt = ws[:1024].view(torch.int32).abs().sum().item()
+    out['numerics'][name] = {'max_rel_err_vs_fp64': worst, 'counters_left': cnt, 'err_word': int(ops._persist_word(torch.device('cuda', 0)).item())}
+    # (behind tanh the reference's scale is 1 while the fp32 rounding of the 2048-deep pre-activation, |x| ~ 45, stays ~1e-5)
+    assert worst < (3e-4 if (fl & F_TANH) else 3e-6) and cnt == 0, (name, worst, cnt)
+
+# bit-identical across launches and under graph replay
+A, B = operands(GEMM_NT, 26624, 1024, 2048, g)
+C1, C2 = torch.empty(26624, 1024, device='cuda'), torch.empty(26624, 1024, device='cuda')
+ops.gemm(GEMM_NT, [(A, B, C1)], flags=F_SK)
+ops.gemm(GEMM_NT, [(A, B, C2)], flags=F_SK)
+torch.cuda.synchronize()
+out['numerics']['bit_identical_across_launches'] = bool(torch.equal(C1, C2))
+assert torch.equal(C1, C2)
+
+# ---------------------------------------------------------------- timing
+TIM = [('NT region projection 26624x1024x2048 x2 groups, bias + tanh', GEMM_NT, 26624, [(1024, 2048)] * 2, F_TANH, True, True),
+       ('NT 26624x1024x2048 (one group)', GEMM_NT, 26624, [(1024, 2048)], 0, False, False),
+       ('TN obj_embed weight gradient 1024x2048x26624 x2, accum', GEMM_TN, 1024, [(2048, 26624)] * 2, F_ACCUM, False, False),
+       ('NN 26624x2048x1024', GEMM_NN, 26624, [(2048, 1024)], 0, False, False),
+       ('NT 8192^3', GEMM_NT, 8192, [(8192, 8192)], 0, False, False),
+       ('TN 4096x1024x1664 x7 accum (decoder weight gradients)', GEMM_TN, 4096, [(1024, 1664)] * 7, F_ACCUM, False, False),
+       ('TN 2048x2048x1664 x3 accum (self-attention weight gradients)', GEMM_TN, 2048, [(2048, 1664)] * 3, F_ACCUM, False, False),
+       ('NT 1664x4096x1024 x2 (BiLSTM input gates)', GEMM_NT, 1664, [(4096, 1024)] * 2, 0, False, False),
+       ('NN 1664x2048x2048 x3', GEMM_NN, 1664, [(2048, 2048)] * 3, 0, False, False),
+       ('NT 1664x2048x2048 x3', GEMM_NT, 1664, [(2048, 2048)] * 3, 0, False, False)]
+if quick:
+    TIM = TIM[:3]
+for name, mode, M, nk, fl, use_bias, shareA in TIM:
+    groups = []
+    A0 = None
+    for N, K in nk:
+        A, B = operands(mode, M, N, K, g)
+        if shareA:
+            A0 = A if A0 is None else A0
+            A = A0
+        Cc = torch.zeros(M, N, device='cuda')
+        bias = torch.randn(N, device='cuda', generator=g) if use_bias else None
+        groups.append((A, B, Cc, bias))
+    gf = sum(2.0 * M * N * K for N, K in nk) / 1e9
+    row = {}
+    for tag, f2 in (('stream_k', F_SK), ('dispatcher_no_sk', F_NOSK), ('tile_256', F_TILE256 | F_NOSK)):
+        try:
+            us = timeit(lambda: ops.gemm(mode, groups, flags=fl | f2))
+            row[tag] = {'us': round(us, 1), 'TFLOPs': round(gf / us * 1e3, 1), 'frac_of_157.3': round(gf / us * 1e3 / 157.3, 3)}
+        except RuntimeError as e:
+            row[tag] = str(e)
+    if len(nk) == 1:
+        A, B, Cc, _ = groups[0]
+        lib = {GEMM_NT: lambda: torch.mm(A, B.t(), out=Cc), GEMM_NN: lambda: torch.mm(A, B, out=Cc), GEMM_TN: lambda: torch.mm(A.t(), B, out=Cc)}[mode]
+        us = timeit(lib)
+        row['library'] = {'us': round(us, 1), 'TFLOPs': round(gf / us * 1e3, 1)}
+    out['timing'][name] = row
+    print(name, json.dumps(row), flush=True)
+print(json.dumps(out, indent=1))
