@@ -127,11 +127,11 @@ def gemm_tn_deep(ops, items, ref):
     if deep and getattr(ops, 'stream_k', False) and all(ops.gemm(GEMM_TN, [it], flags=F_ACCUM, plan_only=True) == V_SK for it in deep):
         # the persistent stream-K kernel cuts the contraction between the workgroups itself (csrc/gemm_sk.hip): one launch for
         # all the products, no slabs, no fold
-        for fl in (0, F_ACCUM):
-            part = [it for it in deep if _accum_flag_peek(ops, it[2]) == fl]
+        parts = {0: [], F_ACCUM: []}
+        for it in deep:
+            parts[_accum_flag(ops, it[2])].append(it)
+        for fl, part in parts.items():
             for i0 in range(0, len(part), 16):
-                for it in part[i0:i0 + 16]:
-                    _accum_flag(ops, it[2])
                 ops.gemm(GEMM_TN, part[i0:i0 + 16], flags=fl)
         return
     by_shape = {}

@@ -8,6 +8,8 @@ import torch
 
 from emul_ops import EmulOps, GEMM_NT, GEMM_NN, GEMM_TN, F_ACCUM, F_TANH, F_BF16X3, F_FORCE64, F_FORCE128, F_TILE256
 
+F_SK, F_NOSK = 4096, 8192          # include/dlsg.h DLSG_GEMM_SK / DLSG_GEMM_NOSK (dlsg_amd.hip needs the library: not imported here)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -125,6 +127,56 @@ def test_gemm_256_tiles(hip, mode, tile, shape):
     both(hip, build, run, ['C', 'C2'], tol=1e-5 * max(1.0, math.sqrt(K)), name='gemm 256 tile %d %s' % (mode, shape))
 
 
+@pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
+@pytest.mark.parametrize('extra', [0, F_ACCUM, F_TANH])
+@pytest.mark.parametrize('shape', [(256, 256, 32), (600, 520, 96), (260, 132, 64), (1700, 1000, 128), (300, 260, 2048)])
+def test_gemm_stream_k(hip, mode, extra, shape):
+    """csrc/gemm_sk.hip (persistent stream-K launch, forced with F_SK): ragged edges, strided views, per-group bias, two groups of
+    different width, store / accumulate / tanh epilogues; tiles cut between 2 .. 14 workgroups (few tiles on 256 CUs), whole
+    tiles plus a cut remainder; twice in a row (the counters in the workspace must come back to zero)"""
+    M, N, K = shape
+
+    def build(g):
+        if mode == GEMM_NT:
+            A, B = rnd(g, M, K + 4), rnd(g, N, K + 4)
+        elif mode == GEMM_NN:
+            A, B = rnd(g, M, K + 4), rnd(g, K, N + 4)
+        else:
+            A, B = rnd(g, K, M + 4), rnd(g, K, N + 4)
+        return dict(A=A, B=B, C=rnd(g, M, N + 8), C2=rnd(g, M, N + 8), bias=rnd(g, N))
+
+    def run(ops, t):
+        N2 = max(4, N // 2 // 4 * 4)
+        if mode == GEMM_NT:
+            A, B, B2 = t['A'][:, :K], t['B'][:, :K], t['B'][:N2, :K]
+        elif mode == GEMM_NN:
+            A, B, B2 = t['A'][:, :K], t['B'][:, :N], t['B'][:, :N2]
+        else:
+            A, B, B2 = t['A'][:, :M], t['B'][:, :N], t['B'][:, :N2]
+        groups = [(A, B, t['C'][:, :N], t['bias']), (A, B2, t['C2'][:, :N2], t['bias'][:N2])]
+        ops.gemm(mode, groups, alpha=0.5, flags=extra | F_SK)
+        if not (extra & F_ACCUM):
+            ops.gemm(mode, groups, alpha=0.5, flags=extra | F_SK)
+    both(hip, build, run, ['C', 'C2'], tol=(1e-4 if extra & F_TANH else 1e-5) * max(1.0, math.sqrt(K)), name='gemm stream-K %d %s' % (mode, shape))
+    ws = hip._gemm_workspace(torch.device('cuda', 0))
+    assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0          # the counter area
+    assert int(hip._persist_word(torch.device('cuda', 0)).item()) == 0
+
+
+def test_gemm_stream_k_is_bit_reproducible_and_refuses_what_it_cannot_take(hip):
+    A, B = torch.randn(3000, 2048, device='cuda'), torch.randn(768, 2048, device='cuda')
+    C1, C2 = torch.empty(3000, 768, device='cuda'), torch.empty(3000, 768, device='cuda')
+    hip.gemm(GEMM_NT, [(A, B, C1)], flags=F_SK)
+    hip.gemm(GEMM_NT, [(A, B, C2)], flags=F_SK)
+    assert torch.equal(C1, C2)
+    ref = (A.double() @ B.double().t())
+    assert ((C1.double() - ref).abs().max() / ref.abs().max()).item() < 2e-6
+    with pytest.raises(RuntimeError):
+        hip.gemm(GEMM_NT, [(A[:, :2040], B[:, :2040], C1)], flags=F_SK)      # K % 32 != 0
+    with pytest.raises(RuntimeError):
+        hip.gemm(GEMM_NT, [(A, B[:766], C1[:, :766])], flags=F_SK)           # width not a multiple of 4
+
+
 def test_gemm_variant_names_the_tile_family(hip):
     """dlsg_gemm_variant == the choice dlsg_gemm makes (include/dlsg.h DLSG_GEMM_V_*), on the shapes DESIGN.md quotes"""
     def plan(mode, M, N, K, G=1, flags=0):
@@ -137,6 +189,16 @@ def test_gemm_variant_names_the_tile_family(hip):
             A, B = torch.empty(K, M, device=dev), torch.empty(K, N, device=dev)
         Cc = torch.empty(M, N, device=dev)
         return hip.gemm(mode, [(A, B, Cc)] * G, flags=flags, plan_only=True)
+    # with the caller's workspace the chip-filling products are one persistent stream-K launch (csrc/gemm_sk.hip) ...
+    assert plan(GEMM_NT, 26624, 1024, 2048, 2) == 7              # region projections of both streams
+    assert plan(GEMM_TN, 1024, 2048, 26624, 2) == 7              # their weight gradients: the contraction is cut inside the launch
+    assert plan(GEMM_TN, 4096, 1024, 1664, 11) == 7              # the 4096-row weight-gradient blocks of the decoder and the BiLSTM
+    assert plan(GEMM_NT, 1664, 2048, 2048, 3) == 1               # (the 1 664-row products tie with the small tiles and stay there)
+    assert plan(GEMM_NT, 26624, 1024, 2046, 2) == 2              # K % 32 != 0: not a stream-K shape
+    assert plan(GEMM_NT, 832, 1024, 2048, 2) != 7                # 832 rows (the goldens' two clips): too little work, 19 % padding
+    # ... without it (F_NOSK: the binding passes no workspace) the tiled kernels' rule is what it was
+    _plan = plan
+    plan = lambda mode, M, N, K, G=1, flags=0: _plan(mode, M, N, K, G, flags | F_NOSK)
     assert plan(GEMM_NT, 64, 4096, 1024, 4) == 3                 # recurrent product: skinny kernels
     assert plan(GEMM_NT, 128, 4096, 1024, 4) == 3
     assert plan(GEMM_TN, 64, 4096, 1024) != 3                    # (row-contiguous A: not a skinny shape)
