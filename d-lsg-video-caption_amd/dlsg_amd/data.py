@@ -439,7 +439,12 @@ class TrainLoader(object):
     frames / regions are device tensors, regions already cut to num_obj; captions / pos_tags are (B, max_words) int64 on the
     device; cap_lens / video_ids are tuples of ints ordered like the batch rows (video id descending, utils/data.py:90)."""
 
-    def __init__(self, captions, features, batch_size, world_size=1, rank=0, shuffle=True, seed=0, drop_last=False):
+    def __init__(self, captions, features, batch_size, world_size=1, rank=0, shuffle=True, seed=None, drop_last=False):
+        """seed None (the default, = the reference): one process shuffles as `DataLoader(shuffle=True)` does -- every pass over
+        the data draws two words from torch's global generator (the DataLoader iterator's base seed, then the RandomSampler's
+        seed: torch/utils/data/dataloader.py, sampler.py), so after the same `torch.manual_seed` (train_debug.py:34-36) the
+        batches are the reference's (tests/golden/loader_ref.npz); several ranks use DistributedSampler's seed 0.  An int:
+        a permutation seeded by seed + epoch, independent of the global generator."""
         self.caps = captions if isinstance(captions, CaptionSet) else CaptionSet(captions)
         self.features, self.batch_size = features, batch_size
         self.world, self.rank, self.shuffle, self.seed, self.drop_last = world_size, rank, shuffle, seed, drop_last
@@ -457,10 +462,16 @@ class TrainLoader(object):
         self.epoch = epoch
 
     def _batches(self):
+        n = len(self.caps)
         if self.world > 1:
-            idx = distributed_indices(len(self.caps), self.world, self.rank, self.epoch, True, self.seed)
-        else:                                           # single process: DataLoader(shuffle=True)
-            idx = distributed_indices(len(self.caps), 1, 0, self.epoch, self.shuffle, self.seed)
+            idx = distributed_indices(n, self.world, self.rank, self.epoch, True, self.seed or 0)
+        elif self.shuffle and self.seed is None:        # single process: DataLoader(shuffle=True) on torch's global generator
+            torch.empty((), dtype=torch.int64).random_()                       # the iterator's base seed (drawn, unused here)
+            g = torch.Generator()
+            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+            idx = torch.randperm(n, generator=g).tolist()
+        else:
+            idx = distributed_indices(n, 1, 0, self.epoch, self.shuffle, self.seed or 0)
         out = []
         for s in range(0, len(idx), self.batch_size):
             b = idx[s:s + self.batch_size]

@@ -819,9 +819,13 @@ def dec_prepare(ops, dec, mems, sv, training, seed):
     H = dec.visual_hidden_size
     plan = DecPlan(dec, H * len(gsrc))
     Q = plan.Q
-    gfeat = _empty(ref, B, plan.G)
-    for i, g in enumerate(gsrc):
-        ops.mean_rows_fwd(g, gfeat[:, i * H:(i + 1) * H])
+    if sv.get('step_feats') is not None:
+        gfeat = sv['step_feats']               # models/layer.py:404-405: a given global feature replaces the proposals' means
+        assert gfeat.shape == (B, plan.G), (tuple(gfeat.shape), (B, plan.G))
+    else:
+        gfeat = _empty(ref, B, plan.G)
+        for i, g in enumerate(gsrc):
+            ops.mean_rows_fwd(g, gfeat[:, i * H:(i + 1) * H])
     Wq = dec.query_lstm.weight_ih
     gq = _empty(ref, B, 4 * Q)
     lin(ops, gfeat, Wq[:, plan.q_glob[0]:plan.q_glob[1]], gq)

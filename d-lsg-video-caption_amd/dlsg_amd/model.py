@@ -110,6 +110,13 @@ class _HipModel(_ArenaModule):
         # ~1e-5 relative error) for the backward products only; 'x3_all' = split-bf16 for forward and backward.
         self.gemm_precision = 'fp32'
 
+    def __setattr__(self, name, value):
+        super().__setattr__(name, value)
+        if name == 'decoder' and isinstance(value, nn.Module):
+            # Decoder.forward called on its own (models/layer.py:394) launches through the owning model's binding and arena
+            import weakref
+            object.__setattr__(value, '_owner', weakref.ref(self))
+
     @staticmethod
     def check_kernel_limits(args, attended_rows, what):
         """The fused decoder-step kernels (csrc/decstep.hip: MAXW, MAXP) hold one batch row's vectors in LDS: widths up to

@@ -172,6 +172,46 @@ class Decoder(nn.Module):
         """models/layer.py:348-350"""
         self.beam_size = beam_size
 
+    def forward(self, cnn_feats, captions, max_words, teacher_forcing_ratio, cnn_feats_2=None, step_feats=None):
+        """models/layer.py:394-447 called on its own (the models call the engine directly): teacher-forced / scheduled-sampling
+        logits + attention weights, or greedy ids when `captions` is None, from given proposals; `step_feats` (B, G) replaces
+        the means of the proposals as the global feature (layer.py:404-405; as there, a non-multi-modal decoder then attends
+        over `cnn_feats` alone).  Forward only (the gradients of the path go through the model's autograd bridge); needs the
+        owning model's kernel binding, so the decoder must belong to one of dlsg_amd's models.  Beam search: model.forward."""
+        from . import engine as E
+        model = self._owner() if getattr(self, '_owner', None) is not None else None
+        if model is None:
+            raise RuntimeError('Decoder.forward needs the model that owns this decoder (its HIP binding and parameter arena)')
+        infer = captions is None
+        if infer and self.beam_size != 1:
+            raise NotImplementedError('beam search runs through the model (dlsg_amd.beam.beam_infer); update_beam_size(1) for greedy ids')
+        L = self.max_words if max_words is None else max_words
+        model.flatten_parameters_()
+        ops = model.ops
+        ops.extra_flags = model._gemm_flags(False)
+        feats1 = cnn_feats.contiguous().float()
+        feats2 = cnn_feats_2.contiguous().float() if cnn_feats_2 is not None else None
+        sv = {'dec_gsrc': [feats1] + ([feats2] if feats2 is not None else [])}
+        if step_feats is not None:
+            sv['step_feats'] = step_feats.contiguous().float()
+        if feats2 is not None and self.multi_modal:
+            mems = [feats1, feats2]
+        elif feats2 is not None and step_feats is None:
+            mems = [torch.cat([feats1, feats2], 1)]          # layer.py:412-413
+        else:
+            mems = [feats1]
+        coins = model._draw_coins(L, infer, teacher_forcing_ratio)
+        with torch.no_grad():
+            s = E.dec_fwd(ops, self, mems, sv, captions, L, coins, self.training and not infer, model.next_seed())
+            if infer:
+                return s['IDS'][1:].t().contiguous(), []
+            B = feats1.shape[0]
+            logits = torch.empty(B, L, self.vocab_size, dtype=torch.float32, device=feats1.device)
+            ops.permute_tb(s['LOGITS'], logits)
+            alpha = torch.empty(B, L, s['ALPHA'].shape[-1], dtype=torch.float32, device=feats1.device)
+            ops.permute_tb(s['ALPHA'], alpha)
+        return logits, [alpha[:, i].unsqueeze(2) for i in range(L)]
+
     def decode_tokens(self, tokens):
         """models/layer.py:464-477: ids -> words until <end>."""
         words = []

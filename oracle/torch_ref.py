@@ -342,17 +342,21 @@ def beam_search(step_fn, start_ids, state, end_index, max_steps, beam):
     return torch.cat(list(reversed(rec)), 2), last_lp
 
 
-def decoder_forward(m, feats1, captions, max_words, tf_ratio, feats2=None, training=False, rng=random):
-    """models/layer.py:394-462.  Returns (outputs, alpha_list)."""
+def decoder_forward(m, feats1, captions, max_words, tf_ratio, feats2=None, training=False, rng=random, step_feats=None):
+    """models/layer.py:394-462.  Returns (outputs, alpha_list).  step_feats (layer.py:404-405): a given global feature; the
+    proposals are then neither averaged nor (non-multi-modal decoders) concatenated."""
     infer = captions is None
     if max_words is None:
         max_words = m.max_words
     B = feats1.size(0)
-    gfeat = feats1.mean(1)
-    if feats2 is not None:
-        gfeat = torch.cat([gfeat, feats2.mean(1)], -1)
-        if not m.multi_modal:
-            feats1 = torch.cat([feats1, feats2], 1)
+    if step_feats is not None:
+        gfeat = step_feats
+    else:
+        gfeat = feats1.mean(1)
+        if feats2 is not None:
+            gfeat = torch.cat([gfeat, feats2.mean(1)], -1)
+            if not m.multi_modal:
+                feats1 = torch.cat([feats1, feats2], 1)
     att1 = _AttCache(m.context_att, feats1)
     att2 = _AttCache(m.context_att_2, feats2) if m.multi_modal else None
     lh = feats1.new_zeros(B, m.decode_hidden_size); lc = lh.clone()

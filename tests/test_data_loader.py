@@ -186,3 +186,78 @@ def test_streamed_prefetch_can_be_abandoned_and_reports_reader_errors(tmp_path):
     assert threading.active_count() <= before
     with pytest.raises(IndexError):                          # a failing read surfaces in the consumer
         list(st.prefetch([[0, 1], [10 ** 6]]))
+
+
+# ------------------------------------------------------------------ against the reference's own loaders (tests/golden/loader_ref.npz)
+import os  # noqa: E402
+
+REF_FX = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'loader_ref.npz')
+
+
+def _check_train(fx, tag, loader, feats, vfeats, caps, tags, num_obj, dev='cpu'):
+    nb = int(fx[tag + '.nbatch'])
+    got = list(loader)
+    assert len(got) == nb == len(loader), (tag, len(got), nb)
+    for bi, (frames, regions, spatials, captions, pos_tags, cap_lens, video_ids) in enumerate(got):
+        pre = '%s.b%d.' % (tag, bi)
+        assert list(video_ids) == fx[pre + 'video_ids'].tolist(), pre
+        assert list(cap_lens) == fx[pre + 'lengths'].tolist(), pre
+        idx = fx[pre + 'index'].tolist()
+        for j, i in enumerate(idx):                                   # the rows are the reference's rows, in its order
+            assert torch.equal(captions[j].cpu(), caps[i]) and torch.equal(pos_tags[j].cpu(), tags[i]), (pre, j)
+        fs = frames.double().sum((1, 2)).cpu().numpy()
+        rs = regions.double().sum((1, 2, 3)).cpu().numpy()
+        assert regions.shape[2] == num_obj
+        assert np.allclose(fs, fx[pre + 'frames_sum'], rtol=0, atol=1e-3) and np.allclose(rs, fx[pre + 'regions_sum'], rtol=0, atol=1e-3), pre
+        assert float(captions.double().sum()) == float(fx[pre + 'captions_sum']) and float(pos_tags.double().sum()) == float(fx[pre + 'pos_tags_sum'])
+
+
+def _check_eval(fx, tag, loader):
+    nb = int(fx[tag + '.nbatch'])
+    got = list(loader)
+    assert len(got) == nb == len(loader), (tag, len(got), nb)
+    for bi, (frames, regions, spatials, video_ids) in enumerate(got):
+        pre = '%s.b%d.' % (tag, bi)
+        assert list(video_ids) == fx[pre + 'video_ids'].tolist(), pre
+        assert np.allclose(frames.double().sum((1, 2)).cpu().numpy(), fx[pre + 'frames_sum'], rtol=0, atol=1e-3)
+        assert np.allclose(regions.double().sum((1, 2, 3)).cpu().numpy(), fx[pre + 'regions_sum'], rtol=0, atol=1e-3)
+
+
+def _reference_loader_cases(tmp_path, make_store):
+    """every batch the REFERENCE's get_train_loader / get_eval_loader / DistributedSampler delivered on this data set (the
+    fixture was written by tests/golden/make_goldens_r5.py from the imported utils/data.py): same rows, same order"""
+    fx = np.load(REF_FX)
+    N, num_obj, bs = int(fx['meta.N']), int(fx['meta.num_obj']), int(fx['meta.batch_size'])
+    fp, rp, cp, feats, vfeats, caps, tags, lens, vids = make_dataset(tmp_path, N=N)
+    store = make_store(fp, rp, num_obj)
+    # one process, DataLoader(shuffle=True) after torch.manual_seed: two passes
+    torch.manual_seed(int(fx['meta.torch_seed']))
+    ld = D.TrainLoader(cp, store, batch_size=bs)
+    _check_train(fx, 'train1.e0', ld, feats, vfeats, caps, tags, num_obj)
+    _check_train(fx, 'train1.e1', ld, feats, vfeats, caps, tags, num_obj)
+    # two ranks: DistributedSampler, epochs 0 and 1
+    for rank in range(2):
+        ld = D.TrainLoader(cp, store, batch_size=bs, world_size=2, rank=rank)
+        for epoch in range(2):
+            ld.set_epoch(epoch)
+            _check_train(fx, 'train2.r%d.e%d' % (rank, epoch), ld, feats, vfeats, caps, tags, num_obj)
+    rng = tuple(int(x) for x in fx['meta.eval_range'])
+    _check_eval(fx, 'eval1', D.EvalLoader(rng, store, batch_size=5))
+    for rank in range(2):
+        _check_eval(fx, 'eval2.r%d' % rank, D.EvalLoader(rng, store, batch_size=5, world_size=2, rank=rank))
+
+
+@needs_h5
+@pytest.mark.parametrize('kind', ['resident', 'streamed'])
+def test_loaders_deliver_the_reference_loaders_batches(tmp_path, kind):
+    mk = (lambda fp, rp, no: D.ResidentFeatures(fp, rp, no, 'cpu', chunk=5)) if kind == 'resident' else \
+         (lambda fp, rp, no: D.StreamedFeatures(fp, rp, no, 'cpu'))
+    _reference_loader_cases(tmp_path, mk)
+
+
+@needs_h5
+@pytest.mark.gpu
+def test_resident_store_on_the_gpu_delivers_the_reference_loaders_batches(tmp_path):
+    from dlsg_amd.hip import HipOps
+    ops = HipOps()
+    _reference_loader_cases(tmp_path, lambda fp, rp, no: D.ResidentFeatures(fp, rp, no, 'cuda', ops=ops))

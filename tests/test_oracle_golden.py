@@ -202,3 +202,19 @@ def test_gan_lambda_handler_state_machine():
     lam = [h.get_current_lambda() for _ in range(5)]
     assert lam[0] <= 0.01 and all(a >= b for a, b in zip(lam, lam[1:]))
     assert abs(min(h.decrease_schedule) - 0.006) < 1e-4 and abs(max(h.decrease_schedule) - 0.01) < 1e-4
+
+
+def test_decoder_forward_with_step_feats():
+    """models/layer.py:394,404-405 (`step_feats`): the oracle's decoder with a given global feature against the reference's
+    (tests/golden/small_stepfeats.npz, make_goldens_r5.py)"""
+    import os
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'small_stepfeats.npz')))
+    step = torch.from_numpy(fx['step_feats'])
+    with torch.no_grad():
+        obj, mot = R.capgnn_encoder(net.encoder, frames, regions)
+        logits, _ = R.decoder_forward(net.decoder, obj, caps, 26, 1.0, feats2=mot, step_feats=step)
+        assert np.abs(logits.numpy() - fx['logits']).max() <= 1e-5
+        net.update_beam_size(1)
+        ids, _ = R.decoder_forward(net.decoder, obj, None, 26, 1.0, feats2=mot, step_feats=step)
+        assert np.array_equal(ids.numpy(), fx['greedy_ids'])
