@@ -77,6 +77,10 @@ class _ArenaModule(nn.Module):
     def flatten_parameters_(self):
         """(Re)pack all parameters into one flat fp32 arena (views keep the nn.Parameter objects alive, so
         state_dict / load_state_dict / optimizers keep working) and allocate the matching gradient arena."""
+        dec = getattr(self, 'decoder', None)
+        if dec is not None and getattr(dec, '_owner', None) is None:
+            import weakref
+            object.__setattr__(dec, '_owner', weakref.ref(self))        # (a deep copy / unpickled model: see _HipModel.__setattr__)
         if self._arena_ok():
             return
         named = list(self.named_parameters())

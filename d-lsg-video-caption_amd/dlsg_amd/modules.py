@@ -172,6 +172,11 @@ class Decoder(nn.Module):
         """models/layer.py:348-350"""
         self.beam_size = beam_size
 
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d.pop('_owner', None)              # a weak reference to the owning model (set by the model): not part of the state
+        return d
+
     def forward(self, cnn_feats, captions, max_words, teacher_forcing_ratio, cnn_feats_2=None, step_feats=None):
         """models/layer.py:394-447 called on its own (the models call the engine directly): teacher-forced / scheduled-sampling
         logits + attention weights, or greedy ids when `captions` is None, from given proposals; `step_feats` (B, G) replaces

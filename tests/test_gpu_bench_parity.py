@@ -29,7 +29,7 @@ def _grad_norms_oracle(orc, frames, regions, caps, lens, tf, R):
     out = orc(frames, regions, caps, 26, tf)
     loss = R.ragged_ce(out[0], caps, lens)
     loss.backward()
-    return out, float(loss), {k: (float(p.grad.double().norm()) if p.grad is not None else None) for k, p in orc.named_parameters()}
+    return out, float(loss.detach()), {k: (float(p.grad.double().norm()) if p.grad is not None else None) for k, p in orc.named_parameters()}
 
 
 @pytest.mark.parametrize('shape,B', [('msvd', 64), ('msvd', 128), ('msrvtt', 64)])
@@ -89,6 +89,7 @@ def test_bench_configuration_against_the_oracle(shape, B):
     # ---- scheduled sampling: the coin order of random.seed(12) on both sides (models/layer.py:432)
     random.seed(12)
     want_ss, want_loss_ss, want_gn_ss = _grad_norms_oracle(orc, frames, regions, caps, lens, 0.6, R)
+    net.load_state_dict({k: v.cuda() for k, v in sd.items()})            # (the trainer's Adam step above moved the weights)
     random.seed(12)
     with torch.no_grad():
         got_ss = net(fg, rg, cg, 26, 0.6)[0].cpu()
