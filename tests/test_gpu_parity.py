@@ -67,7 +67,7 @@ def test_forward_logits_and_intermediates(tag, fused):
                 # o = LayerNorm(y): the fused graph kernel never materialises it -- rebuilt from what it saved (y, mean / rstd)
                 st = s_['ostats']
                 ln = m.obj_norm[1]
-                o = (s_['y'] - st[:, :1]) * st[:, 1:2] * ln.weight + ln.bias
+                o = (s_['y'] - st[:, :1]) * st[:, 1:2] * ln.weight.detach() + ln.bias.detach()
                 got[key + '.o'] = o.view(B, -1, o.shape[-1])
         sp = sv['encoder.motion_pre_encoder']
         got['pre.embed'] = sp['e'].view(B, T, -1)
@@ -78,7 +78,7 @@ def test_forward_logits_and_intermediates(tag, fused):
         checked = 0
         for k, v in got.items():
             if 'i.' + k in g:
-                err = np.abs(v.cpu().numpy() - g['i.' + k]).max()
+                err = np.abs(v.detach().cpu().numpy() - g['i.' + k]).max()
                 assert err <= LOGIT_TOL, (k, err)
                 checked += 1
         assert checked >= 7, checked
