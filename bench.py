@@ -260,7 +260,11 @@ def gemm_roofline(prof, nsteps, root=ROOT):
     parts = gk.split('_')              # gemm_{f32|bf16x3}_mfma_{tile}_{nt|nn|tn}
     tile, mode = parts[3], parts[-1]
     tmpl = {'nt': 'false, false', 'nn': 'false, true', 'tn': 'true, true'}.get(mode, '')
-    if tile == '128x128':
+    if tile == 'streamk':
+        # csrc/gemm_sk.hip: ONE persistent launch of one workgroup per CU, 256 x 256 tiles, the remainder tiles cut between the
+        # workgroups inside the launch
+        sym = 'gemm_sk_kernel<%s>' % tmpl
+    elif tile == '128x128':
         sym = '%s_w3<128, 128, %s, 32>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
     elif tile.startswith('256x'):
         # csrc/gemm_big.hip; '256x256+rest': the row panels that come in whole rounds of the CUs on this tile, the rest of the
@@ -292,11 +296,14 @@ def profile_eager_steps(net, tr, batch, eps, nsteps):
     tr.step(frames, regions, caps, lens, eps)
     torch.cuda.synchronize()
     net.ops.prof = {}
+    net.ops.flop_count = 0.0
     for _ in range(nsteps):
         tr.step(frames, regions, caps, lens, eps)
     torch.cuda.synchronize()
     prof = net.ops.prof_summary()
+    prof['__gemm_flops_per_step__'] = net.ops.flop_count / max(1, nsteps)
     net.ops.prof = None
+    net.ops.flop_count = None
     tr.use_graphs = use_graphs
     return prof
 
@@ -750,10 +757,32 @@ def main():
         if world > 1:
             out['per_rank_ms_per_step'] = per_rank_ms
             out['bucket_timeline'] = timeline
+        gemm_flops = prof.pop('__gemm_flops_per_step__', None)
         out['kernel_time_ms_per_step'] = {k: round(v['ms_total'] / nprof, 3) for k, v in prof.items()}
         rl = gemm_roofline(prof, nprof)
         if rl:
             out['roofline'] = rl
+        sk = {}
+        for k in sorted(prof):
+            if 'streamk' in k:
+                r1 = gemm_roofline({k: prof[k]}, nprof)
+                sk[k] = {kk: r1[kk] for kk in ('achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'ms_per_step_in_this_kernel', 'launch_shapes')}
+        if sk:
+            out['roofline_stream_k'] = dict(sk, kernel='gemm_sk_kernel<...> (csrc/gemm_sk.hip): each call is ONE persistent launch; one entry per '
+                                                        'operand layout, with every launch shape of the step')
+        if gemm_flops:
+            # what the step EXECUTES: every dlsg_gemm call's 2 M N K as launched (the decoder's K / V projections hoisted out of the word
+            # loop, no input gradients for regions / frames) + the MFMA work outside dlsg_gemm: the persistent BiLSTM recurrence
+            # (forward and backward through time, 2 B 4H H per step and direction) and the object->frame graph kernels
+            Hh = args.visual_hidden_size
+            Tt = args.max_frames
+            bil = 2.0 * a.batch * 4 * Hh * Hh * Tt * 2 * 2 if bool(getattr(net.ops, 'persistent_bilstm', False)) else 0.0
+            graph = a.batch * 2 * (44.3e6 + 133e6) * (args.num_obj / 16.0)
+            tot = gemm_flops + bil + graph
+            out['whole_step_mfma_frac'] = {'executed_flops_per_step': tot, 'dlsg_gemm_calls': gemm_flops, 'persistent_bilstm': bil,
+                                           'graph_kernels': graph, 'TFLOPs': round(tot / (dt / a.steps) / 1e12, 2), 'peak': PEAK_FP32_MFMA_TFLOPS,
+                                           'frac': round(tot / (dt / a.steps) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                           'flops_per_clip': round(tot / a.batch / 1e9, 3)}
         tj = {}
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json'))).get('per_launch_shape', {})

@@ -391,6 +391,7 @@ class HipOps(object):
         self.prof = None          # set to {} by bench.py: key -> list of (start event, end event, algorithmic work)
         self.extra_flags = 0      # OR-ed into every dlsg_gemm call (precision policy: F_BF16X3), set by the model
         self.prof_min_flops = 2e9  # dlsg_gemm calls below this are not bracketed by profile events (tools/pmc_step_target.py: 0)
+        self.flop_count = None     # a float: every dlsg_gemm call adds its 2 M N K (bench.py: executed flops of a step)
 
     # ------------------------------------------------------------------ live per-kernel timing (bench.py roofline)
     def _prof_begin(self):
@@ -502,6 +503,8 @@ class HipOps(object):
         if plan_only:
             return int(self.lib.dlsg_gemm_variant(C.byref(a)))
         e0 = None
+        if self.flop_count is not None:
+            self.flop_count += 2.0 * M * nb * sum(grp_[2].shape[-1] * a.g[i].K for i, grp_ in enumerate(groups))
         if self.prof is not None:
             flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))
             if flops >= self.prof_min_flops:     # only the heavy launches are timed, so the events do not perturb the step

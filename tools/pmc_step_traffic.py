@@ -18,6 +18,7 @@ for _mode, _t in (('nt', 'false, false'), ('nn', 'false, true'), ('tn', 'true, t
     SYMS['gemm_f32_mfma_128x64_' + _mode] = ['gemm_kernel_w3<128, 64, %s, 64>' % _t]
     SYMS['gemm_f32_mfma_128x128_' + _mode] = ['gemm_kernel_w3<128, 128, %s, 32>' % _t]
     SYMS['gemm_f32_mfma_256x256_' + _mode] = ['gemm_big_kernel<256, 256, %s>' % _t]
+    SYMS['gemm_f32_mfma_streamk_256x256_' + _mode] = ['gemm_sk_kernel<%s>' % _t]
     # whole rounds on the 256 tile + the remaining rows on a smaller tile, one timed call (csrc/gemm.hip, gemm_plan)
     SYMS['gemm_f32_mfma_256x256+rest_' + _mode] = ['gemm_big_kernel<256, 256, %s>' % _t, '1?gemm_kernel']
 
