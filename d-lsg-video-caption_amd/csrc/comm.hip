@@ -36,6 +36,7 @@ struct RcclApi {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
 };
 
 int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* data) {
@@ -66,6 +67,7 @@ int load_rccl(RcclApi* api) {
     DLSG_SYM(AllReduce, "ncclAllReduce")
     DLSG_SYM(GroupStart, "ncclGroupStart")
     DLSG_SYM(GroupEnd, "ncclGroupEnd")
+    DLSG_SYM(CommGetAsyncError, "ncclCommGetAsyncError")
 #undef DLSG_SYM
     return DLSG_OK;
 }
@@ -154,4 +156,25 @@ extern "C" int dlsg_allreduce_buckets(dlsg_comm* c, float* const* grads, const i
     }
     const ncclResult_t e = c->api.GroupEnd();
     return (r == ncclSuccess && e == ncclSuccess) ? DLSG_OK : DLSG_ELAUNCH;
+}
+
+// words[i] <- max over the ranks of words[i] (int32): how the persistent kernels' time-out word becomes the SAME guard on every
+// rank before Adam (a rank that skipped its update alone would leave the replicas diverged)
+extern "C" int dlsg_allreduce_max_i32(dlsg_comm* c, int32_t* words, int64_t count, void* stream) {
+    if (!c || !c->comm) return DLSG_ENOCOMM;
+    if (count < 0 || (count > 0 && !words)) return DLSG_EINVAL;
+    if (count == 0) return DLSG_OK;
+    const ncclResult_t r =
+        c->api.AllReduce(words, words, static_cast<size_t>(count), ncclInt32, ncclMax, c->comm, reinterpret_cast<hipStream_t>(stream));
+    return r == ncclSuccess ? DLSG_OK : DLSG_ELAUNCH;
+}
+
+// *code <- the communicator's asynchronous error state (ncclCommGetAsyncError: 0 = ncclSuccess); no synchronisation
+extern "C" int dlsg_comm_async_error(dlsg_comm* c, int32_t* code) {
+    if (!c || !c->comm) return DLSG_ENOCOMM;
+    if (!code) return DLSG_EINVAL;
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t r = c->api.CommGetAsyncError(c->comm, &st);
+    *code = static_cast<int32_t>(st);
+    return r == ncclSuccess ? DLSG_OK : DLSG_ELAUNCH;
 }

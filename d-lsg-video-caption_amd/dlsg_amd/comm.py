@@ -79,6 +79,21 @@ class RcclComm(object):
         if rc != 0:
             raise RuntimeError('dlsg_allreduce_bucket failed with code %d' % rc)
 
+    def allreduce_max_word(self, word, stream):
+        """in-place max over all ranks of an int32 device tensor, enqueued on `stream`"""
+        assert word.is_cuda and word.dtype == torch.int32 and word.is_contiguous()
+        rc = self.lib.dlsg_allreduce_max_i32(self._h, C.c_void_p(word.data_ptr()), word.numel(), C.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError('dlsg_allreduce_max_i32 failed with code %d' % rc)
+
+    def async_error(self):
+        """ncclCommGetAsyncError of the communicator (0 = none); None when it cannot be read"""
+        if not self._h:
+            return None
+        code = C.c_int32(0)
+        rc = self.lib.dlsg_comm_async_error(self._h, C.byref(code))
+        return int(code.value) if rc == 0 else None
+
     def close(self):
         if self._h:
             h, self._h = self._h, C.c_void_p()

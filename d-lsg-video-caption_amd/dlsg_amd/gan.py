@@ -516,10 +516,18 @@ class GanTrainer(object):
         out.pop('cap_loss_dev')
         check = getattr(model.ops, 'check_persistent', None)
         if check is not None:
-            if word is not None:
-                check(code=int(vals[4]))   # read back with the losses: the device was idle, the time-out word is final
-            else:
-                check()
+            code = int(vals[4]) if word is not None else None
+            if self.world_size > 1 and code is not None:
+                from .comm import _agree_min
+                code = _agree_min(code, self.trainer.pg, negate=True)      # every rank raises, or none
+            try:
+                check(code=code)           # read back with the losses: the device was idle, the time-out word is final
+            except RuntimeError:
+                # graphs captured on the persistent schedule must not be replayed again: the generator's are captured anew on
+                # the step-by-step BiLSTM; the critic's LSTM has no such form (the message says so)
+                self._cg.clear()
+                self.trainer._graphs = None
+                raise
         return out
 
 

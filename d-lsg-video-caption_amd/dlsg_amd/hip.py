@@ -239,7 +239,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_gemm_varia
            'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd', 'dlsg_bilstm_bwd_x_floats', 'dlsg_bilstm_bwd',
            'dlsg_lstm_seq_supported', 'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_lstm_seq',
            'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
-           'dlsg_allreduce_buckets']
+           'dlsg_allreduce_buckets', 'dlsg_allreduce_max_i32', 'dlsg_comm_async_error']
 
 
 def load_library(path=LIB_PATH):
@@ -336,6 +336,8 @@ def load_library(path=LIB_PATH):
         'dlsg_comm_info': [vp, P(i32), P(i32), P(i32)],
         'dlsg_allreduce_bucket': [vp, vp, i64, vp],
         'dlsg_allreduce_buckets': [vp, P(vp), P(i64), i32, vp],
+        'dlsg_allreduce_max_i32': [vp, vp, i64, vp],
+        'dlsg_comm_async_error': [vp, P(i32)],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -924,9 +926,16 @@ class HipOps(object):
         if code:
             w.zero_()
             self.persistent_bilstm = False
+            if code == 3:
+                self.stream_k = False      # a stream-K workgroup gave up waiting for another one's share (csrc/gemm_sk.hip)
+            # graphs captured so far replay the persistent launches: their owners (Trainer, GanTrainer) compare this count and
+            # capture again on the step-by-step schedule
+            self.persist_timeouts = getattr(self, 'persist_timeouts', 0) + 1
             raise RuntimeError('persistent kernel hand-off timed out (code %d): the launch was not co-resident on this device.  '
                                'No parameter was updated by the steps since; the BiLSTM now runs step by step '
-                               '(ops.persistent_bilstm = False).  Is the GPU shared with another process?' % code)
+                               '(ops.persistent_bilstm = False)%s.  The critic\'s LSTM has no step-by-step form: GAN training needs '
+                               'the device to itself.  Is the GPU shared with another process?'
+                               % (code, ', the large products on the tiled kernels (ops.stream_k = False)' if code == 3 else ''))
 
     # ------------------------------------------------------------------ persistent BiLSTM recurrence
     persistent_bilstm = True      # False: the per-step schedule (grouped skinny GEMM + pointwise launch per step)
@@ -990,17 +999,20 @@ class HipOps(object):
         n, L = ref.shape[0], ref.shape[1]
         H = W.shape[1]
         dev = W.device
-        if not self.lib.dlsg_lstm_seq_supported(L, min(n, 256), H):
-            raise RuntimeError('dlsg_lstm_seq does not take L = %d, H = %d on this device (H in {64, 512}, >= 4 * H / 8 compute units)'
-                               % (L, H))
+        # sequences per launch: as many row groups of 64 as the device can keep co-resident (256 rows need 4 x H / 8 workgroups
+        # = 256 compute units at H = 512; a smaller part takes 192, 128 or 64 rows per launch)
+        chunk = next((c for c in (256, 192, 128, 64) if self.lib.dlsg_lstm_seq_supported(L, min(n, c), H)), 0)
+        if not chunk:
+            raise RuntimeError('dlsg_lstm_seq does not take L = %d, H = %d on this device (H in {64, 512}, >= H / 8 compute units '
+                               'per 64 sequences)' % (L, H))
         self._lstm_seq_err = self._persist_word(dev)
         _chkc(W)
         for name, v in t.items():
             if v is not None:
                 _chkc(v)
                 assert v.dtype == torch.float32 and v.shape[:2] == (n, L) and v.shape[2] in (H, 4 * H), (name, v.shape)
-        for lo in range(0, n, 256):
-            hi = min(n, lo + 256)
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
             a = LstmSeqArgs()
             nx = int(self.lib.dlsg_lstm_seq_x_floats(L, hi - lo, H))
             xbuf = torch.empty(nx, dtype=torch.float32, device=dev)

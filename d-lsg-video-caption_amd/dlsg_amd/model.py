@@ -625,6 +625,8 @@ class Trainer(object):
         self.force_collectives = False  # test hook: issue the all-reduces even with one rank (RCCL path on a 1-GPU box)
         self._works = []
         self._graphs = None
+        self._guard_sent = False
+        self._contact_checked = False
         self._hook_mode, self._hook_sv = False, None
         self.m = self.v = None
         if world_size > 1 and hasattr(model.ops, 'persistent_bilstm_bwd'):
@@ -767,7 +769,31 @@ class Trainer(object):
                 rank = dist.get_rank(self.pg)
             self._rccl = RcclComm(self.world_size, rank, self.pg, lib=getattr(self.model.ops, 'lib', None))
             self._side_stream()
+            self._first_contact(rank)
         return self._rccl
+
+    def _first_contact(self, rank):
+        """One eager all-reduce of a rank-id pattern through the new communicator before anything is captured: every element must
+        come back as 0 + 1 + ... + (N - 1) on every rank.  A communicator that is wired wrongly (a rank on the wrong device, two
+        jobs sharing an id, a transport that drops data) is found here, with the list of ranks that saw a wrong sum, instead
+        of as diverging replicas or a hang inside a replayed graph (run_gun.py:63-64 relies on DDP's own constructor checks)."""
+        if self.world_size <= 1:
+            return
+        import torch.distributed as dist
+        dev = self.model._flat.device
+        side = self._side_stream()
+        t = torch.full((4096,), float(rank), dtype=torch.float32, device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        self._rccl.allreduce([t], side)
+        side.synchronize()
+        want = self.world_size * (self.world_size - 1) / 2.0
+        ok = bool((t == want).all().item())
+        every = [None] * self.world_size
+        dist.all_gather_object(every, (rank, ok, float(t[0].item())), group=self.pg)
+        bad = [(r, v) for r, o, v in every if not o]
+        if bad:
+            raise RuntimeError('RCCL first-contact check failed: the all-reduced rank pattern should be %g everywhere; wrong on ranks %s'
+                               % (want, ', '.join('%d (got %g)' % rv for rv in bad)))
 
     def _side_stream(self):
         if self._comm_stream is None:
@@ -781,10 +807,19 @@ class Trainer(object):
         mode = self._comm_mode()
         ranges = [r for k in (key if isinstance(key, tuple) else (key,)) for r in self._minus_frozen(*self._ranges[k])]
         views = [self.model._gflat[lo:hi] for lo, hi in ranges]
+        # the persistent kernels' time-out word rides with the step's FIRST bucket (max over the ranks): dlsg_adam's guard then
+        # skips the update on every rank or on none -- a rank skipping alone would leave the replicas diverged, its invalid
+        # gradients already summed into everybody's
+        word = None
+        if not self._guard_sent and self.world_size > 1:
+            word = getattr(self.model.ops, 'persist_word_or_none', lambda: None)()
+            self._guard_sent = True
         if mode == 'torch':
             import torch.distributed as dist
             for v in views:
                 self._works.append(dist.all_reduce(v, group=self.pg, async_op=True))
+            if word is not None:
+                self._works.append(dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
             return
         if mode == 'none':
             return
@@ -796,6 +831,8 @@ class Trainer(object):
         ev.record()
         side.wait_event(ev)
         comm.allreduce(views, side)
+        if word is not None:
+            comm.allreduce_max_word(word, side)
         self._comm_pending = True
 
     def _join_comm(self):
@@ -823,9 +860,31 @@ class Trainer(object):
     def check(self):
         """Raise if a persistent kernel's inter-workgroup wait timed out since the last call (ops.check_persistent).  A host
         synchronisation: call it where the loss is read back (per logging interval / epoch), not per step."""
-        chk = getattr(self.model.ops, 'check_persistent', None)
-        if chk is not None:
-            chk()
+        ops = self.model.ops
+        chk = getattr(ops, 'check_persistent', None)
+        if chk is None:
+            return
+        w = ops.persist_word_or_none()
+        code = int(w.item()) if w is not None else 0
+        if self._rccl is not None:
+            ae = self._rccl.async_error()
+            if ae:
+                import sys
+                sys.stderr.write('dlsg_amd.Trainer: RCCL reports asynchronous error %d on this rank (ncclCommGetAsyncError)\n' % ae)
+                code = code or 100 + ae
+        if self.world_size > 1:
+            # every rank learns the worst code before any of them raises: one rank leaving alone would strand its peers in the
+            # next step's in-graph all-reduce (a private communicator has no time-out)
+            from .comm import _agree_min
+            code = _agree_min(code, self.pg, negate=True)
+        if code:
+            self._graphs = None            # captured on the persistent schedule: the next step captures again
+            if code >= 100:
+                raise RuntimeError('RCCL asynchronous error %d on at least one rank (ncclCommGetAsyncError): the gradient exchange '
+                                   'of the steps since the last check is not to be trusted' % (code - 100))
+            if w is not None and int(w.item()) == 0:
+                w.fill_(code)              # (another rank's time-out: the same exception here)
+            chk(code=code)
 
     def close(self):
         """destroy the RCCL communicator (collective: every rank calls it)"""
@@ -841,6 +900,7 @@ class Trainer(object):
         L = captions.shape[1]
         sv = {}
         training = model.training
+        self._guard_sent = False
         # a bucket handed to a reduction (or closing a graph segment) must be complete: deferred weight gradients go out there
         model._flush_at_buckets = self._comm_mode() != 'none' or self.force_graph_cuts
         model._engine_forward(frames, regions, captions, L, coins, training, seed, sv, dev_coins, outputs=False)
@@ -992,7 +1052,7 @@ class Trainer(object):
         err = None
         try:
             self._capture(frames, regions, captions, cap_lens, hook)
-        except RuntimeError as e:
+        except Exception as e:            # (any failure votes: an AssertionError on one rank must not leave the others in the vote)
             err = e
         if self.world_size > 1:
             from .comm import _agree_min

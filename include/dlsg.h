@@ -755,6 +755,11 @@ int dlsg_comm_info(const dlsg_comm* c, int32_t* world, int32_t* rank, int32_t* r
 int dlsg_allreduce_bucket(dlsg_comm* c, float* grads, int64_t count, void* stream);
 /* n ranges of one bucket as one RCCL group (one fused launch) */
 int dlsg_allreduce_buckets(dlsg_comm* c, float* const* grads, const int64_t* counts, int n, void* stream);
+/* words[i] <- max over the ranks (int32), on `stream`: the persistent kernels' time-out word travels with the first gradient
+ * bucket, so that dlsg_adam's guard skips the update on EVERY rank or on none. */
+int dlsg_allreduce_max_i32(dlsg_comm* c, int32_t* words, int64_t count, void* stream);
+/* *code <- ncclCommGetAsyncError of the communicator (0 = no error); does not synchronise. */
+int dlsg_comm_async_error(dlsg_comm* c, int32_t* code);
 
 #ifdef __cplusplus
 }
