@@ -801,7 +801,7 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, int nslab, i
 int dlsg_gemm_bf16x3_dispatch(const dlsg_gemm_args* a, hipStream_t st);   // gemm_bf16x3.hip
 int dlsg_gemm_big_ok(const dlsg_gemm_args* a);                             // gemm_big.hip
 int dlsg_gemm_big_dispatch(const dlsg_gemm_args* a, hipStream_t st, int bn);
-int dlsg_gemm_sk_ok(const dlsg_gemm_args* a);                              // gemm_sk.hip
+int dlsg_gemm_sk_wanted(const dlsg_gemm_args* a);                          // gemm_sk.hip
 int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st);
 
 extern "C" int dlsg_abi_version(void) { return DLSG_ABI_VERSION; }
@@ -819,23 +819,10 @@ static int gemm_plan(const dlsg_gemm_args* a, int64_t* m1_out) {
     if (a->flags & DLSG_GEMM_FORCE128) return DLSG_GEMM_V_128;
     // M <= 128, row-major A (NT / NN): weight-streaming recurrent products -> skinny kernels (64- or 128-row tiles)
     if (a->M <= 128 && a->mode != 2 && a->N >= 64) return DLSG_GEMM_V_SKINNY;
-    // The caller brought a workspace: the products that keep every CU busy for >= 64 stages of 256 x 256 x 32 run as ONE
-    // persistent stream-K launch (gemm_sk.hip) -- no partly filled last round, no second launch for remaining rows, no slab
-    // fold for deep contractions (tools/gemm_sk_probe.py: region projection 1 558 us against 1 799, obj_embed weight gradients
-    // 1 544 against 1 824 + the fold, 26 624 x 2048 x 1024 NN 823 against 958; the 1 664-row products of the step tie with the
-    // small tiles and stay there).  Not when 256-row / 256-column tiles would be > 15 % padding.
-    if (a->ws && !(a->flags & DLSG_GEMM_NOSK) && dlsg_gemm_sk_ok(a)) {
-        const int64_t tm = (a->M + 255) / 256;
-        double useful = 0.0, padded = 0.0;
-        int64_t units = 0;
-        for (int i = 0; i < a->ngroups; ++i) {
-            const int64_t gn = a->g[i].N > 0 ? a->g[i].N : a->N, tn = (gn + 255) / 256;
-            units += tm * tn * (a->g[i].K / 32);
-            useful += (double)a->M * gn * a->g[i].K;
-            padded += (double)tm * 256 * tn * 256 * a->g[i].K;
-        }
-        if (units >= 16384 && useful >= 0.85 * padded) return DLSG_GEMM_V_SK;
-    }
+    // The caller brought a workspace: the products that keep every CU busy long enough run as ONE persistent stream-K launch
+    // (gemm_sk.hip: no partly filled last round, no second launch for remaining rows, no slab fold for deep contractions; the rule
+    // and the measurements behind it are in dlsg_gemm_sk_wanted)
+    if (dlsg_gemm_sk_wanted(a)) return DLSG_GEMM_V_SK;
     // measured on MI355X (tools/gemm_bench.py): the 128x128 tile only wins once it fills the chip several times over
     // (Wave quantisation is not what the 128-tile launches lose: giving that kernel whole 768-slot rounds only and the remaining
     // row panels to the 64-tile kernel was measured 1-3 % SLOWER on the region projection (4.33 rounds) and on the deep weight

@@ -31,9 +31,9 @@
 namespace {
 
 constexpr int SK_THREADS = 256;
-constexpr int SK_BM = 256, SK_BN = 256, SK_BK = 32;
-constexpr int SK_ABYTES = SK_BM * 128, SK_BBYTES = SK_BN * 128, SK_STAGE = SK_ABYTES + SK_BBYTES;      // 64 KB per stage
-constexpr int SK_SLOT_BYTES = SK_BM * SK_BN * 4;
+constexpr int SK_BN = 256, SK_BK = 32;             // tile: BM x 256, BM = 256 or 128 (template parameter), 32-deep stages
+constexpr int SK_BBYTES = SK_BN * 128;
+constexpr int SK_SLOT_BYTES = 256 * SK_BN * 4;     // a workspace slot holds the accumulators of the larger tile
 constexpr int SK_CNT_BYTES = 16384;                // in front of the slots: counters (2 words per split tile) in the first 4 KB; the
                                                    // rest is where a PROBES=1 build leaves its timestamps
 constexpr int SK_MAXSPLIT = 16;                    // contributors per split tile (= sub-blocks a wave can hand out)
@@ -47,7 +47,7 @@ struct SkGroup {
 struct SkArgs {
     int32_t M, ngroups, flags, P;
     int32_t T, rounds, rem, sk_wgs;                // T = rounds * P + rem; sk_wgs: workgroups that share the last rem tiles
-    int32_t sk_nst, pad_;                          // stages per tile of those tiles when they are split (0: one whole tile each)
+    int32_t sk_nst, bm;                            // stages per tile of those tiles when they are split (0: one whole tile each); tile height
     float alpha; int32_t pad2_;
     const int32_t* skip_if;
     float* slots; uint32_t* cnt; int32_t* err;
@@ -135,27 +135,30 @@ __device__ __forceinline__ Item sk_item(const SkArgs& p, int v, int idx) {
     const SkGroup& g = p.g[gi];
     const int local = tile - g.tile0;
     const int tm = local / g.tiles_n, tn = local - tm * g.tiles_n;
-    it.gi = sk_u(gi); it.m0 = sk_u(tm * SK_BM); it.n0 = sk_u(tn * SK_BN); it.Ng = sk_u(g.N);
+    it.gi = sk_u(gi); it.m0 = sk_u(tm * p.bm); it.n0 = sk_u(tn * SK_BN); it.Ng = sk_u(g.N);
     if (s1 < 0) { s0 = 0; s1 = g.nst; }
     it.s0 = sk_u(s0); it.s1 = sk_u(s1); it.kind = sk_u(it.kind); it.r = sk_u(it.r);
     return it;
 }
 
-// per-lane byte offsets of this wave's 8 DMA pieces of one operand, relative to (tile base + stage offset)
+// per-lane byte offsets of this wave's ROWS / 32 DMA pieces (1 KB each) of one operand, relative to (tile base + stage offset)
 //   T == false: element (row, k) at base[row * ld + k] -> image [row][32], 16-B segments swizzled: slot (row, s) holds
 //               k-segment s ^ ((row >> 1) & 7); piece = 8 rows
-//   T == true : element (row, k) at base[k * ld + row] -> image [k][256]; piece = one k row
-template <bool T>
-__device__ __forceinline__ void sk_voff(int (&voff)[8], int w, int lane, int row0, int rmax, int64_t ld) {
+//   T == true : element (row, k) at base[k * ld + row] -> image [k][ROWS]; piece = 256 / ROWS k rows
+template <bool T, int ROWS>
+__device__ __forceinline__ void sk_voff(int (&voff)[ROWS / 32], int w, int lane, int row0, int rmax, int64_t ld) {
+    constexpr int PW = ROWS / 32;                  // pieces per wave
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int pc = w * 8 + i;
+    for (int i = 0; i < PW; ++i) {
+        const int pc = w * PW + i;
         if (!T) {
             const int R = 8 * pc + (lane >> 3);
             const int seg = (lane & 7) ^ ((R >> 1) & 7);
             voff[i] = (int)((min(row0 + R, rmax - 1) - row0) * ld * 4) + 16 * seg;
         } else {
-            voff[i] = (int)(pc * ld * 4) + (min(row0 + 4 * lane, rmax - 4) - row0) * 4;
+            constexpr int KR = 256 / ROWS, LPR = 64 / KR;
+            const int kr = KR * pc + lane / LPR;
+            voff[i] = (int)(kr * ld * 4) + (min(row0 + 4 * (lane % LPR), rmax - 4) - row0) * 4;
         }
     }
 }
@@ -182,6 +185,7 @@ template <class V>
 __device__ __forceinline__ void sk_store_block(const SkArgs& p, const SkGroup& g, const Item& it, const V& val, int i, int j,
                                                int w, int lane, f32x4 bias4, float* bounce) {
     const int r = lane & 31, h = lane >> 5, wm = w >> 1, wn = w & 1;
+    const int WM = p.bm >> 1;                                 // rows of a wave's quadrant
     f32x4* bw = reinterpret_cast<f32x4*>(bounce) + h * 32 + r;
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4) {
@@ -196,7 +200,7 @@ __device__ __forceinline__ void sk_store_block(const SkArgs& p, const SkGroup& g
 #pragma unroll
     for (int c = 0; c < 4; ++c) x[c] = br[c];
     const int col = it.n0 + wn * 128 + j * 32 + 4 * cs;
-    const int row0 = it.m0 + wm * 128 + i * 32 + 4 * G;
+    const int row0 = it.m0 + wm * WM + i * 32 + 4 * G;
     const bool accum = p.flags & DLSG_GEMM_ACCUM, do_tanh = p.flags & DLSG_GEMM_TANH;
     const bool col_ok = col < it.Ng;                          // (widths are multiples of 4: the whole piece is in or out)
     float* cp = g.C + (int64_t)row0 * g.ldc + col;
@@ -231,8 +235,13 @@ __device__ __forceinline__ void sk_bias(const SkArgs& p, const SkGroup& g, const
     }
 }
 
-template <bool AT, bool BT>
+template <int BM, bool AT, bool BT>
 __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_sk_kernel(const SkArgs p) {
+    constexpr int TM = BM / 64;                    // 32-row blocks of a wave (its quadrant is BM / 2 x 128)
+    constexpr int WM = BM / 2;
+    constexpr int SK_ABYTES = BM * 128, SK_STAGE = SK_ABYTES + SK_BBYTES;
+    constexpr int PA = BM / 32, PB = SK_BN / 32, PT = PA + PB;           // DMA pieces per wave and stage
+    constexpr int NSUB = 4 * TM;                   // 32 x 32 sub-blocks of a wave
     extern __shared__ __attribute__((aligned(16))) char sk_lds[];           // 2 stage buffers
     if (p.skip_if && *p.skip_if) return;                                    // block-uniform
     const int lane = threadIdx.x & 63;
@@ -247,9 +256,9 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     SK_STAMP(0);
     const uint32_t lds0 = sk_u((uint32_t)reinterpret_cast<uintptr_t>((sk_lp_t)sk_lds));      // LDS byte address of the stage buffers
 
-    f32x16 acc[4][4];
+    f32x16 acc[TM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -260,19 +269,19 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ks = (2 * q + h) ^ ((r >> 1) & 7);
-        offA[q] = AT ? ((4 * (2 * q + h)) * SK_BM + wm * 128 + r) * 4 : (wm * 128 + r) * 128 + ks * 16;
+        offA[q] = AT ? ((4 * (2 * q + h)) * BM + wm * WM + r) * 4 : (wm * WM + r) * 128 + ks * 16;
         offB[q] = SK_ABYTES + (BT ? ((4 * (2 * q + h)) * SK_BN + wn * 128 + r) * 4 : (wn * 128 + r) * 128 + ks * 16);
     }
-    f32x4 fa[2][4], fb[2][4];
-    auto read_frag = [&](int buf, const char* st, int q, int f) {          // f < 4: A fragment f, else B fragment f - 4
-        if (f < 4) {
+    f32x4 fa[2][TM], fb[2][4];
+    auto read_frag = [&](int buf, const char* st, int q, int f) {          // f < TM: A fragment f, else B fragment f - TM
+        if (f < TM) {
             if (!AT) fa[buf][f] = *reinterpret_cast<const f32x4*>(st + offA[q] + f * 32 * 128);
             else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fa[buf][f][j] = *reinterpret_cast<const float*>(st + offA[q] + (j * SK_BM + f * 32) * 4);
+                for (int j = 0; j < 4; ++j) fa[buf][f][j] = *reinterpret_cast<const float*>(st + offA[q] + (j * BM + f * 32) * 4);
             }
         } else {
-            const int g = f - 4;
+            const int g = f - TM;
             if (!BT) fb[buf][g] = *reinterpret_cast<const f32x4*>(st + offB[q] + g * 32 * 128);
             else {
 #pragma unroll
@@ -284,7 +293,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     // ---- load cursor: the stage whose DMA is issued next.  Past the last stage of the stream it stays on that stage: the
     // pieces it keeps issuing land in buffers nobody reads any more (no branches in the stage body)
     int li = 0, l_left = 0, lpar = 0;              // item index, stages of the item not yet issued, buffer parity
-    int voffA[8], voffB[8];
+    int voffA[PA], voffB[PB];
     const char* lA = nullptr; const char* lB = nullptr;                     // stage bases
     int64_t sA = 0, sB = 0;                                                  // bytes per stage
     auto l_enter = [&](int idx) {
@@ -294,8 +303,8 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         asm volatile("" : "+v"(lane_), "+s"(w_), "+s"(v_));
         const Item it = sk_item(p, v_, idx);
         const SkGroup& g = p.g[it.gi];
-        sk_voff<AT>(voffA, w_, lane_, it.m0, p.M, g.lda);
-        sk_voff<BT>(voffB, w_, lane_, it.n0, it.Ng, g.ldb);
+        sk_voff<AT, BM>(voffA, w_, lane_, it.m0, p.M, g.lda);
+        sk_voff<BT, SK_BN>(voffB, w_, lane_, it.n0, it.Ng, g.ldb);
         const int64_t k0 = (int64_t)it.s0 * SK_BK;
         lA = sk_up(AT ? g.A + it.m0 + k0 * g.lda : g.A + (int64_t)it.m0 * g.lda + k0);
         lB = sk_up(BT ? g.B + it.n0 + k0 * g.ldb : g.B + (int64_t)it.n0 * g.ldb + k0);
@@ -303,10 +312,9 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         sB = BT ? SK_BK * 4 * g.ldb : SK_BK * 4;
         l_left = it.s1 - it.s0;
     };
-    auto l_issue = [&](int pc) {                   // piece pc in [0, 16): A pieces 0..7, B pieces 8..15 of this wave
-        const uint32_t dst = lds0 + lpar * SK_STAGE + (pc < 8 ? 0 : SK_ABYTES) + (w * 8 + (pc & 7)) * 1024;
-        if (pc < 8) sk_glds16(lA, (uint32_t)voffA[pc], dst);
-        else sk_glds16(lB, (uint32_t)voffB[pc - 8], dst);
+    auto l_issue = [&](int pc) {                   // piece pc in [0, PT): A pieces 0 .. PA - 1, then the B pieces of this wave
+        if (pc < PA) sk_glds16(lA, (uint32_t)voffA[pc], lds0 + lpar * SK_STAGE + (w * PA + pc) * 1024);
+        else sk_glds16(lB, (uint32_t)voffB[pc - PA], lds0 + lpar * SK_STAGE + SK_ABYTES + (w * PB + (pc - PA)) * 1024);
     };
     auto l_advance = [&]() {
         lpar ^= 1;
@@ -322,15 +330,16 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 
     // prologue: stage 0 whole, first half of stage 1
 #pragma unroll
-    for (int pc = 0; pc < 16; ++pc) l_issue(pc);
+    for (int pc = 0; pc < PT; ++pc) l_issue(pc);
     l_advance();
 #pragma unroll
-    for (int pc = 0; pc < 8; ++pc) l_issue(pc);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int pc = 0; pc < PT / 2; ++pc) l_issue(pc);
+    if (PT / 2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int f = 0; f < 8; ++f) read_frag(0, sk_lds, 0, f);
+    for (int f = 0; f < TM + 4; ++f) read_frag(0, sk_lds, 0, f);
 
     int stage_no = 0;      // (used by the PROBES build only)
     // one stage: q0 .. q3, 16 slots of four MFMAs each, one fragment read or DMA piece pinned behind each.  FAST: the load cursor
@@ -342,19 +351,22 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int cur = q & 1, nxt = cur ^ 1;
+            // 4 TM slots of four MFMAs; behind slot s: fragment read s of the next k-group (TM + 4 of them), and in q0 / q3 one
+            // of the PT / 2 DMA pieces of that quarter (from the last slot backwards)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int j = s >> 2, i = s & 3;
+            for (int s = 0; s < 4 * TM; ++s) {
+                const int j = s / TM, i = s % TM;
 #pragma unroll
                 for (int jn = 0; jn < 4; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j], acc[i][jn], 0, 0, 0);
-                if (s < 8) {
+                if (s < TM + 4) {
                     if (q < 3) read_frag(nxt, st, q + 1, s);
                     else read_frag(nxt, stn, 0, s);              // the next stage's first fragments (unused after the last stage)
-                } else if (q == 0) {
-                    l_issue(8 + (s - 8));                         // second half of the stage after this one
-                } else if (q == 3) {
-                    l_issue(s - 8);                               // first half of the stage after next
+                }
+                const int d = 4 * TM - 1 - s;                     // DMA piece of this slot
+                if (d < PT / 2) {
+                    if (q == 0) l_issue(PT / 2 + d);              // second half of the stage after this one
+                    else if (q == 3) l_issue(d);                  // first half of the stage after next
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             f32x4 bias4[4];
             sk_bias(p, g, it, w, lane, bias4);                 // before the first store: a later load would wait behind the stores
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     sk_store_block(p, g, it, acc[i][j], i, j, w, lane, bias4[j], bounce);
@@ -405,10 +417,10 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                     __builtin_amdgcn_sched_barrier(0);       // one sub-block's values in flight at a time
                 }
         } else {
-            // share of a split tile: accumulator order, 16-B stores: slot[((w * 16 + i * 4 + j) * 4 + e4) * 64 + lane]
+            // share of a split tile: accumulator order, 16-B stores: slot[((w * NSUB + i * 4 + j) * 4 + e4) * 64 + lane]
             f32x4* slot = reinterpret_cast<f32x4*>(p.slots) + (int64_t)(2 * v + ci) * (SK_SLOT_BYTES / 16);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -416,7 +428,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                         f32x4 t;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) t[e] = acc[i][j][4 * e4 + e];
-                        slot[((w * 16 + i * 4 + j) * 4 + e4) * 64 + lane] = t;
+                        slot[((w * NSUB + i * 4 + j) * 4 + e4) * 64 + lane] = t;
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
@@ -465,7 +477,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         SK_STAMP(28 + 2 * si);
         const SkGroup& g = p.g[S.gi];
         const bool f_bias = (p.flags & DLSG_GEMM_BIAS) && g.bias != nullptr;
-        for (int k = c; k < 16; k += n) {
+        for (int k = c; k < NSUB; k += n) {
             f32x16 sum;
 #pragma unroll
             for (int e = 0; e < 16; ++e) sum[e] = 0.f;
@@ -475,7 +487,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
                 const f32x4* slot = reinterpret_cast<const f32x4*>(p.slots) + (int64_t)sl * (SK_SLOT_BYTES / 16);
                 f32x4 t[4];
 #pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) t[e4] = slot[((w * 16 + k) * 4 + e4) * 64 + lane];
+                for (int e4 = 0; e4 < 4; ++e4) t[e4] = slot[((w * NSUB + k) * 4 + e4) * 64 + lane];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) sum[e] += t[e >> 2][e & 3];
             }
@@ -508,14 +520,14 @@ int sk_cus() {
     return cus;
 }
 
-template <bool AT, bool BT>
+template <int BM, bool AT, bool BT>
 int sk_launch(const SkArgs& k, hipStream_t st) {
-    constexpr int lds_bytes = 2 * SK_STAGE + 4 * SK_BOUNCE;  // two stage buffers + the epilogue's bounce tiles
+    constexpr int lds_bytes = 2 * (BM * 128 + SK_BBYTES) + 4 * SK_BOUNCE;  // two stage buffers + the epilogue's bounce tiles
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<BM, AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     });
-    hipLaunchKernelGGL((gemm_sk_kernel<AT, BT>), dim3(k.P), dim3(SK_THREADS), lds_bytes, st, k);
+    hipLaunchKernelGGL((gemm_sk_kernel<BM, AT, BT>), dim3(k.P), dim3(SK_THREADS), lds_bytes, st, k);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
@@ -561,11 +573,48 @@ int dlsg_gemm_sk_ok(const dlsg_gemm_args* a) {
     return 1;
 }
 
+int sk_pick_bm(const dlsg_gemm_args* a) {
+    if (a->flags & DLSG_GEMM_SK_BM128) return 128;
+    if (a->flags & DLSG_GEMM_SK_BM256) return 256;
+    const int pad256 = (a->M + 255) / 256 * 256;
+    return (pad256 - a->M) * 32 > a->M ? 128 : 256;          // > 3 % of the rows would be padding
+}
+
+// 1: dlsg_gemm sends this call to the stream-K kernel.  Measured on MI355X against the tiled kernels (tools/gemm_sk_probe.py,
+// profiles/r05j_*): it wins wherever a workgroup gets >= ~80 us of stages -- region projections 1 582 us against 1 813, obj_embed
+// weight gradients 1 548 against 1 836 (+ their fold), the 1 664-row products of the step by 8-21 % on 128-row tiles (NT
+// 1664 x 4096 x 1024 x 2: 230 against 266; NT 1664 x 1024 x 6144: 178 against 227; NN 1664 x 2048 x 2048 x 3: 326 against 354) --
+// and loses below that, where the split tiles' fix-up (~30 us) is a third of the launch (NT 1664 x 1024 x 2048: 84 against 80;
+// the vocabulary projection 60 against 44).  A launch whose tiles come in whole rounds has no fix-up and pays from ~40 us.
+int dlsg_gemm_sk_wanted(const dlsg_gemm_args* a) {
+    if (!a->ws || (a->flags & DLSG_GEMM_NOSK) || !dlsg_gemm_sk_ok(a)) return 0;
+    const int cus = sk_cus();
+    if (cus <= 0) return 0;
+    const int bm = sk_pick_bm(a);
+    const int64_t tm = (a->M + bm - 1) / bm;
+    double useful = 0.0, padded = 0.0;
+    int64_t units = 0, tiles = 0;
+    for (int i = 0; i < a->ngroups; ++i) {
+        const int64_t gn = a->g[i].N > 0 ? a->g[i].N : a->N, tn = (gn + SK_BN - 1) / SK_BN;
+        tiles += tm * tn;
+        units += tm * tn * (a->g[i].K / SK_BK);
+        useful += (double)a->M * gn * a->g[i].K;
+        padded += (double)tm * bm * tn * SK_BN * a->g[i].K;
+    }
+    if (useful < 0.85 * padded) return 0;                      // > 15 % of the tiles' area would be padding
+    const double us = (double)((units + cus - 1) / cus) * 7.0 * bm / 256;      // a 256 x 256 x 32 stage takes 7.0 us
+    return us >= ((tiles % cus) ? 80.0 : 40.0);
+}
+
 int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     if (!dlsg_gemm_sk_ok(a)) return DLSG_EINVAL;
     SkArgs k;
-    k.M = a->M; k.ngroups = a->ngroups; k.flags = a->flags; k.alpha = a->alpha; k.skip_if = a->skip_if; k.pad_ = 0;
-    const int tiles_m = (a->M + SK_BM - 1) / SK_BM;
+    k.M = a->M; k.ngroups = a->ngroups; k.flags = a->flags; k.alpha = a->alpha; k.skip_if = a->skip_if;
+    // tile height: 128 rows when 256-row tiles would leave the last row panel mostly padding (M = 1664: 7 panels for 6.5) or
+    // when the launch has few tiles to deal out; DLSG_GEMM_SK_BM128 / _BM256 force one
+    int bm = sk_pick_bm(a);
+    k.bm = bm;
+    const int tiles_m = (a->M + bm - 1) / bm;
     int T = 0;
     for (int i = 0; i < a->ngroups; ++i) {
         const dlsg_gemm_group& g = a->g[i];
@@ -583,7 +632,7 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     const int P = cus;
     k.P = P; k.T = T;
     k.rounds = T / P; k.rem = T % P;
-    k.sk_wgs = 0; k.sk_nst = 0; k.pad_ = 0; k.pad2_ = 0;
+    k.sk_wgs = 0; k.sk_nst = 0; k.pad2_ = 0;
     if (k.rem > 0) {
         // the last rem tiles: split evenly over the workgroups when their tiles are equally deep (the common case; a run of
         // stages then touches at most two tiles), else one whole tile per workgroup
@@ -607,10 +656,13 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     k.slots = reinterpret_cast<float*>(ws + SK_CNT_BYTES);
     k.err = a->err;
     if (2 * k.rem * (int)sizeof(uint32_t) > 4096) return DLSG_EINVAL;
-    switch (a->mode) {
-        case 0: return sk_launch<false, false>(k, st);
-        case 1: return sk_launch<false, true>(k, st);
-        case 2: return sk_launch<true, true>(k, st);
+    switch (a->mode * 2 + (bm == 128 ? 1 : 0)) {
+        case 0: return sk_launch<256, false, false>(k, st);
+        case 1: return sk_launch<128, false, false>(k, st);
+        case 2: return sk_launch<256, false, true>(k, st);
+        case 3: return sk_launch<128, false, true>(k, st);
+        case 4: return sk_launch<256, true, true>(k, st);
+        case 5: return sk_launch<128, true, true>(k, st);
         default: return DLSG_EINVAL;
     }
 }

@@ -594,7 +594,10 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
     s = sv[pfx] = {}
     e = _empty(ref, B * T, H)
     Kf = frames2d.shape[1]
-    if B * T <= 2048 and Kf >= 4096 and Kf % 96 == 0:
+    if getattr(ops, 'stream_k', False) and ops.gemm(GEMM_NT, [(frames2d, m.linear_embed.weight, e, m.linear_embed.bias)], plan_only=True) == V_SK:
+        # one persistent stream-K launch cuts the 6 144-deep contraction between the workgroups itself (178 us against 227)
+        lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
+    elif B * T <= 2048 and Kf >= 4096 and Kf % 96 == 0:
         # a 1 664 x 1 024 output is 416 tiles for a 6 144-deep contraction: three K thirds as groups writing slabs + one fold
         # (210 us against 228, tools/_exp: K-split probe of the mid-size products)
         k3 = Kf // 3

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 ABI_VERSION = 5            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
-F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256, F_SK, F_NOSK = 256, 512, 1024, 2048, 4096, 8192
+F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256, F_SK, F_NOSK, F_SK_BM128, F_SK_BM256 = 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
 MAXG = 16
 
 c_f32p = C.c_void_p

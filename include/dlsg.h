@@ -61,6 +61,8 @@ int dlsg_struct_size(int which);
 #define DLSG_GEMM_SK 4096      /* tuning: force the persistent stream-K kernel of csrc/gemm_sk.hip; EINVAL without a workspace
                                   or when the operands do not meet its conditions (16-B alignment, K % 32 == 0, one batch) */
 #define DLSG_GEMM_NOSK 8192    /* tuning: never the stream-K kernel */
+#define DLSG_GEMM_SK_BM128 16384 /* tuning: the stream-K kernel on 128 x 256 tiles */
+#define DLSG_GEMM_SK_BM256 32768 /* tuning: the stream-K kernel on 256 x 256 tiles */
 #define DLSG_GEMM_BF16X3 1024  /* split-bf16 matrix path: x = hi + lo, 3 bf16 MFMAs per product, fp32 accumulate
                                   (~1e-5 relative error per product instead of 6e-8; see csrc/gemm_bf16x3.hip) */
 typedef struct {

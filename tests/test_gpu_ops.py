@@ -129,8 +129,9 @@ def test_gemm_256_tiles(hip, mode, tile, shape):
 
 @pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
 @pytest.mark.parametrize('extra', [0, F_ACCUM, F_TANH])
+@pytest.mark.parametrize('bm', [0, 16384, 32768])            # the dispatcher's tile height, DLSG_GEMM_SK_BM128, DLSG_GEMM_SK_BM256
 @pytest.mark.parametrize('shape', [(256, 256, 32), (600, 520, 96), (260, 132, 64), (1700, 1000, 128), (300, 260, 2048)])
-def test_gemm_stream_k(hip, mode, extra, shape):
+def test_gemm_stream_k(hip, mode, extra, bm, shape):
     """csrc/gemm_sk.hip (persistent stream-K launch, forced with F_SK): ragged edges, strided views, per-group bias, two groups of
     different width, store / accumulate / tanh epilogues; tiles cut between 2 .. 14 workgroups (few tiles on 256 CUs), whole
     tiles plus a cut remainder; twice in a row (the counters in the workspace must come back to zero)"""
@@ -154,9 +155,9 @@ def test_gemm_stream_k(hip, mode, extra, shape):
         else:
             A, B, B2 = t['A'][:, :M], t['B'][:, :N], t['B'][:, :N2]
         groups = [(A, B, t['C'][:, :N], t['bias']), (A, B2, t['C2'][:, :N2], t['bias'][:N2])]
-        ops.gemm(mode, groups, alpha=0.5, flags=extra | F_SK)
+        ops.gemm(mode, groups, alpha=0.5, flags=extra | F_SK | bm)
         if not (extra & F_ACCUM):
-            ops.gemm(mode, groups, alpha=0.5, flags=extra | F_SK)
+            ops.gemm(mode, groups, alpha=0.5, flags=extra | F_SK | bm)
     both(hip, build, run, ['C', 'C2'], tol=(1e-4 if extra & F_TANH else 1e-5) * max(1.0, math.sqrt(K)), name='gemm stream-K %d %s' % (mode, shape))
     ws = hip._gemm_workspace(torch.device('cuda', 0))
     assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0          # the counter area
@@ -193,7 +194,9 @@ def test_gemm_variant_names_the_tile_family(hip):
     assert plan(GEMM_NT, 26624, 1024, 2048, 2) == 7              # region projections of both streams
     assert plan(GEMM_TN, 1024, 2048, 26624, 2) == 7              # their weight gradients: the contraction is cut inside the launch
     assert plan(GEMM_TN, 4096, 1024, 1664, 11) == 7              # the 4096-row weight-gradient blocks of the decoder and the BiLSTM
-    assert plan(GEMM_NT, 1664, 2048, 2048, 3) == 1               # (the 1 664-row products tie with the small tiles and stay there)
+    assert plan(GEMM_NT, 1664, 2048, 2048, 3) == 7               # the 1 664-row products of the step (on 128-row tiles) ...
+    assert plan(GEMM_NT, 1664, 1024, 2048) == 1                  # ... down to ~80 us per workgroup: below that the small tiles
+    assert plan(GEMM_NT, 1664, 1000, 1024) != 7                  # (the vocabulary projection)
     assert plan(GEMM_NT, 26624, 1024, 2046, 2) == 2              # K % 32 != 0: not a stream-K shape
     assert plan(GEMM_NT, 832, 1024, 2048, 2) != 7                # 832 rows (the goldens' two clips): too little work, 19 % padding
     # ... without it (F_NOSK: the binding passes no workspace) the tiled kernels' rule is what it was

@@ -7,7 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
-from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_TILE256, F_SK, F_NOSK, F_ACCUM, F_TANH  # noqa: E402
+from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_TILE256, F_SK, F_NOSK, F_ACCUM, F_TANH, F_SK_BM128, F_SK_BM256  # noqa: E402
 
 torch.backends.cuda.matmul.allow_tf32 = False
 ops = HipOps()
@@ -84,10 +84,11 @@ for name, mode, M, nk, fl, use_bias in NUM:
         groups.append((A, B, Cc, bias))
         refs.append(r)
     worst = 0.0
-    for rep in range(3):                        # the counters must be back at zero after every launch
-        if rep and (fl & F_ACCUM):
-            break
-        ops.gemm(mode, groups, flags=fl | F_SK)
+    c0 = [gr[2].clone() for gr in groups]
+    for rep, bmf in enumerate((F_SK_BM256, F_SK_BM128, 0)):   # both tile heights, then the dispatcher's own choice; the counters
+        for gr, c in zip(groups, c0):                         # must be back at zero after every launch
+            gr[2].copy_(c)
+        ops.gemm(mode, groups, flags=fl | F_SK | bmf)
         torch.cuda.synchronize()
         for (A, B, Cc, _), r in zip(groups, refs):
             err = ((Cc.double() - r).abs().max() / r.abs().max().clamp_min(1e-30)).item()
@@ -117,7 +118,17 @@ TIM = [('NT region projection 26624x1024x2048 x2 groups, bias + tanh', GEMM_NT, 
        ('TN 2048x2048x1664 x3 accum (self-attention weight gradients)', GEMM_TN, 2048, [(2048, 1664)] * 3, F_ACCUM, False, False),
        ('NT 1664x4096x1024 x2 (BiLSTM input gates)', GEMM_NT, 1664, [(4096, 1024)] * 2, 0, False, False),
        ('NN 1664x2048x2048 x3', GEMM_NN, 1664, [(2048, 2048)] * 3, 0, False, False),
-       ('NT 1664x2048x2048 x3', GEMM_NT, 1664, [(2048, 2048)] * 3, 0, False, False)]
+       ('NT 1664x2048x2048 x3', GEMM_NT, 1664, [(2048, 2048)] * 3, 0, False, False),
+       ('NN 1664x1024x4096', GEMM_NN, 1664, [(1024, 4096)], 0, False, False),
+       ('NT 1664x1024x6144', GEMM_NT, 1664, [(1024, 6144)], 0, False, False),
+       ('TN 1024x6144x1664', GEMM_TN, 1024, [(6144, 1664)], 0, False, False),
+       ('TN 1024x2048x1664', GEMM_TN, 1024, [(2048, 1664)], 0, False, False),
+       ('NT 1664x1024x2048', GEMM_NT, 1664, [(1024, 2048)], 0, False, False),
+       ('TN 1024x1024x512 x8', GEMM_TN, 1024, [(1024, 512)] * 8, 0, False, False),
+       ('NN 512x1024x1024 x2', GEMM_NN, 512, [(1024, 1024)] * 2, 0, False, False),
+       ('NT 1664x1000x1024 (vocabulary projection)', GEMM_NT, 1664, [(1000, 1024)], 0, True, False),
+       ('NN 1664x1024x1000', GEMM_NN, 1664, [(1024, 1000)], 0, False, False),
+       ('TN 1000x1024x1664', GEMM_TN, 1000, [(1024, 1664)], 0, False, False)]
 if quick:
     TIM = TIM[:3]
 for name, mode, M, nk, fl, use_bias, shareA in TIM:
@@ -133,7 +144,7 @@ for name, mode, M, nk, fl, use_bias, shareA in TIM:
         groups.append((A, B, Cc, bias))
     gf = sum(2.0 * M * N * K for N, K in nk) / 1e9
     row = {}
-    for tag, f2 in (('stream_k', F_SK), ('dispatcher_no_sk', F_NOSK), ('tile_256', F_TILE256 | F_NOSK)):
+    for tag, f2 in (('stream_k_bm256', F_SK | F_SK_BM256), ('stream_k_bm128', F_SK | F_SK_BM128), ('dispatcher_no_sk', F_NOSK)):
         try:
             us = timeit(lambda: ops.gemm(mode, groups, flags=fl | f2))
             row[tag] = {'us': round(us, 1), 'TFLOPs': round(gf / us * 1e3, 1), 'frac_of_157.3': round(gf / us * 1e3 / 157.3, 3)}
