@@ -195,7 +195,7 @@ def test_gemm_variant_names_the_tile_family(hip):
     assert plan(GEMM_TN, 1024, 2048, 26624, 2) == 7              # their weight gradients: the contraction is cut inside the launch
     assert plan(GEMM_TN, 4096, 1024, 1664, 11) == 7              # the 4096-row weight-gradient blocks of the decoder and the BiLSTM
     assert plan(GEMM_NT, 1664, 2048, 2048, 3) == 7               # the 1 664-row products of the step (on 128-row tiles) ...
-    assert plan(GEMM_NT, 1664, 1024, 2048) == 1                  # ... down to ~80 us per workgroup: below that the small tiles
+    assert plan(GEMM_NT, 1664, 1024, 2048) in (0, 1)             # ... down to ~80 us per workgroup: below that the small tiles
     assert plan(GEMM_NT, 1664, 1000, 1024) != 7                  # (the vocabulary projection)
     assert plan(GEMM_NT, 26624, 1024, 2046, 2) == 2              # K % 32 != 0: not a stream-K shape
     assert plan(GEMM_NT, 832, 1024, 2048, 2) != 7                # 832 rows (the goldens' two clips): too little work, 19 % padding
