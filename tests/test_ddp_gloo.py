@@ -76,6 +76,55 @@ def test_two_rank_step_equals_mean_of_shard_gradients(tmp_path):
     assert np.abs(net2._flat.numpy() - f0).max() <= 1e-6
 
 
+SHARDS3 = [slice(0, 2), slice(2, 3), slice(3, 4)]        # an uneven last batch: 2 + 1 + 1 clips
+
+
+def _worker3(rank, world, port, out_dir):
+    for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'd-lsg-video-caption_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import dlsg_amd
+    net, frames, regions, caps, lens = _build()
+    sl = SHARDS3[rank]
+    tr = dlsg_amd.Trainer(net, world_size=world)
+    for _ in range(2):                       # two steps: the second one starts from all-reduced weights
+        loss = tr.step(frames[sl], regions[sl], caps[sl], lens[sl], 1.0)
+    tr.check()                               # collective: every rank agrees that no rank reported a time-out
+    np.save(os.path.join(out_dir, 'flat3_%d.npy' % rank), net._flat.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(400)
+def test_three_ranks_with_an_uneven_last_batch(tmp_path):
+    """three ranks holding 2 + 1 + 1 clips (the tail of an epoch whose size the world does not divide, utils/data.py:122-130 pads
+    by wrapping; here the shards simply differ): every rank's loss is the mean over ITS rows and the gradients are averaged with
+    equal weights (DDP's mean of means, run_gun.py:63-64) -- replicas bit-identical after two steps and equal to the single-process
+    emulation of that rule"""
+    port = _free_port()
+    mp.spawn(_worker3, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    f = [np.load(tmp_path / ('flat3_%d.npy' % r)) for r in range(3)]
+    assert np.array_equal(f[0], f[1]) and np.array_equal(f[0], f[2])
+    import dlsg_amd
+    net2, frames, regions, caps, lens = _build()
+    tr2 = dlsg_amd.Trainer(net2)
+    for step in (1, 2):
+        # gradients of each shard at the current weights, then one Adam step on their plain mean
+        probe, *_ = _build()
+        probe.load_state_dict(net2.state_dict())
+        trp = dlsg_amd.Trainer(probe, lr=0.0)
+        tot = None
+        for sl in SHARDS3:
+            trp.step(frames[sl], regions[sl], caps[sl], lens[sl], 1.0)
+            tot = probe._gflat.clone() if tot is None else tot + probe._gflat
+        net2._gflat.copy_(tot)
+        net2.ops.adam(net2._flat, net2._gflat, tr2.m, tr2.v, tr2.lr, 0.5, 0.9, 1e-8, step, 1.0 / 3.0)
+    assert np.abs(net2._flat.numpy() - f[0]).max() <= 1e-5      # (two Adam steps on sums taken in another order)
+
+
 def _worker_torch_ddp(rank, world, port, out_dir):
     for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), 'd-lsg-video-caption_amd')):
         if p not in sys.path:
