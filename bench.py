@@ -428,6 +428,10 @@ def bucket_timeline(tr, batch, eps, dev, world):
         orig_join()
         ev('joined')
     tr._allreduce, tr._join_comm = allreduce, join
+    # the extra pass must not move the weights (the legs behind it would time another model state than the steps before it):
+    # no Adam, and the step count is put back
+    orig_adam, t_saved = tr._adam, tr.t
+    tr._adam = lambda *a_, **k_: None
     try:
         captions = batch[2].contiguous()
         lens = torch.as_tensor(batch[3]).to(device=dev, dtype=torch.int64)
@@ -439,6 +443,7 @@ def bucket_timeline(tr, batch, eps, dev, world):
         torch.cuda.synchronize()
     finally:
         tr._allreduce, tr._join_comm = orig_allreduce, orig_join
+        tr._adam, tr.t = orig_adam, t_saved
     t0 = marks[0][1]
     rows = [(n, t0.elapsed_time(e) * 1e3) for n, e in marks[1:]]
     names = [n for n, _ in rows]
