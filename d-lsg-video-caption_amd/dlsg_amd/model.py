@@ -237,12 +237,15 @@ class CapGnnModel(_HipModel):
         B, T, F = frames.shape
         A = enc.a_feature_size
         f2 = frames.view(B * T, F)
-        ys = [None, None]
-        if regions.shape[2] >= 5 and enc.obj_encoder.obj_embed.weight.shape == enc.motion_encoder.obj_embed.weight.shape:
-            ys = E.region_projections(ops, [enc.obj_encoder, enc.motion_encoder], regions)
         E.tun_frames(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv)
         mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed)
         E.tun_frames(ops, enc.motion_encoder, 'encoder.motion_encoder', mot_in, regions, sv)
+        # the region projections (the step's longest launch) go HERE, behind the frame path's matrix kernels, not first in the
+        # step: directly behind the previous step's Adam -- 0.5 ms of pure memory traffic -- the same launch takes 11 % longer
+        # (1 722 us against 1 555 back to back, tools/sk_sequence_probe.py: the clock the chip holds, not the caches)
+        ys = [None, None]
+        if regions.shape[2] >= 5 and enc.obj_encoder.obj_embed.weight.shape == enc.motion_encoder.obj_embed.weight.shape:
+            ys = E.region_projections(ops, [enc.obj_encoder, enc.motion_encoder], regions)
         E.tun_graph(ops, [(enc.obj_encoder, 'encoder.obj_encoder', ys[0]), (enc.motion_encoder, 'encoder.motion_encoder', ys[1])],
                     regions, sv, self.fused_o2v)
         obj = E.tun_latent(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, training, seed, E.SITE_PSL_OBJ)
