@@ -475,7 +475,7 @@ class HipOps(object):
         a.flags = flags | self.extra_flags | (F_BIAS if (bias is not None or gbias) else 0)
         a.bias = _p(bias)
         a.skip_if = _p(skip_if)          # 1-element int32 device tensor: launch is a no-op when it is non-zero
-        if (self.stream_k or (flags & F_SK)) and not (flags & F_NOSK):
+        if (self.stream_k or (flags & F_SK)) and not ((flags | self.extra_flags) & F_NOSK):
             ws = self._gemm_workspace(C0.device)
             a.ws, a.ws_bytes = _p(ws), ws.numel() * 4
             a.err = _p(self._persist_word(C0.device))

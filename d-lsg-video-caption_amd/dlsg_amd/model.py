@@ -133,11 +133,16 @@ class _HipModel(_ArenaModule):
         if attended_rows > 72:
             raise ValueError('%s = %d: the fused decoder step attends over at most 72 rows per stream' % (what, attended_rows))
 
+    stream_k_in_backward = True        # False (a Trainer with several ranks sets it): the backward's products stay on the tiled kernels
+
     def _gemm_flags(self, backward):
-        from .hip import F_BF16X3
+        from .hip import F_BF16X3, F_NOSK
         mode = self.gemm_precision
         assert mode in ('fp32', 'x3_bwd', 'x3_all'), mode
-        return F_BF16X3 if (mode == 'x3_all' or (mode == 'x3_bwd' and backward)) else 0
+        fl = F_BF16X3 if (mode == 'x3_all' or (mode == 'x3_bwd' and backward)) else 0
+        if backward and not self.stream_k_in_backward:
+            fl |= F_NOSK
+        return fl
 
     merge_weight_grads = True          # see engine.tn_grouped
     _defer_ok = True                   # weight gradients may be collected and launched grouped ...
@@ -641,6 +646,14 @@ class Trainer(object):
             # step (0.60 against 0.50 ms); the forward keeps the persistent launch (no collective is in flight there: the
             # previous step's all-reduces are joined before its Adam).
             model.ops.persistent_bilstm_bwd = False
+        if world_size > 1:
+            # The stream-K GEMM (csrc/gemm_sk.hip) is one workgroup per CU with the whole register file of its SIMDs: a CU that hosts
+            # a wave of an RCCL kernel cannot take one, so the launch's last workgroups would start only when the first ones leave --
+            # up to twice the time for every product that overlaps a bucket's all-reduce, which is most of the backward.  The tiled
+            # kernels' small workgroups fill around a collective gracefully.  Forward products (no collective in flight: the previous
+            # step's buckets are joined before its Adam) keep the stream-K launches.  Unmeasured on hardware like the rest of N > 1;
+            # `model.stream_k_in_backward = True` after construction switches it back.
+            model.stream_k_in_backward = False
         self._bind()
 
     def _bind(self):
