@@ -4,12 +4,14 @@
 // except on the tiles whose contraction is split between workgroups, where the partial chains are added in a fixed order).
 //
 // Schedule (host: sk_plan).  The launch has T tiles (all groups) and P workgroups, T = R * P + rem:
-//   * the last `rem` tiles are "split tiles": each is contracted by n = P / rem (+1) workgroups over disjoint k ranges --
-//     every workgroup starts with its share of one split tile, so all of them stay busy for the same time; the share is
-//     written to a workspace slot in accumulator order (16-B stores), published (release + counter), and finished at the END
-//     of the kernel: contributor c of n sums the n slots of every sub-block k = c (mod n) (16 sub-blocks of 32 x 32 per
-//     wave) in contributor order and runs the epilogue on them.  Between the partial store and the fix-up lie R full tiles,
-//     so nobody waits for anybody in practice; the wait is bounded and reports into an error word instead of hanging;
+//   * the last `rem` tiles are "split tiles": their stages are dealt to the workgroups in equal consecutive runs (a run lies in
+//     one tile or ends one and begins the next), and every workgroup STARTS with its run, so all of them stay busy for the
+//     same time.  A share is written to a workspace slot in accumulator order (16-B stores) and published (release + one
+//     counter per split tile).  It is finished at the END of the kernel: contributor c of n adds up the n slots of every
+//     sub-block k = c (mod n) (16 sub-blocks of 32 x 32 per wave) in contributor order and runs the epilogue on them.  R whole
+//     tiles lie between the share's store and that point, so the tile is complete by then -- and if it is not (the launch is
+//     not co-resident: another tenant on the device), the workgroup does not wait: it leaves its sub-blocks to the contributor
+//     that finishes last.  No workgroup ever waits for another one: such a launch is slower, never stuck;
 //   * then R rounds of whole tiles, workgroup v (virtual id: the 32 workgroups an XCD receives are consecutive) takes tile
 //     j * P + v: the workgroups of one XCD walk one compact block of row panels x column tiles in lock step, so the XCD's
 //     L2 serves every staged A / B block to several of them.
@@ -37,7 +39,8 @@ constexpr int SK_SLOT_BYTES = 256 * SK_BN * 4;     // a workspace slot holds the
 constexpr int SK_CNT_BYTES = 16384;                // in front of the slots: counters (2 words per split tile) in the first 4 KB; the
                                                    // rest is where a PROBES=1 build leaves its timestamps
 constexpr int SK_MAXSPLIT = 16;                    // contributors per split tile (= sub-blocks a wave can hand out)
-constexpr unsigned SK_SPIN_LIMIT = 1u << 22;       // x s_sleep(8): ~1-2 s
+constexpr int SK_PATIENCE = 64;                    // polls (x ~1 us) a contributor spends on an incomplete split tile before it leaves
+                                                   // its sub-blocks to the tile's last finisher
 
 struct SkGroup {
     const float* A; const float* B; float* C; const float* bias;
@@ -440,7 +443,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             if (threadIdx.x == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(p.cnt + 2 * it.r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(p.cnt + 4 * it.r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         SK_STAMP(2 + 2 * ci);
@@ -451,8 +454,16 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the pieces issued past the end of the stream
     SK_STAMP(27);
 
-    // ---- fix-up of the split tiles this workgroup contributed to (its first one or two items)
+    // ---- the split tiles this workgroup contributed to (its first one or two items): contributor c of n adds up the sub-blocks
+    // k = c (mod n), shares in contributor order.  R whole tiles lie between a share's store and this point, so the tile is
+    // complete here; when it is not (no whole-tile rounds, or the launch is not co-resident: another tenant on the device) the
+    // workgroup polls for a bounded few tens of microseconds and then leaves its sub-blocks to the contributor that decides
+    // last.  Counters of split tile r: cnt[4r] shares published, [4r + 1] contributors decided, [4r + 2] bit c set =
+    // contributor c gave its sub-blocks away.
     const int ns = sk_nsplit(p, v);
+    // a decision of thread 0 for the whole workgroup: a word behind the bounce tiles (a static __shared__ variable would be
+    // placed in front of the stage buffers and move them off their 1-KB alignment)
+    volatile int* sk_flag = reinterpret_cast<volatile int*>(sk_lds + 2 * SK_STAGE + 4 * SK_BOUNCE);      // one word per split item
     float* fbounce = reinterpret_cast<float*>(sk_lds + 2 * SK_STAGE + w * SK_BOUNCE);
     for (int si = 0; si < ns; ++si) {
         const Item S = sk_item(p, v, si);
@@ -460,52 +471,69 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         int lo, hi;
         sk_contributors(p, S.r, lo, hi);
         const int n = hi - lo + 1, c = v - lo;
-        uint32_t* cnt = p.cnt + 2 * S.r;
-        if (threadIdx.x == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t)n) {
-                if (++spins > SK_SPIN_LIMIT) {
-                    if (p.err) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+        uint32_t* cnt = p.cnt + 4 * S.r;
+        const SkGroup& g = p.g[S.gi];
+        const bool f_bias = (p.flags & DLSG_GEMM_BIAS) && g.bias != nullptr;
+        auto add_up = [&](int c_) {                  // the sub-blocks of contributor c_
+            for (int k = c_; k < NSUB; k += n) {
+                f32x16 sum;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum[e] = 0.f;
+                for (int v2 = lo; v2 <= hi; ++v2) {
+                    // contributor v2's share of this tile is its first item when its run begins inside the tile, else its second
+                    const int sl = 2 * v2 + ((int)(sk_run0(p, v2) / p.sk_nst) == S.r ? 0 : 1);
+                    const f32x4* slot = reinterpret_cast<const f32x4*>(p.slots) + (int64_t)sl * (SK_SLOT_BYTES / 16);
+                    f32x4 t[4];
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) t[e4] = slot[((w * NSUB + k) * 4 + e4) * 64 + lane];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sum[e] += t[e >> 2][e & 3];
                 }
+                const int bcol = S.n0 + (w & 1) * 128 + (k & 3) * 32 + 4 * (lane & 7);
+                f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (f_bias && bcol < S.Ng) b4 = *reinterpret_cast<const f32x4*>(g.bias + bcol);
+                sk_store_block(p, g, S, sum, k >> 2, k & 3, w, lane, b4, fbounce);
+            }
+        };
+        if (threadIdx.x == 0) {
+            // a short patience (some tens of microseconds: the contributors of a tile whose launch has no whole-tile rounds
+            // publish within microseconds of each other), never an open-ended wait
+            bool ready = false;
+            for (int spin = 0; spin < ((p.flags & DLSG_GEMM_SK_GIVEAWAY) ? 0 : SK_PATIENCE); ++spin) {
+                ready = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (uint32_t)n;
+                if (ready) break;
                 __builtin_amdgcn_s_sleep(8);
             }
+            // decided: count this contributor (behind its mask bit when it gives its sub-blocks away).  The last one to decide
+            // finds every share published -- a share is published before its owner gets here -- takes what was given away and
+            // leaves the counters at zero for the next launch (nobody touches them after its own count).
+            uint32_t d;
+            if (ready) {
+                d = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_fetch_or(cnt + 2, 1u << c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                d = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            uint32_t left = 0;
+            if (d + 1 == (uint32_t)n) {
+                left = __hip_atomic_load(cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            sk_flag[si] = (ready ? 1 : 0) | (int)(left << 1);
         }
         __syncthreads();
         SK_STAMP(28 + 2 * si);
-        const SkGroup& g = p.g[S.gi];
-        const bool f_bias = (p.flags & DLSG_GEMM_BIAS) && g.bias != nullptr;
-        for (int k = c; k < NSUB; k += n) {
-            f32x16 sum;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sum[e] = 0.f;
-            for (int v2 = lo; v2 <= hi; ++v2) {
-                // contributor v2's share of this tile is its first item when its run begins inside the tile, else its second
-                const int sl = 2 * v2 + ((int)(sk_run0(p, v2) / p.sk_nst) == S.r ? 0 : 1);
-                const f32x4* slot = reinterpret_cast<const f32x4*>(p.slots) + (int64_t)sl * (SK_SLOT_BYTES / 16);
-                f32x4 t[4];
-#pragma unroll
-                for (int e4 = 0; e4 < 4; ++e4) t[e4] = slot[((w * NSUB + k) * 4 + e4) * 64 + lane];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sum[e] += t[e >> 2][e & 3];
-            }
-            const int bcol = S.n0 + (w & 1) * 128 + (k & 3) * 32 + 4 * (lane & 7);
-            f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (f_bias && bcol < S.Ng) b4 = *reinterpret_cast<const f32x4*>(g.bias + bcol);
-            sk_store_block(p, g, S, sum, k >> 2, k & 3, w, lane, b4, fbounce);
+        const int fl = sk_flag[si];
+        if (fl & 1) add_up(c);
+        if (fl >> 1) {
+            for (int c2 = 0; c2 < n; ++c2)
+                if ((fl >> 1) & (1 << c2)) add_up(c2);
         }
-        // the contributor that finishes reading last leaves the tile's counters at zero for the next launch
-        __syncthreads();
         SK_STAMP(29 + 2 * si);
-        if (threadIdx.x == 0) {
-            const uint32_t d = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d + 1 == (uint32_t)n) {
-                __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
     }
 }
 
@@ -522,7 +550,7 @@ int sk_cus() {
 
 template <int BM, bool AT, bool BT>
 int sk_launch(const SkArgs& k, hipStream_t st) {
-    constexpr int lds_bytes = 2 * (BM * 128 + SK_BBYTES) + 4 * SK_BOUNCE;  // two stage buffers + the epilogue's bounce tiles
+    constexpr int lds_bytes = 2 * (BM * 128 + SK_BBYTES) + 4 * SK_BOUNCE + 16;  // two stage buffers + the epilogue's bounce tiles + a flag
     static std::once_flag once;
     std::call_once(once, [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<BM, AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -654,8 +682,8 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     char* ws = reinterpret_cast<char*>(a->ws);
     k.cnt = reinterpret_cast<uint32_t*>(ws);
     k.slots = reinterpret_cast<float*>(ws + SK_CNT_BYTES);
-    k.err = a->err;
-    if (2 * k.rem * (int)sizeof(uint32_t) > 4096) return DLSG_EINVAL;
+    k.err = nullptr;
+    if (4 * k.rem * (int)sizeof(uint32_t) > 4096) return DLSG_EINVAL;
     switch (a->mode * 2 + (bm == 128 ? 1 : 0)) {
         case 0: return sk_launch<256, false, false>(k, st);
         case 1: return sk_launch<128, false, false>(k, st);

@@ -19,6 +19,7 @@ ABI_VERSION = 5            # include/dlsg.h DLSG_ABI_VERSION this binding was wr
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256, F_SK, F_NOSK, F_SK_BM128, F_SK_BM256 = 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
+F_SK_GIVEAWAY = 65536      # test hook (include/dlsg.h): the split tiles are finished by their last contributor alone
 MAXG = 16
 
 c_f32p = C.c_void_p
@@ -478,7 +479,6 @@ class HipOps(object):
         if (self.stream_k or (flags & F_SK)) and not ((flags | self.extra_flags) & F_NOSK):
             ws = self._gemm_workspace(C0.device)
             a.ws, a.ws_bytes = _p(ws), ws.numel() * 4
-            a.err = _p(self._persist_word(C0.device))
         assert len(groups) <= MAXG
         for i, grp_ in enumerate(groups):
             A, B, Cc = grp_[:3]
@@ -926,16 +926,13 @@ class HipOps(object):
         if code:
             w.zero_()
             self.persistent_bilstm = False
-            if code == 3:
-                self.stream_k = False      # a stream-K workgroup gave up waiting for another one's share (csrc/gemm_sk.hip)
             # graphs captured so far replay the persistent launches: their owners (Trainer, GanTrainer) compare this count and
             # capture again on the step-by-step schedule
             self.persist_timeouts = getattr(self, 'persist_timeouts', 0) + 1
             raise RuntimeError('persistent kernel hand-off timed out (code %d): the launch was not co-resident on this device.  '
                                'No parameter was updated by the steps since; the BiLSTM now runs step by step '
                                '(ops.persistent_bilstm = False)%s.  The critic\'s LSTM has no step-by-step form: GAN training needs '
-                               'the device to itself.  Is the GPU shared with another process?'
-                               % (code, ', the large products on the tiled kernels (ops.stream_k = False)' if code == 3 else ''))
+                               'the device to itself.  Is the GPU shared with another process?' % (code, ''))
 
     # ------------------------------------------------------------------ persistent BiLSTM recurrence
     persistent_bilstm = True      # False: the per-step schedule (grouped skinny GEMM + pointwise launch per step)

@@ -63,6 +63,9 @@ int dlsg_struct_size(int which);
 #define DLSG_GEMM_NOSK 8192    /* tuning: never the stream-K kernel */
 #define DLSG_GEMM_SK_BM128 16384 /* tuning: the stream-K kernel on 128 x 256 tiles */
 #define DLSG_GEMM_SK_BM256 32768 /* tuning: the stream-K kernel on 256 x 256 tiles */
+#define DLSG_GEMM_SK_GIVEAWAY 65536 /* test hook: no contributor of a split tile finds it complete -- every one gives its
+                                       sub-blocks to the contributor that decides last (the path a launch that is not
+                                       co-resident takes); same result bit for bit */
 #define DLSG_GEMM_BF16X3 1024  /* split-bf16 matrix path: x = hi + lo, 3 bf16 MFMAs per product, fp32 accumulate
                                   (~1e-5 relative error per product instead of 6e-8; see csrc/gemm_bf16x3.hip) */
 typedef struct {
@@ -91,8 +94,8 @@ typedef struct {
                                chip-filling products run on the persistent stream-K kernel (csrc/gemm_sk.hip), which leaves
                                the counter area at the front of it zeroed again; NULL = the tiled kernels only */
     int64_t ws_bytes;
-    int32_t* err;           /* optional device word: set to 3 when a stream-K workgroup gave up waiting for another one's
-                               share of a split tile (~1 s; the result of that launch is then invalid) */
+    int32_t* err;           /* reserved (NULL): the stream-K kernel has no inter-workgroup wait that could time out -- the
+                               contributor that completes a split tile adds the shares up */
     dlsg_gemm_group g[DLSG_GEMM_MAXG];
 } dlsg_gemm_args;
 int dlsg_gemm(const dlsg_gemm_args* args, void* stream);

@@ -178,6 +178,35 @@ def test_gemm_stream_k_is_bit_reproducible_and_refuses_what_it_cannot_take(hip):
         hip.gemm(GEMM_NT, [(A, B[:766], C1[:, :766])], flags=F_SK)           # width not a multiple of 4
 
 
+@pytest.mark.parametrize('mode,extra,shape', [(GEMM_NT, F_TANH, (600, 520, 512)), (GEMM_TN, F_ACCUM, (300, 260, 2048)),
+                                              (GEMM_NN, 0, (1700, 1000, 128)), (GEMM_TN, F_ACCUM, (1024, 2048, 6656))])
+def test_gemm_stream_k_without_waiting(hip, mode, extra, shape):
+    """No workgroup of the stream-K launch waits for another beyond a bounded poll: a contributor that finds its split tile
+    incomplete gives its sub-blocks to the one that decides last.  DLSG_GEMM_SK_GIVEAWAY forces that path for every
+    contributor; the result is the same bit for bit (same contributor-order sums) and the counters are back at zero."""
+    M, N, K = shape
+    g = torch.Generator(device='cuda').manual_seed(3)
+    if mode == GEMM_NT:
+        A, B = torch.randn(M, K, device='cuda', generator=g), torch.randn(N, K, device='cuda', generator=g)
+    elif mode == GEMM_NN:
+        A, B = torch.randn(M, K, device='cuda', generator=g), torch.randn(K, N, device='cuda', generator=g)
+    else:
+        A, B = torch.randn(K, M, device='cuda', generator=g), torch.randn(K, N, device='cuda', generator=g)
+    C0 = torch.randn(M, N, device='cuda', generator=g)
+    bias = torch.randn(N, device='cuda', generator=g)
+    out = []
+    for give in (0, 65536, 0, 65536):
+        for bm in (16384, 32768):
+            Cc = C0.clone()
+            hip.gemm(mode, [(A, B, Cc, bias)], flags=extra | F_SK | bm | give)
+            out.append(Cc)
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        assert torch.equal(out[i], out[i + 2]) and torch.equal(out[i], out[i + 4]) and torch.equal(out[i], out[i + 6])
+    ws = hip._gemm_workspace(torch.device('cuda', 0))
+    assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0
+
+
 def test_gemm_variant_names_the_tile_family(hip):
     """dlsg_gemm_variant == the choice dlsg_gemm makes (include/dlsg.h DLSG_GEMM_V_*), on the shapes DESIGN.md quotes"""
     def plan(mode, M, N, K, G=1, flags=0):

@@ -55,12 +55,12 @@ def run(name, mode, M, nk, fl, use_bias, share_a=False):
     seq = []
     prev = 0.0
     i = 1
-    while i in ev and i + 1 in ev and i < 29:
+    while i in ev and i + 1 in ev and i < 27:
         seq.append({'stages_us': round(ev[i] - prev, 1), 'store_us': round(ev[i + 1] - ev[i], 1)})
         prev = ev[i + 1]
         i += 2
-    tail = {k: round(ev[k] - prev, 1) for k in (29, 30, 31) if k in ev}
-    print('  v=0 items:', json.dumps(seq), 'tail (29 stream end, 30 fix-up wait done, 31 fix-up done):', tail, flush=True)
+    tail = {k: round(ev[k] - prev, 1) for k in (27, 28, 29, 30, 31) if k in ev}
+    print('  v=0 items:', json.dumps(seq), 'tail (27 stream end; 28 / 29 decided / added up for the first split item, 30 / 31 the second):', tail, flush=True)
     ts = [x for x in per_stage if x > 0]
     d = [(b - a) / 100.0 for a, b in zip(ts, ts[1:])]
     if d:
