@@ -21,8 +21,13 @@ __device__ __forceinline__ int crow(int e, int h) { return (e & 3) + 8 * (e >> 2
 
 // ------------------------------------------------------------------------------------------------ LatentPSL forward
 // NX = float4 per lane of one frame row (H <= 256 NX); NX = 4 (H <= 1024) fits 64 registers: two 1024-thread workgroups per CU
+// (both encoder streams in one launch: blockIdx.y picks the argument block -- 64 clips put 64 workgroups on 256 CUs)
+struct PslPack { dlsg_latent_psl_args s[DLSG_PSL_MAXMULTI]; };
+struct PslBwdPack { dlsg_latent_psl_bwd_args s[DLSG_PSL_MAXMULTI]; };
+
 template <int NX>
-__global__ __launch_bounds__(PSL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void latent_psl_fwd_kernel(const dlsg_latent_psl_args a) {
+__global__ __launch_bounds__(PSL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void latent_psl_fwd_kernel(const PslPack pk) {
+    const dlsg_latent_psl_args& a = pk.s[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float smem[];        // theta: [P][H]
     __shared__ float lgs[PSL_MAXT][PSL_MAXP + 1];       // logits, then adj
     __shared__ float red[16 * 8];
@@ -473,7 +478,8 @@ __global__ __launch_bounds__(SA_THREADS) void sa_core_bwd_kernel(const dlsg_sa_c
 // per-clip partials of dtheta = dlg^T ov and of the LayerNorm's dgamma | dbeta.
 // Replaces rowln_bwd + two batched GEMMs + softmax_bwd + two more GEMMs (six launches on 26 x 8 tiles).
 constexpr int PB_MAXP = 8;
-__global__ __launch_bounds__(PSL_THREADS) void latent_psl_bwd_kernel(const dlsg_latent_psl_bwd_args a) {
+__global__ __launch_bounds__(PSL_THREADS) void latent_psl_bwd_kernel(const PslBwdPack pk) {
+    const dlsg_latent_psl_bwd_args& a = pk.s[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ float adjl[PSL_MAXT][PB_MAXP + 1];
     __shared__ float dlgl[PSL_MAXT][PB_MAXP + 1];      // dadj, then dlogits
@@ -601,10 +607,16 @@ __global__ __launch_bounds__(PSL_THREADS) void latent_psl_bwd_kernel(const dlsg_
 
 }  // namespace
 
-extern "C" int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream) {
-    if (!a || a->T < 1 || a->T > PSL_MAXT || a->P < 1 || a->P > PSL_MAXP || a->H < 4 || a->H > 2 * PSL_THREADS || a->H % 4)
-        return DLSG_EINVAL;
-    if ((reinterpret_cast<uintptr_t>(a->ov) | reinterpret_cast<uintptr_t>(a->theta)) & 15) return DLSG_EINVAL;
+extern "C" int dlsg_latent_psl_fwd_multi(const dlsg_latent_psl_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > DLSG_PSL_MAXMULTI) return DLSG_EINVAL;
+    PslPack pk;
+    for (int i = 0; i < count; ++i) {
+        const dlsg_latent_psl_args& x = a[i];
+        if (x.T < 1 || x.T > PSL_MAXT || x.P < 1 || x.P > PSL_MAXP || x.H < 4 || x.H > 2 * PSL_THREADS || x.H % 4) return DLSG_EINVAL;
+        if (x.B != a->B || x.P != a->P || x.H != a->H) return DLSG_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(x.ov) | reinterpret_cast<uintptr_t>(x.theta)) & 15) return DLSG_EINVAL;
+        pk.s[i] = x;
+    }
     if (a->B == 0) return DLSG_OK;
     const int lds_bytes = a->P * a->H * 4;              // theta
     if (lds_bytes > 64 * 1024) return DLSG_EINVAL;
@@ -616,12 +628,13 @@ extern "C" int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream) 
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     });
     if (a->H <= 1024)
-        hipLaunchKernelGGL(latent_psl_fwd_kernel<4>, dim3(a->B), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), *a);
+        hipLaunchKernelGGL(latent_psl_fwd_kernel<4>, dim3(a->B, count), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), pk);
     else
-        hipLaunchKernelGGL(latent_psl_fwd_kernel<8>, dim3(a->B), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), *a);
+        hipLaunchKernelGGL(latent_psl_fwd_kernel<8>, dim3(a->B, count), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), pk);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
+extern "C" int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream) { return dlsg_latent_psl_fwd_multi(a, 1, stream); }
 
 extern "C" int dlsg_sa_core_fwd(const dlsg_sa_core_args* a, void* stream) {
     if (!a || a->T < 1 || a->T > 32 || a->D < 64 || a->D % 64) return DLSG_EINVAL;
@@ -658,10 +671,16 @@ extern "C" int dlsg_sa_core_bwd(const dlsg_sa_core_bwd_args* a, void* stream) {
     return DLSG_OK;
 }
 
-extern "C" int dlsg_latent_psl_bwd(const dlsg_latent_psl_bwd_args* a, void* stream) {
-    if (!a || a->T < 1 || a->T > PSL_MAXT || a->P < 1 || a->P > PB_MAXP || a->H < 4 || a->H > 2 * PSL_THREADS || a->H % 4)
-        return DLSG_EINVAL;
-    if (reinterpret_cast<uintptr_t>(a->ov) & 15) return DLSG_EINVAL;
+extern "C" int dlsg_latent_psl_bwd_multi(const dlsg_latent_psl_bwd_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > DLSG_PSL_MAXMULTI) return DLSG_EINVAL;
+    PslBwdPack pk;
+    for (int i = 0; i < count; ++i) {
+        const dlsg_latent_psl_bwd_args& x = a[i];
+        if (x.T < 1 || x.T > PSL_MAXT || x.P < 1 || x.P > PB_MAXP || x.H < 4 || x.H > 2 * PSL_THREADS || x.H % 4) return DLSG_EINVAL;
+        if (x.B != a->B || x.T != a->T || x.H != a->H) return DLSG_EINVAL;
+        if (reinterpret_cast<uintptr_t>(x.ov) & 15) return DLSG_EINVAL;
+        pk.s[i] = x;
+    }
     if (a->B == 0) return DLSG_OK;
     const int lds_bytes = (a->T + PB_MAXP) * a->H * 4;
     if (lds_bytes > 150 * 1024) return DLSG_EINVAL;
@@ -670,7 +689,8 @@ extern "C" int dlsg_latent_psl_bwd(const dlsg_latent_psl_bwd_args* a, void* stre
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&latent_psl_bwd_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     });
-    hipLaunchKernelGGL(latent_psl_bwd_kernel, dim3(a->B), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), *a);
+    hipLaunchKernelGGL(latent_psl_bwd_kernel, dim3(a->B, count), dim3(PSL_THREADS), lds_bytes, reinterpret_cast<hipStream_t>(stream), pk);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
+extern "C" int dlsg_latent_psl_bwd(const dlsg_latent_psl_bwd_args* a, void* stream) { return dlsg_latent_psl_bwd_multi(a, 1, stream); }

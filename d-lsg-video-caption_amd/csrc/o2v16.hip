@@ -63,20 +63,27 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int f = lane & 15, g = lane >> 4;
     const int T = a.T, NO = a.NO;
+    const int dbg = STAMP ? (tiles_per_split >> 16) : 0;      // diagnostic build: phases switched off (timing only, wrong results)
+    tiles_per_split &= 0xffff;
     const int n_begin = sp * tiles_per_split * O16_TILE;
     const int n_end = min(NO, n_begin + tiles_per_split * O16_TILE);
 
     // ---- LDS-DMA of one tile: wave w fetches rows 2w, 2w+1 (rows past the end are clamped here and zeroed by the LayerNorm pass)
+    // as NP pieces of 64 lanes x VB bytes.  Only the first tile is requested in one go: inside the loop the pieces of tile i+1
+    // are issued one by one between the MFMA blocks of tile i -- all 256 workgroups of a launch walk their tiles in step, and
+    // 64 KB per CU requested at the same instant is a 17-MB burst that the memory system serves at its peak rate for ~2 us
+    // while every wave sits in its DMA issue (4.1 k of 16.8 k cycles per tile, tools/o2v_stamps.py), then idles for 6 us.
+    auto issue_piece = [&](int n0, float* dst, int pc) {
+        const int rr = pc / G::PPR, q = pc % G::PPR;
+        const int row = 2 * w + rr;
+        const int n = min(n0 + row, NO - 1);
+        const char* src = reinterpret_cast<const char*>(a.y + ((int64_t)b * NO + n) * H) + lane * G::VB;
+        char* d = reinterpret_cast<char*>(dst + row * G::LDO);
+        glds<G::VB>(src + q * 64 * G::VB, d + q * 64 * G::VB);
+    };
     auto issue_tile = [&](int n0, float* dst) {
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int row = 2 * w + rr;
-            const int n = min(n0 + row, NO - 1);
-            const char* src = reinterpret_cast<const char*>(a.y + ((int64_t)b * NO + n) * H) + lane * G::VB;
-            char* d = reinterpret_cast<char*>(dst + row * G::LDO);
-#pragma unroll
-            for (int q = 0; q < G::PPR; ++q) glds<G::VB>(src + q * 64 * G::VB, d + q * 64 * G::VB);
-        }
+        for (int pc = 0; pc < G::NP; ++pc) issue_piece(n0, dst, pc);
     };
     if (n_begin < n_end) issue_tile(n_begin, smem);
 
@@ -178,42 +185,61 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
             }
         }
     };
-    if (n_begin < n_end) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int step = 0; step < 8; ++step) stats_step(step, smem, stat_l, n_begin);
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the first tile: this wave's rows landed; behind the barrier, everyone's
     lds_barrier();
 
     int it = 0;
     for (int n0 = n_begin; n0 < n_end; n0 += O16_TILE, ++it) {
         float* cur = smem + (it & 1) * G::BUF;
         float* nxt = smem + ((it + 1) & 1) * G::BUF;
-        const float* st_cur = stat_l + (it & 1) * 32;
-        float* st_nxt = stat_l + ((it + 1) & 1) * 32;
+        float* st_cur = stat_l;
         const bool more = n0 + O16_TILE < n_end;
         stamp(it, 0);
-        if (more) issue_tile(n0 + O16_TILE, nxt);       // `nxt` was released by the barrier that ended the previous tile
         stamp(it, 1);
         stamp(it, 2);
         stamp(it, 3);
 
-        // ---- partial S over this wave's k slice: D[obj 4g+i][frame 16fb+f]
+        // ---- partial S over this wave's k slice: D[obj 4g+i][frame 16fb+f].  In the MFMA shadows: the first half of the next
+        // tile's DMA pieces (`nxt` was released by the barrier that ended the previous tile) and the row statistics of THIS tile
+        // for the two rows this wave fetched itself (they landed before that barrier; needed by the softmax behind the next one)
+        constexpr int NPH = G::NP / 2;                 // pieces issued in this phase; the rest between the aggregation blocks
         f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if (w < G::KW) {
             const float* ap = cur + f * G::LDO + w * G::HS + 4 * g;        // A[m = f][k = 16c + 4g + s]
+            f32x4 a_nx = *reinterpret_cast<const f32x4*>(ap);
 #pragma unroll
             for (int c = 0; c < G::NCHUNK; ++c) {
-                const f32x4 a4 = *reinterpret_cast<const f32x4*>(ap + 16 * c);
+                // the next chunk's fragment is requested before this chunk's MFMAs (one LDS round trip per chunk otherwise)
+                const f32x4 a4 = a_nx;
+                if (c + 1 < G::NCHUNK) a_nx = *reinterpret_cast<const f32x4*>(ap + 16 * (c + 1));
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) {
                     sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_], vreg[0][4 * c + s_], sacc[0], 0, 0, 0);
                     sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[s_], vreg[1][4 * c + s_], sacc[1], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && !(dbg & 2)) {
+#pragma unroll
+                    for (int pc = 0; pc < NPH; ++pc)
+                        if (pc * G::NCHUNK / NPH == c) issue_piece(n0 + O16_TILE, nxt, pc);
+                }
+                if (!(dbg & 1)) {
+#pragma unroll
+                    for (int step = 0; step < 8; ++step)
+                        if (step * G::NCHUNK / 8 == c) stats_step(step, cur, st_cur, n0);
+                }
             }
             f32x4* r4 = reinterpret_cast<f32x4*>(red);
             r4[(w * 2 + 0) * 64 + lane] = sacc[0];
             r4[(w * 2 + 1) * 64 + lane] = sacc[1];
+        } else {
+            if (more) {
+#pragma unroll
+                for (int pc = 0; pc < NPH; ++pc) issue_piece(n0 + O16_TILE, nxt, pc);
+            }
+#pragma unroll
+            for (int step = 0; step < 8; ++step) stats_step(step, cur, st_cur, n0);
         }
         stamp(it, 4);
         lds_barrier();
@@ -272,26 +298,39 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc_o[fb][c][i] *= arow[i];
         }
-        if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // next tile landed (this wave's own rows)
+        float b_nx[4];
+        {
+            const float* bp = cur + min(w * G::CBW, G::NCB - 1) * 16 + f;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) b_nx[jj] = bp[(4 * g + jj) * G::LDO];
+        }
 #pragma unroll
         for (int c = 0; c < G::CBW; ++c) {
             const int cb = w * G::CBW + c;
+            float bvv[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) bvv[jj] = b_nx[jj];
+            if (c + 1 < G::CBW) {
+                const float* bp = cur + min(cb + 1, G::NCB - 1) * 16 + f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) b_nx[jj] = bp[(4 * g + jj) * G::LDO];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             if (cb < G::NCB) {
-                const float* bp = cur + cb * 16 + f;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const float bvv = bp[(4 * g + jj) * G::LDO];
-                    acc_o[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][jj], bvv, acc_o[0][c], 0, 0, 0);
-                    acc_o[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[1][jj], bvv, acc_o[1][c], 0, 0, 0);
+                    acc_o[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[0][jj], bvv[jj], acc_o[0][c], 0, 0, 0);
+                    acc_o[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(p[1][jj], bvv[jj], acc_o[1][c], 0, 0, 0);
                 }
             }
-            if (more) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (more && !(dbg & 2)) {
 #pragma unroll
-                for (int step = 0; step < 8; ++step)
-                    if (step * G::CBW / 8 == c) stats_step(step, nxt, st_nxt, n0 + O16_TILE);
+                for (int pc = NPH; pc < G::NP; ++pc)
+                    if ((pc - NPH) * G::CBW / (G::NP - NPH) == c) issue_piece(n0 + O16_TILE, nxt, pc);
             }
-            // (no sched_barrier here: pinning the slices also pins the B-operand LDS reads behind the previous MFMAs)
         }
+        if (more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's rows of the next tile landed
         stamp(it, 7);
         lds_barrier();      // `cur` is free for the DMA of tile i+2, `red` for the next partials, tile i+1's statistics are out
         stamp(it, 8);
@@ -404,7 +443,8 @@ int o2v16_launch_t(const dlsg_o2v_args* a, int count, hipStream_t st) {
 #ifdef DLSG_PROBES
     static const bool stamps = getenv("DLSG_O2V_STAMPS") != nullptr;
     if (stamps && a->nsplit == 1) {
-        hipLaunchKernelGGL((o2v16_kernel<H, true>), grid, dim3(O16_THREADS), lds_bytes, st, pk, tps);
+        const char* d = getenv("DLSG_O2V_DBG");
+        hipLaunchKernelGGL((o2v16_kernel<H, true>), grid, dim3(O16_THREADS), lds_bytes, st, pk, tps | ((d ? atoi(d) : 0) << 16));
         return hipGetLastError() == hipSuccess ? DLSG_OK : DLSG_ELAUNCH;
     }
 #endif

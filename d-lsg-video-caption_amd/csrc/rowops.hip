@@ -12,8 +12,13 @@ constexpr int LN_THREADS = 256;
 constexpr int LN_MAXPT = 8;  // n <= 2048
 
 // ------------------------------------------------------------------------------------------------ rowln fwd
-__global__ __launch_bounds__(LN_THREADS) void rowln_fwd_kernel(const dlsg_rowln_args a) {
+// (several norms of one shape per launch -- the two encoder streams' obj_visual_norm, visual_norm: blockIdx.y picks the block)
+struct RowLnPack { dlsg_rowln_args s[DLSG_ROWLN_MAXMULTI]; };
+struct RowLnBwdPack { dlsg_rowln_bwd_args s[DLSG_ROWLN_MAXMULTI]; };
+
+__global__ __launch_bounds__(LN_THREADS) void rowln_fwd_kernel(const RowLnPack pk) {
     __shared__ float red[16];
+    const dlsg_rowln_args& a = pk.s[blockIdx.y];
     const int n = a.n;
     const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
     // gamma / beta are the same for every row, the positional row is known up front: requested with the row itself, not a
@@ -73,8 +78,9 @@ __global__ __launch_bounds__(LN_THREADS) void rowln_fwd_kernel(const dlsg_rowln_
 
 // ------------------------------------------------------------------------------------------------ rowln bwd
 // Each block walks rows blockIdx.x, +gridDim.x, ... and keeps per-column dgamma/dbeta partial sums in registers.
-__global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const dlsg_rowln_bwd_args b) {
+__global__ __launch_bounds__(LN_THREADS) void rowln_bwd_kernel(const RowLnBwdPack pk) {
     __shared__ float red[16];
+    const dlsg_rowln_bwd_args& b = pk.s[blockIdx.y];
     const dlsg_rowln_args& a = b.f;
     const int n = a.n;
     const uint64_t seed = a.seed + (a.seed_ptr ? *a.seed_ptr : 0ull);
@@ -935,14 +941,20 @@ inline int grid_for(int64_t total, int threads = 256, int cap = 4096) {
 
 }  // namespace
 
-extern "C" int dlsg_rowln_fwd(const dlsg_rowln_args* a, void* stream) {
-    if (!a || a->n < 1 || a->n > LN_THREADS * LN_MAXPT) return DLSG_EINVAL;
+extern "C" int dlsg_rowln_fwd_multi(const dlsg_rowln_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > DLSG_ROWLN_MAXMULTI) return DLSG_EINVAL;
+    RowLnPack pk;
+    for (int i = 0; i < count; ++i) {
+        if (a[i].n < 1 || a[i].n > LN_THREADS * LN_MAXPT || a[i].rows != a[0].rows) return DLSG_EINVAL;
+        pk.s[i] = a[i];
+    }
     if (a->rows == 0) return DLSG_OK;
     int grid = a->rows < 4096 ? a->rows : 4096;
-    hipLaunchKernelGGL(rowln_fwd_kernel, dim3(grid), dim3(LN_THREADS), 0, ST(stream), *a);
+    hipLaunchKernelGGL(rowln_fwd_kernel, dim3(grid, count), dim3(LN_THREADS), 0, ST(stream), pk);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
+extern "C" int dlsg_rowln_fwd(const dlsg_rowln_args* a, void* stream) { return dlsg_rowln_fwd_multi(a, 1, stream); }
 // grid of the backward = number of per-block dgamma/dbeta partial rows: enough blocks to fill the chip on tall inputs
 extern "C" int dlsg_rowln_bwd_nblk(int rows) {
     if (rows < 1) return 1;
@@ -950,15 +962,21 @@ extern "C" int dlsg_rowln_bwd_nblk(int rows) {
     if (rows <= 4096) return (rows + 1) / 2 < 1024 ? (rows + 1) / 2 : 1024;   // two rows per block: 1664-row norms ran at 0.6 TB/s on 256
     return 1024;
 }
-extern "C" int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream) {
-    if (!a || a->f.n < 1 || a->f.n > LN_THREADS * LN_MAXPT) return DLSG_EINVAL;
-    if (a->f.rows == 0) return DLSG_OK;
+extern "C" int dlsg_rowln_bwd_multi(const dlsg_rowln_bwd_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > DLSG_ROWLN_MAXMULTI) return DLSG_EINVAL;
     const int grid = dlsg_rowln_bwd_nblk(a->f.rows);
-    if (a->dgb_part && a->nblk != grid) return DLSG_EINVAL;
-    hipLaunchKernelGGL(rowln_bwd_kernel, dim3(grid), dim3(LN_THREADS), 0, ST(stream), *a);
+    RowLnBwdPack pk;
+    for (int i = 0; i < count; ++i) {
+        if (a[i].f.n < 1 || a[i].f.n > LN_THREADS * LN_MAXPT || a[i].f.rows != a[0].f.rows) return DLSG_EINVAL;
+        if (a[i].dgb_part && a[i].nblk != grid) return DLSG_EINVAL;
+        pk.s[i] = a[i];
+    }
+    if (a->f.rows == 0) return DLSG_OK;
+    hipLaunchKernelGGL(rowln_bwd_kernel, dim3(grid, count), dim3(LN_THREADS), 0, ST(stream), pk);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
+extern "C" int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream) { return dlsg_rowln_bwd_multi(a, 1, stream); }
 static int colsum_chunks(int rows) {
     if (rows < 4096) return 1;
     const int chunks = (rows + 1023) / 1024;

@@ -306,18 +306,34 @@ def tun_fwd(ops, m, pfx, visual, regions, sv, training, seed, psl_site, fused_o2
 
 def tun_frames(ops, m, pfx, visual, regions, sv):
     """frame nodes v = LN(tanh(visual_embed(x))) (layer.py:179-180; the Linear is skipped when use_embed is False)"""
+    tun_frames_multi(ops, [(m, pfx, visual)], regions, sv)
+
+
+def tun_frames_multi(ops, items, regions, sv):
+    """tun_frames of several streams; items: [(module, prefix, visual)].  Streams whose frame nodes have one width share ONE
+    visual_embed launch (those that have the Linear) and ONE visual_norm launch."""
     B, T, O, R = regions.shape
-    H = m.visual_norm[1].weight.numel()
     ref = regions
-    s = sv[pfx] = {}
-    if m.use_embed:
-        v_pre = _empty(ref, B * T, H)
-        lin(ops, visual, m.visual_embed.weight, v_pre, m.visual_embed.bias)
-    else:
-        v_pre = visual
-    v = _empty(ref, B * T, H); st_v = _empty(ref, B * T, 2)
-    ops.rowln_fwd(v_pre, m.visual_norm[1].weight, m.visual_norm[1].bias, v, st_v, pre_tanh=1)
-    s.update(visual=visual, v_pre=v_pre, v=v, st_v=st_v)
+    Hs = [m.visual_norm[1].weight.numel() for m, _, _ in items]
+    if len(items) > 1 and len(set(Hs)) > 1:
+        for it in items:
+            tun_frames_multi(ops, [it], regions, sv)
+        return
+    H = Hs[0]
+    groups, calls = [], []
+    for m, pfx, visual in items:
+        s = sv[pfx] = {}
+        if m.use_embed:
+            v_pre = _empty(ref, B * T, H)
+            groups.append((visual, m.visual_embed.weight, v_pre, m.visual_embed.bias))
+        else:
+            v_pre = visual
+        v = _empty(ref, B * T, H); st_v = _empty(ref, B * T, 2)
+        calls.append(dict(x=v_pre, gamma=m.visual_norm[1].weight, beta=m.visual_norm[1].bias, y=v, stats=st_v, pre_tanh=1))
+        s.update(visual=visual, v_pre=v_pre, v=v, st_v=st_v)
+    if groups:
+        ops.gemm(GEMM_NT, groups)
+    ops.rowln_fwd_multi(calls)
 
 
 O2V_MAX_NSPLIT = 64      # csrc/attention.hip: dlsg_o2v_fwd_multi / dlsg_o2v_bwd refuse more chunks per clip
@@ -377,39 +393,68 @@ def tun_graph(ops, items, regions, sv, fused_o2v=True, nsplit=None):
         ops.gemm(GEMM_TN, [(Pm, o.view(B, NO, H), z.view(B, T, H))], flags=F_ACCUM)
 
 
+def _same_shapes(mods):
+    m0 = mods[0]
+    return all(m.visual_norm[1].weight.numel() == m0.visual_norm[1].weight.numel() and m.v2l_layer.theta.shape == m0.v2l_layer.theta.shape
+               and m.baseline == m0.baseline for m in mods)
+
+
 def tun_latent(ops, m, pfx, regions, sv, training, seed, psl_site):
     """ov = LN(tanh(agg + v)) (layer.py:192-193) and LatentPSL (layer.py:199, sublayer.py:189-198); baseline streams return ov."""
+    return tun_latent_multi(ops, [(m, pfx, psl_site)], regions, sv, training, seed)[0]
+
+
+def tun_latent_multi(ops, items, regions, sv, training, seed):
+    """tun_latent of several streams; items: [(module, prefix, psl_site)].  Streams of one shape share ONE obj_visual_norm launch and
+    ONE LatentPSL launch (CapGnnEncoder: one workgroup per clip -- 64 clips of one stream leave three quarters of the chip idle)."""
+    if len(items) > 1 and not _same_shapes([it[0] for it in items]):
+        return [tun_latent_multi(ops, [it], regions, sv, training, seed)[0] for it in items]
     B, T, O, R = regions.shape
-    H = m.visual_norm[1].weight.numel()
-    P = m.v2l_layer.theta.shape[0]
     ref = regions
-    s = sv[pfx]
+    m0 = items[0][0]
+    H = m0.visual_norm[1].weight.numel()
+    P = m0.v2l_layer.theta.shape[0]
+    ovs = []
     if O >= 5:
-        ov = _empty(ref, B * T, H); st_ov = _empty(ref, B * T, 2)
-        ops.rowln_fwd(s['z'], m.obj_visual_norm[1].weight, m.obj_visual_norm[1].bias, ov, st_ov, pre_tanh=1)
-        s.update(ov=ov, st_ov=st_ov)
+        calls = []
+        for m, pfx, _ in items:
+            s = sv[pfx]
+            ov = _empty(ref, B * T, H); st_ov = _empty(ref, B * T, 2)
+            calls.append(dict(x=s['z'], gamma=m.obj_visual_norm[1].weight, beta=m.obj_visual_norm[1].bias, y=ov, stats=st_ov, pre_tanh=1))
+            s.update(ov=ov, st_ov=st_ov)
+            ovs.append(ov)
+        ops.rowln_fwd_multi(calls)
     else:
-        ov = s['v']
-        s.update(ov=ov)
-    if m.baseline:
-        return ov
+        for m, pfx, _ in items:
+            sv[pfx].update(ov=sv[pfx]['v'])
+            ovs.append(sv[pfx]['v'])
+    if m0.baseline:
+        return ovs
     # LatentPSL (models/sublayer.py:189-198)
-    theta = m.v2l_layer.theta
-    adj = _empty(ref, B, T, P)
-    u = _empty(ref, B * P, H)
-    psl = _empty(ref, B * P, H); st_p = _empty(ref, B * P, 2)
-    ln = m.v2l_layer.out_norm[1]
     pd = 0.3 if training else 0.0
-    if ops.latent_psl_supported(T, P, H):
-        ops.latent_psl_fwd(ov.view(B, T, H), theta, ln.weight, ln.bias, adj, u, psl, st_p, p=pd, site=psl_site, seed=seed)
-    else:
-        lg = _empty(ref, B, T, P)
-        ops.gemm(GEMM_NT, [(ov.view(B, T, H), theta.unsqueeze(0).expand(B, P, H), lg)])
-        ops.softmax_fwd(lg, adj, B, T, P)
-        ops.gemm(GEMM_TN, [(adj, ov.view(B, T, H), u.view(B, P, H))])
-        ops.rowln_fwd(u, ln.weight, ln.bias, psl, st_p, pre_tanh=1, p1=pd, site1=psl_site, seed=seed)
-    s.update(adj=adj, u=u, st_p=st_p, pd=pd, psl_site=psl_site)
-    return psl.view(B, P, H)
+    outs, calls = [], []
+    fused = ops.latent_psl_supported(T, P, H)
+    for (m, pfx, psl_site), ov in zip(items, ovs):
+        s = sv[pfx]
+        theta = m.v2l_layer.theta
+        adj = _empty(ref, B, T, P)
+        u = _empty(ref, B * P, H)
+        psl = _empty(ref, B * P, H); st_p = _empty(ref, B * P, 2)
+        ln = m.v2l_layer.out_norm[1]
+        if fused:
+            calls.append(dict(ov=ov.view(B, T, H), theta=theta, gamma=ln.weight, beta=ln.bias, adj=adj, u=u, out=psl, stats=st_p, p=pd,
+                              site=psl_site, seed=seed))
+        else:
+            lg = _empty(ref, B, T, P)
+            ops.gemm(GEMM_NT, [(ov.view(B, T, H), theta.unsqueeze(0).expand(B, P, H), lg)])
+            ops.softmax_fwd(lg, adj, B, T, P)
+            ops.gemm(GEMM_TN, [(adj, ov.view(B, T, H), u.view(B, P, H))])
+            ops.rowln_fwd(u, ln.weight, ln.bias, psl, st_p, pre_tanh=1, p1=pd, site1=psl_site, seed=seed)
+        s.update(adj=adj, u=u, st_p=st_p, pd=pd, psl_site=psl_site)
+        outs.append(psl.view(B, P, H))
+    if calls:
+        ops.latent_psl_fwd_multi(calls)
+    return outs
 
 
 def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed, defer_dw=None):
@@ -421,33 +466,54 @@ def tun_bwd(ops, m, pfx, regions, sv, G, dpsl, training, seed, defer_dw=None):
 
 def tun_bwd_head(ops, m, pfx, regions, sv, G, dpsl, training, seed):
     """LatentPSL and obj_visual_norm backward: leaves dz = d(agg + v) in sv[pfx] (or d(v) directly when the graph is skipped)."""
+    tun_bwd_head_multi(ops, [(m, pfx, dpsl)], regions, sv, G, training, seed)
+
+
+def tun_bwd_head_multi(ops, items, regions, sv, G, training, seed):
+    """tun_bwd_head of several streams; items: [(module, prefix, dpsl)].  Streams of one shape share ONE launch of the LatentPSL
+    backward and ONE of the obj_visual_norm backward."""
+    if len(items) > 1 and not _same_shapes([it[0] for it in items]):
+        for it in items:
+            tun_bwd_head_multi(ops, [it], regions, sv, G, training, seed)
+        return
     B, T, O, R = regions.shape
-    s = sv[pfx]
-    H = m.visual_norm[1].weight.numel()
-    P = m.v2l_layer.theta.shape[0]
     ref = regions
-    name = pfx
-    if m.baseline:
+    m0 = items[0][0]
+    H = m0.visual_norm[1].weight.numel()
+    P = m0.v2l_layer.theta.shape[0]
+    dovs = []
+    if m0.baseline:
         # baseline streams return the frame nodes ov themselves (layer.py:197-198): dpsl is d(ov), (B,T,H)
-        dov = dpsl.reshape(B * T, H)
-    else:
-        ln = m.v2l_layer.out_norm[1]
-        ov, adj, theta = s['ov'], s['adj'], m.v2l_layer.theta
-        dov = _empty(ref, B * T, H)
-        if ops.latent_psl_bwd_supported(T, P, H):
+        dovs = [dpsl.reshape(B * T, H) for _, _, dpsl in items]
+    elif ops.latent_psl_bwd_supported(T, P, H):
+        calls, after = [], []
+        for m, pfx, dpsl in items:
+            s = sv[pfx]
+            ln = m.v2l_layer.out_norm[1]
+            dov = _empty(ref, B * T, H)
             part = _empty(ref, B, 2, H)
             dth = _empty(ref, B, P * H)
-            ops.latent_psl_bwd(dpsl.reshape(B * P, H), s['u'], s['st_p'], ln.weight, adj, ov.view(B, T, H), theta, dov,
-                               dth.view(B, P, H), part, p=s['pd'], site=s['psl_site'], seed=seed)
-            ln_grads(ops, part, G, name + '.v2l_layer.out_norm.1', H)
-            ops.colsum(dth, G[name + '.v2l_layer.theta'].view(P * H), accum=True)
-        else:
+            calls.append(dict(dout=dpsl.reshape(B * P, H), u=s['u'], stats=s['st_p'], gamma=ln.weight, adj=s['adj'], ov=s['ov'].view(B, T, H),
+                              theta=m.v2l_layer.theta, dov=dov, dtheta_part=dth.view(B, P, H), part=part, p=s['pd'], site=s['psl_site'],
+                              seed=seed))
+            after.append((pfx, part, dth))
+            dovs.append(dov)
+        ops.latent_psl_bwd_multi(calls)
+        for pfx, part, dth in after:
+            ln_grads(ops, part, G, pfx + '.v2l_layer.out_norm.1', H)
+            ops.colsum(dth, G[pfx + '.v2l_layer.theta'].view(P * H), accum=True)
+    else:
+        for m, pfx, dpsl in items:
+            s = sv[pfx]
+            ln = m.v2l_layer.out_norm[1]
+            ov, adj, theta = s['ov'], s['adj'], m.v2l_layer.theta
+            dov = _empty(ref, B * T, H)
             nb = ops.rowln_bwd_nblk(B * P)
             part = _empty(ref, nb, 2, H)
             du = _empty(ref, B * P, H)
             ops.rowln_bwd(dpsl.reshape(B * P, H), s['u'], ln.weight, ln.bias, du, stats=s['st_p'], pre_tanh=1, p1=s['pd'],
                           site1=s['psl_site'], seed=seed, dgb_part=part)
-            ln_grads(ops, part, G, name + '.v2l_layer.out_norm.1', H)
+            ln_grads(ops, part, G, pfx + '.v2l_layer.out_norm.1', H)
             du3 = du.view(B, P, H)
             dadj = _empty(ref, B, T, P)
             ops.gemm(GEMM_NT, [(ov.view(B, T, H), du3, dadj)])
@@ -455,17 +521,25 @@ def tun_bwd_head(ops, m, pfx, regions, sv, G, dpsl, training, seed):
             dlg = _empty(ref, B, T, P)
             ops.softmax_bwd(adj, dadj, dlg, B, T, P)
             ops.gemm(GEMM_NN, [(dlg, theta.unsqueeze(0).expand(B, P, H), dov.view(B, T, H))], flags=F_ACCUM)
-            ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[name + '.v2l_layer.theta'])], flags=F_ACCUM)
+            ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[pfx + '.v2l_layer.theta'])], flags=F_ACCUM)
+            dovs.append(dov)
     if O >= 5:
-        lnv = m.obj_visual_norm[1]
         nb = ops.rowln_bwd_nblk(B * T)
-        part = _empty(ref, nb, 2, H)
-        dz = _empty(ref, B * T, H)
-        ops.rowln_bwd(dov, s['z'], lnv.weight, lnv.bias, dz, stats=s['st_ov'], pre_tanh=1, dgb_part=part)
-        ln_grads(ops, part, G, name + '.obj_visual_norm.1', H)
-        s['dz'] = dz
+        calls, after = [], []
+        for (m, pfx, _), dov in zip(items, dovs):
+            s = sv[pfx]
+            lnv = m.obj_visual_norm[1]
+            part = _empty(ref, nb, 2, H)
+            dz = _empty(ref, B * T, H)
+            calls.append(dict(dy=dov, x=s['z'], gamma=lnv.weight, beta=lnv.bias, dx=dz, stats=s['st_ov'], pre_tanh=1, dgb_part=part))
+            after.append((pfx, part))
+            s['dz'] = dz
+        ops.rowln_bwd_multi(calls)
+        for pfx, part in after:
+            ln_grads(ops, part, G, pfx + '.obj_visual_norm.1', H)
     else:
-        s['dv'] = dov
+        for (m, pfx, _), dov in zip(items, dovs):
+            sv[pfx]['dv'] = dov
 
 
 def tun_graph_bwd(ops, items, regions, sv, G):

@@ -223,7 +223,7 @@ class DecattCacheGradsArgs(C.Structure):
 
 
 # every symbol include/dlsg.h declares (checked by tests/test_abi.py against the header text)
-SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_gemm_variant', 'dlsg_gemm_ws_bytes', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd',
+SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_gemm_variant', 'dlsg_gemm_ws_bytes', 'dlsg_slab_reduce', 'dlsg_rowln_fwd', 'dlsg_rowln_bwd', 'dlsg_rowln_fwd_multi', 'dlsg_rowln_bwd_multi',
            'dlsg_rowln_bwd_nblk', 'dlsg_colsum', 'dlsg_colsum2', 'dlsg_colsum_ws_floats', 'dlsg_colsum_multi', 'dlsg_colsum_multi_ok', 'dlsg_o2v_workspace_bytes', 'dlsg_o2v_fwd', 'dlsg_o2v_fwd_multi',
            'dlsg_softmax_fwd', 'dlsg_softmax_bwd', 'dlsg_decatt_fwd', 'dlsg_decatt_bwd', 'dlsg_lstm_pw_fwd',
            'dlsg_lstm_pw_bwd', 'dlsg_lstm_pw_fwd_n', 'dlsg_lstm_pw_bwd_n', 'dlsg_mean_rows_fwd', 'dlsg_mean_rows_bwd', 'dlsg_embed_fwd', 'dlsg_embed_bwd',
@@ -231,7 +231,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_gemm_varia
            'dlsg_adam', 'dlsg_permute_tb', 'dlsg_gather_rows', 'dlsg_dec_mid_fwd', 'dlsg_dec_tail_fwd',
            'dlsg_dec_mid_bwd', 'dlsg_decatt_cache_grads', 'dlsg_o2v_bwd', 'dlsg_o2v_bwd_multi',
            'dlsg_latent_psl_fwd', 'dlsg_sa_core_fwd', 'dlsg_beam_select', 'dlsg_gather_rows_multi',
-           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd',
+           'dlsg_sa_core_bwd', 'dlsg_latent_psl_bwd', 'dlsg_latent_psl_fwd_multi', 'dlsg_latent_psl_bwd_multi',
            'dlsg_crit_embed_mix', 'dlsg_crit_embed_mix_bwd', 'dlsg_crit_vocab_scatter', 'dlsg_crit_relu_taps', 'dlsg_crit_relu_taps_bwd',
            'dlsg_cln_ws_floats', 'dlsg_cln_fwd', 'dlsg_cln_bwd', 'dlsg_cln_bwd2', 'dlsg_crit_sa_fwd', 'dlsg_crit_sa_bwd', 'dlsg_crit_sa_bwd2',
            'dlsg_crit_pattn_fwd', 'dlsg_crit_pattn_bwd', 'dlsg_crit_pattn_bwd2', 'dlsg_crit_tsum_fwd', 'dlsg_crit_tsum_bwd',
@@ -260,6 +260,8 @@ def load_library(path=LIB_PATH):
         'dlsg_slab_reduce': [vp, i32, i64, vp, vp, i64, i32, i32, i32, vp],
         'dlsg_rowln_fwd': [P(RowLnArgs), vp],
         'dlsg_rowln_bwd': [P(RowLnBwdArgs), vp],
+        'dlsg_rowln_fwd_multi': [P(RowLnArgs), i32, vp],
+        'dlsg_rowln_bwd_multi': [P(RowLnBwdArgs), i32, vp],
         'dlsg_rowln_bwd_nblk': [i32],
         'dlsg_colsum_ws_floats': [i32, i32],
         'dlsg_colsum': [vp, i64, i32, i32, vp, i32, vp, vp],
@@ -298,11 +300,13 @@ def load_library(path=LIB_PATH):
         'dlsg_o2v_bwd': [P(O2VBwdArgs), vp],
         'dlsg_o2v_bwd_multi': [P(O2VBwdArgs), i32, vp],
         'dlsg_latent_psl_fwd': [P(LatentPslArgs), vp],
+        'dlsg_latent_psl_fwd_multi': [P(LatentPslArgs), i32, vp],
         'dlsg_sa_core_fwd': [P(SaCoreArgs), vp],
         'dlsg_beam_select': [P(BeamSelectArgs), vp],
         'dlsg_gather_rows_multi': [P(GatherMultiArgs), vp],
         'dlsg_sa_core_bwd': [P(SaCoreBwdArgs), vp],
         'dlsg_latent_psl_bwd': [P(LatentPslBwdArgs), vp],
+        'dlsg_latent_psl_bwd_multi': [P(LatentPslBwdArgs), i32, vp],
         'dlsg_bilstm_supported': [i32, i32, i32],
         'dlsg_bilstm_hx_floats': [i32, i32],
         'dlsg_bilstm_flag_words': [i32, i32],
@@ -568,6 +572,38 @@ class HipOps(object):
         a = self._rowln_args(x, gamma, beta, y, stats, res, pe, pre_tanh, post_tanh, p1, site1, p2, site2, seed, eps)
         self._check(self.lib.dlsg_rowln_fwd(C.byref(a), self._stream()), 'dlsg_rowln_fwd')
 
+    def rowln_fwd_multi(self, items):
+        """several norms of the same number of rows in ONE launch; items: dicts of rowln_fwd's arguments (x, gamma, beta, y, ...)"""
+        n = len(items)
+        if n == 1:
+            return self.rowln_fwd(**items[0])
+        arr = (RowLnArgs * n)()
+        for i, it in enumerate(items):
+            d = dict(stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0, site1=0, p2=0.0, site2=0, seed=0, eps=1e-5)
+            d.update(it)
+            arr[i] = self._rowln_args(d['x'], d['gamma'], d['beta'], d['y'], d['stats'], d['res'], d['pe'], d['pre_tanh'],
+                                      d['post_tanh'], d['p1'], d['site1'], d['p2'], d['site2'], d['seed'], d['eps'])
+        self._check(self.lib.dlsg_rowln_fwd_multi(arr, n, self._stream()), 'dlsg_rowln_fwd_multi')
+
+    def rowln_bwd_multi(self, items):
+        """several norm backwards of the same number of rows in ONE launch; items: dicts of rowln_bwd's arguments"""
+        n = len(items)
+        if n == 1:
+            return self.rowln_bwd(**items[0])
+        arr = (RowLnBwdArgs * n)()
+        for i, it in enumerate(items):
+            d = dict(stats=None, res=None, pe=None, pre_tanh=0, post_tanh=0, p1=0.0, site1=0, p2=0.0, site2=0, seed=0, eps=1e-5,
+                     dgb_part=None, accum_dx=False)
+            d.update(it)
+            b = arr[i]
+            b.f = self._rowln_args(d['x'], d['gamma'], d['beta'], None, d['stats'], d['res'], d['pe'], d['pre_tanh'], d['post_tanh'],
+                                   d['p1'], d['site1'], d['p2'], d['site2'], d['seed'], d['eps'])
+            b.dy, b.lddy, b.dx, b.lddx = _p(d['dy']), d['dy'].stride(0), _p(d['dx']), d['dx'].stride(0)
+            b.accum_dx = int(d['accum_dx'])
+            b.dgb_part = _p(d['dgb_part'])
+            b.nblk = d['dgb_part'].size(0) if d['dgb_part'] is not None else 0
+        self._check(self.lib.dlsg_rowln_bwd_multi(arr, n, self._stream()), 'dlsg_rowln_bwd_multi')
+
     def rowln_bwd_nblk(self, rows):
         return self.lib.dlsg_rowln_bwd_nblk(int(rows))
 
@@ -730,34 +766,56 @@ class HipOps(object):
     def latent_psl_supported(self, T, P, H):
         return T <= 32 and P <= 32 and H % 4 == 0 and H <= 2048 and T * H * 4 <= 140 * 1024
 
-    def latent_psl_fwd(self, ov, theta, gamma, beta, adj, u, out, stats, p=0.0, site=0, seed=0, eps=1e-5):
-        """ov (B,T,H), theta (P,H) -> adj (B,T,P), u (B*P,H) pre-activation, out (B*P,H), stats (B*P,2); one launch."""
+    def _psl_args(self, a, ov, theta, gamma, beta, adj, u, out, stats, p=0.0, site=0, seed=0, eps=1e-5):
         B, T, H = ov.shape
         P = theta.shape[0]
         for t in (ov, theta, adj, u, out, stats):
             _chkc(t)
-        a = LatentPslArgs()
         a.ov, a.theta, a.gamma, a.beta, a.adj, a.u, a.out, a.stats = _p(ov), _p(theta), _p(gamma), _p(beta), _p(adj), _p(u), \
             _p(out), _p(stats)
         a.B, a.T, a.P, a.H, a.p, a.site, a.eps = B, T, P, H, p, site, eps
         a.seed, a.seed_ptr = _seed(seed)
+
+    def latent_psl_fwd(self, ov, theta, gamma, beta, adj, u, out, stats, p=0.0, site=0, seed=0, eps=1e-5):
+        """ov (B,T,H), theta (P,H) -> adj (B,T,P), u (B*P,H) pre-activation, out (B*P,H), stats (B*P,2); one launch."""
+        a = LatentPslArgs()
+        self._psl_args(a, ov, theta, gamma, beta, adj, u, out, stats, p, site, seed, eps)
         self._check(self.lib.dlsg_latent_psl_fwd(C.byref(a), self._stream()), 'dlsg_latent_psl_fwd')
+
+    def latent_psl_fwd_multi(self, items):
+        """several LatentPSL modules of one shape in ONE launch; items: dicts of latent_psl_fwd's arguments"""
+        n = len(items)
+        arr = (LatentPslArgs * n)()
+        for i, it in enumerate(items):
+            self._psl_args(arr[i], **it)
+        self._check(self.lib.dlsg_latent_psl_fwd_multi(arr, n, self._stream()), 'dlsg_latent_psl_fwd_multi')
 
     def latent_psl_bwd_supported(self, T, P, H):
         return T <= 32 and P <= 8 and H % 4 == 0 and H <= 2048 and (T + 8) * H * 4 <= 150 * 1024
 
-    def latent_psl_bwd(self, dout, u, stats, gamma, adj, ov, theta, dov, dtheta_part, part, p=0.0, site=0, seed=0):
-        """backward of latent_psl_fwd: dout (B*P,H) -> dov (B*T,H), dtheta_part (B,P,H), part (B,2,H); one launch."""
+    def _psl_bwd_args(self, a, dout, u, stats, gamma, adj, ov, theta, dov, dtheta_part, part, p=0.0, site=0, seed=0):
         B, T, H = ov.shape
         P = theta.shape[0]
         for t in (dout, u, stats, adj, ov, theta, dov, dtheta_part, part):
             _chkc(t)
-        a = LatentPslBwdArgs()
         a.dout, a.u, a.stats, a.gamma, a.adj, a.ov, a.theta = _p(dout), _p(u), _p(stats), _p(gamma), _p(adj), _p(ov), _p(theta)
         a.dov, a.dtheta_part, a.part = _p(dov), _p(dtheta_part), _p(part)
         a.B, a.T, a.P, a.H, a.p, a.site = B, T, P, H, p, site
         a.seed, a.seed_ptr = _seed(seed)
+
+    def latent_psl_bwd(self, dout, u, stats, gamma, adj, ov, theta, dov, dtheta_part, part, p=0.0, site=0, seed=0):
+        """backward of latent_psl_fwd: dout (B*P,H) -> dov (B*T,H), dtheta_part (B,P,H), part (B,2,H); one launch."""
+        a = LatentPslBwdArgs()
+        self._psl_bwd_args(a, dout, u, stats, gamma, adj, ov, theta, dov, dtheta_part, part, p, site, seed)
         self._check(self.lib.dlsg_latent_psl_bwd(C.byref(a), self._stream()), 'dlsg_latent_psl_bwd')
+
+    def latent_psl_bwd_multi(self, items):
+        """several LatentPSL backwards of one shape in ONE launch; items: dicts of latent_psl_bwd's arguments"""
+        n = len(items)
+        arr = (LatentPslBwdArgs * n)()
+        for i, it in enumerate(items):
+            self._psl_bwd_args(arr[i], **it)
+        self._check(self.lib.dlsg_latent_psl_bwd_multi(arr, n, self._stream()), 'dlsg_latent_psl_bwd_multi')
 
     def sa_core_supported(self, T, D):
         return T <= 32 and D % 64 == 0

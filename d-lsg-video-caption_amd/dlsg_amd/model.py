@@ -242,9 +242,9 @@ class CapGnnModel(_HipModel):
         B, T, F = frames.shape
         A = enc.a_feature_size
         f2 = frames.view(B * T, F)
-        E.tun_frames(ops, enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A], regions, sv)
         mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed)
-        E.tun_frames(ops, enc.motion_encoder, 'encoder.motion_encoder', mot_in, regions, sv)
+        E.tun_frames_multi(ops, [(enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A]), (enc.motion_encoder, 'encoder.motion_encoder', mot_in)],
+                           regions, sv)
         # the region projections (the step's longest launch) go HERE, behind the frame path's matrix kernels, not first in the
         # step: directly behind the previous step's Adam -- 0.5 ms of pure memory traffic -- the same launch takes 11 % longer
         # (1 722 us against 1 555 back to back, tools/sk_sequence_probe.py: the clock the chip holds, not the caches)
@@ -253,8 +253,8 @@ class CapGnnModel(_HipModel):
             ys = E.region_projections(ops, [enc.obj_encoder, enc.motion_encoder], regions)
         E.tun_graph(ops, [(enc.obj_encoder, 'encoder.obj_encoder', ys[0]), (enc.motion_encoder, 'encoder.motion_encoder', ys[1])],
                     regions, sv, self.fused_o2v)
-        obj = E.tun_latent(ops, enc.obj_encoder, 'encoder.obj_encoder', regions, sv, training, seed, E.SITE_PSL_OBJ)
-        mot = E.tun_latent(ops, enc.motion_encoder, 'encoder.motion_encoder', regions, sv, training, seed, E.SITE_PSL_MOT)
+        obj, mot = E.tun_latent_multi(ops, [(enc.obj_encoder, 'encoder.obj_encoder', E.SITE_PSL_OBJ),
+                                            (enc.motion_encoder, 'encoder.motion_encoder', E.SITE_PSL_MOT)], regions, sv, training, seed)
         return obj, mot
 
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
@@ -321,8 +321,7 @@ class CapGnnModel(_HipModel):
         mot, obj = (enc.motion_encoder, 'encoder.motion_encoder'), (enc.obj_encoder, 'encoder.obj_encoder')
         # both streams' LatentPSL / obj_visual_norm backward first, so that the object->frame graph of BOTH streams runs its
         # backward as one launch per pass (2 x 64 clips: two object chunks per clip instead of four)
-        E.tun_bwd_head(ops, mot[0], mot[1], regions, sv, G, dmo, training, seed)
-        E.tun_bwd_head(ops, obj[0], obj[1], regions, sv, G, dob, training, seed)
+        E.tun_bwd_head_multi(ops, [(mot[0], mot[1], dmo), (obj[0], obj[1], dob)], regions, sv, G, training, seed)
         E.tun_graph_bwd(ops, [mot, obj], regions, sv, G)
         dmot_in = E.tun_bwd_tail(ops, mot[0], mot[1], regions, sv, G, defer_dw=deep)
         E.encvis_bwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, G, dmot_in, training, seed)

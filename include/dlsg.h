@@ -139,6 +139,10 @@ typedef struct {
     const uint64_t* seed_ptr;              /* optional device word added to `seed` (graph replay: new masks per replay) */
 } dlsg_rowln_args;
 int dlsg_rowln_fwd(const dlsg_rowln_args* a, void* stream);
+/* `count` (<= DLSG_ROWLN_MAXMULTI) norms of the same number of rows in one launch (the two encoder streams' visual_norm /
+ * obj_visual_norm: 1 664 rows each put half the chip to work) */
+#define DLSG_ROWLN_MAXMULTI 2
+int dlsg_rowln_fwd_multi(const dlsg_rowln_args* a, int count, void* stream);
 /* backward: dy -> dx (same shape as x; residual gets the same gradient), dgamma/dbeta partial sums are written
  * to dgb_part (nblk x 2 x n) and folded by dlsg_colsum. */
 typedef struct {
@@ -149,6 +153,7 @@ typedef struct {
     float* dgb_part; int32_t nblk;         /* workspace: nblk x 2 x n ; nblk = grid size used */
 } dlsg_rowln_bwd_args;
 int dlsg_rowln_bwd(const dlsg_rowln_bwd_args* a, void* stream);
+int dlsg_rowln_bwd_multi(const dlsg_rowln_bwd_args* a, int count, void* stream);
 int dlsg_rowln_bwd_nblk(int rows);
 /* out[j] (+)= sum_r part[r*ld + j], r < rows.  Tall inputs (rows >= 4096, e.g. the 26 624-row bias gradient of the region
  * projection) are summed in row chunks: with ws (>= dlsg_colsum_ws_floats(rows, n) floats of caller scratch) the chunk
@@ -232,6 +237,10 @@ typedef struct {
     uint64_t seed; const uint64_t* seed_ptr;
 } dlsg_latent_psl_args;
 int dlsg_latent_psl_fwd(const dlsg_latent_psl_args* a, void* stream);
+/* `count` (<= DLSG_PSL_MAXMULTI) LatentPSL modules of one shape (B, P, H equal) in one launch: CapGnnEncoder's object and
+ * motion stream (one workgroup per clip: 64 clips alone leave three quarters of the chip idle) */
+#define DLSG_PSL_MAXMULTI 2
+int dlsg_latent_psl_fwd_multi(const dlsg_latent_psl_args* a, int count, void* stream);
 /* backward (P <= 8, (T+8)*H*4 <= 150 KB of LDS): dout (B*P,H) -> dov (B*T,H) written, dtheta_part (B,P,H) and
  * part (B,2,H) = per-clip partials of dtheta and of out_norm's dgamma | dbeta (fold with dlsg_colsum / dlsg_colsum2).
  * u, stats, adj are the forward's outputs; p/site/seed the forward's dropout. */
@@ -244,6 +253,7 @@ typedef struct {
     uint64_t seed; const uint64_t* seed_ptr;
 } dlsg_latent_psl_bwd_args;
 int dlsg_latent_psl_bwd(const dlsg_latent_psl_bwd_args* a, void* stream);
+int dlsg_latent_psl_bwd_multi(const dlsg_latent_psl_bwd_args* a, int count, void* stream);
 
 /* ---------------------------------------------------------------- SelfAttention 26x26 core (sublayer.py:69-78), one launch
  * w (B,T,T) = softmax_j(K_i . Q_j * scale) (optional mask (B,T,T): mask <= 0 -> -9e15 as sublayer.py:70-72);

@@ -123,6 +123,14 @@ class EmulOps(CriticEmul):
             stats.copy_(torch.cat([mean, rstd], 1))
         y.copy_(v)
 
+    def rowln_fwd_multi(self, items):
+        for it in items:
+            self.rowln_fwd(**it)
+
+    def rowln_bwd_multi(self, items):
+        for it in items:
+            self.rowln_bwd(**it)
+
     def rowln_bwd_nblk(self, rows):
         if rows <= 256:
             return max(rows, 1)
@@ -284,6 +292,14 @@ class EmulOps(CriticEmul):
         adj.copy_(torch.softmax(lg, 1))
         u.copy_((adj.transpose(1, 2) @ ov).reshape(B * P, H))
         self.rowln_fwd(u, gamma, beta, out, stats, pre_tanh=1, p1=p, site1=site, seed=seed, eps=eps)
+
+    def latent_psl_fwd_multi(self, items):
+        for it in items:
+            self.latent_psl_fwd(**it)
+
+    def latent_psl_bwd_multi(self, items):
+        for it in items:
+            self.latent_psl_bwd(**it)
 
     def latent_psl_bwd_supported(self, T, P, H):
         return self.fused_supported and T <= 32 and P <= 8 and H % 4 == 0

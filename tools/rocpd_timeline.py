@@ -1,5 +1,5 @@
 """Timeline of ONE replayed train step from a rocprofv3 (rocpd / SQLite) kernel trace of tools/profile_step.py ... graphs:
-python3 tools/rocpd_timeline.py <results.db> [step=-2]
+python3 tools/rocpd_timeline.py <results.db> [step=-2] [sequence.txt]
 
 The step is cut at its Adam launches (one per step); inside it the kernels are put into phases by name (encoder forward, word
 loop forward, loss + head, word loop backward, encoder backward, Adam) and for each phase the tool prints its wall time, the
@@ -86,4 +86,9 @@ for name, a, b in bounds:
                           'sum_of_kernels_us': round(sum(e - s for _, s, e in part) / 1e3, 1),
                           'device_idle_us': round((w1 - w0 - c1) / 1e3, 1), 'two_or_more_running_us': round(c2 / 1e3, 1),
                           'top': [{'kernel': k, 'calls': v[0], 'us': round(v[1], 1)} for k, v in top]})
+if len(sys.argv) > 3:
+    # the launch sequence of the step: offset from its start (us), duration (us), kernel
+    with open(sys.argv[3], 'w') as f:
+        for n, a, b in step:
+            f.write('%9.1f %8.1f  %s\n' % ((a - t0) / 1e3, (b - a) / 1e3, short(n)))
 print(json.dumps(out, indent=1))
