@@ -221,9 +221,11 @@ def tn_grouped(ops, items, defer=None):
     if defer is not None:
         defer.extend(items)
         return
+    # (one launch = one height AND one depth: the stream-K kernel cuts its remainder tiles between the workgroups only when they
+    #  are equally deep -- 1 664-deep and 512-deep blocks in one launch ran 0.52 ms instead of 0.37 + 0.09)
     by_m = {}
     for dy, x, gout in items:
-        by_m.setdefault(dy.shape[1], []).append((dy, x, gout))
+        by_m.setdefault((dy.shape[1], dy.shape[0]), []).append((dy, x, gout))
     for grp in by_m.values():
         # two triples writing the same gradient block must not share a launch (accumulating groups would race)
         waves, seen = [[]], [set()]
@@ -309,21 +311,25 @@ def tun_frames(ops, m, pfx, visual, regions, sv):
     tun_frames_multi(ops, [(m, pfx, visual)], regions, sv)
 
 
-def tun_frames_multi(ops, items, regions, sv):
+def tun_frames_multi(ops, items, regions, sv, pre=None):
     """tun_frames of several streams; items: [(module, prefix, visual)].  Streams whose frame nodes have one width share ONE
-    visual_embed launch (those that have the Linear) and ONE visual_norm launch."""
+    visual_embed launch (those that have the Linear) and ONE visual_norm launch.  pre: {prefix: v_pre} for streams whose
+    visual_embed output exists already."""
     B, T, O, R = regions.shape
     ref = regions
     Hs = [m.visual_norm[1].weight.numel() for m, _, _ in items]
+    pre = pre or {}
     if len(items) > 1 and len(set(Hs)) > 1:
         for it in items:
-            tun_frames_multi(ops, [it], regions, sv)
+            tun_frames_multi(ops, [it], regions, sv, pre)
         return
     H = Hs[0]
     groups, calls = [], []
     for m, pfx, visual in items:
         s = sv[pfx] = {}
-        if m.use_embed:
+        if m.use_embed and pfx in pre:
+            v_pre = pre[pfx]                   # visual_embed already ran (as a group of another launch)
+        elif m.use_embed:
             v_pre = _empty(ref, B * T, H)
             groups.append((visual, m.visual_embed.weight, v_pre, m.visual_embed.bias))
         else:
@@ -623,7 +629,7 @@ def tun_bwd_tail(ops, m, pfx, regions, sv, G, defer_dw=None):
     ops.rowln_bwd(dv, s['v_pre'], lnv.weight, lnv.bias, dv_pre, stats=s['st_v'], pre_tanh=1, dgb_part=part)
     ln_grads(ops, part, G, name + '.visual_norm.1', H)
     if m.use_embed:
-        ops.gemm(GEMM_TN, [(dv_pre, s['visual'], G[name + '.visual_embed.weight'])], flags=F_ACCUM)
+        tn_grouped(ops, [(dv_pre, s['visual'], G[name + '.visual_embed.weight'])], sv.get('tn_defer'))
         ops.colsum(dv_pre, G[name + '.visual_embed.bias'], accum=True)
         return None
     return dv_pre
@@ -661,17 +667,25 @@ def _bilstm_steps_fwd(ops, xg, Whh, bih, bhh, out, hprev, cst, gates, B, T, H, r
         ops.lstm_pw_fwd_multi(calls)            # both directions: one launch
 
 
-def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
-    """EncoderVisual.forward (models/layer.py:46-61).  frames2d (B*T, A+M).  Returns (B*T, H)."""
+def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed, extra=None):
+    """EncoderVisual.forward (models/layer.py:46-61).  frames2d (B*T, A+M).  Returns (B*T, H).
+    extra: independent NT products (x, W, out, bias) on the same B*T rows that ride in the linear_embed launch (the object stream's
+    visual_embed: 82 us as a launch of its own on the small tiles, ~58 us as one more group of the stream-K launch)."""
     H = m.hidden_size
     ref = frames2d
     s = sv[pfx] = {}
     e = _empty(ref, B * T, H)
     Kf = frames2d.shape[1]
-    if getattr(ops, 'stream_k', False) and ops.gemm(GEMM_NT, [(frames2d, m.linear_embed.weight, e, m.linear_embed.bias)], plan_only=True) == V_SK:
+    extra = list(extra or [])
+    main = [(frames2d, m.linear_embed.weight, e, m.linear_embed.bias)]
+    # (only products as deep as linear_embed's may share its launch: the stream-K kernel deals out equally deep tiles)
+    ride = [g for g in extra if g[0].shape[1] == Kf]
+    extra = [g for g in extra if g[0].shape[1] != Kf]
+    if getattr(ops, 'stream_k', False) and ops.gemm(GEMM_NT, main + ride, plan_only=True) == V_SK:
         # one persistent stream-K launch cuts the 6 144-deep contraction between the workgroups itself (178 us against 227)
-        lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
+        ops.gemm(GEMM_NT, main + ride)
     elif B * T <= 2048 and Kf >= 4096 and Kf % 96 == 0:
+        extra = ride + extra
         # a 1 664 x 1 024 output is 416 tiles for a 6 144-deep contraction: three K thirds as groups writing slabs + one fold
         # (210 us against 228, tools/_exp: K-split probe of the mid-size products)
         k3 = Kf // 3
@@ -679,7 +693,10 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed):
         ops.gemm(GEMM_NT, [(frames2d[:, i * k3:(i + 1) * k3], m.linear_embed.weight[:, i * k3:(i + 1) * k3], sl[i]) for i in range(3)])
         ops.slab_reduce(sl, e, bias=m.linear_embed.bias)
     else:
+        extra = ride + extra
         lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
+    if extra:
+        ops.gemm(GEMM_NT, extra)
     lstm = m.lstm
     Wih = [lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]
     Whh = [lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]
@@ -779,7 +796,7 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
     D2 = 2 * H
     dout = _empty(ref, B * T, D2)
     if m.baseline:
-        ops.gemm(GEMM_TN, [(dres, s['hl'], G[name + '.out_try.weight'])], flags=F_ACCUM)
+        tn_grouped(ops, [(dres, s['hl'], G[name + '.out_try.weight'])], sv.get('tn_defer'))
         ops.colsum(dres, G[name + '.out_try.bias'], accum=True)
         dhl = _empty(ref, B * T, D2)
         ops.gemm(GEMM_NN, [(dres, m.out_try.weight, dhl)])
@@ -798,7 +815,7 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
         if s['psa'] > 0:
             ops.dropout(dso, dso, s['psa'], seed, SITE_SA)
         att, w, Kp, Qp, Vp, x, scale = s['att'], s['w'], s['Kp'], s['Qp'], s['Vp'], s['x'], s['scale']
-        ops.gemm(GEMM_TN, [(dso, att, G[name + '.self_attention.output_layer.0.weight'])], flags=F_ACCUM)
+        tn_grouped(ops, [(dso, att, G[name + '.self_attention.output_layer.0.weight'])], sv.get('tn_defer'))
         datt = _empty(ref, B * T, D2)
         ops.gemm(GEMM_NN, [(dso, sa.output_layer[0].weight, datt)])
         datt3 = datt.view(B, T, D2)
@@ -859,7 +876,7 @@ def encvis_bwd(ops, m, pfx, frames2d, B, T, sv, G, dres, training, seed):
             ops.gemm(GEMM_NN, [(dgs[d], Wih[d], de)], flags=F_ACCUM if d else 0)
     for d in range(2):
         ops.colsum2(dgs[d], G[name + '.lstm.bias_ih_l0' + sfx[d]], G[name + '.lstm.bias_hh_l0' + sfx[d]], accum=True)
-    ops.gemm(GEMM_TN, [(de, frames2d, G[name + '.linear_embed.weight'])], flags=F_ACCUM)
+    tn_grouped(ops, [(de, frames2d, G[name + '.linear_embed.weight'])], sv.get('tn_defer'))
     ops.colsum(de, G[name + '.linear_embed.bias'], accum=True)
 
 
@@ -1058,7 +1075,7 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     n = L * B
     dl2 = dlogits_tm.view(n, V)
     # ---- vocab projection + tanh(LN(lang_h))
-    ops.gemm(GEMM_TN, [(dl2, s['DOUT'].view(n, D), G['decoder.word_restore.weight'])], flags=F_ACCUM)
+    tn_grouped(ops, [(dl2, s['DOUT'].view(n, D), G['decoder.word_restore.weight'])], sv.get('tn_defer'))
     ops.colsum(dl2, G['decoder.word_restore.bias'], accum=True)
     ddout = _empty(ref, n, D)
     ops.gemm(GEMM_NN, [(dl2, dec.word_restore.weight, ddout)])

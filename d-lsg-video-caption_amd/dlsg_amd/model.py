@@ -242,9 +242,15 @@ class CapGnnModel(_HipModel):
         B, T, F = frames.shape
         A = enc.a_feature_size
         f2 = frames.view(B * T, F)
-        mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed)
+        # the object stream's visual_embed (independent of everything else) rides in the pre-encoder's first launch
+        pre, extra = {}, []
+        oe = enc.obj_encoder
+        if oe.use_embed:
+            pre['encoder.obj_encoder'] = torch.empty(B * T, oe.visual_embed.weight.shape[0], dtype=torch.float32, device=frames.device)
+            extra.append((f2[:, :A], oe.visual_embed.weight, pre['encoder.obj_encoder'], oe.visual_embed.bias))
+        mot_in = E.encvis_fwd(ops, enc.motion_pre_encoder, 'encoder.motion_pre_encoder', f2, B, T, sv, training, seed, extra=extra)
         E.tun_frames_multi(ops, [(enc.obj_encoder, 'encoder.obj_encoder', f2[:, :A]), (enc.motion_encoder, 'encoder.motion_encoder', mot_in)],
-                           regions, sv)
+                           regions, sv, pre)
         # the region projections (the step's longest launch) go HERE, behind the frame path's matrix kernels, not first in the
         # step: directly behind the previous step's Adam -- 0.5 ms of pure memory traffic -- the same launch takes 11 % longer
         # (1 722 us against 1 555 back to back, tools/sk_sequence_probe.py: the clock the chip holds, not the caches)

@@ -1,6 +1,6 @@
 """In-kernel timeline of the stream-K GEMM (a `make PROBES=1` build of csrc/gemm_sk.hip): 100-MHz stamps of workgroups v < 8 at the
 start, after the last stage of every item, after its store, at the end of the stream and around the fix-up.
-usage: python3 tools/gemm_sk_stamps.py"""
+usage: python3 tools/gemm_sk_stamps.py [mid]      (mid: the step's mid-size products, where the launch's fixed costs show)"""
 import json
 import os
 import sys
@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
-from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_SK, F_ACCUM, F_TANH  # noqa: E402
+from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_SK, F_ACCUM, F_TANH, F_SK_BM128, F_SK_BM256  # noqa: E402
 
 ops = HipOps()
 dev = torch.device('cuda', 0)
@@ -70,6 +70,13 @@ def run(name, mode, M, nk, fl, use_bias, share_a=False):
     ws[1024:4096].zero_()
 
 
+if len(sys.argv) > 1 and sys.argv[1] == 'mid':
+    run('NT 1664x1024x2048 bm128', GEMM_NT, 1664, [(1024, 2048)], F_SK_BM128, True)
+    run('NT 1664x1024x2048 bm256', GEMM_NT, 1664, [(1024, 2048)], F_SK_BM256, True)
+    run('TN 1024x2048x1664 bm128', GEMM_TN, 1024, [(2048, 1664)], F_SK_BM128, False)
+    run('NT 1664x1000x1024 bm128', GEMM_NT, 1664, [(1000, 1024)], F_SK_BM128, True)
+    run('NN 1664x2048x2048 x3 bm128', GEMM_NN, 1664, [(2048, 2048)] * 3, F_SK_BM128, False)
+    sys.exit(0)
 run('region NT 26624x1024x2048 x2 bias tanh', GEMM_NT, 26624, [(1024, 2048)] * 2, F_TANH, True, True)
 run('region NT 26624x1024x2048 x2 plain', GEMM_NT, 26624, [(1024, 2048)] * 2, 0, False, True)
 run('TN 1024x2048x26624 x2 accum', GEMM_TN, 1024, [(2048, 26624)] * 2, F_ACCUM, False)
