@@ -695,8 +695,9 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed, extra=None):
     else:
         extra = ride + extra
         lin(ops, frames2d, m.linear_embed.weight, e, m.linear_embed.bias)
-    if extra:
+    if extra and m.baseline:
         ops.gemm(GEMM_NT, extra)
+        extra = []
     lstm = m.lstm
     Wih = [lstm.weight_ih_l0, lstm.weight_ih_l0_reverse]
     Whh = [lstm.weight_hh_l0, lstm.weight_hh_l0_reverse]
@@ -737,7 +738,12 @@ def encvis_fwd(ops, m, pfx, frames2d, B, T, sv, training, seed, extra=None):
     ops.rowln_fwd(out2, ln.weight, ln.bias, x, st_l, pe=pe, p1=pd, site1=SITE_LSTM, p2=0.2 if training else 0.0,
                   site2=SITE_PE, seed=seed)
     Kp, Qp, Vp = _empty(ref, B * T, D2), _empty(ref, B * T, D2), _empty(ref, B * T, D2)
-    ops.gemm(GEMM_NT, [(x, sa.K.weight, Kp), (x, sa.Q.weight, Qp), (x, sa.V.weight, Vp)])
+    # (riders as deep as the three projections join their launch: a fourth group of the stream-K launch instead of 82 us alone)
+    ride = [g for g in extra if g[0].shape[1] == D2]
+    extra = [g for g in extra if g[0].shape[1] != D2]
+    ops.gemm(GEMM_NT, [(x, sa.K.weight, Kp), (x, sa.Q.weight, Qp), (x, sa.V.weight, Vp)] + ride)
+    if extra:
+        ops.gemm(GEMM_NT, extra)
     scale = 1.0 / math.sqrt(sa.attention_size)
     w = _empty(ref, B, T, T)
     att = _empty(ref, B * T, D2)
@@ -1078,7 +1084,14 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
     tn_grouped(ops, [(dl2, s['DOUT'].view(n, D), G['decoder.word_restore.weight'])], sv.get('tn_defer'))
     ops.colsum(dl2, G['decoder.word_restore.bias'], accum=True)
     ddout = _empty(ref, n, D)
-    ops.gemm(GEMM_NN, [(dl2, dec.word_restore.weight, ddout)])
+    k32 = V // 32 * 32
+    if V - k32 and k32 >= 4096 and getattr(ops, 'stream_k', False):
+        # a 10 000-word vocabulary: the stream-K kernel takes contractions in whole 32-deep stages, so the product runs on it up to
+        # 9 984 and the last 16 words are added by a second, tiny launch (553 us on the small tiles against 420 + 15)
+        ops.gemm(GEMM_NN, [(dl2[:, :k32], dec.word_restore.weight[:k32], ddout)])
+        ops.gemm(GEMM_NN, [(dl2[:, k32:], dec.word_restore.weight[k32:], ddout)], flags=F_ACCUM)
+    else:
+        ops.gemm(GEMM_NN, [(dl2, dec.word_restore.weight, ddout)])
     lnl = dec.lang_lstm_layernorm
     nb = ops.rowln_bwd_nblk(n)
     part = _empty(ref, nb, 2, D)
