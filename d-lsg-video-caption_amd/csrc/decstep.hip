@@ -249,11 +249,70 @@ __global__ __launch_bounds__(DT) void dec_tail_fwd_kernel(const dlsg_dec_tail_ar
     float mean, rstd;
     ln_stats(hb, D, a.eps, red, mean, rstd);
     if (threadIdx.x == 0) { a.st_l[2 * b] = mean; a.st_l[2 * b + 1] = rstd; }
+    const bool sample = a.s_coins != nullptr && a.s_coins[a.s_t] == 0;        // block-uniform
+    float dv[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
         const int j = threadIdx.x + i * DT;
+        dv[i] = 0.f;
         if (j >= D) break;
-        a.dout[(int64_t)b * D + j] = tanhf((hb[j] - mean) * rstd * lg[i] + lb[i]);
+        dv[i] = tanhf((hb[j] - mean) * rstd * lg[i] + lb[i]);
+        a.dout[(int64_t)b * D + j] = dv[i];
+    }
+    if (!sample) return;
+    // ---- the next word is sampled from this row's own logits: project it (dout . s_W^T + s_b), first maximum, embed
+    __syncthreads();                              // (hb was read by everyone above)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        const int j = threadIdx.x + i * DT;
+        if (j < D) hb[j] = dv[i];
+    }
+    __syncthreads();
+    __shared__ int s_bi[DT / 64];
+    __shared__ int64_t s_chosen;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    constexpr int CU4 = 4;                        // vocabulary rows per wave and trip: their loads are in flight together
+    for (int v0 = w * CU4; v0 < a.s_V; v0 += (DT / 64) * CU4) {
+        float acc[CU4];
+#pragma unroll
+        for (int u = 0; u < CU4; ++u) {
+            acc[u] = 0.f;
+            const int v = min(v0 + u, a.s_V - 1);
+            const float* wr = a.s_W + (int64_t)v * D;
+            if (V == 4) {
+                for (int j = 4 * lane; j < D; j += 256) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(hb + j);
+                    const f32x4 y = *reinterpret_cast<const f32x4*>(wr + j);
+                    acc[u] += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+                }
+            } else {
+                for (int j = lane; j < D; j += 64) acc[u] += hb[j] * wr[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CU4; ++u) {
+            const int v = v0 + u;
+            float s_ = wave_sum(acc[u]);
+            if (a.s_b) s_ += a.s_b[min(v, a.s_V - 1)];
+            if (v < a.s_V && (s_ > best || (s_ == best && v < bidx))) { best = s_; bidx = v; }
+        }
+    }
+    if (lane == 0) { red[w] = best; s_bi[w] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < DT / 64; ++k)
+            if (red[k] > best || (red[k] == best && s_bi[k] < bidx)) { best = red[k]; bidx = s_bi[k]; }
+        s_chosen = bidx;
+        a.s_ids[b] = bidx;
+    }
+    __syncthreads();
+    const int64_t id = s_chosen;
+    for (int j = threadIdx.x; j < a.s_Wd; j += DT) {
+        float e = a.s_E[id * a.s_Wd + j];
+        if (a.s_p > 0.f) e *= drop_scale(seed, a.s_site, (uint64_t)(a.s_row0 + b) * a.s_Wd + j, a.s_p);
+        a.s_we[(int64_t)b * a.s_ldwe + j] = e;
     }
 }
 
@@ -537,8 +596,9 @@ extern "C" int dlsg_dec_mid_fwd(const dlsg_dec_mid_args* a, void* stream) {
 extern "C" int dlsg_dec_tail_fwd(const dlsg_dec_tail_args* a, void* stream) {
     if (!a || a->D < 1 || a->D > MAXW) return DLSG_EINVAL;
     if (a->B == 0) return DLSG_OK;
+    if (a->s_coins && (!a->s_W || !a->s_E || !a->s_ids || !a->s_we || a->s_V < 1 || a->s_Wd < 1)) return DLSG_EINVAL;
     const bool v4 = a->D % 4 == 0 && a->slab_stride % 4 == 0 && vec_ok(a->slabs) && vec_ok(a->b_ih) && vec_ok(a->b_hh) &&
-                    vec_ok(a->gates);
+                    vec_ok(a->gates) && (!a->s_coins || vec_ok(a->s_W));
     hipLaunchKernelGGL(v4 ? dec_tail_fwd_kernel<4> : dec_tail_fwd_kernel<1>, dim3(a->B), dim3(DT), 0,
                        reinterpret_cast<hipStream_t>(stream), *a);
     DLSG_CHECK_LAUNCH();

@@ -945,7 +945,7 @@ def dec_prepare(ops, dec, mems, sv, training, seed):
     return s
 
 
-def dec_step(ops, dec, s, t, ref, training, seed, B, word_dropout=True):
+def dec_step(ops, dec, s, t, ref, training, seed, B, word_dropout=True, sample=None):
     """One Decoder.decode (models/layer.py:569-602) on time-major state buffers; step t reads slot t, writes t+1."""
     plan = s['plan']
     H, Q, D = plan.H, plan.Q, plan.D
@@ -976,7 +976,12 @@ def dec_step(ops, dec, s, t, ref, training, seed, B, word_dropout=True):
     slabs = seg_gemm_nt(ops, segs, B, 4 * D, ref)
     lnl = dec.lang_lstm_layernorm
     ops.dec_tail_fwd(slabs, ll.bias_ih, ll.bias_hh, s['LC'][t], s['LC'][t + 1], s['LHP'][t + 1], s['GL'][t],
-                     (lnl.weight, lnl.bias), s['DOUT'][t], s['ST_L'][t], pd, site + SITE_LANG, seed=seed)
+                     (lnl.weight, lnl.bias), s['DOUT'][t], s['ST_L'][t], pd, site + SITE_LANG, seed=seed,
+                     **({'sample': sample} if sample is not None else {}))
+
+
+def plan_D(s):
+    return s['plan'].D
 
 
 def dec_logits(ops, dec, s, t0, t1, skip_if=None):
@@ -1041,7 +1046,17 @@ def dec_fwd(ops, dec, mems, sv, captions, L, coins, training, seed, dev_coins=No
             # (utils ss epsilon 0.95 .. ) that is about one step in twenty
             ids[1:L].copy_(captions[:, :L - 1].t())
             ops.embed_fwd(E, ids[1:L].reshape(-1), s['WE'][1:L].view((L - 1) * B, -1), p=pw, seed=seed, site=SITE_WORD, row0=B)
+        # small vocabularies: the language cell's launch samples the next word itself on the steps whose coin says so (every
+        # workgroup projects its own row) -- instead of a vocabulary projection and a select launch per step that do nothing
+        # on the ~19 teacher-forced steps out of 20 but cost a launch each
+        fused_sample = pre and getattr(ops, 'dec_tail_sample_supported', None) is not None and \
+            ops.dec_tail_sample_supported(dec.vocab_size, plan_D(s))
         for t in range(L):
+            if fused_sample and t + 1 < L:
+                dec_step(ops, dec, s, t, ref, training, seed, B,
+                         sample=dict(coins=dev_coins, t=t, W=dec.word_restore.weight, b=dec.word_restore.bias, E=E, ids_out=ids[t + 1],
+                                     we_out=s['WE'][t + 1], p=pw, site=SITE_WORD, row0=(t + 1) * B))
+                continue
             dec_step(ops, dec, s, t, ref, training, seed, B)
             if t + 1 < L:
                 # the step's logits are needed now only if the next word is sampled from them: on a teacher-forced step

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 
-ABI_VERSION = 5            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
+ABI_VERSION = 6            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256, F_SK, F_NOSK, F_SK_BM128, F_SK_BM256 = 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
@@ -202,7 +202,9 @@ class DecTailArgs(C.Structure):
     _fields_ = [('slabs', c_f32p), ('nslab', i32), ('pad_', i32), ('slab_stride', i64), ('b_ih', c_f32p), ('b_hh', c_f32p),
                 ('c_prev', c_f32p), ('c', c_f32p), ('hd', c_f32p), ('gates', c_f32p), ('ln_g', c_f32p), ('ln_b', c_f32p),
                 ('dout', c_f32p), ('st_l', c_f32p), ('p', f32), ('site', u32), ('B', i32), ('D', i32), ('eps', f32),
-                ('seed', u64), ('seed_ptr', c_f32p)]
+                ('seed', u64), ('seed_ptr', c_f32p),
+                ('s_coins', c_f32p), ('s_t', i32), ('s_V', i32), ('s_W', c_f32p), ('s_b', c_f32p), ('s_E', c_f32p), ('s_Wd', i32),
+                ('s_site', u32), ('s_ids', c_f32p), ('s_we', c_f32p), ('s_ldwe', i64), ('s_row0', i64), ('s_p', f32), ('pad2_', f32)]
 
 
 class DecMidBwdArgs(C.Structure):
@@ -898,9 +900,25 @@ class HipOps(object):
         a.seed, a.seed_ptr = _seed(seed)
         self._check(self.lib.dlsg_dec_mid_fwd(C.byref(a), self._stream()), 'dlsg_dec_mid_fwd')
 
-    def dec_tail_fwd(self, slabs, b_ih, b_hh, c_prev, c, hd, gates, ln, dout, st_l, p, site, seed=0, eps=1e-5):
-        """language cell pointwise (+dropout on h) -> tanh(LN(h)); one launch."""
+    DEC_TAIL_SAMPLE_MAX_WEIGHTS = 1 << 21      # vocabulary x width up to which a workgroup projects its own row (dec_tail_fwd sample=)
+
+    def dec_tail_sample_supported(self, V, D):
+        return V * D <= self.DEC_TAIL_SAMPLE_MAX_WEIGHTS
+
+    def dec_tail_fwd(self, slabs, b_ih, b_hh, c_prev, c, hd, gates, ln, dout, st_l, p, site, seed=0, eps=1e-5, sample=None):
+        """language cell pointwise (+dropout on h) -> tanh(LN(h)); one launch.
+        sample: optional dict(coins (int32 device vector), t, W (V,D), b (V) or None, E (V,Wd), ids_out (B) int64, we_out (B,Wd),
+        p, site, row0): the next step's word is sampled inside the launch when coins[t] == 0 (include/dlsg.h)."""
         a = DecTailArgs()
+        if sample is not None:
+            sm = sample
+            for t_ in (sm['W'], sm['E'], sm['ids_out']):
+                _chkc(t_)
+            assert sm['W'].shape[1] == c.size(1) and sm['we_out'].stride(1) == 1 and sm['ids_out'].dtype == torch.int64
+            a.s_coins, a.s_t, a.s_V = _p(sm['coins']), int(sm['t']), sm['W'].shape[0]
+            a.s_W, a.s_b, a.s_E, a.s_Wd = _p(sm['W']), _p(sm.get('b')), _p(sm['E']), sm['E'].shape[1]
+            a.s_site, a.s_ids, a.s_we, a.s_ldwe = sm.get('site', 0), _p(sm['ids_out']), _p(sm['we_out']), sm['we_out'].stride(0)
+            a.s_row0, a.s_p = int(sm.get('row0', 0)), float(sm.get('p', 0.0))
         a.slabs, a.nslab, a.slab_stride = _p(slabs), slabs.size(0), slabs.stride(0)
         a.b_ih, a.b_hh, a.c_prev, a.c, a.hd, a.gates = _p(b_ih), _p(b_hh), _p(c_prev), _p(c), _p(hd), _p(gates)
         for t in (c, hd, gates, dout):

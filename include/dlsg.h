@@ -21,7 +21,7 @@ extern "C" {
  * dlsg_lstm_cell_*, dlsg_tanh_ln_*, dlsg_conv_taps, dlsg_softmax_bwd2, dlsg_gemm_narrow -- gave way to the blocks of its schedule,
  * dlsg_crit_* / dlsg_cln_*; dlsg_lstm_seq takes batch-major arrays.  5: dlsg_gemm_args carries a workspace and an error word for the
  * stream-K kernel, dlsg_gemm_ws_bytes added; dlsg_adam takes `guard` before the stream and dlsg_select_embed `prefilled`.) */
-#define DLSG_ABI_VERSION 5
+#define DLSG_ABI_VERSION 6
 int dlsg_abi_version(void);
 
 /* Return codes of every entry point that returns int: 0 or one of these. */
@@ -343,6 +343,17 @@ typedef struct {
     int32_t B, D;
     float eps;
     uint64_t seed; const uint64_t* seed_ptr;
+    /* optional (s_coins != NULL): scheduled sampling of the NEXT step's word inside this launch (models/layer.py:432-441).  When
+     * s_coins[s_t] == 0 every workgroup projects its row onto the vocabulary (s_W (V x D), s_b), takes the first maximum, writes
+     * it to s_ids[b] and its embedding row (s_E (V x W), word dropout s_p / s_site at row s_row0 + b, the mask stream of
+     * dlsg_embed_fwd / dlsg_select_embed) to s_we; when the coin is set (teacher-forced step, ids and embedding filled in up
+     * front) nothing more happens.  One weight read per workgroup: for vocabularies up to ~2 M weights; larger ones keep
+     * dlsg_gemm + dlsg_select_embed.  Replaces two launches per word step that do nothing on ~19 steps out of 20. */
+    const int32_t* s_coins; int32_t s_t; int32_t s_V;
+    const float* s_W; const float* s_b;
+    const float* s_E; int32_t s_Wd; uint32_t s_site;
+    int64_t* s_ids; float* s_we; int64_t s_ldwe;
+    int64_t s_row0; float s_p; float pad2_;
 } dlsg_dec_tail_args;
 int dlsg_dec_tail_fwd(const dlsg_dec_tail_args* a, void* stream);
 /* Backward of dlsg_dec_mid_fwd for one word step, one workgroup per batch row.  Consumes the slabs of the language

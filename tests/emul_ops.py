@@ -375,10 +375,20 @@ class EmulOps(CriticEmul):
             self.rowln_fwd(cpre[i], lnc[i][0], lnc[i][1], ctx[i], st_c[i], pre_tanh=1, p1=p_att[i], site1=site_att[i],
                            seed=seed, eps=eps)
 
-    def dec_tail_fwd(self, slabs, b_ih, b_hh, c_prev, c, hd, gates, ln, dout, st_l, p, site, seed=0, eps=1e-5):
+    def dec_tail_sample_supported(self, V, D):
+        return self.fused_supported and V * D <= (1 << 21)
+
+    def dec_tail_fwd(self, slabs, b_ih, b_hh, c_prev, c, hd, gates, ln, dout, st_l, p, site, seed=0, eps=1e-5, sample=None):
         B, D = c.shape
         self.lstm_pw_fwd(slabs, c, B, D, b_ih=b_ih, b_hh=b_hh, c_prev=c_prev, h2=hd, gates=gates, p=p, site=site, seed=seed)
         self.rowln_fwd(hd, ln[0], ln[1], dout, st_l, post_tanh=1, eps=eps)
+        if sample is not None and int(sample['coins'][sample['t']]) == 0:
+            lg = dout @ sample['W'].t()
+            if sample.get('b') is not None:
+                lg = lg + sample['b']
+            sample['ids_out'].copy_(lg.max(1)[1])
+            self.embed_fwd(sample['E'], sample['ids_out'], sample['we_out'], p=sample.get('p', 0.0), seed=seed,
+                           site=sample.get('site', 0), row0=sample.get('row0', 0))
 
     def dec_mid_bwd(self, slabs, dlh_rec, cpre, st_c, lnc_g, part_c, dcpre, p_att, site_att, Kp, Vp, alpha, dalpha, ds, qh,
                     st_q, lnq_g, part_q, p_q, site_q, rec_slabs, gates, c, c_prev, dc, dgates, scale, seed=0):

@@ -839,6 +839,31 @@ def test_dec_step_fused_fwd(hip, dims):
     both(hip, build, run, outs, tol=3e-5, name='dec_step %s' % (dims,))
 
 
+@pytest.mark.parametrize('dims', [(3, 40, 57, 12), (64, 1024, 1000, 300), (5, 80, 130, 33), (7, 1024, 2048, 300)])
+@pytest.mark.parametrize('coin', [0, 1])
+def test_dec_tail_samples_the_next_word(hip, dims, coin):
+    """dec_tail_fwd(sample=...): on a step whose coin is 0 the launch projects every row onto the vocabulary, takes the first
+    maximum and writes the id and its (word-dropped) embedding for the next step -- what dlsg_gemm + dlsg_select_embed did in two
+    more launches; with the coin set (teacher-forced) it leaves the prefilled id and embedding alone.  ids bit-exact (the
+    vocabulary rows are well separated here), embedding rows equal."""
+    B, D, V, W = dims
+
+    def build(g):
+        Wv = rnd(g, V, D)
+        d = dict(slabs2=rnd(g, 2, B, 4 * D), bi2=rnd(g, 4 * D), bh2=rnd(g, 4 * D), cp2=rnd(g, B, D), c2=torch.zeros(B, D),
+                 hd=torch.zeros(B, D), gates2=torch.zeros(B, 4 * D), gl=rnd(g, D), bl=rnd(g, D), dout=torch.zeros(B, D),
+                 stl=torch.zeros(B, 2), Wv=Wv, bv=rnd(g, V), E=rnd(g, V, W), ids=torch.full((B,), 3, dtype=torch.int64),
+                 we=torch.full((B, W + 4), 7.0), coins=torch.tensor([1, coin, 1], dtype=torch.int32))
+        return d
+
+    def run(ops, t):
+        ops.dec_tail_fwd(t['slabs2'], t['bi2'], t['bh2'], t['cp2'], t['c2'], t['hd'], t['gates2'], (t['gl'], t['bl']),
+                         t['dout'], t['stl'], 0.3, 31, seed=5,
+                         sample=dict(coins=t['coins'], t=1, W=t['Wv'], b=t['bv'], E=t['E'], ids_out=t['ids'], we_out=t['we'][:, :W],
+                                     p=0.25, site=9, row0=2 * B))
+    both(hip, build, run, ['c2', 'hd', 'gates2', 'dout', 'stl', 'ids', 'we'], tol=3e-5, name='dec_tail sample %s coin %d' % (dims, coin))
+
+
 @pytest.mark.parametrize('dims', [(3, 48, 32, 40, 5, 2, 3), (64, 1024, 1024, 1024, 8, 2, 5), (5, 96, 64, 80, 3, 1, 1),
                                   (2, 600, 520, 300, 32, 2, 6)])
 @pytest.mark.parametrize('last', [False, True])

@@ -44,7 +44,8 @@ for key, syms in SYMS.items():
         # walk the step: every dispatch of syms[0] opens a launch group, followers join it
         groups, cur, prev_head, prev_name = [], None, False, ''
         for r in rows:
-            n = r['Kernel_Name']
+            # (both tile heights of the stream-K kernel are one prof key)
+            n = r['Kernel_Name'].replace('gemm_sk_kernel<256, ', 'gemm_sk_kernel<').replace('gemm_sk_kernel<128, ', 'gemm_sk_kernel<')
             was, prev_name = prev_name, n
             if '256' not in key and any(h in was for h in rest_heads):
                 continue                    # the smaller-tile launch right behind a '+rest' head belongs to THAT call
