@@ -77,9 +77,14 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
         const int rr = pc / G::PPR, q = pc % G::PPR;
         const int row = 2 * w + rr;
         const int n = min(n0 + row, NO - 1);
-        const char* src = reinterpret_cast<const char*>(a.y + ((int64_t)b * NO + n) * H) + lane * G::VB;
+        const char* rowp = reinterpret_cast<const char*>(a.y + ((int64_t)b * NO + n) * H);
         char* d = reinterpret_cast<char*>(dst + row * G::LDO);
-        glds<G::VB>(src + q * 64 * G::VB, d + q * 64 * G::VB);
+        if constexpr (G::VB == 16) {
+            const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)reinterpret_cast<uintptr_t>((lds_ptr_t)d)) + q * 1024;
+            glds16_asm(uniform_ptr(rowp), (uint32_t)(lane * 16 + q * 1024), la);
+        } else {
+            glds<G::VB>(rowp + lane * G::VB + q * 64 * G::VB, d + q * 64 * G::VB);
+        }
     };
     auto issue_tile = [&](int n0, float* dst) {
 #pragma unroll
@@ -159,17 +164,18 @@ __global__ __launch_bounds__(O16_THREADS) void o2v16_kernel(const O16Pack pk, in
                 break;
             }
             case 1: {
-                float s_ = 0.f;
+                // (four partial sums: a single 16-deep chain of dependent adds is ~100 cycles in which this wave issues nothing else)
+                float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < G::EPL; ++i) s_ += sx[i];
-                smean = wave_sum_dpp(s_) / H;
+                for (int i = 0; i < G::EPL; ++i) s4[i & 3] += sx[i];
+                smean = wave_sum_dpp((s4[0] + s4[1]) + (s4[2] + s4[3])) / H;
                 break;
             }
             case 2: {
-                float q = 0.f;
+                float q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < G::EPL; ++i) { const float d = sx[i] - smean; q += d * d; }
-                srstd = rsqrtf(wave_sum_dpp(q) / H + a.eps);
+                for (int i = 0; i < G::EPL; ++i) { const float d = sx[i] - smean; q4[i & 3] += d * d; }
+                srstd = rsqrtf(wave_sum_dpp((q4[0] + q4[1]) + (q4[2] + q4[3])) / H + a.eps);
                 break;
             }
             default: {

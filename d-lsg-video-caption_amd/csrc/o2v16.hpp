@@ -52,5 +52,19 @@ __device__ __forceinline__ void glds(const char* src, char* dst) {
 #endif
 }
 
+// The same 16-byte piece with the request written out (wave-uniform row base in SGPRs, per-lane byte offset, LDS byte address
+// through m0).  The compiler treats the builtin as an LDS access of unknown extent and puts `s_waitcnt lgkmcnt(0)` (and its
+// own vmcnt bookkeeping) around every piece -- between MFMA blocks that is a stall per piece; the kernels order these
+// requests themselves (explicit vmcnt before the barrier that publishes a tile).
+__device__ __forceinline__ void glds16_asm(const char* base, uint32_t voff, uint32_t lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_addr), "v"(voff), "s"(base) : "memory", "m0");
+#endif
+}
+__device__ __forceinline__ const char* uniform_ptr(const void* q) {
+    const uint64_t u = reinterpret_cast<uint64_t>(q);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 
 }  // namespace o16

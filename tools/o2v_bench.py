@@ -37,15 +37,15 @@ for O in (16, 36):
         print('O=%d B=%d  %s' % (O, B, '  '.join(res)))
         # backward (scores pass + apply pass); bytes = y read once + dy written + dz, v read + dv written
         dz = torch.randn(B, T, H, device='cuda'); dy = torch.empty(B, NO, H, device='cuda')
-        dv = torch.empty(B, T, H, device='cuda'); part = torch.empty(B, 2, H, device='cuda')
+        dv = torch.empty(B, T, H, device='cuda')
         ns = max(1, min(tiles, 256 // B))
         for _ in range(2):
-            ops.o2v_bwd(y, st, g, b_, v, z.view(B, T, H), dz, S, ml, dy, dv, part, 1 / math.sqrt(2048), ns)
+            ops.o2v_bwd(y, st, g, b_, v, z.view(B, T, H), dz, S, ml, dy, dv, 1 / math.sqrt(2048), ns)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
-            ops.o2v_bwd(y, st, g, b_, v, z.view(B, T, H), dz, S, ml, dy, dv, part, 1 / math.sqrt(2048), ns)
+            ops.o2v_bwd(y, st, g, b_, v, z.view(B, T, H), dz, S, ml, dy, dv, 1 / math.sqrt(2048), ns)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
