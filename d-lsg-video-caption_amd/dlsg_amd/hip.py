@@ -514,7 +514,7 @@ class HipOps(object):
         if self.flop_count is not None:
             self.flop_count += 2.0 * M * nb * sum(grp_[2].shape[-1] * a.g[i].K for i, grp_ in enumerate(groups))
         if self.prof is not None:
-            flops = 2.0 * M * N * nb * sum(a.g[i].K for i in range(len(groups)))
+            flops = 2.0 * M * nb * sum(grp_[2].shape[-1] * a.g[i].K for i, grp_ in enumerate(groups))     # (groups of different widths)
             if flops >= self.prof_min_flops:     # only the heavy launches are timed, so the events do not perturb the step
                 e0 = self._prof_begin()
         self._check(self.lib.dlsg_gemm(C.byref(a), self._stream()), 'dlsg_gemm')
@@ -535,7 +535,9 @@ class HipOps(object):
                            5: '256x128', 6: '256x256+rest', 7: 'streamk_256x256'}[v]
             # one key per kernel symbol (arithmetic, tile, operand layout), as rocprofv3 --stats lists them
             ks = sorted(set(a.g[i].K for i in range(len(groups))))
-            shape = '%s M=%d N=%d K=%s groups=%d batch=%d' % (('NT', 'NN', 'TN')[mode], M, N, '/'.join(map(str, ks)), len(groups), nb)
+            ns_ = sorted(set(grp_[2].shape[-1] for grp_ in groups))
+            shape = '%s M=%d N=%s K=%s groups=%d batch=%d' % (('NT', 'NN', 'TN')[mode], M, '/'.join(map(str, ns_)), '/'.join(map(str, ks)),
+                                                              len(groups), nb)
             # bytes of the operands and results of one launch, every group's counted on its own (groups that share an operand --
             # the two streams' region projections read the same regions -- make the unique bytes smaller than this)
             ob = 0
