@@ -49,6 +49,7 @@ def timeit(fn, n=20, graph=False):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
+            fn()                                # (per-stream scratch -- the stream-K workspace -- must exist before the capture)
             gr.capture_begin()
             fn()
             gr.capture_end()
