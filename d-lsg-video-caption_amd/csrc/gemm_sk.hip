@@ -630,6 +630,22 @@ int dlsg_gemm_sk_wanted(const dlsg_gemm_args* a) {
         padded += (double)tm * bm * tn * SK_BN * a->g[i].K;
     }
     if (useful < 0.85 * padded) return 0;                      // > 15 % of the tiles' area would be padding
+    // the tiles that do not fill a whole round are cut between the workgroups only when they are equally deep; otherwise each
+    // goes to one workgroup whole (a 6 144-deep and a 2 048-deep group in one launch: 708 us for what takes 181 + 82 apart) --
+    // such a launch is left to the tiled kernels unless it is forced here
+    if (tiles % cus) {
+        int64_t t0 = 0;
+        int depth = -1;
+        for (int i = 0; i < a->ngroups; ++i) {
+            const int64_t gn = a->g[i].N > 0 ? a->g[i].N : a->N, tn = (gn + SK_BN - 1) / SK_BN;
+            const int64_t t1 = t0 + tm * tn;
+            if (t1 > tiles / cus * cus) {                      // this group owns tiles of the last, partial round
+                if (depth >= 0 && depth != a->g[i].K / SK_BK) return 0;
+                depth = a->g[i].K / SK_BK;
+            }
+            t0 = t1;
+        }
+    }
     const double us = (double)((units + cus - 1) / cus) * 7.0 * bm / 256;      // a 256 x 256 x 32 stage takes 7.0 us
     return us >= ((tiles % cus) ? 80.0 : 40.0);
 }

@@ -228,6 +228,11 @@ def test_gemm_variant_names_the_tile_family(hip):
     assert plan(GEMM_NT, 1664, 1000, 1024) != 7                  # (the vocabulary projection)
     assert plan(GEMM_NT, 26624, 1024, 2046, 2) == 2              # K % 32 != 0: not a stream-K shape
     assert plan(GEMM_NT, 832, 1024, 2048, 2) != 7                # 832 rows (the goldens' two clips): too little work, 19 % padding
+    # groups of different depth whose tiles do not fill whole rounds are not dealt out evenly: left to the tiled kernels
+    x, w1, w2 = torch.empty(1664, 6144, device='cuda'), torch.empty(1024, 6144, device='cuda'), torch.empty(1024, 2048, device='cuda')
+    c1, c2 = torch.empty(1664, 1024, device='cuda'), torch.empty(1664, 1024, device='cuda')
+    assert hip.gemm(GEMM_NT, [(x, w1, c1), (x[:, :2048], w2, c2)], plan_only=True) != 7
+    assert hip.gemm(GEMM_NT, [(x, w1, c1), (x, w1, c2)], plan_only=True) == 7
     # ... without it (F_NOSK: the binding passes no workspace) the tiled kernels' rule is what it was
     _plan = plan
     plan = lambda mode, M, N, K, G=1, flags=0: _plan(mode, M, N, K, G, flags | F_NOSK)
