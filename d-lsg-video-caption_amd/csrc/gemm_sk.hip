@@ -51,7 +51,7 @@ struct SkArgs {
     int32_t M, ngroups, flags, P;
     int32_t T, rounds, rem, sk_wgs;                // T = rounds * P + rem; sk_wgs: workgroups that share the last rem tiles
     int32_t sk_nst, bm;                            // stages per tile of those tiles when they are split (0: one whole tile each); tile height
-    float alpha; int32_t pad2_;
+    float alpha; int32_t xmap;                     // > 1: the launch has no whole-tile rounds and every tile exactly xmap contributors -- see the kernel's virtual id
     const int32_t* skip_if;
     float* slots; uint32_t* cnt; int32_t* err;
     SkGroup g[DLSG_GEMM_MAXG];
@@ -251,9 +251,15 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     const int w = sk_u(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
-    // virtual id: the workgroups an XCD receives (blockIdx % 8) are consecutive -- speed only
+    // virtual id: the workgroups an XCD receives (blockIdx % 8) are consecutive -- speed only.  A launch without whole-tile rounds
+    // whose tiles all have n = xmap contributors (the deep weight gradients: 64 tiles x 4 K-quarters): an XCD takes ONE K-slice
+    // of a compact block of tiles instead of all slices of eight tiles -- its L2 then holds a quarter of the contraction range of
+    // both operands (82 MB per XCD instead of the whole of B: 218 MB), the contributors of a tile sit on n different XCDs (their
+    // shares travel through memory either way)
     const int bid = blockIdx.x;
-    const int v = sk_u((p.P & 7) ? bid : (bid & 7) * (p.P >> 3) + (bid >> 3));
+    int v_ = (p.P & 7) ? bid : (bid & 7) * (p.P >> 3) + (bid >> 3);
+    if (p.xmap > 1) v_ = (((bid & 7) / p.xmap) * (p.P >> 3) + (bid >> 3)) * p.xmap + ((bid & 7) % p.xmap);
+    const int v = sk_u(v_);
     const int n_items = sk_u(p.rounds + sk_nsplit(p, v));
     if (n_items == 0) return;
     SK_STAMP(0);
@@ -676,7 +682,7 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     const int P = cus;
     k.P = P; k.T = T;
     k.rounds = T / P; k.rem = T % P;
-    k.sk_wgs = 0; k.sk_nst = 0; k.pad2_ = 0;
+    k.sk_wgs = 0; k.sk_nst = 0; k.xmap = 0;
     if (k.rem > 0) {
         // the last rem tiles: split evenly over the workgroups when their tiles are equally deep (the common case; a run of
         // stages then touches at most two tiles), else one whole tile per workgroup
@@ -691,6 +697,9 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
             if (wgs > (int64_t)k.rem * (SK_MAXSPLIT - 2)) wgs = (int64_t)k.rem * (SK_MAXSPLIT - 2);
             if (wgs > U) wgs = U;
             k.sk_wgs = (int)wgs; k.sk_nst = nst;
+            if (k.rounds == 0 && wgs == P && (P & 7) == 0 && P % k.rem == 0 && (P / k.rem == 2 || P / k.rem == 4 || P / k.rem == 8) &&
+                nst % (P / k.rem) == 0 && !(a->flags & DLSG_GEMM_SK_NOXMAP))
+                k.xmap = P / k.rem;
         } else {
             k.sk_wgs = k.rem; k.sk_nst = 0;
         }
