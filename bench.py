@@ -228,7 +228,8 @@ def gan_iteration_leg(dev, batch, with_eager=True, iters=10, product=True):
 
 
 def gemm_roofline(prof, nsteps, root=ROOT):
-    """`roofline` object of the GEMM kernel symbol with the largest share of the timed step.  prof: HipOps.prof_summary().
+    """`roofline` object of the GEMM kernel symbol with the largest share of the timed step (headline: its dominant launch shape).
+    prof: HipOps.prof_summary().
     `traffic` = PMC-measured HBM-side bytes per launch (profiles/traffic.json, keyed by kernel symbol + launch shape), averaged
     over the launches that were timed -- only when the file has EVERY launch shape this kernel ran in the step, else null."""
     gk = max((k for k in prof if k.startswith('gemm_')), key=lambda k: prof[k]['ms_total'], default=None)
@@ -276,15 +277,24 @@ def gemm_roofline(prof, nsteps, root=ROOT):
         sym = '%s<64, 64, %s, 64>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
     else:
         sym = ('skinny_x3_kernel' if is_x3 else 'skinny_kernel') + ('<false>' if mode == 'nt' else '<true>')
+    # the headline figures are those of the symbol's DOMINANT LAUNCH SHAPE (most time per step): a symbol runs launches of very
+    # different sizes (the stream-K TN kernel: 1.7-ms deep weight gradients down to 0.3-ms mid-size groups) and "flops per launch
+    # / average launch duration" only means something for one shape; the symbol-wide totals (what rocprofv3 --stats averages) are
+    # in `symbol_total`, every shape in `launch_shapes`
+    top = shapes[0]
     return {'kernel': gk + (' (3 x v_mfma_f32_32x32x16_bf16 per product; peak = 2500/3)' if is_x3
                             else ' (v_mfma_f32_32x32x2_f32)') + '; rocprof symbol: ' + sym,
+            'launch_shape': top['shape'],
+            'symbol_total': {'achieved': round(ach, 2), 'frac': round(ach / peak, 4), 'launches_timed': g['launches'],
+                             'avg_launch_ms': round(g['ms_total'] / g['launches'], 4),
+                             'traffic': round(tsum / tn) if (all_known and tn) else None},
             'traffic_note': 'HBM-side bytes/launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the real '
                             'step, keyed by kernel + launch shape; Infinity-Cache hits are counted), mean over the timed launches; null '
                             'unless every launch shape of this kernel is in the file.  operand_bytes counts every group\'s operands on '
                             'their own',
-            'bound': 'mfma', 'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': round(tsum / tn) if (all_known and tn) else None, 'launches_timed': g['launches'],
-            'avg_launch_ms': round(g['ms_total'] / g['launches'], 4),
+            'bound': 'mfma', 'achieved': top['achieved'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': top['frac'],
+            'traffic': top['traffic'], 'traffic_over_operand_bytes': top['traffic_over_operand_bytes'],
+            'launches_timed': top['launches_timed'], 'avg_launch_ms': top['avg_launch_ms'],
             'ms_per_step_in_this_kernel': round(g['ms_total'] / max(1, nsteps), 3), 'launch_shapes': shapes}
 
 
@@ -346,7 +356,7 @@ def msrvtt_leg(dev, a):
                    '10000, dropout on; BASELINE configs[2] per-GPU shard', 'batch_per_gpu': B, 'n_gpus': 1,
            'ms_per_step': round(1e3 * dt / a.steps, 3), 'clips_per_s': round(B * a.steps / dt, 1), 'steps': a.steps,
            'gemm_arithmetic': a.gemm, 'launch': launch_mode(tr, not a.no_graphs), 'final_loss': round(float(loss), 5)}
-    nprof = min(2, a.steps)
+    nprof = min(3, a.steps)
     prof = profile_eager_steps(net, tr, fb, eps, nprof)
     out['roofline'] = gemm_roofline(prof, nprof)
     for key, name, label in (('o2v_graph_fwd', 'roofline_graph_attention', 'o2v16_kernel'), ('o2v_graph_bwd', 'roofline_graph_attention_bwd', O2V_BWD_KERNELS)):
@@ -652,7 +662,7 @@ def main():
     launch = launch_mode(tr, not a.no_graphs)
     comm_info.update(tr.collectives_info())
     # per-kernel HIP-event timing for the roofline objects (every rank runs it: the step has collectives)
-    nprof = max(1, min(3, a.steps))
+    nprof = max(1, min(5, a.steps))
     prof = profile_eager_steps(net, tr, (frames, regions, caps, lens), eps, nprof)
     barrier()
     # the same step under the other GEMM arithmetic policies (informational; `value` is the --gemm policy)
@@ -771,7 +781,10 @@ def main():
         for k in sorted(prof):
             if 'streamk' in k:
                 r1 = gemm_roofline({k: prof[k]}, nprof)
-                sk[k] = {kk: r1[kk] for kk in ('achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms', 'ms_per_step_in_this_kernel', 'launch_shapes')}
+                st_ = r1['symbol_total']          # (per operand layout: the symbol-wide figures; every shape below)
+                sk[k] = {'achieved': st_['achieved'], 'peak': r1['peak'], 'unit': r1['unit'], 'frac': st_['frac'], 'traffic': st_['traffic'],
+                         'avg_launch_ms': st_['avg_launch_ms'], 'ms_per_step_in_this_kernel': r1['ms_per_step_in_this_kernel'],
+                         'launch_shapes': r1['launch_shapes']}
         if sk:
             out['roofline_stream_k'] = dict(sk, kernel='gemm_sk_kernel<...> (csrc/gemm_sk.hip): each call is ONE persistent launch; one entry per '
                                                         'operand layout, with every launch shape of the step')

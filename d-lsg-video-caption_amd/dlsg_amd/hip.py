@@ -423,14 +423,20 @@ class HipOps(object):
         torch.cuda.synchronize().  A kernel symbol runs several launch shapes in a step; traffic counters are per shape."""
         out = {}
         for key, rec in (self.prof or {}).items():
-            shapes = {}
-            tot = 0.0
+            shapes, samples = {}, {}
             for a, b, w, shp, ob in rec:
-                ms = a.elapsed_time(b)
-                tot += ms
                 d = shapes.setdefault(shp, dict(launches=0, ms_total=0.0, work_total=0.0, operand_bytes=ob))
-                d['launches'] += 1; d['ms_total'] += ms; d['work_total'] += float(w)
-            out[key] = dict(launches=len(rec), ms_total=tot, work_total=float(sum(r[2] for r in rec)), shapes=shapes)
+                d['launches'] += 1; d['work_total'] += float(w)
+                samples.setdefault(shp, []).append(a.elapsed_time(b))
+            # a shape's time = launches x the MEDIAN of its samples: the span between two events also holds whatever the host
+            # took to issue the launch while the device sat idle (the first launch of an eager step: one sample of 10 ms among
+            # three turned a 0.2-ms launch into "3.6 ms" in one run)
+            for shp, ms in samples.items():
+                ms = sorted(ms)
+                med = ms[len(ms) // 2] if len(ms) % 2 else 0.5 * (ms[len(ms) // 2 - 1] + ms[len(ms) // 2])
+                shapes[shp]['ms_total'] = med * len(ms)
+            out[key] = dict(launches=len(rec), ms_total=sum(d['ms_total'] for d in shapes.values()),
+                            work_total=float(sum(r[2] for r in rec)), shapes=shapes)
         return out
 
     # ------------------------------------------------------------------ plumbing
