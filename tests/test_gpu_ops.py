@@ -207,6 +207,39 @@ def test_gemm_stream_k_without_waiting(hip, mode, extra, shape):
     assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0
 
 
+@pytest.mark.parametrize('mode,M,N,K,G', [(GEMM_TN, 1024, 2048, 1024, 2), (GEMM_NT, 2048, 4096, 512, 1), (GEMM_NN, 1024, 2048, 768, 1)])
+def test_gemm_stream_k_slice_per_xcd_map(hip, mode, M, N, K, G):
+    """Launches without whole-tile rounds whose tiles all have 4, 2 or 8 contributors run with an XCD on ONE K-slice of a block of
+    tiles (csrc/gemm_sk.hip, SkArgs::xmap); DLSG_GEMM_SK_NOXMAP keeps every tile's contributors on one XCD.  The map only permutes
+    which workgroup does what: same bits either way, and both agree with fp64."""
+    F_NOXMAP = 131072
+    g = torch.Generator(device='cuda').manual_seed(7)
+    groups, refs = [], []
+    for _ in range(G):
+        if mode == GEMM_NT:
+            A, B = torch.randn(M, K, device='cuda', generator=g), torch.randn(N, K, device='cuda', generator=g)
+            r = A.double() @ B.double().t()
+        elif mode == GEMM_NN:
+            A, B = torch.randn(M, K, device='cuda', generator=g), torch.randn(K, N, device='cuda', generator=g)
+            r = A.double() @ B.double()
+        else:
+            A, B = torch.randn(K, M, device='cuda', generator=g), torch.randn(K, N, device='cuda', generator=g)
+            r = A.double().t() @ B.double()
+        groups.append((A, B))
+        refs.append(r)
+    outs = []
+    for fl in (0, F_NOXMAP):
+        Cs = [torch.full((M, N), float('nan'), device='cuda') for _ in range(G)]
+        hip.gemm(mode, [(a_, b_, c_) for (a_, b_), c_ in zip(groups, Cs)], flags=F_SK | 32768 | fl)      # 256 x 256 tiles
+        outs.append(Cs)
+    torch.cuda.synchronize()
+    for c0, c1, r in zip(outs[0], outs[1], refs):
+        assert torch.equal(c0, c1)
+        assert ((c0.double() - r).abs().max() / r.abs().max()).item() < 3e-6
+    ws = hip._gemm_workspace(torch.device('cuda', 0))
+    assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0
+
+
 def test_gemm_variant_names_the_tile_family(hip):
     """dlsg_gemm_variant == the choice dlsg_gemm makes (include/dlsg.h DLSG_GEMM_V_*), on the shapes DESIGN.md quotes"""
     def plan(mode, M, N, K, G=1, flags=0):
