@@ -33,8 +33,8 @@
 namespace {
 
 constexpr int SK_THREADS = 256;
-constexpr int SK_BN = 256, SK_BK = 32;             // tile: BM x 256, BM = 256 or 128 (template parameter), 32-deep stages
-constexpr int SK_BBYTES = SK_BN * 128;
+constexpr int SK_BN = 256, SK_BK = 32;             // tile: BM x BN, (BM, BN) = (256, 256), (128, 256) or (128, 128) (template parameters);
+                                                   // SK_BN = the widest; 32-deep stages
 constexpr int SK_SLOT_BYTES = 256 * SK_BN * 4;     // a workspace slot holds the accumulators of the larger tile
 constexpr int SK_CNT_BYTES = 16384;                // in front of the slots: counters (2 words per split tile) in the first 4 KB; the
                                                    // rest is where a PROBES=1 build leaves its timestamps
@@ -51,6 +51,7 @@ struct SkArgs {
     int32_t M, ngroups, flags, P;
     int32_t T, rounds, rem, sk_wgs;                // T = rounds * P + rem; sk_wgs: workgroups that share the last rem tiles
     int32_t sk_nst, bm;                            // stages per tile of those tiles when they are split (0: one whole tile each); tile height
+    int32_t bn, pad3_;                             // tile width
     float alpha; int32_t xmap;                     // > 1: the launch has no whole-tile rounds and every tile exactly xmap contributors -- see the kernel's virtual id
     const int32_t* skip_if;
     float* slots; uint32_t* cnt; int32_t* err;
@@ -138,7 +139,7 @@ __device__ __forceinline__ Item sk_item(const SkArgs& p, int v, int idx) {
     const SkGroup& g = p.g[gi];
     const int local = tile - g.tile0;
     const int tm = local / g.tiles_n, tn = local - tm * g.tiles_n;
-    it.gi = sk_u(gi); it.m0 = sk_u(tm * p.bm); it.n0 = sk_u(tn * SK_BN); it.Ng = sk_u(g.N);
+    it.gi = sk_u(gi); it.m0 = sk_u(tm * p.bm); it.n0 = sk_u(tn * p.bn); it.Ng = sk_u(g.N);
     if (s1 < 0) { s0 = 0; s1 = g.nst; }
     it.s0 = sk_u(s0); it.s1 = sk_u(s1); it.kind = sk_u(it.kind); it.r = sk_u(it.r);
     return it;
@@ -202,7 +203,7 @@ __device__ __forceinline__ void sk_store_block(const SkArgs& p, const SkGroup& g
     f32x4 x[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) x[c] = br[c];
-    const int col = it.n0 + wn * 128 + j * 32 + 4 * cs;
+    const int col = it.n0 + wn * (p.bn >> 1) + j * 32 + 4 * cs;
     const int row0 = it.m0 + wm * WM + i * 32 + 4 * G;
     const bool accum = p.flags & DLSG_GEMM_ACCUM, do_tanh = p.flags & DLSG_GEMM_TANH;
     const bool col_ok = col < it.Ng;                          // (widths are multiples of 4: the whole piece is in or out)
@@ -228,23 +229,25 @@ __device__ __forceinline__ void sk_store_block(const SkArgs& p, const SkGroup& g
 }
 
 // this lane's bias values for the four column blocks j of its wave (zeros without a bias or past the group's width)
-__device__ __forceinline__ void sk_bias(const SkArgs& p, const SkGroup& g, const Item& it, int w, int lane, f32x4 (&bias4)[4]) {
+template <int TNB>
+__device__ __forceinline__ void sk_bias(const SkArgs& p, const SkGroup& g, const Item& it, int w, int lane, f32x4 (&bias4)[TNB]) {
     const bool use_bias = (p.flags & DLSG_GEMM_BIAS) && g.bias != nullptr;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = it.n0 + (w & 1) * 128 + j * 32 + 4 * (lane & 7);
+    for (int j = 0; j < TNB; ++j) {
+        const int col = it.n0 + (w & 1) * (p.bn >> 1) + j * 32 + 4 * (lane & 7);
         bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (use_bias && col < it.Ng) bias4[j] = *reinterpret_cast<const f32x4*>(g.bias + col);
     }
 }
 
-template <int BM, bool AT, bool BT>
+template <int BM, int BN, bool AT, bool BT>
 __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_sk_kernel(const SkArgs p) {
-    constexpr int TM = BM / 64;                    // 32-row blocks of a wave (its quadrant is BM / 2 x 128)
-    constexpr int WM = BM / 2;
+    constexpr int TM = BM / 64, TNB = BN / 64;     // 32-row / 32-column blocks of a wave (its quadrant is BM / 2 x BN / 2)
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int SK_BBYTES = BN * 128;
     constexpr int SK_ABYTES = BM * 128, SK_STAGE = SK_ABYTES + SK_BBYTES;
-    constexpr int PA = BM / 32, PB = SK_BN / 32, PT = PA + PB;           // DMA pieces per wave and stage
-    constexpr int NSUB = 4 * TM;                   // 32 x 32 sub-blocks of a wave
+    constexpr int PA = BM / 32, PB = BN / 32, PT = PA + PB;              // DMA pieces per wave and stage
+    constexpr int NSUB = TNB * TM;                 // 32 x 32 sub-blocks of a wave
     extern __shared__ __attribute__((aligned(16))) char sk_lds[];           // 2 stage buffers
     if (p.skip_if && *p.skip_if) return;                                    // block-uniform
     const int lane = threadIdx.x & 63;
@@ -265,11 +268,11 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     SK_STAMP(0);
     const uint32_t lds0 = sk_u((uint32_t)reinterpret_cast<uintptr_t>((sk_lp_t)sk_lds));      // LDS byte address of the stage buffers
 
-    f32x16 acc[TM][4];
+    f32x16 acc[TM][TNB];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < TNB; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -279,9 +282,9 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     for (int q = 0; q < 4; ++q) {
         const int ks = (2 * q + h) ^ ((r >> 1) & 7);
         offA[q] = AT ? ((4 * (2 * q + h)) * BM + wm * WM + r) * 4 : (wm * WM + r) * 128 + ks * 16;
-        offB[q] = SK_ABYTES + (BT ? ((4 * (2 * q + h)) * SK_BN + wn * 128 + r) * 4 : (wn * 128 + r) * 128 + ks * 16);
+        offB[q] = SK_ABYTES + (BT ? ((4 * (2 * q + h)) * BN + wn * WN + r) * 4 : (wn * WN + r) * 128 + ks * 16);
     }
-    f32x4 fa[2][TM], fb[2][4];
+    f32x4 fa[2][TM], fb[2][TNB];
     auto read_frag = [&](int buf, const char* st, int q, int f) {          // f < TM: A fragment f, else B fragment f - TM
         if (f < TM) {
             if (!AT) fa[buf][f] = *reinterpret_cast<const f32x4*>(st + offA[q] + f * 32 * 128);
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             if (!BT) fb[buf][g] = *reinterpret_cast<const f32x4*>(st + offB[q] + g * 32 * 128);
             else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[buf][g][j] = *reinterpret_cast<const float*>(st + offB[q] + (j * SK_BN + g * 32) * 4);
+                for (int j = 0; j < 4; ++j) fb[buf][g][j] = *reinterpret_cast<const float*>(st + offB[q] + (j * BN + g * 32) * 4);
             }
         }
     };
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const Item it = sk_item(p, v_, idx);
         const SkGroup& g = p.g[it.gi];
         sk_voff<AT, BM>(voffA, w_, lane_, it.m0, p.M, g.lda);
-        sk_voff<BT, SK_BN>(voffB, w_, lane_, it.n0, it.Ng, g.ldb);
+        sk_voff<BT, BN>(voffB, w_, lane_, it.n0, it.Ng, g.ldb);
         const int64_t k0 = (int64_t)it.s0 * SK_BK;
         lA = sk_up(AT ? g.A + it.m0 + k0 * g.lda : g.A + (int64_t)it.m0 * g.lda + k0);
         lB = sk_up(BT ? g.B + it.n0 + k0 * g.ldb : g.B + (int64_t)it.n0 * g.ldb + k0);
@@ -343,12 +346,11 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     l_advance();
 #pragma unroll
     for (int pc = 0; pc < PT / 2; ++pc) l_issue(pc);
-    if (PT / 2 == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PT / 2) : "memory");       // stage 0 landed, the half of stage 1 stays in flight
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 #pragma unroll
-    for (int f = 0; f < TM + 4; ++f) read_frag(0, sk_lds, 0, f);
+    for (int f = 0; f < TM + TNB; ++f) read_frag(0, sk_lds, 0, f);
 
     int stage_no = 0;      // (used by the PROBES build only)
     // one stage: q0 .. q3, 16 slots of four MFMAs each, one fragment read or DMA piece pinned behind each.  FAST: the load cursor
@@ -366,9 +368,9 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
             for (int s = 0; s < 4 * TM; ++s) {
                 const int j = s / TM, i = s % TM;
 #pragma unroll
-                for (int jn = 0; jn < 4; ++jn)
+                for (int jn = 0; jn < TNB; ++jn)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][i][j], fb[cur][jn][j], acc[i][jn], 0, 0, 0);
-                if (s < TM + 4) {
+                if (s < TM + TNB) {
                     if (q < 3) read_frag(nxt, st, q + 1, s);
                     else read_frag(nxt, stn, 0, s);              // the next stage's first fragments (unused after the last stage)
                 }
@@ -414,30 +416,30 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
         const SkGroup& g = p.g[it.gi];
         if (it.kind == 1) {
             float* bounce = reinterpret_cast<float*>(sk_lds + 2 * SK_STAGE + w * SK_BOUNCE);
-            f32x4 bias4[4];
-            sk_bias(p, g, it, w, lane, bias4);                 // before the first store: a later load would wait behind the stores
+            f32x4 bias4[TNB];
+            sk_bias<TNB>(p, g, it, w, lane, bias4);                 // before the first store: a later load would wait behind the stores
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TNB; ++j) {
                     sk_store_block(p, g, it, acc[i][j], i, j, w, lane, bias4[j], bounce);
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
                     __builtin_amdgcn_sched_barrier(0);       // one sub-block's values in flight at a time
                 }
         } else {
-            // share of a split tile: accumulator order, 16-B stores: slot[((w * NSUB + i * 4 + j) * 4 + e4) * 64 + lane]
+            // share of a split tile: accumulator order, 16-B stores: slot[((w * NSUB + i * TNB + j) * 4 + e4) * 64 + lane]
             f32x4* slot = reinterpret_cast<f32x4*>(p.slots) + (int64_t)(2 * v + ci) * (SK_SLOT_BYTES / 16);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TNB; ++j) {
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4) {
                         f32x4 t;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) t[e] = acc[i][j][4 * e4 + e];
-                        slot[((w * NSUB + i * 4 + j) * 4 + e4) * 64 + lane] = t;
+                        slot[((w * NSUB + i * TNB + j) * 4 + e4) * 64 + lane] = t;
                     }
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
@@ -495,10 +497,10 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
 #pragma unroll
                     for (int e = 0; e < 16; ++e) sum[e] += t[e >> 2][e & 3];
                 }
-                const int bcol = S.n0 + (w & 1) * 128 + (k & 3) * 32 + 4 * (lane & 7);
+                const int bcol = S.n0 + (w & 1) * WN + (k % TNB) * 32 + 4 * (lane & 7);
                 f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (f_bias && bcol < S.Ng) b4 = *reinterpret_cast<const f32x4*>(g.bias + bcol);
-                sk_store_block(p, g, S, sum, k >> 2, k & 3, w, lane, b4, fbounce);
+                sk_store_block(p, g, S, sum, k / TNB, k % TNB, w, lane, b4, fbounce);
             }
         };
         if (threadIdx.x == 0) {
@@ -554,14 +556,14 @@ int sk_cus() {
     return cus;
 }
 
-template <int BM, bool AT, bool BT>
+template <int BM, int BN, bool AT, bool BT>
 int sk_launch(const SkArgs& k, hipStream_t st) {
-    constexpr int lds_bytes = 2 * (BM * 128 + SK_BBYTES) + 4 * SK_BOUNCE + 16;  // two stage buffers + the epilogue's bounce tiles + a flag
+    constexpr int lds_bytes = 2 * (BM * 128 + BN * 128) + 4 * SK_BOUNCE + 16;  // two stage buffers + the epilogue's bounce tiles + a flag
     static std::once_flag once;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<BM, AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<BM, BN, AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     });
-    hipLaunchKernelGGL((gemm_sk_kernel<BM, AT, BT>), dim3(k.P), dim3(SK_THREADS), lds_bytes, st, k);
+    hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, AT, BT>), dim3(k.P), dim3(SK_THREADS), lds_bytes, st, k);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
@@ -607,11 +609,42 @@ int dlsg_gemm_sk_ok(const dlsg_gemm_args* a) {
     return 1;
 }
 
-int sk_pick_bm(const dlsg_gemm_args* a) {
-    if (a->flags & DLSG_GEMM_SK_BM128) return 128;
-    if (a->flags & DLSG_GEMM_SK_BM256) return 256;
-    const int pad256 = (a->M + 255) / 256 * 256;
-    return (pad256 - a->M) * 32 > a->M ? 128 : 256;          // > 3 % of the rows would be padding
+// tiles of the launch on (bm x bn) tiles, and the deepest contraction among its groups
+static int64_t sk_count_tiles(const dlsg_gemm_args* a, int bm, int bn, int* kmax) {
+    const int64_t tm = (a->M + bm - 1) / bm;
+    int64_t tiles = 0;
+    int km = 0;
+    for (int i = 0; i < a->ngroups; ++i) {
+        const int64_t gn = a->g[i].N > 0 ? a->g[i].N : a->N;
+        tiles += tm * ((gn + bn - 1) / bn);
+        km = a->g[i].K > km ? a->g[i].K : km;
+    }
+    if (kmax) *kmax = km;
+    return tiles;
+}
+// Tile of a launch (DLSG_GEMM_SK_BM128 / _BM256 / _BN128 force one).  Measured per shape with tools/gemm_sk_probe.py and the
+// round's tile table:
+//   * 128 rows when 256-row tiles would leave > 3 % of the last row panel empty (M = 1664: 7 panels for 6.5);
+//   * 128 rows also when the launch has fewer 256 x 256 tiles than the chip has CUs and its contractions are not deep: every tile
+//     is then cut between workgroups, and twice as many tiles mean whole-tile rounds and shares of half the size (TN 2048 x 2048
+//     x 1664 x 3: 323 us against 337; the 1024-row weight-gradient group 275 against 292; TN 10 000 x 1536 x 1664: 401 against
+//     414).  The deep weight gradients (64 tiles x 832 stages) stay on 256 rows: their fix-up is nothing beside 208 stages;
+//   * 128 x 128 only for one-round launches of few, deep tiles (NT 1664 x 1024 x 6144: 171 us against 176): elsewhere the
+//     narrower tile is within 3 us of the wider one or of the tiled kernels, either way.
+void sk_pick_tile(const dlsg_gemm_args* a, int* bm_, int* bn_) {
+    int bm = 256, bn = 256;
+    if (a->flags & DLSG_GEMM_SK_BN128) { bm = 128; bn = 128; }
+    else if (a->flags & DLSG_GEMM_SK_BM128) bm = 128;
+    else if (a->flags & DLSG_GEMM_SK_BM256) bm = 256;
+    else {
+        const int cus = sk_cus() > 0 ? sk_cus() : 256;
+        const int pad256 = (a->M + 255) / 256 * 256;
+        int kmax = 0;
+        if ((pad256 - a->M) * 32 > a->M) bm = 128;
+        else if (a->M >= 256 && sk_count_tiles(a, 256, 256, &kmax) < cus && kmax <= 8192) bm = 128;
+        if (bm == 128 && a->ngroups == 1 && sk_count_tiles(a, 128, 256, &kmax) * 4 <= cus && kmax >= 4096) bn = 128;
+    }
+    *bm_ = bm; *bn_ = bn;
 }
 
 // 1: dlsg_gemm sends this call to the stream-K kernel.  Measured on MI355X against the tiled kernels (tools/gemm_sk_probe.py,
@@ -624,16 +657,17 @@ int dlsg_gemm_sk_wanted(const dlsg_gemm_args* a) {
     if (!a->ws || (a->flags & DLSG_GEMM_NOSK) || !dlsg_gemm_sk_ok(a)) return 0;
     const int cus = sk_cus();
     if (cus <= 0) return 0;
-    const int bm = sk_pick_bm(a);
+    int bm, bn;
+    sk_pick_tile(a, &bm, &bn);
     const int64_t tm = (a->M + bm - 1) / bm;
     double useful = 0.0, padded = 0.0;
     int64_t units = 0, tiles = 0;
     for (int i = 0; i < a->ngroups; ++i) {
-        const int64_t gn = a->g[i].N > 0 ? a->g[i].N : a->N, tn = (gn + SK_BN - 1) / SK_BN;
+        const int64_t gn = a->g[i].N > 0 ? a->g[i].N : a->N, tn = (gn + bn - 1) / bn;
         tiles += tm * tn;
         units += tm * tn * (a->g[i].K / SK_BK);
         useful += (double)a->M * gn * a->g[i].K;
-        padded += (double)tm * bm * tn * SK_BN * a->g[i].K;
+        padded += (double)tm * bm * tn * bn * a->g[i].K;
     }
     if (useful < 0.85 * padded) return 0;                      // > 15 % of the tiles' area would be padding
     // the tiles that do not fill a whole round are cut between the workgroups only when they are equally deep; otherwise each
@@ -643,7 +677,7 @@ int dlsg_gemm_sk_wanted(const dlsg_gemm_args* a) {
         int64_t t0 = 0;
         int depth = -1;
         for (int i = 0; i < a->ngroups; ++i) {
-            const int64_t gn = a->g[i].N > 0 ? a->g[i].N : a->N, tn = (gn + SK_BN - 1) / SK_BN;
+            const int64_t gn = a->g[i].N > 0 ? a->g[i].N : a->N, tn = (gn + bn - 1) / bn;
             const int64_t t1 = t0 + tm * tn;
             if (t1 > tiles / cus * cus) {                      // this group owns tiles of the last, partial round
                 if (depth >= 0 && depth != a->g[i].K / SK_BK) return 0;
@@ -652,8 +686,10 @@ int dlsg_gemm_sk_wanted(const dlsg_gemm_args* a) {
             t0 = t1;
         }
     }
-    const double us = (double)((units + cus - 1) / cus) * 7.0 * bm / 256;      // a 256 x 256 x 32 stage takes 7.0 us
-    return us >= ((tiles % cus) ? 80.0 : 40.0);
+    const double us = (double)((units + cus - 1) / cus) * 7.0 * bm / 256 * bn / 256;      // a 256 x 256 x 32 stage takes 7.0 us
+    // (a launch whose tiles come in whole rounds has no fix-up: TN 1024 x 1024 x 320 x 8 on 128-row tiles is exactly one round,
+    //  49.6 us against 61.5 on the small tiles)
+    return us >= ((tiles % cus) ? 80.0 : 30.0);
 }
 
 int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
@@ -662,8 +698,9 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     k.M = a->M; k.ngroups = a->ngroups; k.flags = a->flags; k.alpha = a->alpha; k.skip_if = a->skip_if;
     // tile height: 128 rows when 256-row tiles would leave the last row panel mostly padding (M = 1664: 7 panels for 6.5) or
     // when the launch has few tiles to deal out; DLSG_GEMM_SK_BM128 / _BM256 force one
-    int bm = sk_pick_bm(a);
-    k.bm = bm;
+    int bm, bn;
+    sk_pick_tile(a, &bm, &bn);
+    k.bm = bm; k.bn = bn; k.pad3_ = 0;
     const int tiles_m = (a->M + bm - 1) / bm;
     int T = 0;
     for (int i = 0; i < a->ngroups; ++i) {
@@ -674,7 +711,7 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
         s.lda = g.lda; s.ldb = g.ldb; s.ldc = g.ldc ? g.ldc : (int64_t)a->ldc;
         s.N = g.N > 0 ? g.N : a->N;
         s.nst = g.K / SK_BK;
-        s.tiles_n = (s.N + SK_BN - 1) / SK_BN;
+        s.tiles_n = (s.N + bn - 1) / bn;
         s.tile0 = T;
         T += tiles_m * s.tiles_n;
     }
@@ -709,13 +746,16 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     k.slots = reinterpret_cast<float*>(ws + SK_CNT_BYTES);
     k.err = nullptr;
     if (4 * k.rem * (int)sizeof(uint32_t) > 4096) return DLSG_EINVAL;
-    switch (a->mode * 2 + (bm == 128 ? 1 : 0)) {
-        case 0: return sk_launch<256, false, false>(k, st);
-        case 1: return sk_launch<128, false, false>(k, st);
-        case 2: return sk_launch<256, false, true>(k, st);
-        case 3: return sk_launch<128, false, true>(k, st);
-        case 4: return sk_launch<256, true, true>(k, st);
-        case 5: return sk_launch<128, true, true>(k, st);
+    switch (a->mode * 3 + (bn == 128 ? 2 : (bm == 128 ? 1 : 0))) {
+        case 0: return sk_launch<256, 256, false, false>(k, st);
+        case 1: return sk_launch<128, 256, false, false>(k, st);
+        case 2: return sk_launch<128, 128, false, false>(k, st);
+        case 3: return sk_launch<256, 256, false, true>(k, st);
+        case 4: return sk_launch<128, 256, false, true>(k, st);
+        case 5: return sk_launch<128, 128, false, true>(k, st);
+        case 6: return sk_launch<256, 256, true, true>(k, st);
+        case 7: return sk_launch<128, 256, true, true>(k, st);
+        case 8: return sk_launch<128, 128, true, true>(k, st);
         default: return DLSG_EINVAL;
     }
 }

@@ -19,6 +19,7 @@ ABI_VERSION = 6            # include/dlsg.h DLSG_ABI_VERSION this binding was wr
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256, F_SK, F_NOSK, F_SK_BM128, F_SK_BM256 = 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
+F_SK_BN128 = 262144
 F_SK_NOXMAP = 131072
 F_SK_GIVEAWAY = 65536      # test hook (include/dlsg.h): the split tiles are finished by their last contributor alone
 MAXG = 16

@@ -63,6 +63,7 @@ int dlsg_struct_size(int which);
 #define DLSG_GEMM_NOSK 8192    /* tuning: never the stream-K kernel */
 #define DLSG_GEMM_SK_BM128 16384 /* tuning: the stream-K kernel on 128 x 256 tiles */
 #define DLSG_GEMM_SK_BM256 32768 /* tuning: the stream-K kernel on 256 x 256 tiles */
+#define DLSG_GEMM_SK_BN128 262144 /* tuning: the stream-K kernel on 128 x 128 tiles (shares half the size of the 128 x 256 tile's) */
 #define DLSG_GEMM_SK_NOXMAP 131072 /* tuning: the stream-K kernel keeps all contributors of a tile on one XCD (no K-slice per XCD map) */
 #define DLSG_GEMM_SK_GIVEAWAY 65536 /* test hook: no contributor of a split tile finds it complete -- every one gives its
                                        sub-blocks to the contributor that decides last (the path a launch that is not

@@ -129,7 +129,7 @@ def test_gemm_256_tiles(hip, mode, tile, shape):
 
 @pytest.mark.parametrize('mode', [GEMM_NT, GEMM_NN, GEMM_TN])
 @pytest.mark.parametrize('extra', [0, F_ACCUM, F_TANH])
-@pytest.mark.parametrize('bm', [0, 16384, 32768])            # the dispatcher's tile height, DLSG_GEMM_SK_BM128, DLSG_GEMM_SK_BM256
+@pytest.mark.parametrize('bm', [0, 16384, 32768, 262144])    # the dispatcher's tile, DLSG_GEMM_SK_BM128, _BM256, _BN128 (128 x 128)
 @pytest.mark.parametrize('shape', [(256, 256, 32), (600, 520, 96), (260, 132, 64), (1700, 1000, 128), (300, 260, 2048)])
 def test_gemm_stream_k(hip, mode, extra, bm, shape):
     """csrc/gemm_sk.hip (persistent stream-K launch, forced with F_SK): ragged edges, strided views, per-group bias, two groups of
@@ -196,13 +196,13 @@ def test_gemm_stream_k_without_waiting(hip, mode, extra, shape):
     bias = torch.randn(N, device='cuda', generator=g)
     out = []
     for give in (0, 65536, 0, 65536):
-        for bm in (16384, 32768):
+        for bm in (16384, 32768, 262144):
             Cc = C0.clone()
             hip.gemm(mode, [(A, B, Cc, bias)], flags=extra | F_SK | bm | give)
             out.append(Cc)
     torch.cuda.synchronize()
-    for i in (0, 1):
-        assert torch.equal(out[i], out[i + 2]) and torch.equal(out[i], out[i + 4]) and torch.equal(out[i], out[i + 6])
+    for i in (0, 1, 2):
+        assert torch.equal(out[i], out[i + 3]) and torch.equal(out[i], out[i + 6]) and torch.equal(out[i], out[i + 9])
     ws = hip._gemm_workspace(torch.device('cuda', 0))
     assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0
 
