@@ -381,9 +381,9 @@ __global__ __launch_bounds__(512 / NSL) void o2v16_bwd_apply_kernel(const B16Pac
                 dzv[c][4 * j + s] = t < T ? *src : 0.f;
             }
     }
-    float gsum[G::CBW], bsum[G::CBW];
+    float gsum[G::CBW], bsum[G::CBW], ysum[G::CBW];          // obj_norm dgamma, dbeta; column sums of dy (obj_embed's bias gradient)
 #pragma unroll
-    for (int c = 0; c < G::CBW; ++c) { gsum[c] = 0.f; bsum[c] = 0.f; }
+    for (int c = 0; c < G::CBW; ++c) { gsum[c] = 0.f; bsum[c] = 0.f; ysum[c] = 0.f; }
 
     // pd rows (A operand: lane (f, g) holds pd[object f][16 j + 4 g .. + 3]) and the statistics of objects 4g .. 4g+3
     f32x4 pa[4];
@@ -431,7 +431,9 @@ __global__ __launch_bounds__(512 / NSL) void o2v16_bwd_apply_kernel(const B16Pac
                     const float dd = (n0 + row < n_end) ? acc[i] : 0.f;
                     gsum[c] += dd * xh;
                     bsum[c] += dd;
-                    yp[row * G::LDO] = rs4[i] * (dd * gcol[c] - m14[i] - xh * m24[i]) * (1.f - yv * yv);
+                    const float dyv = rs4[i] * (dd * gcol[c] - m14[i] - xh * m24[i]) * (1.f - yv * yv);
+                    yp[row * G::LDO] = dyv;
+                    ysum[c] += (n0 + row < n_end) ? dyv : 0.f;
                 }
             }
         }
@@ -465,11 +467,13 @@ __global__ __launch_bounds__(512 / NSL) void o2v16_bwd_apply_kernel(const B16Pac
     for (int c = 0; c < G::CBW; ++c) {
         gsum[c] += __shfl_xor(gsum[c], 16, 64); gsum[c] += __shfl_xor(gsum[c], 32, 64);
         bsum[c] += __shfl_xor(bsum[c], 16, 64); bsum[c] += __shfl_xor(bsum[c], 32, 64);
+        ysum[c] += __shfl_xor(ysum[c], 16, 64); ysum[c] += __shfl_xor(ysum[c], 32, 64);
         const int cb = w * G::CBW + c;
         if (g == 0 && cb < G::NCB) {
             float* pp = a.part + ((int64_t)b * a.nsplit + sp) * 2 * H + col0 + cb * 16 + f;
             pp[0] = gsum[c];
             pp[H] = bsum[c];
+            if (a.dysum) a.dysum[((int64_t)b * a.nsplit + sp) * H + col0 + cb * 16 + f] = ysum[c];
         }
     }
 }

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 
-ABI_VERSION = 6            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
+ABI_VERSION = 7            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256, F_SK, F_NOSK, F_SK_BM128, F_SK_BM256 = 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
@@ -60,7 +60,7 @@ class O2VArgs(C.Structure):
 class O2VBwdArgs(C.Structure):
     _fields_ = [(n, c_f32p) for n in ('y', 'ostats', 'g_obj', 'b_obj', 'v', 'z', 'dz', 'S', 'ml', 'pd', 'm12', 'dy', 'dv',
                                       'part', 'ws')] + [('ws_bytes', i64), ('B', i32), ('T', i32), ('NO', i32), ('H', i32),
-                                                        ('nsplit', i32), ('scale', f32)]
+                                                        ('nsplit', i32), ('scale', f32), ('dysum', c_f32p)]
 
 
 class LatentPslArgs(C.Structure):
@@ -726,7 +726,8 @@ class HipOps(object):
 
     def o2v_bwd_multi(self, items, scale, nsplit):
         """the backward of several object->frame graphs of one shape, one launch per pass (both encoder streams).
-        items: dicts with y (B,NO,H), ostats, g_obj, b_obj, v, z, dz (B,T,H), S, ml, dy, dv.  Returns the list of `part` arrays."""
+        items: dicts with y (B,NO,H), ostats, g_obj, b_obj, v, z, dz (B,T,H), S, ml, dy, dv and optionally dysum (B*nsplit,H): the
+        column sums of dy per (clip, object chunk).  Returns the list of `part` arrays."""
         n = len(items)
         B, NO, H = items[0]['y'].shape
         T = items[0]['v'].shape[1]
@@ -747,6 +748,10 @@ class HipOps(object):
             for k in ('y', 'ostats', 'g_obj', 'b_obj', 'v', 'z', 'dz', 'S', 'ml', 'dy', 'dv'):
                 setattr(a, k, _p(it[k]))
             a.pd, a.m12, a.part, a.ws, a.ws_bytes = _p(pd), _p(m12), _p(part), _p(ws), wsb
+            if it.get('dysum') is not None:
+                _chkc(it['dysum'])
+                assert it['dysum'].shape == (B * nsplit, H)
+                a.dysum = _p(it['dysum'])
             a.B, a.T, a.NO, a.H, a.nsplit, a.scale = B, T, NO, H, nsplit, scale
         e0 = self._prof_begin()
         self._check(self.lib.dlsg_o2v_bwd_multi(arr, n, self._stream()), 'dlsg_o2v_bwd_multi')

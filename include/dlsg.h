@@ -21,7 +21,7 @@ extern "C" {
  * dlsg_lstm_cell_*, dlsg_tanh_ln_*, dlsg_conv_taps, dlsg_softmax_bwd2, dlsg_gemm_narrow -- gave way to the blocks of its schedule,
  * dlsg_crit_* / dlsg_cln_*; dlsg_lstm_seq takes batch-major arrays.  5: dlsg_gemm_args carries a workspace and an error word for the
  * stream-K kernel, dlsg_gemm_ws_bytes added; dlsg_adam takes `guard` before the stream and dlsg_select_embed `prefilled`.) */
-#define DLSG_ABI_VERSION 6
+#define DLSG_ABI_VERSION 7
 int dlsg_abi_version(void);
 
 /* Return codes of every entry point that returns int: 0 or one of these. */
@@ -208,7 +208,9 @@ int dlsg_o2v_fwd_multi(const dlsg_o2v_args* a, int count, void* stream);
  * the forward's LDS-DMA tile pipeline): given dz (B,T,H) it writes
  *   dy (B,NO,H)  grad wrt the obj_embed pre-activation (through obj_norm's LayerNorm and the tanh of the GEMM epilogue),
  *   dv (B,T,H)   grad wrt the frame nodes v (includes the residual dz),
- *   part (B*nsplit,2,H) dgamma | dbeta of obj_norm per (clip, object chunk) (fold with dlsg_colsum2).
+ *   part (B*nsplit,2,H) dgamma | dbeta of obj_norm per (clip, object chunk) (fold with dlsg_colsum2),
+ *   dysum (B*nsplit,H), optional: the column sums of dy per (clip, object chunk) -- obj_embed's bias gradient without another
+ *                pass over the (B*NO)-row dy (fold with dlsg_colsum).
  * y, ostats, S, ml, z are the forward's inputs / outputs; pd (B,NO,64) and m12 (B,NO,2) are workspaces, ws = dlsg_o2v_workspace_bytes
  * (B, T, H, nsplit) bytes of chunk partials of dv (needed when nsplit > 1).  dlsg_o2v_bwd_multi: `count` (<= DLSG_O2V_MAXMULTI)
  * graphs of one shape in one launch per pass (the object and the motion stream of CapGnnEncoder).
@@ -223,6 +225,7 @@ typedef struct {
     float* ws; int64_t ws_bytes;
     int32_t B, T, NO, H, nsplit;
     float scale;
+    float* dysum;
 } dlsg_o2v_bwd_args;
 int dlsg_o2v_bwd_multi(const dlsg_o2v_bwd_args* a, int count, void* stream);
 int dlsg_o2v_bwd(const dlsg_o2v_bwd_args* a, void* stream);

@@ -230,8 +230,14 @@ class EmulOps(CriticEmul):
             self.o2v_fwd(it['y'], it['v'], it['g_obj'], it['b_obj'], it['z'], it['ml'], it['ostats'], it['S'], scale, nsplit, eps)
 
     def o2v_bwd_multi(self, items, scale, nsplit, eps=1e-5):
-        return [self.o2v_bwd(it['y'], it['ostats'], it['g_obj'], it['b_obj'], it['v'], it['z'], it['dz'], it['S'], it['ml'], it['dy'],
-                             it['dv'], scale, nsplit, eps) for it in items]
+        parts = [self.o2v_bwd(it['y'], it['ostats'], it['g_obj'], it['b_obj'], it['v'], it['z'], it['dz'], it['S'], it['ml'], it['dy'],
+                              it['dv'], scale, nsplit, eps) for it in items]
+        for it in items:
+            if it.get('dysum') is not None:                      # column sums of dy per clip, in the first chunk's row
+                B = it['y'].shape[0]
+                it['dysum'].zero_()
+                it['dysum'].view(B, nsplit, -1)[:, 0] = it['dy'].sum(1)
+        return parts
 
     def o2v_bwd(self, y, ostats, g_obj, b_obj, v, z, dz, S, ml, dy, dv, scale, nsplit, eps=1e-5):
         """returns part (B*nsplit, 2, H): the per-clip dgamma | dbeta in the first chunk's rows, zeros in the others"""

@@ -662,16 +662,19 @@ def test_o2v_fused_backward(hip, case):
     def build(g):
         return dict(y=torch.tanh(rnd(g, B, NO, H)), v=rnd(g, B, T, H), go=1 + 0.2 * rnd(g, H), bo=0.2 * rnd(g, H),
                     z=torch.zeros(B * T, H), ml=torch.zeros(B * T, 2), os=torch.zeros(B * NO, 2), S=torch.zeros(B, NO, T),
-                    dz=rnd(g, B, T, H), dy=torch.zeros(B, NO, H), dv=torch.zeros(B, T, H), part=torch.zeros(B, 2, H))
+                    dz=rnd(g, B, T, H), dy=torch.zeros(B, NO, H), dv=torch.zeros(B, T, H), part=torch.zeros(B, 2, H),
+                    dysum=torch.zeros(B, H))
 
     def run(ops, t):
         sc = 1.0 / math.sqrt(H / 4.0)
         ops.o2v_fwd(t['y'], t['v'], t['go'], t['bo'], t['z'], t['ml'], t['os'], t['S'], sc, ns)
-        part = ops.o2v_bwd(t['y'], t['os'], t['go'], t['bo'], t['v'], t['z'].view(B, T, H), t['dz'], t['S'], t['ml'], t['dy'], t['dv'],
-                           sc, ns)
+        dysum = torch.full((B * ns, H), float('nan'), device=t['dy'].device)
+        part = ops.o2v_bwd_multi([dict(y=t['y'], ostats=t['os'], g_obj=t['go'], b_obj=t['bo'], v=t['v'], z=t['z'].view(B, T, H), dz=t['dz'],
+                                       S=t['S'], ml=t['ml'], dy=t['dy'], dv=t['dv'], dysum=dysum)], sc, ns)[0]
         assert part.shape == (B * ns, 2, H)
         t['part'] = part.view(B, ns, 2, H).sum(1)
-    both(hip, build, run, ['dy', 'dv', 'part'], tol=5e-5, name='o2v bwd %s' % (case,))
+        t['dysum'] = dysum.view(B, ns, H).sum(1)      # the column sums of dy per clip (obj_embed's bias gradient before the fold)
+    both(hip, build, run, ['dy', 'dv', 'part', 'dysum'], tol=5e-5, name='o2v bwd %s' % (case,))
 
 
 def test_o2v_fused_backward_two_streams_one_launch(hip):
