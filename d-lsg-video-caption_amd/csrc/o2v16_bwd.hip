@@ -338,8 +338,10 @@ struct ApGeom {
     static constexpr int BUF = O16_TILE * LDO;
 };
 
+// (at least two waves per SIMD: at H = 1024 two of these workgroups share a CU out of phase -- with the column sums of dy the
+//  allocation went to 260 registers and ONE workgroup per CU, 177 us instead of 117; held at 256 it spills three words)
 template <int H, int NSL>
-__global__ __launch_bounds__(512 / NSL) void o2v16_bwd_apply_kernel(const B16Pack pk, int tiles_per_split) {
+__global__ __launch_bounds__(512 / NSL) __attribute__((amdgpu_waves_per_eu(2))) void o2v16_bwd_apply_kernel(const B16Pack pk, int tiles_per_split) {
     using G = ApGeom<H, NSL>;
     const dlsg_o2v_bwd_args& a = pk.s[blockIdx.z / NSL];
     const int col0 = (blockIdx.z % NSL) * G::W;
