@@ -264,7 +264,7 @@ def gemm_roofline(prof, nsteps, root=ROOT):
     if tile == 'streamk':
         # csrc/gemm_sk.hip: ONE persistent launch of one workgroup per CU, 256 x 256 tiles, the remainder tiles cut between the
         # workgroups inside the launch
-        sym = 'gemm_sk_kernel<%s>' % tmpl
+        sym = 'gemm_sk_kernel<BM, BN, %s> (BM x BN = 256 x 256, 128 x 256 or 128 x 128)' % tmpl
     elif tile == '128x128':
         sym = '%s_w3<128, 128, %s, 32>' % ('gemm_x3_kernel' if is_x3 else 'gemm_kernel', tmpl)
     elif tile.startswith('256x'):

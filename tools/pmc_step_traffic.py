@@ -6,6 +6,7 @@ usage: python3 tools/pmc_step_traffic.py <fetch counter_collection.csv> <write c
 import collections
 import csv
 import json
+import re
 import sys
 
 SYMS = {   # prof key -> (kernel symbols of one launch group, in dispatch order; '?' = optional follower, '1?' = at most one,
@@ -45,7 +46,7 @@ for key, syms in SYMS.items():
         groups, cur, prev_head, prev_name = [], None, False, ''
         for r in rows:
             # (both tile heights of the stream-K kernel are one prof key)
-            n = r['Kernel_Name'].replace('gemm_sk_kernel<256, ', 'gemm_sk_kernel<').replace('gemm_sk_kernel<128, ', 'gemm_sk_kernel<')
+            n = re.sub(r'gemm_sk_kernel<(\d+, )+', 'gemm_sk_kernel<', r['Kernel_Name'])
             was, prev_name = prev_name, n
             if '256' not in key and any(h in was for h in rest_heads):
                 continue                    # the smaller-tile launch right behind a '+rest' head belongs to THAT call
