@@ -411,6 +411,182 @@ def inference_leg(dev, a):
     return out
 
 
+def smi_sclk_mhz():
+    """current shader clock from `rocm-smi --showclocks` (a child process: nothing of it touches this process's GPU state); None when
+    the tool is missing or says nothing parseable"""
+    import re
+    import subprocess
+    try:
+        r = subprocess.run(['rocm-smi', '--showclocks'], capture_output=True, text=True, timeout=10)
+        m = re.search(r'sclk[^\n]*?\((\d+)\s*Mhz\)', r.stdout, flags=re.I)
+        return int(m.group(1)) if m else None
+    except Exception:
+        return None
+
+
+def sustained_leg(dev, a, seconds=10.0, clips=320):
+    """The train loop as run_gun.py:147-160 feeds it: EVERY step a new batch, gathered on the device from an HBM-resident feature
+    store straight into the replayed graph's static input buffers (dlsg_amd.data.ResidentFeatures.batch(ids, out=...)), captions
+    copied from the host, epsilon on the reference's schedule (run_gun.py:136), the loss read back and the persistent kernels'
+    word checked every 100 steps -- for >= `seconds` of wall clock.  The capture and the warm-up are outside the clock."""
+    import threading
+    import numpy as np
+    import dlsg_amd
+    from dlsg_amd import data as D
+    from dlsg_amd.hip import host_to_device
+    from dlsg_amd.synth import synth_state_dict
+    args, V, B = dlsg_amd.msvd_shaped(), 1000, a.batch
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, dlsg_amd.make_vocab(V))
+    net.load_state_dict(synth_state_dict(net.state_dict(), 0))
+    net = net.to(dev).train()
+    net.gemm_precision = a.gemm
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    T, F, O, R = args.max_frames, args.a_feature_size + args.m_feature_size, args.num_obj, args.region_feature_size
+    store = D.ResidentFeatures.from_arrays(torch.randn(clips, T, F, device=dev, generator=g),
+                                           torch.randn(clips, T, O, R, device=dev, generator=g), O, dev, ops=net.ops)
+    rng = np.random.RandomState(5)
+    ncap = clips * 8                                   # 8 captions per clip, lengths 5..26, ids as synth_batch draws them
+    lens = rng.randint(5, 27, size=ncap)
+    caps = np.zeros((ncap, 26), dtype=np.int64)
+    for i, n in enumerate(lens):
+        caps[i, :n - 1] = rng.randint(4, V, size=n - 1)
+        caps[i, n - 1] = 2
+    caps_t = torch.from_numpy(caps)
+    vid = rng.randint(0, clips, size=ncap)
+    steps_per_epoch = ncap // B
+    tr = dlsg_amd.Trainer(net, use_graphs=not a.no_graphs, graph_fallback=True)
+    random.seed(12)
+
+    def batch_ids(step):
+        ep, k = divmod(step, steps_per_epoch)
+        perm = np.random.RandomState(100 + ep).permutation(ncap)[k * B:(k + 1) * B]
+        return ep, sorted(perm.tolist(), key=lambda i: vid[i], reverse=True)     # video id descending (utils/data.py:90)
+    ep, ids = batch_ids(0)
+    f0, r0 = store.batch([int(vid[i]) for i in ids])
+    for _ in range(3):                                 # capture + warm
+        tr.step(f0, r0, host_to_device(caps_t[ids], torch.int64, dev), lens[ids].tolist(), dlsg_amd.ss_epsilon(0))
+    st = tr.static_inputs()
+    sf, sr = (st[0], st[1]) if st is not None else (f0, r0)
+    clk, stop = [], threading.Event()
+
+    def sample():
+        while not stop.wait(2.0):
+            clk.append(smi_sclk_mhz())
+    th = threading.Thread(target=sample, daemon=True)
+    torch.cuda.synchronize()
+    th.start()
+    t0 = time.perf_counter()
+    n, losses, t_stage = 0, [], 0.0
+    while True:
+        ep, ids = batch_ids(n)
+        h0 = time.perf_counter()
+        store.batch([int(vid[i]) for i in ids], out=(sf, sr))
+        cb = host_to_device(caps_t[ids], torch.int64, dev)
+        lb = lens[ids].tolist()
+        t_stage += time.perf_counter() - h0
+        loss = tr.step(sf, sr, cb, lb, dlsg_amd.ss_epsilon(ep))
+        n += 1
+        if n % 100 == 0:
+            losses.append(round(float(loss), 4))       # (a host synchronisation, as a logging interval has)
+            tr.check()
+            if time.perf_counter() - t0 >= seconds:
+                break
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stop.set()
+    # what the per-step staging costs on the device: the two gathers alone, HIP events
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        store.batch([int(vid[i]) for i in ids], out=(sf, sr))
+    e1.record()
+    torch.cuda.synchronize()
+    gather_ms = e0.elapsed_time(e1) / 20
+    clk = [c for c in clk if c]
+    out = {'what': 'loader-fed loop: every step a new %d-clip batch gathered from a %d-clip HBM-resident store into the graph\'s static '
+                   'inputs, eps on the reference schedule, loss read every 100 steps' % (B, clips),
+           'seconds': round(dt, 2), 'steps': n, 'ms_per_step': round(1e3 * dt / n, 3), 'clips_per_s': round(B * n / dt, 1),
+           'launch': launch_mode(tr, not a.no_graphs), 'device_gather_ms_per_step': round(gather_ms, 4),
+           'host_staging_ms_per_step': round(1e3 * t_stage / n, 4),
+           'sclk_mhz_samples': clk[:8], 'loss_every_100': losses[:3] + (['...'] if len(losses) > 4 else []) + losses[-1:]}
+    del tr, net, store
+    torch.cuda.empty_cache()
+    return out
+
+
+def dp_schedule_leg(dev, a, batches=(64,)):
+    """BASELINE configs[2] / [3] on ONE GPU: the step as a rank of an N-rank job runs it (`Trainer(rehearse_ranks=8)`: multi-rank
+    kernel choices, weight gradients flushed per bucket, every bucket through the RCCL communicator inside the captured step),
+    timed with and without a co-tenant of an all-reduce's shape on the side stream (dlsg_comm_rehearsal: 32 x 256 threads
+    streaming each bucket for about as long as an 8-rank ring all-reduce over xGMI would take), for three backward policies:
+    stream-K on every CU (the default with several ranks: it measured fastest), stream-K on the CUs the collective leaves
+    free (dlsg_gemm_args.cu_budget = CUs - 32), tiled kernels only (round 5's unmeasured default)."""
+    import dlsg_amd
+    from dlsg_amd.synth import synth_state_dict, synth_batch
+    args, V = dlsg_amd.msvd_shaped(), 1000
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(args, dlsg_amd.make_vocab(V))
+    net.load_state_dict(synth_state_dict(net.state_dict(), 0))
+    net = net.to(dev).train()
+    net.gemm_precision = a.gemm
+    eps = dlsg_amd.ss_epsilon(0)
+    cus = net.ops.device_cus()
+    out = {'what': 'one rank of an 8-rank job rehearsed on one GPU: in-graph RCCL (world 1), per-bucket flush, BiLSTM backward step by '
+                   'step; co-tenant = 32 x 256 threads streaming each bucket on the side stream', 'cus': cus}
+    # co-tenant calibration: passes so that a bucket's stand-in lasts what an 8-rank ring all-reduce of it would (2 * 7/8 of the bytes
+    # per GPU at ~300 GB/s of xGMI bus bandwidth, DESIGN.md section 6)
+    probe = torch.zeros(45 * 1024 * 1024, device=dev)          # 180 MB: the decoder bucket's size
+    net.ops.comm_rehearsal(probe, 32, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    net.ops.comm_rehearsal(probe, 32, 4)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_per_pass = e0.elapsed_time(e1) / 4
+    target_ms = 2.0 * 7 / 8 * probe.numel() * 4 / 300e9 * 1e3
+    passes = max(1, int(round(target_ms / ms_per_pass)))
+    out['cotenant'] = {'workgroups': 32, 'passes': passes, 'alone_ms_per_pass_180MB': round(ms_per_pass, 3),
+                       'target_ms_180MB': round(target_ms, 3)}
+    del probe
+    comm = None                                        # one communicator for all the trainers of this leg
+    for B in batches:
+        batch = [t.to(dev) for t in synth_batch(args, V, B, 1)]
+        res = {}
+        for name, sk, budget in (('stream_k_all_cus', True, 0), ('stream_k_cu_budget', True, max(8, cus - 32)), ('tiled_backward', False, 0)):
+            for co in (False, True):
+                tr = dlsg_amd.Trainer(net, use_graphs=not a.no_graphs, graph_fallback=True, rehearse_ranks=8)
+                tr._rccl = comm
+                default = (net.stream_k_in_backward, net.sk_backward_cu_budget) == (sk, budget)
+                net.stream_k_in_backward, net.sk_backward_cu_budget = sk, budget
+                tr.rehearse_cotenant = dict(workgroups=32, passes=passes) if co else None
+                random.seed(12)
+                for _ in range(2):
+                    tr.step(*batch, eps)
+                fb = tr.static_inputs() or batch
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    tr.step(*fb, eps)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) / a.steps * 1e3
+                res[name + ('+cotenant' if co else '')] = round(ms, 3)
+                if default:
+                    out['multi_rank_default'] = name          # what Trainer(world_size > 1) runs (model.Trainer._use_multi_rank_schedule)
+                    out.setdefault('collectives', tr.collectives_info())
+                tr.check()
+                comm, tr._rccl = tr._rccl, None
+                del tr
+        out['batch_%d_ms_per_step' % B] = res
+        del batch
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
+    del net
+    torch.cuda.empty_cache()
+    return out
+
+
 def bucket_timeline(tr, batch, eps, dev, world):
     """Where an N > 1 step spends its exchange: ONE extra kernel-by-kernel step with HIP events at every gradient-bucket hand-off
     (main stream: `ready_us`, since the start of the step), behind its all-reduce on the side stream (`reduced_us`) and around the
@@ -530,6 +706,30 @@ def spawn_ranks(n, argv):
     return 0
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write there behind Python's back (RCCL prints a version banner through C
+    stdio when a communicator is created -- it would land behind the JSON line when the buffer is flushed at exit): from here on
+    file descriptor 1 IS stderr, and the line goes to a private duplicate of the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + '\n').encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode()); sys.stdout.flush()
+        return
+    while data:
+        n = os.write(_JSON_FD, data)
+        data = data[n:]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -551,6 +751,8 @@ def main():
                     help='(internal) run only this side leg and print its JSON: the parent bench starts it as a child process')
     ap.add_argument('--no-inference', action='store_true', help='skip the inference leg (BASELINE configs[4])')
     ap.add_argument('--no-msrvtt', action='store_true', help='skip the MSR-VTT-shaped batch-64 leg (BASELINE configs[2] per GPU)')
+    ap.add_argument('--no-sustained', action='store_true', help='skip the loader-fed >= 10 s leg')
+    ap.add_argument('--no-dp-schedule', action='store_true', help='skip the one-GPU rehearsal of a data-parallel rank\'s step')
     ap.add_argument('--comm', default='auto', choices=['auto', 'rccl', 'torch'],
                     help='gradient all-reduce: "rccl" = librccl called through the C ABI and captured inside the step\'s hipGraph; '
                          '"torch" = torch.distributed between graph segments; "auto" = rccl on the nccl backend')
@@ -562,10 +764,12 @@ def main():
     # first HIP call of this process, i.e. before torch.cuda.set_device below
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if a.leg == 'gan_eager':
-        print(json.dumps(gan_iteration_leg(torch.device('cuda', 0), a.batch, with_eager=True, product=False)))
+        claim_stdout()
+        emit(gan_iteration_leg(torch.device('cuda', 0), a.batch, with_eager=True, product=False))
         return
     if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
         sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+    claim_stdout()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -866,6 +1070,18 @@ def main():
             leg('inference', lambda: inference_leg(dev, a))
         if side and not a.no_msrvtt:
             leg('msrvtt_b64', lambda: msrvtt_leg(dev, a))
+        if side and not a.no_sustained:
+            def sus():
+                r = sustained_leg(dev, a)
+                r['vs_headline_ms_per_step'] = round(r['ms_per_step'] / out['ms_per_step'], 4)
+                return r
+            leg('sustained', sus)
+        if side and not a.no_dp_schedule and not a.no_graphs:
+            def dps():
+                r = dp_schedule_leg(dev, a, batches=(64, 128))
+                r['one_rank_ms_per_step'] = {'batch_64': out['ms_per_step'], 'batch_128': (out.get('batch_128') or {}).get('ms_per_step')}
+                return r
+            leg('dp_schedule_world1', dps)
         if world == 1 and not a.no_eager_baseline and a.shape == 'msvd':
             leg('vs_pytorch_rocm_eager', eager_leg)
         if world == 1 and not a.no_gan and a.shape == 'msvd' and a.gemm == 'fp32' and not a.no_graphs:
@@ -887,8 +1103,7 @@ def main():
                                        'MFMAs per product, fp32 accumulate (rel. error ~1e-5)',
                              'x3_all': 'all products: fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate'}[a.gemm]
         out['other_gemm_arithmetic'] = other
-        print(json.dumps(out))
-        sys.stdout.flush()
+        emit(out)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -169,6 +169,33 @@ extern "C" int dlsg_allreduce_max_i32(dlsg_comm* c, int32_t* words, int64_t coun
     return r == ncclSuccess ? DLSG_OK : DLSG_ELAUNCH;
 }
 
+// ---- single-GPU rehearsal of a collective's footprint.  With one rank an all-reduce is the identity and RCCL launches nothing
+// of substance, so what a step pays for SHARING the chip with a bucket's ring all-reduce cannot be seen on a one-GPU box.  This
+// kernel stands in for it: `workgroups` x 256 threads (RCCL's launch shape on gfx942 / gfx950: one workgroup per channel) that
+// stream the bucket `passes` times, read-modify-write with a factor of 1.0f -- the values are unchanged, so a rehearsed step
+// is still bit-identical to the plain one -- holding `workgroups` CUs' worth of wave slots and their share of HBM for about as
+// long as the caller asks.  Test / bench instrument only (dlsg_amd.Trainer.rehearse_cotenant); nothing in a real run calls it.
+namespace {
+__global__ __launch_bounds__(256) void comm_rehearsal_kernel(float* buf, int64_t n4, int passes, float one) {
+    float4* b = reinterpret_cast<float4*>(buf);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int p = 0; p < passes; ++p)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            float4 v = b[i];
+            v.x *= one; v.y *= one; v.z *= one; v.w *= one;
+            b[i] = v;
+        }
+}
+}  // namespace
+
+extern "C" int dlsg_comm_rehearsal(float* buf, int64_t count, int workgroups, int passes, void* stream) {
+    if (count < 0 || workgroups < 1 || workgroups > 1024 || passes < 0 || (count > 0 && !buf)) return DLSG_EINVAL;
+    if (reinterpret_cast<uintptr_t>(buf) & 15) return DLSG_EALIGN;
+    if (count < 4 || passes == 0) return DLSG_OK;
+    hipLaunchKernelGGL(comm_rehearsal_kernel, dim3(workgroups), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), buf, count / 4, passes, 1.0f);
+    return hipGetLastError() == hipSuccess ? DLSG_OK : DLSG_ELAUNCH;
+}
+
 // *code <- the communicator's asynchronous error state (ncclCommGetAsyncError: 0 = ncclSuccess); no synchronisation
 extern "C" int dlsg_comm_async_error(dlsg_comm* c, int32_t* code) {
     if (!c || !c->comm) return DLSG_ENOCOMM;

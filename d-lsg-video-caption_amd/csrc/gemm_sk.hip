@@ -39,8 +39,8 @@ constexpr int SK_SLOT_BYTES = 256 * SK_BN * 4;     // a workspace slot holds the
 constexpr int SK_CNT_BYTES = 16384;                // in front of the slots: counters (2 words per split tile) in the first 4 KB; the
                                                    // rest is where a PROBES=1 build leaves its timestamps
 constexpr int SK_MAXSPLIT = 16;                    // contributors per split tile (= sub-blocks a wave can hand out)
-constexpr int SK_PATIENCE = 64;                    // polls (x ~1 us) a contributor spends on an incomplete split tile before it leaves
-                                                   // its sub-blocks to the tile's last finisher
+constexpr int SK_PATIENCE = 64;                    // polls (s_sleep(8) + one L2 round trip each: ~15 us in all) a contributor spends on an
+                                                   // incomplete split tile before it leaves its sub-blocks to the tile's last finisher
 
 struct SkGroup {
     const float* A; const float* B; float* C; const float* bias;
@@ -545,30 +545,46 @@ __global__ __launch_bounds__(SK_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1
     }
 }
 
-int sk_cus() {
-    static int cus = 0;
+int sk_cus_, sk_lds_max_;
+void sk_query() {
     static std::once_flag once;
     std::call_once(once, [] {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) return;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipDeviceGetAttribute(&sk_cus_, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipDeviceGetAttribute(&sk_lds_max_, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
     });
-    return cus;
 }
+int sk_cus() { sk_query(); return sk_cus_; }
+int sk_lds_max() { sk_query(); return sk_lds_max_; }
+
+constexpr int sk_lds_bytes(int bm, int bn) { return 2 * (bm * 128 + bn * 128) + 4 * SK_BOUNCE + 16; }   // two stage buffers + the epilogue's bounce tiles + a flag
 
 template <int BM, int BN, bool AT, bool BT>
 int sk_launch(const SkArgs& k, hipStream_t st) {
-    constexpr int lds_bytes = 2 * (BM * 128 + BN * 128) + 4 * SK_BOUNCE + 16;  // two stage buffers + the epilogue's bounce tiles + a flag
+    constexpr int lds_bytes = sk_lds_bytes(BM, BN);
     static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<BM, BN, AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sk_kernel<BM, BN, AT, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     });
+    if (attr_rc != hipSuccess) return DLSG_ELAUNCH;
     hipLaunchKernelGGL((gemm_sk_kernel<BM, BN, AT, BT>), dim3(k.P), dim3(SK_THREADS), lds_bytes, st, k);
     DLSG_CHECK_LAUNCH();
     return DLSG_OK;
 }
 
 }  // namespace
+
+// Workgroups of a launch: one per CU, or the caller's budget (dlsg_gemm_args.cu_budget) rounded down to a multiple of 8 (one share
+// per XCD).  A workgroup of this kernel needs a CU to itself (147 KB of LDS, all 512 registers of its SIMDs): when another tenant
+// holds CUs -- a collective's kernels on a side stream under the backward -- a launch of one workgroup per CU would run its last
+// workgroups only after the first ones left; with a budget that leaves those CUs free it stays one co-resident wave.
+static int sk_workgroups(const dlsg_gemm_args* a) {
+    int p = sk_cus();
+    if (a->cu_budget > 0 && a->cu_budget < p) p = a->cu_budget >= 16 ? (a->cu_budget & ~7) : 8;
+    return p;
+}
 
 // stages per tile of the first group that owns a tile at or behind linear tile id `from`
 static int max_nst_sk(const SkArgs& k, int from, int tiles_m) {
@@ -589,6 +605,10 @@ int dlsg_gemm_sk_ok(const dlsg_gemm_args* a) {
     const bool at = a->mode == 2, bt = a->mode != 0;
     if (a->nbatch != 1 || a->M < 4 || a->N < 4) return 0;
     if (!a->ws || a->ws_bytes < dlsg_gemm_ws_bytes() || dlsg_gemm_ws_bytes() == 0) return 0;
+    // what the dispatch relies on, checked HERE so that gemm_plan falls back to the tiled kernels instead of failing the call: the
+    // counter area holds four words per split tile (fewer than P of them), a workgroup's stage buffers fit the device's LDS
+    if (4 * (sk_workgroups(a) - 1) * (int)sizeof(uint32_t) > 4096) return 0;
+    if (sk_lds_max() < sk_lds_bytes(256, 256)) return 0;
     if (at && (a->M % 4)) return 0;
     for (int i = 0; i < a->ngroups; ++i) {
         const dlsg_gemm_group& g = a->g[i];
@@ -637,7 +657,7 @@ void sk_pick_tile(const dlsg_gemm_args* a, int* bm_, int* bn_) {
     else if (a->flags & DLSG_GEMM_SK_BM128) bm = 128;
     else if (a->flags & DLSG_GEMM_SK_BM256) bm = 256;
     else {
-        const int cus = sk_cus() > 0 ? sk_cus() : 256;
+        const int cus = sk_cus() > 0 ? sk_workgroups(a) : 256;
         const int pad256 = (a->M + 255) / 256 * 256;
         int kmax = 0;
         if ((pad256 - a->M) * 32 > a->M) bm = 128;
@@ -655,8 +675,8 @@ void sk_pick_tile(const dlsg_gemm_args* a, int* bm_, int* bn_) {
 // the vocabulary projection 60 against 44).  A launch whose tiles come in whole rounds has no fix-up and pays from ~40 us.
 int dlsg_gemm_sk_wanted(const dlsg_gemm_args* a) {
     if (!a->ws || (a->flags & DLSG_GEMM_NOSK) || !dlsg_gemm_sk_ok(a)) return 0;
-    const int cus = sk_cus();
-    if (cus <= 0) return 0;
+    if (sk_cus() <= 0) return 0;
+    const int cus = sk_workgroups(a);
     int bm, bn;
     sk_pick_tile(a, &bm, &bn);
     const int64_t tm = (a->M + bm - 1) / bm;
@@ -715,8 +735,7 @@ int dlsg_gemm_sk_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
         s.tile0 = T;
         T += tiles_m * s.tiles_n;
     }
-    const int cus = sk_cus();
-    const int P = cus;
+    const int P = sk_workgroups(a);
     k.P = P; k.T = T;
     k.rounds = T / P; k.rem = T % P;
     k.sk_wgs = 0; k.sk_nst = 0; k.xmap = 0;

@@ -224,6 +224,12 @@ class CaptionSet(object):
         return len(self.video_ids)
 
 
+def _h2d(values, dtype, device):
+    """small host arrays (gather indices, caption rows) to the device without stalling the host (hip.host_to_device)"""
+    from .hip import host_to_device
+    return host_to_device(values, dtype, device)
+
+
 # ================================================================================================ feature stores
 class _Features(object):
     """(frames `feats`, regions `vfeats`) of one dataset; regions are cut to the first `num_obj` objects (run_gun.py:158)."""
@@ -273,9 +279,29 @@ class ResidentFeatures(_Features):
             self.dev_regions[s:s + c].copy_(sr[:c], non_blocking=False)
         self.bytes = (self.dev_frames.numel() + self.dev_regions.numel()) * 4
 
+    @classmethod
+    def from_arrays(cls, frames, regions, num_obj, device, ops=None):
+        """A resident store over arrays that are already in memory (synthetic feature sets, tests, bench.py's `sustained` leg):
+        frames (N, T, F), regions (N, T, O, R) as torch tensors or numpy arrays; regions are cut to the first `num_obj` objects as
+        `_Features` does for a file.  No HDF5 involved; `batch()` is the same device gather."""
+        self = cls.__new__(cls)
+        frames, regions = torch.as_tensor(frames), torch.as_tensor(regions)
+        if frames.dim() != 3 or regions.dim() != 4:
+            raise ValueError('expected feats (N,T,F) and vfeats (N,T,O,R), got %s / %s' % (tuple(frames.shape), tuple(regions.shape)))
+        self.h5f = self.h5r = self.frames = self.regions = None
+        self.n = min(frames.shape[0], regions.shape[0])
+        self.num_obj = min(num_obj, regions.shape[2])
+        self.frame_shape = tuple(frames.shape[1:])
+        self.region_shape = (regions.shape[1], self.num_obj, regions.shape[3])
+        self.device, self.ops = torch.device(device), ops
+        self.dev_frames = frames[:self.n].reshape(self.n, -1).to(device=self.device, dtype=torch.float32).contiguous()
+        self.dev_regions = regions[:self.n, :, :self.num_obj].reshape(self.n, -1).to(device=self.device, dtype=torch.float32).contiguous()
+        self.bytes = (self.dev_frames.numel() + self.dev_regions.numel()) * 4
+        return self
+
     def batch(self, video_ids, out=None):
         """out: optional (frames, regions) device tensors of the batch shape to gather into (e.g. `Trainer.static_inputs()`)"""
-        idx = torch.as_tensor(list(video_ids), dtype=torch.int64, device=self.device)
+        idx = _h2d(list(video_ids), torch.int64, self.device)
         B = idx.numel()
         if out is not None:
             f, r = out[0].view(B, -1), out[1].view(B, -1)
@@ -492,7 +518,7 @@ class TrainLoader(object):
 
         def pack(b, f, r):
             ib = torch.as_tensor(b, dtype=torch.int64)
-            return (f, r, None, caps.captions[ib].to(dev, non_blocking=True), caps.pos_tags[ib].to(dev, non_blocking=True),
+            return (f, r, None, _h2d(caps.captions[ib], torch.int64, dev), _h2d(caps.pos_tags[ib], torch.int64, dev),
                     tuple(caps.lengths[i] for i in b), tuple(caps.video_ids[i] for i in b))
         if isinstance(self.features, StreamedFeatures):
             vids = [[caps.video_ids[i] for i in b] for b in batches]

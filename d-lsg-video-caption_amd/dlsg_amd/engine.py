@@ -114,6 +114,15 @@ def _accum_flag(ops, gout):
     return 0
 
 
+def _accum_always(ops, gout):
+    """F_ACCUM for a writer that always adds (it is not known to be the block's first), and the block is marked as written: a
+    tracked writer that comes later must not take itself for the first and store over this contribution"""
+    seen = getattr(ops, 'grad_written', None)
+    if seen is not None:
+        seen.add((gout.data_ptr(), tuple(gout.shape), tuple(gout.stride())))
+    return F_ACCUM
+
+
 def gemm_tn_deep(ops, items, ref):
     """gout_i (Nout, Kin) += dy_i^T x_i for very deep contractions (rows >= 8192: the 26624-row obj_embed weight gradients):
     the output has too few tiles to fill the chip, so the rows are split over groups writing slabs (measured 98 vs 86
@@ -151,7 +160,7 @@ def gemm_tn_deep(ops, items, ref):
             ops.gemm(GEMM_TN, [(dy[k0:k1], x[k0:k1], sl[i]) for (dy, x, _), sl in zip(part, slabs)
                                for i, (k0, k1) in enumerate(bounds)])
             for (_, _, gout), sl in zip(part, slabs):
-                ops.slab_reduce(sl, gout, flags=F_ACCUM)
+                ops.slab_reduce(sl, gout, flags=_accum_always(ops, gout))
 
 
 def _accum_flag_peek(ops, gout):
@@ -527,7 +536,7 @@ def tun_bwd_head_multi(ops, items, regions, sv, G, training, seed):
             dlg = _empty(ref, B, T, P)
             ops.softmax_bwd(adj, dadj, dlg, B, T, P)
             ops.gemm(GEMM_NN, [(dlg, theta.unsqueeze(0).expand(B, P, H), dov.view(B, T, H))], flags=F_ACCUM)
-            ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[pfx + '.v2l_layer.theta'])], flags=F_ACCUM)
+            ops.gemm(GEMM_TN, [(dlg.view(B * T, P), ov, G[pfx + '.v2l_layer.theta'])], flags=_accum_always(ops, G[pfx + '.v2l_layer.theta']))
             dovs.append(dov)
     if O >= 5:
         nb = ops.rowln_bwd_nblk(B * T)
@@ -1176,7 +1185,8 @@ def dec_bwd(ops, dec, sv, G, dlogits_tm, seed, training, dalpha_tm=None):
                [(dgl2, s['CTX'][i].view(n, H), Gl_ih[:, plan.l_ctx[i][0]:plan.l_ctx[i][1]]) for i in range(ns)] +
                [(dgl2, s['QCUR'].view(n, Q), Gl_ih[:, plan.l_q[0]:plan.l_q[1]]),
                 (dgl2, lhp, G['decoder.lang_lstm.weight_hh'])], sv.get('tn_defer'))
-    ops.gemm(GEMM_TN, [(dgq_sum, s['gfeat'], Gq_ih[:, plan.q_glob[0]:plan.q_glob[1]])], flags=F_ACCUM)
+    gq_glob = Gq_ih[:, plan.q_glob[0]:plan.q_glob[1]]
+    ops.gemm(GEMM_TN, [(dgq_sum, s['gfeat'], gq_glob)], flags=_accum_always(ops, gq_glob))
     ops.colsum2(dgq2, G['decoder.query_lstm.bias_ih'], G['decoder.query_lstm.bias_hh'], accum=True)
     ops.colsum2(dgl2, G['decoder.lang_lstm.bias_ih'], G['decoder.lang_lstm.bias_hh'], accum=True)
     # ---- word embedding rows

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .critic import CriticEngine, C as WIDTH, PW as PSL_WIDTH
-from .model import _ArenaModule, _ALIGN
+from .model import _ArenaModule, _ALIGN, _capture_stream, _copy_h2d
 from .modules import LatentPSL, SelfAttention
 
 
@@ -338,7 +338,7 @@ class GanTrainer(object):
 
     def _capture_critic(self, st):
         eng = self.D.engine
-        side = torch.cuda.Stream(device=st['logits'].device)
+        side = _capture_stream(st['logits'].device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             eng.proposals(st['ws'], st['obj'], st['mot'], st['alpha'], st['smask'])       # warm-up on the capture stream
@@ -383,8 +383,8 @@ class GanTrainer(object):
             self.t_D += 1
             if self.use_graphs:
                 st['eps'].copy_(eps, non_blocking=True)
-                st['seed'].copy_(torch.tensor([seed], dtype=torch.int64), non_blocking=True)
-                st['hyper'].copy_(torch.tensor(self._hyper_D(), dtype=torch.float32), non_blocking=True)
+                _copy_h2d(st['seed'], [seed])
+                _copy_h2d(st['hyper'], self._hyper_D())
                 st['graphs'][1].replay()
                 self._allreduce_D()
                 st['graphs'][2].replay()
@@ -432,9 +432,9 @@ class GanTrainer(object):
             st['ws'] = eng.prepare(dev, B, L, V, st['smask'], 1)
             self._cg[key] = st
         st['smask'].copy_(smask, non_blocking=True)
-        st['seed'].copy_(torch.tensor([eng.next_seed()], dtype=torch.int64), non_blocking=True)
+        _copy_h2d(st['seed'], [eng.next_seed()])
         if st['graph'] is None:
-            side = torch.cuda.Stream(device=dev)
+            side = _capture_stream(dev)
             side.wait_stream(torch.cuda.current_stream())
 
             def run():

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdlsg_hip.so')
 
-ABI_VERSION = 7            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
+ABI_VERSION = 8            # include/dlsg.h DLSG_ABI_VERSION this binding was written against
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
 F_ACCUM, F_BIAS, F_TANH = 1, 2, 4
 F_FORCE64, F_FORCE128, F_BF16X3, F_TILE256, F_SK, F_NOSK, F_SK_BM128, F_SK_BM256 = 256, 512, 1024, 2048, 4096, 8192, 16384, 32768
@@ -35,7 +35,7 @@ class GemmGroup(C.Structure):
 
 class GemmArgs(C.Structure):
     _fields_ = [('mode', i32), ('M', i32), ('N', i32), ('ldc', i32), ('ngroups', i32), ('nbatch', i32), ('flags', i32),
-                ('pad_', i32), ('bsa', i64), ('bsb', i64), ('bsc', i64), ('alpha', f32), ('pad2_', i32),
+                ('cu_budget', i32), ('bsa', i64), ('bsb', i64), ('bsc', i64), ('alpha', f32), ('pad2_', i32),
                 ('bias', c_f32p), ('skip_if', c_f32p), ('ws', c_f32p), ('ws_bytes', i64), ('err', c_f32p), ('g', GemmGroup * MAXG)]
 
 
@@ -244,7 +244,7 @@ SYMBOLS = ['dlsg_abi_version', 'dlsg_struct_size', 'dlsg_gemm', 'dlsg_gemm_varia
            'dlsg_bilstm_supported', 'dlsg_bilstm_hx_floats', 'dlsg_bilstm_flag_words', 'dlsg_bilstm_fwd', 'dlsg_bilstm_bwd_x_floats', 'dlsg_bilstm_bwd',
            'dlsg_lstm_seq_supported', 'dlsg_lstm_seq_x_floats', 'dlsg_lstm_seq_flag_words', 'dlsg_lstm_seq',
            'dlsg_comm_unique_id', 'dlsg_comm_init', 'dlsg_comm_destroy', 'dlsg_comm_info', 'dlsg_allreduce_bucket',
-           'dlsg_allreduce_buckets', 'dlsg_allreduce_max_i32', 'dlsg_comm_async_error']
+           'dlsg_allreduce_buckets', 'dlsg_allreduce_max_i32', 'dlsg_comm_rehearsal', 'dlsg_comm_async_error']
 
 
 def load_library(path=LIB_PATH):
@@ -347,6 +347,7 @@ def load_library(path=LIB_PATH):
         'dlsg_allreduce_buckets': [vp, P(vp), P(i64), i32, vp],
         'dlsg_allreduce_max_i32': [vp, vp, i64, vp],
         'dlsg_comm_async_error': [vp, P(i32)],
+        'dlsg_comm_rehearsal': [vp, i64, i32, i32, vp],
     }
     assert sorted(sig) == sorted(SYMBOLS)
     for name, args in sig.items():
@@ -379,6 +380,27 @@ def _seed(seed):
     if torch.is_tensor(seed):
         return 0, C.c_void_p(seed.data_ptr())
     return int(seed), None
+
+
+def host_to_device(values, dtype, device):
+    """A small host array (per-step scalars: coins, seeds, Adam's bias corrections, caption lengths, gather indices) as a device
+    tensor WITHOUT stalling the host.  A copy from pageable memory is synchronous on ROCm -- it waits until the stream has run dry --
+    so a loop that sends three scalars per step never gets ahead of the device, and every microsecond of host work between two
+    steps is device idle time (bench.py `sustained`: 0.8 ms per step).  Staged through the caching pinned allocator the copy is
+    enqueued and the host moves on; the allocator keeps the block until the copy's event has passed."""
+    t = values.to(dtype) if torch.is_tensor(values) else torch.as_tensor(values, dtype=dtype)
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
+def copy_to_device(dst, values, dtype=None):
+    """dst (device tensor) <- values, same staging as `host_to_device`"""
+    t = values.to(dtype or dst.dtype) if torch.is_tensor(values) else torch.as_tensor(values, dtype=dtype or dst.dtype)
+    if dst.is_cuda and not t.is_cuda:
+        t = t.contiguous().pin_memory()
+    dst.copy_(t.view(dst.shape), non_blocking=True)
 
 
 def _chk2(t):
@@ -454,21 +476,51 @@ class HipOps(object):
 
     # ------------------------------------------------------------------ GEMM
     stream_k = True           # False: dlsg_gemm gets no workspace, so every product runs on the tiled kernels
+    sk_cu_budget = 0          # > 0: stream-K launches use at most this many workgroups (dlsg_gemm_args.cu_budget): the backward of a
+                              # Trainer with several ranks leaves CUs to the bucket all-reduces that run beside it
+
+    # process-wide (class attributes): launches on one stream are serialised, so every model, trainer and captured graph that
+    # launches on a stream can share that stream's workspace; captures all run on ONE side stream per device (capture_stream), so a
+    # process holds two workspaces per device (~134 MB each on 256 CUs), not one per captured graph
+    _gemm_ws = {}
+    _capture_streams = {}
+
+    @classmethod
+    def capture_stream(cls, dev):
+        """the side stream every hipGraph capture of this process runs on (Trainer, GanTrainer, GreedyGraph, BeamGraph): captures
+        are sequential and replays go to the caller's current stream, so one stream -- and one stream-K workspace, warmed by the
+        eager pass each capture site runs first -- serves them all"""
+        dev = torch.device(dev)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        st = cls._capture_streams.get(idx)
+        if st is None:
+            st = cls._capture_streams[idx] = torch.cuda.Stream(device=idx)
+        return st
 
     def _gemm_workspace(self, dev):
-        """the stream-K kernel's scratch (csrc/gemm_sk.hip): counters + one accumulator slot per CU, zero-filled once; one per
-        (device, stream), because two launches that may overlap must not share it"""
+        """the stream-K kernel's scratch (csrc/gemm_sk.hip): counters + two accumulator slots per CU, zero-filled once; one per
+        (device, stream), because two launches that may overlap must not share it.  None while a capture is running on a stream
+        that has no workspace yet (no allocation + fill inside a capture): the call then runs on the tiled kernels."""
         key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
-        d = self.__dict__.setdefault('_gemm_ws', {})
-        ws = d.get(key)
+        ws = HipOps._gemm_ws.get(key)
         if ws is None:
             n = int(self.lib.dlsg_gemm_ws_bytes())
             if n <= 0:
                 raise RuntimeError('dlsg_gemm_ws_bytes() failed: no device?')
             if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError('the stream-K workspace of this stream must exist before a capture starts (run the step once eagerly)')
-            ws = d[key] = torch.zeros((n + 3) // 4, dtype=torch.float32, device=dev)
+                return None
+            ws = HipOps._gemm_ws[key] = torch.zeros((n + 3) // 4, dtype=torch.float32, device=dev)
         return ws
+
+    def device_cus(self):
+        """compute units of the current device (what a stream-K launch fills: the workspace is two slots per CU)"""
+        n = int(self.lib.dlsg_gemm_ws_bytes())
+        return max(0, (n - 16384) // (2 * 256 * 256 * 4))
+
+    def comm_rehearsal(self, view, workgroups, passes):
+        """one-GPU stand-in for the footprint of a ring all-reduce over `view` (dlsg_comm_rehearsal), on the current stream"""
+        self._check(self.lib.dlsg_comm_rehearsal(_p(view), i64(view.numel()), int(workgroups), int(passes), self._stream()),
+                    'dlsg_comm_rehearsal')
 
     def gemm(self, mode, groups, alpha=1.0, flags=0, bias=None, skip_if=None, plan_only=False):
         """groups: list of (A, B, C[, bias]) views (2-d, or 3-d batched with identical batch strides across groups).
@@ -492,7 +544,9 @@ class HipOps(object):
         a.skip_if = _p(skip_if)          # 1-element int32 device tensor: launch is a no-op when it is non-zero
         if (self.stream_k or (flags & F_SK)) and not ((flags | self.extra_flags) & F_NOSK):
             ws = self._gemm_workspace(C0.device)
-            a.ws, a.ws_bytes = _p(ws), ws.numel() * 4
+            if ws is not None:
+                a.ws, a.ws_bytes = _p(ws), ws.numel() * 4
+                a.cu_budget = int(self.sk_cu_budget)
         assert len(groups) <= MAXG
         for i, grp_ in enumerate(groups):
             A, B, Cc = grp_[:3]

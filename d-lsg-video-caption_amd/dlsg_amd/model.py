@@ -133,7 +133,9 @@ class _HipModel(_ArenaModule):
         if attended_rows > 72:
             raise ValueError('%s = %d: the fused decoder step attends over at most 72 rows per stream' % (what, attended_rows))
 
-    stream_k_in_backward = True        # False (a Trainer with several ranks sets it): the backward's products stay on the tiled kernels
+    stream_k_in_backward = True        # False: the backward's products stay on the tiled kernels
+    sk_backward_cu_budget = 0          # > 0 (a Trainer with several ranks sets it): workgroups of the backward's stream-K launches,
+                                       # the other CUs are left to the gradient all-reduces that run beside the backward
 
     def _gemm_flags(self, backward):
         from .hip import F_BF16X3, F_NOSK
@@ -143,6 +145,14 @@ class _HipModel(_ArenaModule):
         if backward and not self.stream_k_in_backward:
             fl |= F_NOSK
         return fl
+
+    def _gemm_policy(self, backward):
+        """what every dlsg_gemm call of the pass that starts here carries: arithmetic + stream-K flags, the stream-K CU budget"""
+        ops = self.ops
+        ops.extra_flags = self._gemm_flags(backward)
+        ops.sk_cu_budget = self.sk_backward_cu_budget if backward else 0
+        if backward:
+            ops.grad_written = set()        # engine._accum_flag: the first product into a gradient block stores, later ones add
 
     merge_weight_grads = True          # see engine.tn_grouped
     _defer_ok = True                   # weight gradients may be collected and launched grouped ...
@@ -265,7 +275,7 @@ class CapGnnModel(_HipModel):
 
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
         ops = self.ops
-        ops.extra_flags = self._gemm_flags(False)
+        self._gemm_policy(False)
         if getattr(ops, 'colsum_defer', None) is not None:
             ops.colsum_defer = None         # (a backward that raised half-way must not leave the collector armed)
         frames = frames.contiguous().float()
@@ -286,10 +296,9 @@ class CapGnnModel(_HipModel):
 
     def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed, on_bucket=None):
         ops, enc = self.ops, self.encoder
-        ops.extra_flags = self._gemm_flags(True)
+        self._gemm_policy(True)
         G = self._G
         ops.fill(self._gflat, 0.0)
-        ops.grad_written = set()            # engine._accum_flag: the first product into a gradient block stores, later ones add
         if self.merge_weight_grads and self._defer_ok:
             sv['tn_defer'] = []             # mid-size weight gradients of every module: launched together at the end
         collect = hasattr(ops, 'colsum_flush')
@@ -394,7 +403,7 @@ class CapBaseline1(_HipModel):
 
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
         ops = self.ops
-        ops.extra_flags = self._gemm_flags(False)
+        self._gemm_policy(False)
         frames = frames.contiguous().float()
         B, T, F = frames.shape
         H = self.decoder.visual_hidden_size
@@ -409,7 +418,7 @@ class CapBaseline1(_HipModel):
 
     def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed, on_bucket=None):
         ops = self.ops
-        ops.extra_flags = self._gemm_flags(True)
+        self._gemm_policy(True)
         G = self._G
         ops.fill(self._gflat, 0.0)
         frames = sv['frames']
@@ -486,7 +495,7 @@ class CapBaselineModel(_HipModel):
 
     def _engine_forward(self, frames, regions, captions, L, coins, training, seed, sv, dev_coins=None, outputs=True):
         ops = self.ops
-        ops.extra_flags = self._gemm_flags(False)
+        self._gemm_policy(False)
         frames = frames.contiguous().float()
         regions = regions.contiguous().float()
         mot = self._motion_nodes(frames, regions, training, seed, sv)
@@ -500,7 +509,7 @@ class CapBaselineModel(_HipModel):
 
     def _engine_backward(self, sv, dlogits_tm, dobj, dmot, dalpha_tm, training, seed, on_bucket=None):
         ops, enc = self.ops, self.encoder
-        ops.extra_flags = self._gemm_flags(True)
+        self._gemm_policy(True)
         G = self._G
         ops.fill(self._gflat, 0.0)
         frames, regions = sv['frames'], sv['regions']
@@ -517,6 +526,22 @@ class CapBaselineModel(_HipModel):
     forward = CapBaseline1.forward
 
 
+def _h2d(values, dtype, device):
+    from .hip import host_to_device
+    return host_to_device(values, dtype, device)
+
+
+def _copy_h2d(dst, values):
+    from .hip import copy_to_device
+    copy_to_device(dst, values)
+
+
+def _capture_stream(dev):
+    """the one side stream per device all hipGraph captures of this process run on (hip.HipOps.capture_stream)"""
+    from .hip import HipOps
+    return HipOps.capture_stream(dev)
+
+
 class GreedyGraph(object):
     """hipGraph-captured greedy inference (BASELINE configs[4]: 'hipGraph-captured decode step'): encoder + the 26
     decode steps (argmax and embedding gather stay on device) are captured once for a batch shape and replayed; the
@@ -528,7 +553,7 @@ class GreedyGraph(object):
         dev = frames.device
         self.frames, self.regions = frames.clone(), regions.clone()
         L = model.decoder.max_words
-        side = torch.cuda.Stream(device=dev)
+        side = _capture_stream(dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             model._engine_forward(self.frames, self.regions, None, L, [False] * L, False, 0, {})     # warm-up
@@ -562,7 +587,7 @@ class BeamGraph(object):
         model.flatten_parameters_()
         dev = frames.device
         self.frames, self.regions = frames.clone(), regions.clone()
-        side = torch.cuda.Stream(device=dev)
+        side = _capture_stream(dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             beam_device(model, self.frames, self.regions, early_exit=False)                       # warm-up
@@ -610,14 +635,19 @@ class Trainer(object):
     memory: inputs (static buffers), the dropout seed, the scheduled-sampling coins, the Adam bias corrections."""
 
     def __init__(self, model, lr=1.6e-4, betas=(0.5, 0.9), eps=1e-8, process_group=None, world_size=1, use_graphs=False,
-                 device_coins=None, graph_fallback=False, comm='auto', check_every=100):
+                 device_coins=None, graph_fallback=False, comm='auto', check_every=100, rehearse_ranks=0):
         """comm: how the gradient buckets are summed over ranks.
           'rccl'  -- librccl through the C ABI (dlsg_allreduce_bucket) on a side stream forked by an event: the collectives
                      are part of the captured step, so one iteration is ONE hipGraph replay and a bucket's all-reduce runs
                      under the backward that follows it;
           'torch' -- torch.distributed.all_reduce(async_op=True) issued by the host between hipGraph segments (any backend:
                      this is what the CPU / gloo tests run);
-          'auto'  -- 'rccl' when the model lives on a GPU, else 'torch'."""
+          'auto'  -- 'rccl' when the model lives on a GPU, else 'torch'.
+        rehearse_ranks: N > 1 with world_size == 1 runs, on ONE GPU, exactly the step a rank of an N-rank job runs -- the
+          multi-rank kernel choices of `_use_multi_rank_schedule`, weight gradients flushed at every bucket, every bucket handed
+          to the communicator (world 1: the all-reduce is the identity, Adam's 1 / world stays 1) -- so that this schedule can be
+          checked against the oracle and timed where only one device exists (tests/test_gpu_bench_parity.py, bench.py's
+          `dp_schedule_world1`).  `rehearse_cotenant` adds the chip-sharing a real all-reduce brings."""
         assert comm in ('auto', 'rccl', 'torch'), comm
         self.comm = comm
         # every `check_every` steps the persistent kernels' time-out word is read back (one host synchronisation): a launch that
@@ -636,30 +666,50 @@ class Trainer(object):
         self.graph_fallback = graph_fallback   # True: a failed capture downgrades to eager launches (with a warning)
         self.force_graph_cuts = False   # test hook: segment the capture at bucket boundaries even on one GPU
         self.force_collectives = False  # test hook: issue the all-reduces even with one rank (RCCL path on a 1-GPU box)
+        # rehearsal hook (one GPU): None, or dict(workgroups=32, passes=n) -- behind every bucket's all-reduce the side stream also
+        # runs dlsg_comm_rehearsal over the bucket: `workgroups` x 256 threads streaming it `passes` times, i.e. the CUs and the
+        # HBM share a ring all-reduce over xGMI would hold while the backward goes on (values unchanged)
+        self.rehearse_cotenant = None
+        self.rehearse_ranks = int(rehearse_ranks)
         self._works = []
         self._graphs = None
-        self._guard_sent = False
         self._contact_checked = False
         self._hook_mode, self._hook_sv = False, None
         self.m = self.v = None
-        if world_size > 1 and hasattr(model.ops, 'persistent_bilstm_bwd'):
-            # The persistent BiLSTM kernels need all of their workgroups (one per CU at H = 1024, 152 KB of LDS each) resident
-            # together.  The encoder's backward runs while the decoder bucket's all-reduce is in flight: a CU that hosts an
-            # RCCL workgroup has no room for a 152-KB one, so the launch would sit half-resident, its workgroups polling for
-            # partners that cannot start, until the collective ends -- no deadlock (RCCL does not depend on it), but the CUs
-            # it holds and the overlap window are lost.  With several ranks the backward through time therefore runs step by
-            # step (0.60 against 0.50 ms); the forward keeps the persistent launch (no collective is in flight there: the
-            # previous step's all-reduces are joined before its Adam).
-            model.ops.persistent_bilstm_bwd = False
-        if world_size > 1:
-            # The stream-K GEMM (csrc/gemm_sk.hip) is one workgroup per CU with the whole register file of its SIMDs: a CU that hosts
-            # a wave of an RCCL kernel cannot take one, so the launch's last workgroups would start only when the first ones leave --
-            # up to twice the time for every product that overlaps a bucket's all-reduce, which is most of the backward.  The tiled
-            # kernels' small workgroups fill around a collective gracefully.  Forward products (no collective in flight: the previous
-            # step's buckets are joined before its Adam) keep the stream-K launches.  Unmeasured on hardware like the rest of N > 1;
-            # `model.stream_k_in_backward = True` after construction switches it back.
-            model.stream_k_in_backward = False
+        if world_size > 1 or self.rehearse_ranks > 1:
+            assert world_size == 1 or not self.rehearse_ranks, 'rehearse_ranks is for one-rank runs'
+            self._use_multi_rank_schedule()
+            self.force_collectives = self.force_collectives or self.rehearse_ranks > 1
         self._bind()
+
+    # CUs a bucket's all-reduce holds while the backward runs beside it: RCCL launches one 256-thread workgroup per channel (up
+    # to 32 on this part).  What a stream-K launch would be budgeted to leave free (`model.sk_backward_cu_budget = cus - COMM_CUS`).
+    COMM_CUS = 32
+
+    def _use_multi_rank_schedule(self):
+        """The kernel choices of a rank that shares its GPU with gradient all-reduces (set once, at construction, for
+        world_size > 1 and for one-GPU rehearsals of it; run_gun.py:63-64 leaves all of this to DDP + NCCL).
+        * The persistent BiLSTM kernels need all of their workgroups (one per CU at H = 1024, 152 KB of LDS each) resident
+          together.  The encoder's backward runs while the decoder bucket's all-reduce is in flight: a CU that hosts an RCCL
+          workgroup has no room for a 152-KB one, so the launch would sit half-resident, its workgroups polling for partners that
+          cannot start, until the collective ends -- no deadlock (RCCL does not depend on it), but the CUs it holds and the overlap
+          window are lost.  The backward through time therefore runs step by step (0.60 against 0.50 ms); the forward keeps the
+          persistent launch (no collective is in flight there: the previous step's all-reduces are joined before its Adam).
+        * The stream-K GEMM (csrc/gemm_sk.hip) is one workgroup per CU with the whole register file of its SIMDs, so beside a
+          collective its last workgroups start only when CUs come free.  Round 5 put the backward on the tiled kernels for that
+          reason, unmeasured.  Round 6 measured it (bench.py `dp_schedule_world1`, DESIGN.md section 6: this schedule on one GPU
+          with a co-tenant of RCCL's launch shape -- 32 x 256 threads streaming every bucket for the ~1.1 ms per 180 MB an 8-rank
+          ring takes -- on the side stream): stream-K on every CU 14.79 ms per step, tiled backward 15.07, stream-K on a budget
+          of 224 workgroups (the 32 CUs left free) 15.33; batch 128: 24.17 / 25.39 / 25.10; without the co-tenant 12.99 / 13.38 /
+          13.49 against 12.93 for the one-rank schedule.  The kernel never waits for a workgroup that has not started (shares
+          are given away, csrc/gemm_sk.hip), so a launch that is not co-resident is slower by what the co-tenant holds, not by a
+          round.  Hence: the backward KEEPS the stream-K launches, on every CU (`model.sk_backward_cu_budget = 0`); the budget
+          and `model.stream_k_in_backward = False` remain as switches."""
+        model = self.model
+        if hasattr(model.ops, 'persistent_bilstm_bwd'):
+            model.ops.persistent_bilstm_bwd = False
+        model.stream_k_in_backward = True
+        model.sk_backward_cu_budget = 0
 
     def _bind(self):
         """(Re)attach to the model's arenas: Adam moments, bucket ranges, trainable ranges.  Runs again whenever the model
@@ -828,19 +878,10 @@ class Trainer(object):
         mode = self._comm_mode()
         ranges = [r for k in (key if isinstance(key, tuple) else (key,)) for r in self._minus_frozen(*self._ranges[k])]
         views = [self.model._gflat[lo:hi] for lo, hi in ranges]
-        # the persistent kernels' time-out word rides with the step's FIRST bucket (max over the ranks): dlsg_adam's guard then
-        # skips the update on every rank or on none -- a rank skipping alone would leave the replicas diverged, its invalid
-        # gradients already summed into everybody's
-        word = None
-        if not self._guard_sent and self.world_size > 1:
-            word = getattr(self.model.ops, 'persist_word_or_none', lambda: None)()
-            self._guard_sent = True
         if mode == 'torch':
             import torch.distributed as dist
             for v in views:
                 self._works.append(dist.all_reduce(v, group=self.pg, async_op=True))
-            if word is not None:
-                self._works.append(dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
             return
         if mode == 'none':
             return
@@ -852,8 +893,35 @@ class Trainer(object):
         ev.record()
         side.wait_event(ev)
         comm.allreduce(views, side)
-        if word is not None:
-            comm.allreduce_max_word(word, side)
+        if self.rehearse_cotenant and self.world_size == 1:
+            co = self.rehearse_cotenant
+            with torch.cuda.stream(side):
+                for v in views:
+                    self.model.ops.comm_rehearsal(v, int(co.get('workgroups', self.COMM_CUS)), int(co['passes']))
+        self._comm_pending = True
+
+    def _reduce_guard(self):
+        """The persistent kernels' time-out word (BiLSTM, critic LSTM), max over the ranks, BEHIND the last launch of the backward
+        and in front of Adam: dlsg_adam's guard then skips the update on every rank or on none -- a rank skipping alone would leave
+        the replicas diverged, its invalid gradients already summed into everybody's.  (Until round 5 the word rode with the FIRST
+        bucket: a time-out in the encoder's backward, behind that bucket, was not agreed.)  Four bytes behind the step's last,
+        already exposed bucket on the same side stream."""
+        mode = self._comm_mode()
+        if mode == 'none':
+            return
+        word = getattr(self.model.ops, 'persist_word_or_none', lambda: None)()
+        if word is None:
+            return
+        if mode == 'torch':
+            import torch.distributed as dist
+            self._works.append(dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
+            return
+        comm = self._rccl_comm()
+        side = self._side_stream()
+        ev = torch.cuda.Event()
+        ev.record()
+        side.wait_event(ev)
+        comm.allreduce_max_word(word, side)
         self._comm_pending = True
 
     def _join_comm(self):
@@ -921,7 +989,6 @@ class Trainer(object):
         L = captions.shape[1]
         sv = {}
         training = model.training
-        self._guard_sent = False
         # a bucket handed to a reduction (or closing a graph segment) must be complete: deferred weight gradients go out there
         model._flush_at_buckets = self._comm_mode() != 'none' or self.force_graph_cuts
         model._engine_forward(frames, regions, captions, L, coins, training, seed, sv, dev_coins, outputs=False)
@@ -954,7 +1021,8 @@ class Trainer(object):
         model, ops = self.model, self.model.ops
         self._check_binding()
         captions = captions[:, :max_len].contiguous()
-        cap_lens = torch.as_tensor(cap_lens).to(device=captions.device, dtype=torch.int64)
+        if not (torch.is_tensor(cap_lens) and cap_lens.device == captions.device and cap_lens.dtype == torch.int64):
+            cap_lens = _h2d(cap_lens, torch.int64, captions.device)
         L = captions.shape[1]
         coins = model._draw_coins(L, False, tf_ratio)
         seed = model.next_seed()
@@ -975,9 +1043,10 @@ class Trainer(object):
             self.t += 1
         dev_coins = None
         if self.device_coins:
-            dev_coins = torch.tensor([int(c) for c in coins], dtype=torch.int32).to(captions.device)
+            dev_coins = _h2d([int(c) for c in coins], torch.int32, captions.device)
         self._works = []
         loss = self._schedule(frames, regions, captions, cap_lens, coins, seed, dev_coins, self._allreduce, extra_dlogits)
+        self._reduce_guard()
         for w in self._works:
             w.wait()
         self._join_comm()
@@ -993,7 +1062,7 @@ class Trainer(object):
                                  lens=cap_lens.clone(), coins=torch.ones(L, dtype=torch.int32, device=dev),
                                  seed=torch.zeros(1, dtype=torch.int64, device=dev),
                                  hyper=torch.zeros(2, dtype=torch.float32, device=dev))
-        side = torch.cuda.Stream(device=dev)
+        side = _capture_stream(dev)
         side.wait_stream(torch.cuda.current_stream())
         graphs = []
         mode = self._comm_mode()
@@ -1007,6 +1076,8 @@ class Trainer(object):
             #  nothing is updated: Adam is not part of the schedule)
             self._schedule(st['frames'], st['regions'], st['captions'], st['lens'], None, st['seed'], st['coins'],
                            self._allreduce if mode == 'rccl' else None)
+            if mode == 'rccl':
+                self._reduce_guard()
             self._join_comm()
             side.synchronize()
             if self._comm_stream is not None:
@@ -1047,6 +1118,7 @@ class Trainer(object):
                 if mode != 'torch':
                     # no host-issued collective between backward and update: Adam is part of the graph, behind the join of the
                     # side stream's collectives; with host-issued collectives it follows their waits
+                    self._reduce_guard()
                     self._join_comm()
                     self._adam(1, hyper=st['hyper'])
                 cur[0].capture_end()
@@ -1102,8 +1174,8 @@ class Trainer(object):
         for k, src in (('frames', frames), ('regions', regions), ('captions', captions)):
             if src.data_ptr() != st[k].data_ptr():
                 st[k].copy_(src, non_blocking=True)
-        st['coins'].copy_(torch.tensor([int(c) for c in coins], dtype=torch.int32), non_blocking=True)
-        st['seed'].copy_(torch.tensor([seed], dtype=torch.int64), non_blocking=True)
+        _copy_h2d(st['coins'], [int(c) for c in coins])
+        _copy_h2d(st['seed'], [seed])
         self._graphs[0][0].replay()
         logits_tm, sv = self._hook_sv
         # time_major: the logits as the decoder wrote them, (L,B,V) -- what the critic's schedule reads (gan.GanTrainer)
@@ -1151,9 +1223,9 @@ class Trainer(object):
         for k, src in (('frames', frames), ('regions', regions), ('captions', captions), ('lens', cap_lens)):
             if src.data_ptr() != st[k].data_ptr():
                 st[k].copy_(src, non_blocking=True)
-        st['coins'].copy_(torch.tensor([int(c) for c in coins], dtype=torch.int32), non_blocking=True)
-        st['seed'].copy_(torch.tensor([seed], dtype=torch.int64), non_blocking=True)
-        st['hyper'].copy_(torch.tensor(self._hyper(), dtype=torch.float32), non_blocking=True)
+        _copy_h2d(st['coins'], [int(c) for c in coins])
+        _copy_h2d(st['seed'], [seed])
+        _copy_h2d(st['hyper'], self._hyper())
         self._works = []
         for g, key in self._graphs:
             g.replay()
@@ -1165,6 +1237,7 @@ class Trainer(object):
             elif key is not None:
                 self._allreduce(key)
         if not self._adam_in_graph:
+            self._reduce_guard()
             for w in self._works:
                 w.wait()
             # same arithmetic as the captured Adam launch (bias corrections read from the device word the host just wrote),

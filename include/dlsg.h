@@ -20,8 +20,10 @@ extern "C" {
  * must refuse a library whose version differs from the header it was written against.  (4: the critic's per-op entry points --
  * dlsg_lstm_cell_*, dlsg_tanh_ln_*, dlsg_conv_taps, dlsg_softmax_bwd2, dlsg_gemm_narrow -- gave way to the blocks of its schedule,
  * dlsg_crit_* / dlsg_cln_*; dlsg_lstm_seq takes batch-major arrays.  5: dlsg_gemm_args carries a workspace and an error word for the
- * stream-K kernel, dlsg_gemm_ws_bytes added; dlsg_adam takes `guard` before the stream and dlsg_select_embed `prefilled`.) */
-#define DLSG_ABI_VERSION 7
+ * stream-K kernel, dlsg_gemm_ws_bytes added; dlsg_adam takes `guard` before the stream and dlsg_select_embed `prefilled`.
+ * 6: dlsg_gemm_args.err reserved, the stream-K kernel no longer waits.  7: dlsg_dec_tail_args samples the next word in the launch
+ * (`s_*`), dlsg_o2v_bwd_args.dysum.  8: dlsg_gemm_args.cu_budget (was padding), dlsg_comm_rehearsal.) */
+#define DLSG_ABI_VERSION 8
 int dlsg_abi_version(void);
 
 /* Return codes of every entry point that returns int: 0 or one of these. */
@@ -84,7 +86,11 @@ typedef struct {
 } dlsg_gemm_group;
 typedef struct {
     int32_t mode, M, N, ldc;
-    int32_t ngroups, nbatch, flags, pad_;
+    int32_t ngroups, nbatch, flags;
+    int32_t cu_budget;     /* 0 = the stream-K kernel launches one workgroup per CU; n > 0: at most n (rounded down to a multiple of
+                              8), leaving the other CUs to a co-tenant -- a collective's kernels on another stream.  A stream-K
+                              workgroup needs a whole CU, so without the budget its last workgroups would start only when the
+                              first ones leave.  The tiled kernels ignore it */
     int64_t bsa, bsb, bsc; /* batch strides in elements */
     float alpha;
     int32_t pad2_;
@@ -789,6 +795,11 @@ int dlsg_allreduce_buckets(dlsg_comm* c, float* const* grads, const int64_t* cou
 /* words[i] <- max over the ranks (int32), on `stream`: the persistent kernels' time-out word travels with the first gradient
  * bucket, so that dlsg_adam's guard skips the update on EVERY rank or on none. */
 int dlsg_allreduce_max_i32(dlsg_comm* c, int32_t* words, int64_t count, void* stream);
+/* Rehearsal instrument for one-GPU boxes (with one rank an all-reduce moves nothing): `workgroups` x 256 threads -- RCCL's launch
+ * shape -- stream buf[0..count) `passes` times, read-modify-write with a factor of 1.0f (values unchanged), on `stream`: the
+ * CUs and the HBM share a bucket's ring all-reduce would hold while the backward runs beside it.  No communicator involved;
+ * buf 16-B aligned. */
+int dlsg_comm_rehearsal(float* buf, int64_t count, int workgroups, int passes, void* stream);
 /* *code <- ncclCommGetAsyncError of the communicator (0 = no error); does not synchronise. */
 int dlsg_comm_async_error(dlsg_comm* c, int32_t* code);
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(hip.SYMBOLS) == names
-    assert lib.dlsg_abi_version() == hip.ABI_VERSION == 7
+    assert lib.dlsg_abi_version() == hip.ABI_VERSION == 8
 
 
 def test_struct_layouts_match_the_compiler():

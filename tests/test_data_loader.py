@@ -134,6 +134,21 @@ def test_resident_batch_gathers_into_given_buffers(tmp_path):
 
 
 @needs_h5
+def test_resident_store_from_arrays_equals_the_file_backed_one(tmp_path):
+    """ResidentFeatures.from_arrays (bench.py's `sustained` leg, synthetic stores): same rows, same object cut as the HDF5 store"""
+    fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
+    a = D.ResidentFeatures(fp, rp, 16, 'cpu')
+    b = D.ResidentFeatures.from_arrays(feats, vfeats, 16, 'cpu')
+    assert b.n == a.n and b.frame_shape == tuple(a.frame_shape) and b.region_shape == tuple(a.region_shape) and b.bytes == a.bytes
+    for ids in ([5, 0, 22], [1], list(range(a.n))[::-1]):
+        fa, ra = a.batch(ids)
+        fb, rb = b.batch(ids)
+        assert torch.equal(fa, fb) and torch.equal(ra, rb)
+    with pytest.raises(ValueError):
+        D.ResidentFeatures.from_arrays(feats[0], vfeats, 16, 'cpu')
+
+
+@needs_h5
 def test_eval_loader_range_and_order(tmp_path):
     fp, rp, cp, feats, vfeats, *_ = make_dataset(tmp_path)
     fs = D.ResidentFeatures(fp, rp, 36, 'cpu')

@@ -2,17 +2,25 @@
 and 128, MSR-VTT-shaped batch 64).  At these sizes the dispatcher takes other kernels than on the two-clip goldens -- the
 persistent stream-K GEMM for the region projections and the deep weight gradients, 128-row skinny tiles, grouped K-split launches --
 so the reference-generated fixtures (B = 2) do not cover them.  The oracle (oracle/torch_ref.py, pinned to the reference by
-tests/test_oracle_golden.py) runs on the host's cores: ~10-20 s per forward + backward.
+tests/test_oracle_golden.py) runs on the host's cores: ~10-20 s per forward + backward; its results are computed once per
+configuration and shared by the schedules below.
 
 Compared (run_gun.py:183-198 semantics, dropout off so that both sides see the same arithmetic):
   * teacher-forced logits: max |dlogit| <= 1e-3 (north_star), the proposals and attention weights likewise;
   * greedy ids: bit-exact;
   * CrossEntropy over the ragged rows: |dloss| <= 1e-3; every parameter's gradient norm within 5e-3 relative;
   * the same under scheduled sampling (tf = 0.6, random.seed(12): 11 of 26 steps feed their own argmax).
+
+Two schedules of the train step are held to that:
+  * `one_rank`: what `python bench.py` times (kernel by kernel here);
+  * `dp_rank`: the step as ONE RANK OF A DATA-PARALLEL JOB runs it (run_gun.py:63-64,181-234; BASELINE configs[2], [3]) --
+    `Trainer(rehearse_ranks=8)`: the BiLSTM backward step by step, weight gradients flushed at every bucket, every bucket handed to the RCCL communicator (world
+    1 on this box) INSIDE the captured step, Adam behind the join -- one hipGraph replay.  A second variant adds the co-tenant
+    kernel of an all-reduce's shape on the side stream (dlsg_comm_rehearsal): gradients must not change by a bit.
 """
+import functools
 import random
 
-import numpy as np
 import pytest
 import torch
 
@@ -29,11 +37,13 @@ def _grad_norms_oracle(orc, frames, regions, caps, lens, tf, R):
     out = orc(frames, regions, caps, 26, tf)
     loss = R.ragged_ce(out[0], caps, lens)
     loss.backward()
-    return out, float(loss.detach()), {k: (float(p.grad.double().norm()) if p.grad is not None else None) for k, p in orc.named_parameters()}
+    return [o.detach() for o in out], float(loss.detach()), \
+        {k: (float(p.grad.double().norm()) if p.grad is not None else None) for k, p in orc.named_parameters()}
 
 
-@pytest.mark.parametrize('shape,B', [('msvd', 64), ('msvd', 128), ('msrvtt', 64)])
-def test_bench_configuration_against_the_oracle(shape, B):
+@functools.lru_cache(maxsize=None)
+def _case(shape, B):
+    """weights, inputs and everything the oracle says about them (teacher-forced, scheduled sampling, greedy ids)"""
     from oracle import torch_ref as R
     args = msvd_shaped() if shape == 'msvd' else msrvtt_shaped()
     V = 1000 if shape == 'msvd' else 10000
@@ -41,58 +51,119 @@ def test_bench_configuration_against_the_oracle(shape, B):
     torch.manual_seed(0)
     net = dlsg_amd.CapGnnModel(args, vocab).eval()
     sd = synth_state_dict(net.state_dict(), 11)
-    net.load_state_dict(sd)
     orc = R.CapGnnModelRef(args, vocab).eval()
     orc.load_state_dict(sd)
     frames, regions, caps, lens = synth_batch(args, V, B, 12)
-    net = net.cuda()
+    tf = _grad_norms_oracle(orc, frames, regions, caps, lens, 1.0, R)
+    random.seed(12)
+    ss = _grad_norms_oracle(orc, frames, regions, caps, lens, 0.6, R)
+    orc.update_beam_size(1)
+    with torch.no_grad():
+        ids = orc(frames, regions, None)[0]
+    return dict(args=args, vocab=vocab, sd=sd, batch=(frames, regions, caps, lens), tf=tf, ss=ss, ids=ids)
+
+
+def _net(c):
+    torch.manual_seed(0)
+    net = dlsg_amd.CapGnnModel(c['args'], c['vocab']).eval()
+    net.load_state_dict(c['sd'])
+    return net.cuda()
+
+
+def _trainer(net, schedule):
+    if schedule == 'one_rank':
+        return dlsg_amd.Trainer(net)
+    tr = dlsg_amd.Trainer(net, use_graphs=True, rehearse_ranks=8)
+    # exactly what model.Trainer._use_multi_rank_schedule sets for world_size > 1
+    assert tr.force_collectives and net.ops.persistent_bilstm_bwd is False and net.stream_k_in_backward
+    assert net.sk_backward_cu_budget == 0
+    if schedule == 'dp_rank_cotenant':
+        tr.rehearse_cotenant = dict(workgroups=32, passes=2)
+    if schedule == 'dp_rank_cu_budget':
+        # the stream-K launches of the backward on the CUs a collective leaves free (dlsg_gemm_args.cu_budget): measured slower than
+        # all CUs, kept as a switch -- and held to the same parity
+        cus = net.ops.device_cus()
+        assert cus > tr.COMM_CUS
+        net.sk_backward_cu_budget = cus - tr.COMM_CUS
+    return tr
+
+
+def _check_step(net, c, schedule, tf, want_loss, want_gn, tag):
+    frames, regions, caps, lens = c['batch']
+    fg, rg, cg = frames.cuda(), regions.cuda(), caps.cuda()
+    net.load_state_dict({k: v.cuda() for k, v in c['sd'].items()})
+    tr = _trainer(net, schedule)
+    loss = float(tr.step(fg, rg, cg, lens, tf))
+    if schedule != 'one_rank':
+        info = tr.collectives_info()
+        assert len(tr._graphs) == 1 and tr._adam_in_graph and info['where'] == "inside the step's hipGraph", info
+        assert tr._rccl is not None and tr._rccl.world == 1
+    assert abs(loss - want_loss) <= 1e-3, (tag, loss, want_loss)
+    G = net.grad_views()
+    worst = 0.0
+    for k, ref in want_gn.items():
+        gn = float(G[k].double().norm())
+        if ref is None:
+            assert gn == 0.0, (tag, k)
+            continue
+        rel = abs(gn - ref) / max(ref, 1e-12)
+        worst = max(worst, rel)
+        assert rel <= 5e-3, (tag, k, gn, ref)
+    tr.check()
+    flat = net._gflat.clone()
+    tr.close()
+    return flat
+
+
+@pytest.mark.parametrize('shape,B', [('msvd', 64), ('msvd', 128), ('msrvtt', 64)])
+def test_bench_configuration_against_the_oracle(shape, B):
+    c = _case(shape, B)
+    frames, regions, caps, lens = c['batch']
+    net = _net(c)
     fg, rg, cg = frames.cuda(), regions.cuda(), caps.cuda()
 
     # ---- teacher-forced forward
-    want, want_loss, want_gn = _grad_norms_oracle(orc, frames, regions, caps, lens, 1.0, R)
+    want, want_loss, want_gn = c['tf']
     with torch.no_grad():
         got = net(fg, rg, cg, 26, 1.0)
-    err = (got[0].cpu() - want[0].detach()).abs().max().item()
+    err = (got[0].cpu() - want[0]).abs().max().item()
     assert err <= 1e-3, ('logits', err)
-    assert (got[1].cpu() - want[1].detach()).abs().max().item() <= 1e-3 and (got[2].cpu() - want[2].detach()).abs().max().item() <= 1e-3
-    assert (got[3].cpu() - want[3].detach()).abs().max().item() <= 1e-3
+    assert (got[1].cpu() - want[1]).abs().max().item() <= 1e-3 and (got[2].cpu() - want[2]).abs().max().item() <= 1e-3
+    assert (got[3].cpu() - want[3]).abs().max().item() <= 1e-3
 
     # ---- greedy ids
-    orc.update_beam_size(1)
     net.update_beam_size(1)
     with torch.no_grad():
-        ids_want = orc(frames, regions, None)[0]
         ids_got = net(fg, rg, None)[0].cpu()
-    assert torch.equal(ids_got, ids_want), int((ids_got != ids_want).sum())
+    assert torch.equal(ids_got, c['ids']), int((ids_got != c['ids']).sum())
 
-    # ---- loss and gradients of one step (the trainer's own schedule: hipGraph replay, fused CE, Adam behind it)
-    def check_step(tf, want_loss, want_gn, tag):
-        net.load_state_dict({k: v.cuda() for k, v in sd.items()})
-        tr = dlsg_amd.Trainer(net)
-        loss = float(tr.step(fg, rg, cg, lens, tf))
-        assert abs(loss - want_loss) <= 1e-3, (tag, loss, want_loss)
-        G = net.grad_views()
-        worst = 0.0
-        for k, ref in want_gn.items():
-            gn = float(G[k].double().norm())
-            if ref is None:
-                assert gn == 0.0, (tag, k)
-                continue
-            rel = abs(gn - ref) / max(ref, 1e-12)
-            worst = max(worst, rel)
-            assert rel <= 5e-3, (tag, k, gn, ref)
-        tr.close() if hasattr(tr, 'close') else None
-        return worst
-
-    check_step(1.0, want_loss, want_gn, 'teacher-forced')
+    # ---- loss and gradients of one step (the trainer's own schedule: fused CE, Adam behind it)
+    _check_step(net, c, 'one_rank', 1.0, want_loss, want_gn, 'teacher-forced')
 
     # ---- scheduled sampling: the coin order of random.seed(12) on both sides (models/layer.py:432)
-    random.seed(12)
-    want_ss, want_loss_ss, want_gn_ss = _grad_norms_oracle(orc, frames, regions, caps, lens, 0.6, R)
-    net.load_state_dict({k: v.cuda() for k, v in sd.items()})            # (the trainer's Adam step above moved the weights)
+    want_ss, want_loss_ss, want_gn_ss = c['ss']
+    net.load_state_dict({k: v.cuda() for k, v in c['sd'].items()})            # (the trainer's Adam step above moved the weights)
     random.seed(12)
     with torch.no_grad():
         got_ss = net(fg, rg, cg, 26, 0.6)[0].cpu()
-    assert (got_ss - want_ss[0].detach()).abs().max().item() <= 1e-3
+    assert (got_ss - want_ss[0]).abs().max().item() <= 1e-3
     random.seed(12)
-    check_step(0.6, want_loss_ss, want_gn_ss, 'scheduled sampling')
+    _check_step(net, c, 'one_rank', 0.6, want_loss_ss, want_gn_ss, 'scheduled sampling')
+
+
+@pytest.mark.parametrize('shape,B', [('msvd', 64), ('msvd', 128), ('msrvtt', 64)])
+def test_data_parallel_rank_schedule_against_the_oracle(shape, B):
+    """configs[2] / [3]'s per-GPU step AS A RANK RUNS IT, replayed from one hipGraph with the RCCL calls inside"""
+    c = _case(shape, B)
+    want, want_loss, want_gn = c['tf']
+    net = _net(c)
+    g_plain = _check_step(net, c, 'dp_rank', 1.0, want_loss, want_gn, 'dp rank, teacher-forced')
+    # a co-tenant of an all-reduce's shape on the side stream under the backward: same gradients, bit for bit
+    net2 = _net(c)
+    g_co = _check_step(net2, c, 'dp_rank_cotenant', 1.0, want_loss, want_gn, 'dp rank + co-tenant')
+    assert torch.equal(g_plain, g_co)
+    if (shape, B) == ('msvd', 64):
+        _check_step(_net(c), c, 'dp_rank_cu_budget', 1.0, want_loss, want_gn, 'dp rank, stream-K on a CU budget')
+    want_ss, want_loss_ss, want_gn_ss = c['ss']
+    random.seed(12)
+    _check_step(net, c, 'dp_rank', 0.6, want_loss_ss, want_gn_ss, 'dp rank, scheduled sampling')

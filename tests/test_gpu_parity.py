@@ -34,7 +34,7 @@ def build(tag, fused=True):
 def test_native_library_is_what_runs():
     from dlsg_amd.hip import HipOps, LIB_PATH, ABI_VERSION
     ops = HipOps()
-    assert ops.lib.dlsg_abi_version() == ABI_VERSION == 7
+    assert ops.lib.dlsg_abi_version() == ABI_VERSION == 8
     with open('/proc/self/maps') as f:
         assert 'libdlsg_hip.so' in f.read(), LIB_PATH
 
