@@ -304,6 +304,7 @@ __global__ __launch_bounds__(DT) void dec_tail_fwd_kernel(const dlsg_dec_tail_ar
     if (threadIdx.x == 0) {
         for (int k = 1; k < DT / 64; ++k)
             if (red[k] > best || (red[k] == best && s_bi[k] < bidx)) { best = red[k]; bidx = s_bi[k]; }
+        if (bidx == 0x7fffffff) bidx = 0;       // a row without a maximum (all NaN / -inf): word 0, never an out-of-range gather below
         s_chosen = bidx;
         a.s_ids[b] = bidx;
     }

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; ++k)
             if (bv[k] > best || (bv[k] == best && bi[k] < idx)) { best = bv[k]; idx = bi[k]; }
-        ids[r] = idx;
+        ids[r] = idx == 0x7fffffff ? 0 : idx;            // no maximum (a row of NaN / -inf): 0, as torch.argmax gives for -inf rows
     }
 }
 
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void select_embed_kernel(const float* __restri
         if (threadIdx.x == 0) {
             for (int k = 1; k < 4; ++k)
                 if (bv[k] > best || (bv[k] == best && bi[k] < idx)) { best = bv[k]; idx = bi[k]; }
-            chosen = idx;
+            chosen = idx == 0x7fffffff ? 0 : idx;        // no maximum (a row of NaN / -inf): word 0, not an out-of-range row of E
         }
     }
     __syncthreads();

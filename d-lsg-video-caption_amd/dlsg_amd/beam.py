@@ -31,7 +31,7 @@ def beam_device(model, visual_feats, region_feats, early_exit=True):
     BeamGraph captures into a hipGraph.  Returns the tensors beam_finish needs."""
     model.flatten_parameters_()
     ops, dec = model.ops, model.decoder
-    ops.extra_flags = model._gemm_flags(False)
+    model._gemm_policy(False)
     k = dec.beam_size
     seed = model.next_seed()
     sv = {}
@@ -49,6 +49,19 @@ def beam_device(model, visual_feats, region_feats, early_exit=True):
         enc = E.encvis_fwd(ops, model.encoder, 'encoder', frames.view(B0 * T, F), B0, T, sv, False, seed)
         enc = enc.view(B0, T, -1)
         mems, sv['dec_gsrc'] = [enc], [enc]
+    extras = (sv['dec_gsrc'][0], sv['dec_gsrc'][-1]) if hasattr(model, '_encode') else None
+    return beam_search_from(model, mems, sv, seed, early_exit, extras)
+
+
+@torch.no_grad()
+def beam_search_from(model, mems, sv, seed, early_exit=True, extras=None):
+    """The search itself from given attended memories (`mems`: the proposals of the encoder streams, or whatever a caller of
+    `Decoder.forward` hands in -- models/layer.py:449-455 builds its start state from `cnn_feats` / `cnn_feats_2` / `global_feat`
+    the same way); `sv['dec_gsrc']` are the tensors whose row means form the global feature, `sv['step_feats']` replaces them
+    (layer.py:404-405)."""
+    ops, dec = model.ops, model.decoder
+    k = dec.beam_size
+    frames = mems[0]                                   # (reference tensor for device / dtype of the scratch arrays)
     s = E.dec_prepare(ops, dec, mems, sv, False, seed)
     B = frames.shape[0]
     V = dec.vocab_size
@@ -102,7 +115,6 @@ def beam_device(model, visual_feats, region_feats, early_exit=True):
         cur, nxt = lps[t % 2], lps[(t + 1) % 2]
         ops.beam_select(s['LOGITS'][t], preds[t - 1], cur, preds[t], nxt, backs[t], rows, k, end, ended_count=ended[t:t + 1])
         done = t + 1
-    extras = (sv['dec_gsrc'][0], sv['dec_gsrc'][-1]) if hasattr(model, '_encode') else None
     return preds, backs, lps, ended, done, B, k, R, L, extras
 
 

@@ -516,8 +516,9 @@ class GanTrainer(object):
         out.pop('cap_loss_dev')
         check = getattr(model.ops, 'check_persistent', None)
         if check is not None:
-            code = int(vals[4]) if word is not None else None
-            if self.world_size > 1 and code is not None:
+            code = int(vals[4]) if word is not None else 0
+            if self.world_size > 1:
+                # (every rank takes part, whether or not one of its own kernels ever created the word)
                 from .comm import _agree_min
                 code = _agree_min(code, self.trainer.pg, negate=True)      # every rank raises, or none
             try:

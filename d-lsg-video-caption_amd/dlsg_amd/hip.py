@@ -1052,6 +1052,8 @@ class HipOps(object):
             w = self._persist_err = torch.zeros(1, dtype=torch.int32, device=dev)
         return w
 
+    guard_word = _persist_word        # (public name: the word a Trainer with several ranks max-reduces in front of Adam)
+
     def persist_word_or_none(self):
         """the time-out word (int32 device tensor) if a persistent kernel ran in this process: a caller that reads scalars back
         anyway appends it to that read and hands the value to `check_persistent(code=...)` -- one host synchronisation, not two"""

@@ -909,9 +909,12 @@ class Trainer(object):
         mode = self._comm_mode()
         if mode == 'none':
             return
-        word = getattr(self.model.ops, 'persist_word_or_none', lambda: None)()
-        if word is None:
+        # (the word is created here if no persistent kernel has run yet: whether a rank takes part in this collective must not
+        #  depend on what its kernels happened to do)
+        mk = getattr(self.model.ops, 'guard_word', None)
+        if mk is None:
             return
+        word = mk(self.model._flat.device)
         if mode == 'torch':
             import torch.distributed as dist
             self._works.append(dist.all_reduce(word, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))

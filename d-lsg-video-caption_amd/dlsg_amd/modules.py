@@ -182,18 +182,18 @@ class Decoder(nn.Module):
         logits + attention weights, or greedy ids when `captions` is None, from given proposals; `step_feats` (B, G) replaces
         the means of the proposals as the global feature (layer.py:404-405; as there, a non-multi-modal decoder then attends
         over `cnn_feats` alone).  Forward only (the gradients of the path go through the model's autograd bridge); needs the
-        owning model's kernel binding, so the decoder must belong to one of dlsg_amd's models.  Beam search: model.forward."""
+        owning model's kernel binding, so the decoder must belong to one of dlsg_amd's models.  With `captions` None and
+        beam_size != 1 the reference's decoder runs its beam search itself (layer.py:449-460): so does this one
+        (`beam.beam_search_from` with the given proposals), returning (ids of the best beam, [])."""
         from . import engine as E
         model = self._owner() if getattr(self, '_owner', None) is not None else None
         if model is None:
             raise RuntimeError('Decoder.forward needs the model that owns this decoder (its HIP binding and parameter arena)')
         infer = captions is None
-        if infer and self.beam_size != 1:
-            raise NotImplementedError('beam search runs through the model (dlsg_amd.beam.beam_infer); update_beam_size(1) for greedy ids')
         L = self.max_words if max_words is None else max_words
         model.flatten_parameters_()
         ops = model.ops
-        ops.extra_flags = model._gemm_flags(False)
+        model._gemm_policy(False)
         feats1 = cnn_feats.contiguous().float()
         feats2 = cnn_feats_2.contiguous().float() if cnn_feats_2 is not None else None
         sv = {'dec_gsrc': [feats1] + ([feats2] if feats2 is not None else [])}
@@ -205,6 +205,10 @@ class Decoder(nn.Module):
             mems = [torch.cat([feats1, feats2], 1)]          # layer.py:412-413
         else:
             mems = [feats1]
+        if infer and self.beam_size != 1:
+            # layer.py:449-460 (the search always runs self.max_words steps: BeamSearch(max_steps=max_words) is built in __init__)
+            from .beam import beam_search_from, beam_finish
+            return beam_finish(model, *beam_search_from(model, mems, sv, model.next_seed(), early_exit=True))[0], []
         coins = model._draw_coins(L, infer, teacher_forcing_ratio)
         with torch.no_grad():
             s = E.dec_fwd(ops, self, mems, sv, captions, L, coins, self.training and not infer, model.next_seed())

@@ -655,7 +655,30 @@ class EmulOps(CriticEmul):
     def log_softmax(self, logits, out):
         out.copy_(torch.log_softmax(logits, 1))
 
+    # the persistent kernels' time-out word and dlsg_adam's guard (hip.HipOps._persist_word / check_persistent): no emulated kernel
+    # ever times out; tests set the word by hand to drive the N > 1 agreement logic of dlsg_amd.Trainer
+    def _persist_word(self, dev=None):
+        if getattr(self, '_persist_err', None) is None:
+            self._persist_err = torch.zeros(1, dtype=torch.int32)
+        return self._persist_err
+
+    guard_word = _persist_word
+
+    def persist_word_or_none(self):
+        return getattr(self, '_persist_err', None)
+
+    def check_persistent(self, code=None):
+        w = getattr(self, '_persist_err', None)
+        if w is None:
+            return
+        code = int(w.item()) if code is None else code
+        if code:
+            w.zero_()
+            raise RuntimeError('persistent kernel hand-off timed out (code %d)' % code)
+
     def adam(self, p, g, m, v, lr, b1, b2, eps, step, grad_scale=1.0, hyper=None):
+        if int(self._persist_word().item()) != 0:
+            return                      # dlsg_adam(..., guard): a step whose recurrence timed out does not update the weights
         gi = g * grad_scale
         m.mul_(b1).add_(gi, alpha=1 - b1)
         v.mul_(b2).addcmul_(gi, gi, value=1 - b2)

@@ -1010,6 +1010,24 @@ def test_movers_embed_argmax(hip):
     both(hip, build, run, ['out', 'dx', 'we', 'dE', 'am', 'dst', 'dro', 'f'], tol=1e-5, name='movers')
 
 
+def test_argmax_of_rows_without_a_maximum_is_word_zero(hip):
+    """a logit row of all NaN / all -inf has no maximum: the kernels answer 0 (torch.argmax's answer for -inf rows) and gather
+    row 0 of the embedding -- never an id outside the vocabulary (the id indexes E in the same launch)"""
+    lg = torch.randn(4, 300, device='cuda')
+    lg[1] = float('nan')
+    lg[2] = float('-inf')
+    am = torch.full((4,), -1, dtype=torch.int64, device='cuda')
+    hip.argmax(lg, am)
+    want = lg.argmax(1)
+    assert am[0] == want[0] and am[3] == want[3] and am[1] == 0 and am[2] == 0
+    E = torch.randn(300, 20, device='cuda')
+    ids = torch.full((4,), -1, dtype=torch.int64, device='cuda')
+    out = torch.zeros(4, 20, device='cuda')
+    hip.select_embed(lg, torch.zeros(4, 26, dtype=torch.int64, device='cuda'), 0, torch.zeros(26, dtype=torch.int32, device='cuda'), E, ids, out)
+    torch.cuda.synchronize()
+    assert torch.equal(ids, am) and torch.equal(out, E[am])
+
+
 @pytest.mark.parametrize('tm', [True, False])
 def test_ce_ragged_and_log_softmax(hip, tm):
     B, L, V = 5, 26, 61

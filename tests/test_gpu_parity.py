@@ -117,6 +117,24 @@ def test_decoder_forward_with_step_feats():
         assert np.abs(logits2.cpu().numpy() - g['logits']).max() <= LOGIT_TOL
 
 
+def test_decoder_forward_beam_branch_on_its_own():
+    """models/layer.py:449-460: the decoder called on its own with beam_size != 1 searches itself -- best-beam ids of the
+    reference's decoder from the encoder's proposals, with and without `step_feats` (tests/golden/small_decbeam.npz)"""
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    fx = dict(np.load(os.path.join(here, 'small_decbeam.npz')))
+    step = torch.from_numpy(np.load(os.path.join(here, 'small_stepfeats.npz'))['step_feats']).cuda()
+    with torch.no_grad():
+        obj, mot = net._encode(frames, regions, False, net.next_seed(), {})
+        for k in (3, 5):
+            net.update_beam_size(k)
+            ids, alphas = net.decoder(obj, None, None, 1.0, cnn_feats_2=mot)
+            assert alphas == [] and np.array_equal(ids.cpu().numpy(), fx['beam%d_ids' % k])
+            ids, _ = net.decoder(obj, None, None, 1.0, cnn_feats_2=mot, step_feats=step)
+            assert np.array_equal(ids.cpu().numpy(), fx['beam%d_ids_stepfeats' % k])
+            assert np.array_equal(net(frames, regions, None)[0].cpu().numpy(), fx['beam%d_ids' % k])
+
+
 @pytest.mark.parametrize('tag', SMALL)
 def test_beam5_ids_bit_exact(tag):
     net, g, frames, regions, caps, lens, kind = build(tag)

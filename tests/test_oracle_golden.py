@@ -218,3 +218,21 @@ def test_decoder_forward_with_step_feats():
         net.update_beam_size(1)
         ids, _ = R.decoder_forward(net.decoder, obj, None, 26, 1.0, feats2=mot, step_feats=step)
         assert np.array_equal(ids.numpy(), fx['greedy_ids'])
+
+
+def test_decoder_forward_beam_branch_on_its_own():
+    """models/layer.py:449-460: `Decoder.forward(cnn_feats, None, ...)` with beam_size != 1 runs the beam search itself -- the
+    oracle's decoder against the reference's (tests/golden/small_decbeam.npz, make_goldens_r6.py), with and without `step_feats`"""
+    import os
+    net, g, frames, regions, caps, lens, kind = build('small_msvd')
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    fx = dict(np.load(os.path.join(here, 'small_decbeam.npz')))
+    step = torch.from_numpy(np.load(os.path.join(here, 'small_stepfeats.npz'))['step_feats'])
+    with torch.no_grad():
+        obj, mot = R.capgnn_encoder(net.encoder, frames, regions)
+        for k in (3, 5):
+            net.update_beam_size(k)
+            ids, _ = R.decoder_forward(net.decoder, obj, None, None, 1.0, feats2=mot)
+            assert np.array_equal(ids.numpy(), fx['beam%d_ids' % k])
+            ids, _ = R.decoder_forward(net.decoder, obj, None, None, 1.0, feats2=mot, step_feats=step)
+            assert np.array_equal(ids.numpy(), fx['beam%d_ids_stepfeats' % k])
