@@ -243,7 +243,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& p) {
 
 // Two entry points over one body: the 128 x 128 tile is compiled for 3 waves per SIMD (<= 170 registers; the compiler's
 // own choice is 182-196, i.e. two workgroups per CU): measured +7 % on the region projection and +11 % on deep TN
-// products (tools/gemm_fp32_probe.py); the 64 x 64 tile already fits 3-4 waves and keeps the compiler's allocation.
+// products (tools/archive/gemm_fp32_probe.py); the 64 x 64 tile already fits 3-4 waves and keeps the compiler's allocation.
 template <int BM, int BN, bool AT, bool BT, int BK>
 __global__ __launch_bounds__(NT) void gemm_kernel(const KArgs p) { gemm_body<BM, BN, AT, BT, BK>(p); }
 template <int BM, int BN, bool AT, bool BT, int BK>
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NT) void skinny_kernel(const KArgs p) {
 //   * k order inside a stage: lane half h supplies k-segments 2q + h, the same for A and B.
 // Needs 16-B aligned, 4-float-strided operands and K % 4 == 0 (a partial last stage is masked after the read); anything
 // else goes to skinny_kernel.
-// Measured (tools/recurrent_gemm_bench.py, batch 64): query gates 21.5 us (first kernel 23.5), BiLSTM step 16.8 (18.8), language
+// Measured (tools/archive/recurrent_gemm_bench.py, batch 64): query gates 21.5 us (first kernel 23.5), BiLSTM step 16.8 (18.8), language
 // gates 30.4 (29.8).  What bounds it is NOT the pipeline: with every DMA address pinned to cache-hot lines AND the MFMAs
 // removed, the loop still takes 20 of the 30 us -- the per-CU global -> LDS path (~40 GB/s per CU in this access shape) has to
 // move 6 KB per 16 MFMAs at M = 64, two thirds of it the activations that every 32-column tile re-fetches.  An
@@ -823,15 +823,15 @@ static int gemm_plan(const dlsg_gemm_args* a, int64_t* m1_out) {
     // (gemm_sk.hip: no partly filled last round, no second launch for remaining rows, no slab fold for deep contractions; the rule
     // and the measurements behind it are in dlsg_gemm_sk_wanted)
     if (dlsg_gemm_sk_wanted(a)) return DLSG_GEMM_V_SK;
-    // measured on MI355X (tools/gemm_bench.py): the 128x128 tile only wins once it fills the chip several times over
+    // measured on MI355X (tools/archive/gemm_bench.py): the 128x128 tile only wins once it fills the chip several times over
     // (Wave quantisation is not what the 128-tile launches lose: giving that kernel whole 768-slot rounds only and the remaining
     // row panels to the 64-tile kernel was measured 1-3 % SLOWER on the region projection (4.33 rounds) and on the deep weight
-    // gradient (2.67 rounds), tools/gemm_split_probe.py -- workgroups of a partly filled last round simply run faster.)
+    // gradient (2.67 rounds), tools/archive/gemm_split_probe.py -- workgroups of a partly filled last round simply run faster.)
     if (tilesL >= 1000) {
         // 256 x 256 tiles (gemm_big.hip: one workgroup per CU, 64 flop per staged byte) for as many row panels as come in whole
         // rounds of the 256 CUs -- a launch that leaves its last round mostly empty loses more than the tile gains (region
         // projection as one launch of 832 tiles = 3.25 rounds: 108 TFLOP/s against 122 on the 128 x 128 tile, 135-142 per full
-        // round) -- and the remaining rows through this choice again.  tools/gemm_vs_rocblas.py, tools/gemm_census.py.
+        // round) -- and the remaining rows through this choice again.  tools/archive/gemm_vs_rocblas.py, tools/gemm_census.py.
         // (groups of different widths -- the decoder's weight-gradient blocks 4096 x {1024 x 10, 300} -- stay on the 128 tile: eight
         // of the full-width groups as two rounds of 256 tiles and the rest behind them measured 1 313 us against 1 305)
         bool plain = dlsg_gemm_big_ok(a) != 0;
@@ -851,14 +851,14 @@ static int gemm_plan(const dlsg_gemm_args* a, int64_t* m1_out) {
         }
         return DLSG_GEMM_V_128;
     }
-    // Mid-size launches (tools/gemm_tile_probe.py; M = 1664 = 26 frames x 64 clips and the weight gradients over them), when
+    // Mid-size launches (tools/archive/gemm_tile_probe.py; M = 1664 = 26 frames x 64 clips and the weight gradients over them), when
     // the 128-row panels waste < 10 % of their rows: the TN form takes the 128 x 128 tile from 500 tiles (2048 x 2048 x 1664 x 3
     // TN: 402 us against 445; NT / NN only from 1000), between 200 tiles and that a 128 x 64 tile (21 flop per staged byte instead of 16, twice the
     // workgroups of the square tile) wins 3-8 % over the 64 x 64 one; below that only the small tile fills the chip.
     const int padM = (a->M + 127) / 128 * 128;
     if ((padM - a->M) * 10 <= a->M) {
         // (500-999 tiles: only the TN form gains from the square tile -- 2048 x 2048 x 1664 x 3: 343 us against 354; the BiLSTM's
-        // input projection NT 1664 x 4096 x 1024 x 2 runs 264 us on 128 x 64 against 284, tools/gemm_mid_probe.py)
+        // input projection NT 1664 x 4096 x 1024 x 2 runs 264 us on 128 x 64 against 284, tools/archive/gemm_mid_probe.py)
         if (tilesL >= 500 && a->mode == 2) return DLSG_GEMM_V_128;       // (1024 x 1024 x 512 x 8 groups: 82 us against 100)
         if (tilesL >= 200) return DLSG_GEMM_V_128x64;
     }

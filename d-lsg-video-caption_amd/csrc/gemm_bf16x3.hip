@@ -247,7 +247,7 @@ __device__ __forceinline__ void gemm_x3_body(const KArgs& p) {
 
 // Two entry points over one body: the 128 x 128 tile is compiled for 3 waves per SIMD (<= 170 registers; the compiler's
 // own choice is 182-196, i.e. two workgroups per CU): measured +7 % on the region projection and +11 % on deep TN
-// products (tools/gemm_fp32_probe.py); the 64 x 64 tile already fits 3-4 waves and keeps the compiler's allocation.
+// products (tools/archive/gemm_fp32_probe.py); the 64 x 64 tile already fits 3-4 waves and keeps the compiler's allocation.
 template <int BM, int BN, bool AT, bool BT, int BK>
 __global__ __launch_bounds__(NT) void gemm_x3_kernel(const KArgs p) { gemm_x3_body<BM, BN, AT, BT, BK>(p); }
 template <int BM, int BN, bool AT, bool BT, int BK>
@@ -514,7 +514,7 @@ int dlsg_gemm_bf16x3_dispatch(const dlsg_gemm_args* a, hipStream_t st) {
     if (a->flags & DLSG_GEMM_FORCE64) return launch<64, 64, 64>(a, st);
     if (a->flags & DLSG_GEMM_FORCE128) return launch<128, 128, 32>(a, st);
     if (a->M <= 64 && a->mode != 2 && a->N >= 64) return launch_skinny_x3(a, st);
-    // measured (tools/gemm_bench.py): the 128x128 tile wins only once it fills the chip several times over
+    // measured (tools/archive/gemm_bench.py): the 128x128 tile wins only once it fills the chip several times over
     if (tilesL >= 1000) return launch<128, 128, 32>(a, st);
     return launch<64, 64, 64>(a, st);
 }

@@ -4,7 +4,7 @@
 //
 // Why a second tile family: the 128 x 128 kernel of gemm.hip stages 32 flop per operand byte through LDS with two barriers
 // per 32-deep K tile and leans on three workgroups per CU to cover them; on the step's largest launches it runs at 111-122
-// TFLOP/s where the vendor library's 256 x 256 kernel reaches 136-138 (tools/gemm_vs_rocblas.py).  Here:
+// TFLOP/s where the vendor library's 256 x 256 kernel reaches 136-138 (tools/archive/gemm_vs_rocblas.py).  Here:
 //   * 4 waves as 2 x 2, each wave a 128 x 128 (or 128 x 64) block of the tile = 16 (8) accumulators of 32 x 32: one LDS
 //     fragment feeds four MFMAs, 64 flop per staged byte;
 //   * stage = 32 k of both operands, filled by LDS-DMA (`global_load_lds_dwordx4`, no staging registers, no ds_write) into

@@ -181,7 +181,7 @@ class CriticEngine(object):
         ops.crit_relu_taps(h, h, p['bc'], 0.3, x1, taps)                       # ResBlock: in-place ReLU feeds the skip too
         ops.gemm(GEMM_NT, [(taps.view(R, 3 * C), p['Wc'], x1.view(R, C))], alpha=0.3, flags=F_ACCUM)
         xin = b['xin'][:nf]
-        # (tiles: tools/critic_gemm_probe.py on an MI355X -- 4992 x 2048 x 512: 107 us on 64 x 64 tiles, 124 on the dispatcher's choice)
+        # (tiles: tools/archive/critic_gemm_probe.py on an MI355X -- 4992 x 2048 x 512: 107 us on 64 x 64 tiles, 124 on the dispatcher's choice)
         ops.gemm(GEMM_NT, [(x1.view(R, C), p['W_ih'], xin.view(R, 4 * C))], flags=F_FORCE64 if R >= 4096 else 0)
         ops.lstm_seq_fwd(xin, p['W_hh'], p['b_ih'], p['b_hh'], b['As'][:nf], b['Hs'][:nf], b['Cs'][:nf], b['Hprev'][:nf])
         y = b['y'][:nf]
@@ -353,7 +353,7 @@ class CriticEngine(object):
     def _tn(self, ws, key, items, alpha=1.0):
         """out = alpha A^T B for every (A (K, M), B (K, N), out) of `items` (same shapes) in ONE launch.  A weight gradient of the
         critic has few output tiles (512 x 512 .. 2048 x 512) and a deep contraction (K = every caption row): the K rows go to
-        `ns` groups of the launch, each writing its own slab, folded in a fixed order by slab_reduce (tools/critic_gemm_probe.py on
+        `ns` groups of the launch, each writing its own slab, folded in a fixed order by slab_reduce (tools/archive/critic_gemm_probe.py on
         an MI355X: 512 x 512 x 6656: 147 us as one group, 50 us with 4; 512 x 1536 x 6656: 151 -> 108 us with 8)"""
         ops = self.D.ops
         A0, B0, _ = items[0]

@@ -263,7 +263,7 @@ class CapGnnModel(_HipModel):
                            regions, sv, pre)
         # the region projections (the step's longest launch) go HERE, behind the frame path's matrix kernels, not first in the
         # step: directly behind the previous step's Adam -- 0.5 ms of pure memory traffic -- the same launch takes 11 % longer
-        # (1 722 us against 1 555 back to back, tools/sk_sequence_probe.py: the clock the chip holds, not the caches)
+        # (1 722 us against 1 555 back to back, tools/archive/sk_sequence_probe.py: the clock the chip holds, not the caches)
         ys = [None, None]
         if regions.shape[2] >= 5 and enc.obj_encoder.obj_embed.weight.shape == enc.motion_encoder.obj_embed.weight.shape:
             ys = E.region_projections(ops, [enc.obj_encoder, enc.motion_encoder], regions)

@@ -1,11 +1,11 @@
 """Tile / K-split choices for the products of a critic update (dlsg_amd/critic.py) at batch 64: every (mode, M, N, K) of the schedule
 under the dispatcher's default tile, each forced tile, and -- for the deep TN weight gradients -- K split over groups writing slabs
-(+ the slab_reduce that folds them).  usage: python3 tools/critic_gemm_probe.py [batch=64]"""
+(+ the slab_reduce that folds them).  usage: python3 tools/archive/critic_gemm_probe.py [batch=64]"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_FORCE64, F_FORCE128  # noqa: E402

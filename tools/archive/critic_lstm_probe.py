@@ -1,11 +1,11 @@
 """The critic's persistent LSTM launches (csrc/critic_lstm.hip) in both array layouts: time-major (L, n, .) against batch-major
-(n, L, .), levels 0 / 1 / 2, for the 192 captions of a critic pass and the 64 of its mixed set.  usage: python3 tools/critic_lstm_probe.py"""
+(n, L, .), levels 0 / 1 / 2, for the 192 captions of a critic pass and the 64 of its mixed set.  usage: python3 tools/archive/critic_lstm_probe.py"""
 import ctypes as C
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd import hip  # noqa: E402

@@ -1,9 +1,9 @@
 """Times the fused decoder-step kernels in isolation (HIP events, MSVD-shaped sizes).
-usage: python3 tools/decstep_bench.py [batch]"""
+usage: python3 tools/archive/decstep_bench.py [batch]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps  # noqa: E402

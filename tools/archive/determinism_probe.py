@@ -1,7 +1,7 @@
 """Diagnostic: is one eager train step bit-reproducible?  (same weights, same batch, lr = 0, run N times)"""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402

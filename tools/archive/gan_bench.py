@@ -1,13 +1,13 @@
 """One RunGAN iteration (run_gun.py:147-234) at the bench shape: generator and DiscV2 critic on the HIP kernels
 (dlsg_amd/gan.py, dlsg_amd/critic.py).  Prints ms per phase (no-grad generator forward, num_D critic updates, generator step
-incl. the GAN term) and clips/s of the whole iteration.  usage: python tools/gan_bench.py [batch=64] [iters=8] [num_D=5]"""
+incl. the GAN term) and clips/s of the whole iteration.  usage: python tools/archive/gan_bench.py [batch=64] [iters=8] [num_D=5]"""
 import json
 import os
 import random
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 import dlsg_amd  # noqa: E402

@@ -1,9 +1,9 @@
 """GPU microbenchmark of dlsg_gemm over the GEMM shapes of the batch-64 MSVD-shaped train step, per block-tile config.
-Usage (GPU box): python tools/gemm_bench.py > gpurun_out/gemm_bench.txt"""
+Usage (GPU box): python tools/archive/gemm_bench.py > gpurun_out/gemm_bench.txt"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN  # noqa: E402

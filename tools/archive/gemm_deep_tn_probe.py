@@ -1,9 +1,9 @@
 """obj_embed weight gradient (1024 x 2048, contraction 26624): row-group split of the contraction, 128x128 split-bf16 tiles.
-usage: python3 tools/gemm_deep_tn_probe.py"""
+usage: python3 tools/archive/gemm_deep_tn_probe.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_TN  # noqa: E402

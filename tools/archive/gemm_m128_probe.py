@@ -1,9 +1,9 @@
 """Recurrent gate products at batch 128 per GPU (M = 128): 64x64 tile vs 128x128 tile, contraction split over slabs.
-usage: python3 tools/gemm_m128_probe.py"""
+usage: python3 tools/archive/gemm_m128_probe.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN  # noqa: E402

@@ -1,10 +1,10 @@
 """The train step's mid-size products (1 664 = 26 frames x 64 clips rows, 512-6 144 wide: 3.4 ms of the step at 55-114 TFLOP/s,
 tools/gemm_census.py) under every tile the library has and under a K split into groups writing slabs + one slab_reduce:
-which launches would gain from a different dispatch.  usage: python tools/gemm_mid_probe.py"""
+which launches would gain from a different dispatch.  usage: python tools/archive/gemm_mid_probe.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_FORCE64, F_FORCE128  # noqa: E402

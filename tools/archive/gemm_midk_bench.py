@@ -1,9 +1,9 @@
 """Mid-size (1664-row) forward GEMMs of the batch-64 step: 64x64 tile vs 128x128 tile with the contraction split over
-slabs (+ the slab_reduce that folds them).  usage: python3 tools/gemm_midk_bench.py"""
+slabs (+ the slab_reduce that folds them).  usage: python3 tools/archive/gemm_midk_bench.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN  # noqa: E402

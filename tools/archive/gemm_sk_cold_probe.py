@@ -1,11 +1,11 @@
 """Does the stream-K launch run slower from cold caches?  The region projection (NT 26624 x 1024 x 2048 x 2, bias + tanh) and the deep
 weight gradient (TN 1024 x 2048 x 26624 x 2) timed (a) back to back, (b) each behind a 1-GB fill that evicts L2 / Infinity Cache,
-(c) behind a burst of small kernels.  HIP events around single launches.  usage: python3 tools/gemm_sk_cold_probe.py"""
+(c) behind a burst of small kernels.  HIP events around single launches.  usage: python3 tools/archive/gemm_sk_cold_probe.py"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_TN, F_SK, F_TANH  # noqa: E402

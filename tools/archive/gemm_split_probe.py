@@ -5,7 +5,7 @@ row-panel split that gave the 128-tile kernel whole 768-slot rounds and the rest
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_TN, F_TANH  # noqa: E402

@@ -1,10 +1,10 @@
 """Block-tile probe for the mid-size products of the train step (M = 1664 = 26 frames x 64 clips and the weight gradients
 over them): 64x64, 128x64 (FORCE64|FORCE128; BK from DLSG_GEMM_12864_BK) and 128x128 tiles, ms and TFLOP/s per launch.
-usage: python tools/gemm_tile_probe.py"""
+usage: python tools/archive/gemm_tile_probe.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN  # noqa: E402

@@ -1,10 +1,10 @@
 """The step's largest products on this repo's fp32 GEMM against PyTorch-ROCm's library call (rocBLAS / hipBLASLt, TF32 off) on the
-same operands: a ceiling check, not a product path.  usage: python3 tools/gemm_vs_rocblas.py"""
+same operands: a ceiling check, not a product path.  usage: python3 tools/archive/gemm_vs_rocblas.py"""
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN, GEMM_TN, F_TILE256, F_FORCE128  # noqa: E402

@@ -1,5 +1,5 @@
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'd-lsg-video-caption_amd'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'd-lsg-video-caption_amd'))
 import torch
 from dlsg_amd.hip import HipOps
 ops = HipOps()

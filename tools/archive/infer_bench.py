@@ -3,7 +3,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 import dlsg_amd  # noqa: E402

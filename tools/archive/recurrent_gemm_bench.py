@@ -1,10 +1,10 @@
 """The recurrent (M = batch = 64) gate products of one word step / BiLSTM step as the engine launches them, timed in
 isolation: grouped NT launches writing K-split slabs (forward) and grouped NN launches (input gradients).
-    python tools/recurrent_gemm_bench.py"""
+    python tools/archive/recurrent_gemm_bench.py"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_NN  # noqa: E402

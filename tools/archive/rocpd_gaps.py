@@ -1,4 +1,4 @@
-"""Idle time between kernels in a rocprofv3 (rocpd / SQLite) trace: python3 tools/rocpd_gaps.py <results.db> [skip_first_ms=0] [length_ms]
+"""Idle time between kernels in a rocprofv3 (rocpd / SQLite) trace: python3 tools/archive/rocpd_gaps.py <results.db> [skip_first_ms=0] [length_ms]
 (skip_first_ms < 0: counted back from the end of the trace)
 Prints the busy time (union of kernel intervals), the wall time of the traced span and the largest gaps with the kernels around them."""
 import re

@@ -1,17 +1,17 @@
 """What does the launch in front of a stream-K GEMM do to its duration?  Sequences of launches, each sequence repeated back to back
 (asynchronously queued, the GPU never idles inside a sequence), run under `rocprofv3 --kernel-trace`; the per-dispatch durations of
-the region-projection launch are then grouped by sequence (tools/sk_sequence_report.py reads the kernel-trace CSV).
+the region-projection launch are then grouped by sequence (tools/archive/sk_sequence_report.py reads the kernel-trace CSV).
   A: NT NT NT ...                              (back to back)
   B: [0.5-ms memory-bound update, NT]          (what Adam -> region projection looks like in the replayed step)
   C: [100 x 20-us light kernels, NT]           (a word loop's worth of light launches in front)
   D: [TN deep, NT]                             (heavy matrix kernel in front)
   E: [idle 2 ms (host sleep), NT]              (the stream runs dry)
-usage: rocprofv3 --kernel-trace --output-format csv -d <out> -- python3 tools/sk_sequence_probe.py"""
+usage: rocprofv3 --kernel-trace --output-format csv -d <out> -- python3 tools/archive/sk_sequence_probe.py"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'd-lsg-video-caption_amd'))
 import torch  # noqa: E402
 from dlsg_amd.hip import HipOps, GEMM_NT, GEMM_TN, F_SK, F_TANH  # noqa: E402

@@ -1,4 +1,4 @@
-"""Group the region-projection dispatches of tools/sk_sequence_probe.py by sequence.  usage: python3 tools/sk_sequence_report.py <kernel_trace.csv>"""
+"""Group the region-projection dispatches of tools/archive/sk_sequence_probe.py by sequence.  usage: python3 tools/archive/sk_sequence_report.py <kernel_trace.csv>"""
 import csv
 import json
 import sys

@@ -1,6 +1,6 @@
 """Idle time between the kernels of the replayed train step, from a rocprofv3 --kernel-trace CSV of bench.py:
 for the last `steps` steps (found by their Adam launch) prints step wall time, summed kernel time, summed idle gaps on the
-busiest stream and the gap histogram.  usage: python tools/trace_gaps.py <kernel_trace.csv> [steps=3]"""
+busiest stream and the gap histogram.  usage: python tools/archive/trace_gaps.py <kernel_trace.csv> [steps=3]"""
 import collections
 import csv
 import sys
