@@ -14,7 +14,7 @@ for cfg in "64 msvd" "128 msvd" "64 msrvtt"; do
   F=$(find $O/pmc_fetch_$N -name "*counter_collection.csv" | head -1); W=$(find $O/pmc_write_$N -name "*counter_collection.csv" | head -1)
   python3 $R/tools/pmc_step_traffic.py $F $W $O/calls_$N.json > $O/traffic_$N.json 2> $O/traffic_$N.err
   rm -rf $O/pmc_fetch_$N $O/pmc_write_$N
-  EXTRA="--no-pass --no-cpu-baseline --no-eager-baseline --no-batch128 --no-gan --no-inference --no-msrvtt"
+  EXTRA="--no-pass --no-cpu-baseline --no-eager-baseline --no-batch128 --no-gan --no-inference --no-msrvtt --no-sustained --no-dp-schedule"
   rocprofv3 --kernel-trace --stats -d $O/trace_$N -o t -- python3 $R/bench.py --batch $B --shape $S --steps 20 --warmup 5 $EXTRA > $O/bench_line_under_rocprof_$N.json 2> $O/trace_$N.log
   D=$(find $O/trace_$N -name "*.db" | head -1)
   python3 $R/tools/rocpd_stats.py $D 60 1 > $O/kernel_stats_bench_$N.csv
