@@ -240,6 +240,43 @@ def test_gemm_stream_k_slice_per_xcd_map(hip, mode, M, N, K, G):
     assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0
 
 
+@pytest.mark.parametrize('mode,M,N,K,G', [(GEMM_TN, 1024, 2048, 6656, 2), (GEMM_NT, 3000, 1024, 2048, 1), (GEMM_NN, 1664, 2048, 2048, 3)])
+@pytest.mark.parametrize('budget', [224, 100, 8, 3, 100000])
+def test_gemm_stream_k_on_a_cu_budget(hip, mode, M, N, K, G, budget):
+    """dlsg_gemm_args.cu_budget (ABI 8): a stream-K launch with at most that many workgroups (rounded down to a multiple of 8, at
+    least 8; more than the chip has = every CU) -- the CUs it leaves are for a co-tenant, a collective's kernels on another
+    stream.  Any budget gives the fp64 answer, the same bits twice in a row, and leaves the workspace counters at zero."""
+    g = torch.Generator(device='cuda').manual_seed(11)
+    groups, refs = [], []
+    for _ in range(G):
+        if mode == GEMM_NT:
+            A, B = torch.randn(M, K, device='cuda', generator=g), torch.randn(N, K, device='cuda', generator=g)
+            r = A.double() @ B.double().t()
+        elif mode == GEMM_NN:
+            A, B = torch.randn(M, K, device='cuda', generator=g), torch.randn(K, N, device='cuda', generator=g)
+            r = A.double() @ B.double()
+        else:
+            A, B = torch.randn(K, M, device='cuda', generator=g), torch.randn(K, N, device='cuda', generator=g)
+            r = A.double().t() @ B.double()
+        groups.append((A, B))
+        refs.append(r)
+    outs = []
+    hip.sk_cu_budget = budget
+    try:
+        for _ in range(2):
+            Cs = [torch.full((M, N), float('nan'), device='cuda') for _ in range(G)]
+            hip.gemm(mode, [(a_, b_, c_) for (a_, b_), c_ in zip(groups, Cs)], flags=F_SK)
+            outs.append(Cs)
+    finally:
+        hip.sk_cu_budget = 0
+    torch.cuda.synchronize()
+    for c0, c1, r in zip(outs[0], outs[1], refs):
+        assert torch.equal(c0, c1)
+        assert ((c0.double() - r).abs().max() / r.abs().max()).item() < 3e-6
+    ws = hip._gemm_workspace(torch.device('cuda', 0))
+    assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0
+
+
 def test_gemm_variant_names_the_tile_family(hip):
     """dlsg_gemm_variant == the choice dlsg_gemm makes (include/dlsg.h DLSG_GEMM_V_*), on the shapes DESIGN.md quotes"""
     def plan(mode, M, N, K, G=1, flags=0):
