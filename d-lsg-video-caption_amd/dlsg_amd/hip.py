@@ -390,7 +390,7 @@ def host_to_device(values, dtype, device):
     enqueued and the host moves on; the allocator keeps the block until the copy's event has passed."""
     t = values.to(dtype) if torch.is_tensor(values) else torch.as_tensor(values, dtype=dtype)
     device = torch.device(device)
-    if device.type != 'cuda':
+    if device.type != 'cuda' or t.is_cuda:
         return t.to(device)
     return t.contiguous().pin_memory().to(device, non_blocking=True)
 
