@@ -1062,9 +1062,15 @@ class Trainer(object):
         L = captions.shape[1]
         self._hook_mode, self._hook_sv = hook, None
         st = self._static = dict(frames=frames.clone(), regions=regions.clone(), captions=captions.clone(),
-                                 lens=cap_lens.clone(), coins=torch.ones(L, dtype=torch.int32, device=dev),
-                                 seed=torch.zeros(1, dtype=torch.int64, device=dev),
-                                 hyper=torch.zeros(2, dtype=torch.float32, device=dev))
+                                 lens=cap_lens.clone())
+        # what changes every step besides the batch -- the scheduled-sampling coins, the dropout seed, Adam's bias corrections --
+        # lives in ONE device buffer (int32 words: coins | seed (int64) | hyper (2 x float32)), so that a step sends it as one copy
+        Lp = (L + 1) // 2 * 2
+        st['scalars'] = torch.zeros(Lp + 4, dtype=torch.int32, device=dev)
+        st['coins'] = st['scalars'][:L]
+        st['coins'].fill_(1)
+        st['seed'] = st['scalars'][Lp:Lp + 2].view(torch.int64)
+        st['hyper'] = st['scalars'][Lp + 2:Lp + 4].view(torch.float32)
         side = _capture_stream(dev)
         side.wait_stream(torch.cuda.current_stream())
         graphs = []
@@ -1177,13 +1183,28 @@ class Trainer(object):
         for k, src in (('frames', frames), ('regions', regions), ('captions', captions)):
             if src.data_ptr() != st[k].data_ptr():
                 st[k].copy_(src, non_blocking=True)
-        _copy_h2d(st['coins'], [int(c) for c in coins])
-        _copy_h2d(st['seed'], [seed])
+        self._send_scalars(coins, seed, None)
         self._graphs[0][0].replay()
         logits_tm, sv = self._hook_sv
         # time_major: the logits as the decoder wrote them, (L,B,V) -- what the critic's schedule reads (gan.GanTrainer)
         return (logits_tm if time_major else logits_tm.transpose(0, 1)), sv['dec_gsrc'][0], sv['dec_gsrc'][1], \
             sv['dec']['ALPHA'].transpose(0, 1)
+
+    def _send_scalars(self, coins, seed, hyper):
+        """coins, dropout seed and (optionally) Adam's bias corrections of this step into the graphs' static words: one host buffer,
+        one asynchronous copy (hyper None: the words keep their value)"""
+        st = self._static
+        n = st['scalars'].numel()
+        L = st['coins'].numel()
+        host = torch.empty(n, dtype=torch.int32)
+        host[:L] = torch.tensor([int(c) for c in coins], dtype=torch.int32)
+        host[L:n - 4] = 0
+        host[n - 4:n - 2].view(torch.int64)[0] = seed
+        if hyper is None:
+            _copy_h2d(st['scalars'][:n - 2], host[:n - 2])
+            return
+        host[n - 2:].view(torch.float32).copy_(torch.tensor(hyper, dtype=torch.float32))
+        _copy_h2d(st['scalars'], host)
 
     def static_inputs(self):
         """The captured graphs read their batch from these device buffers: (frames, regions, captions, cap_lens), or None
@@ -1226,9 +1247,7 @@ class Trainer(object):
         for k, src in (('frames', frames), ('regions', regions), ('captions', captions), ('lens', cap_lens)):
             if src.data_ptr() != st[k].data_ptr():
                 st[k].copy_(src, non_blocking=True)
-        _copy_h2d(st['coins'], [int(c) for c in coins])
-        _copy_h2d(st['seed'], [seed])
-        _copy_h2d(st['hyper'], self._hyper())
+        self._send_scalars(coins, seed, self._hyper())
         self._works = []
         for g, key in self._graphs:
             g.replay()
