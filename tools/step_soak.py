@@ -1,4 +1,4 @@
-"""Soak of the plain train step (replayed hipGraphs, scheduled sampling with the reference's epsilon schedule, four alternating
+"""Soak of the plain train step (replayed hipGraphs; each step copies one of four resident batches into the graph's static inputs, scheduled sampling with the reference's epsilon schedule, four alternating
 batches): N steps in one process, the loss read back and the persistent kernels' time-out word checked every 100 steps.
 Prints one JSON line.  usage: PYTHONFAULTHANDLER=1 python3 tools/step_soak.py [steps=3000] [batch=64]"""
 import faulthandler
@@ -26,7 +26,7 @@ net = dlsg_amd.CapGnnModel(args, dlsg_amd.make_vocab(V))
 net.load_state_dict(synth_state_dict(net.state_dict(), 0))
 net = net.cuda().train()
 batches = [[t.cuda() for t in synth_batch(args, V, B, 1 + k)] for k in range(4)]
-tr = dlsg_amd.Trainer(net)
+tr = dlsg_amd.Trainer(net, use_graphs=True)       # (until round 6 this said Trainer(net): eager launches, host-bound at ~13.8 ms)
 t0 = time.time()
 log = []
 for i in range(N):
