@@ -639,6 +639,30 @@ def test_graph_trainer_follows_lr_changes_and_resumes_from_torch_adam_state():
     assert torch.equal(net._flat, net2._flat)
 
 
+@pytest.mark.parametrize('tag', SMALL)
+def test_rank_schedule_equals_the_one_rank_schedule_on_every_model(tag):
+    """`Trainer(rehearse_ranks=8)` -- the schedule of a data-parallel rank: per-bucket flush, buckets through the RCCL communicator
+    inside the captured step (world 1), the all-rank Adam guard behind the last launch, BiLSTM backward step by step -- on every
+    model family (CapGnnModel hands over five buckets, the baselines one): three train-mode steps with scheduled sampling land
+    on the weights of the plain replayed trainer (the two BiLSTM backward forms differ in the last bits only)."""
+    res = []
+    for ranks in (0, 8):
+        net, g, frames, regions, caps, lens, kind = build(tag)
+        net.train()
+        tr = dlsg_amd.Trainer(net, use_graphs=True, rehearse_ranks=ranks)
+        random.seed(5)
+        losses = [float(tr.step(frames, regions, caps, lens, 0.8)) for _ in range(3)]
+        if ranks:
+            info = tr.collectives_info()
+            assert len(tr._graphs) == 1 and tr._adam_in_graph and info['where'] == "inside the step's hipGraph", info
+            assert net.ops.persistent_bilstm_bwd is False and net.stream_k_in_backward and net.sk_backward_cu_budget == 0
+        tr.check()
+        res.append((losses, net._flat.clone()))
+        tr.close()
+    assert np.allclose(res[0][0], res[1][0], rtol=0, atol=2e-6), (res[0][0], res[1][0])
+    assert (res[0][1] - res[1][1]).abs().max().item() <= 2e-6
+
+
 def test_graph_trainer_with_an_extra_logit_gradient_matches_eager():
     """Trainer.step(extra_dlogits=...) in graph mode (forward + CrossEntropy | the caller's term | backward + Adam): the term
     sees the logits / loss / attention weights of THIS step and its result reaches the backward -- equal to the kernel-by-
