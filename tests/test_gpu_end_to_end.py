@@ -74,6 +74,39 @@ def test_caption_training_memorises_a_tiny_corpus_and_scores_it(tmp_path):
         assert scores['Bleu_4'] > 0.8 and scores['ROUGE_L'] > 0.85 and scores['CIDEr'] > 5.0, scores
 
 
+def test_gathering_into_the_graphs_static_inputs_equals_passing_batches(tmp_path):
+    """bench.py's `sustained` loop (run_gun.py:147-160 with an HBM-resident store): every step the next batch is gathered straight
+    into the replayed graph's static input buffers (`ResidentFeatures.batch(ids, out=...)`), captions and lengths go up through
+    the pinned, asynchronous copies -- the weights after six steps are those of a trainer that is handed fresh batch tensors, bit
+    for bit, and the host never has to wait for the device in between."""
+    args, vocab, fp, rp, cp, tp = corpus(tmp_path)
+    feats_np = D.H5File(fp)['feats'].read_rows(0, N)
+    vfeats_np = D.H5File(rp)['vfeats'].read_rows(0, N)
+    caps_t, _, lens, vids = pickle.load(open(cp, 'rb'))
+    caps_t = torch.stack(caps_t)
+    order = [list(np.random.RandomState(3 + k).permutation(N)[:8]) for k in range(6)]
+    flats = []
+    for static in (False, True):
+        torch.manual_seed(0)
+        random.seed(12)
+        model = dlsg_amd.CapGnnModel(args, vocab).cuda().train()
+        store = D.ResidentFeatures.from_arrays(feats_np, vfeats_np, args.num_obj, 'cuda', ops=model.ops)
+        tr = dlsg_amd.Trainer(model, use_graphs=True)
+        for k, ids in enumerate(order):
+            ids = sorted(ids, reverse=True)
+            cb, lb = caps_t[ids], [lens[i] for i in ids]
+            st = tr.static_inputs() if static else None
+            if st is not None:
+                f, r = store.batch(ids, out=(st[0], st[1]))
+                assert f.data_ptr() == st[0].data_ptr() and r.data_ptr() == st[1].data_ptr()
+            else:
+                f, r = store.batch(ids)
+            tr.step(f, r, cb.cuda(), lb, 0.9)
+        tr.check()
+        flats.append(model._flat.clone())
+    assert torch.equal(flats[0], flats[1])
+
+
 def test_gan_loop_over_loader_batches(tmp_path):
     args, vocab, fp, rp, cp, tp = corpus(tmp_path, seed=1, make_args=lambda: gan_args(use_visual_gan=True))
     torch.manual_seed(0)
